@@ -1,0 +1,189 @@
+/*
+ * jaeger_hip.h - C-ABI of libjaeger_hip.so, the MI355X (gfx950) engine for the
+ * Jaeger `predict` hot path: window table -> 6-frame codon ids -> conv forward.
+ *
+ * The reference has no FFI: its de-facto plugin boundary is the duck-typed
+ * inference-engine class selected in src/jaeger/commands/predict.py:688-745
+ * (InferModel / TFLiteInferModel / ONNXEngine / TensorRTEngine,
+ * src/jaeger/nnlib/inference.py:300,486,626,925).  Each entry point below names
+ * the reference code it replaces; jaeger_amd/engine.py wraps them into that
+ * duck type (class_map, string_processor_config, predict()).
+ *
+ * Conventions: every function returns 0 on success and a negative jg_status on
+ * failure (jg_last_error() then holds a message); nothing throws across the
+ * ABI; the caller owns every buffer it passes in; the library owns its device
+ * workspace.  A handle is bound to one GPU and is not thread-safe; distinct
+ * handles are independent.  Pointers marked "dev/host" may be either: pass
+ * JG_PTR_DEVICE or JG_PTR_HOST in the matching *_loc argument.  `stream` is a
+ * hipStream_t passed as void* (NULL = the handle's own stream).
+ */
+#ifndef JAEGER_HIP_H
+#define JAEGER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JG_ABI_VERSION 1
+#define JG_MAX_STAGES 8
+#define JG_MAX_BUFS 6      /* activation / mask buffer slots */
+#define JG_MAX_VECS 12     /* per-window vector slots */
+
+typedef enum {
+  JG_OK = 0,
+  JG_ERR_INVALID = -1,      /* bad argument / malformed program */
+  JG_ERR_HIP = -2,          /* a HIP runtime call failed */
+  JG_ERR_UNSUPPORTED = -3,  /* op or geometry the kernels do not implement */
+  JG_ERR_NOMEM = -4
+} jg_status;
+
+enum { JG_PTR_HOST = 0, JG_PTR_DEVICE = 1 };
+
+/* ---- op program (the compiled layer plan) ------------------------------ */
+typedef enum {
+  JG_OP_CONV = 1,      /* MaskedConv1D (+ fused epilogue stages)  layers.py:1128-1332 */
+  JG_OP_MASK = 2,      /* conv output-mask rule                    layers.py:1226-1255 */
+  JG_OP_POOL = 3,      /* MaskedGlobalMax/AvgPooling               layers.py:455-538   */
+  JG_OP_DENSE = 4,     /* Dense head layer                         builder.py:295      */
+  JG_OP_ELTWISE = 5,   /* standalone norm / activation stages                          */
+  JG_OP_NMD_FINAL = 6, /* NMDLayer mean - moving_mean              nmd.py:52-77        */
+  JG_OP_OODSIG = 7,    /* OODSignalLayer                           layers.py:1632-1667 */
+  JG_OP_MAXPOOL1D = 8, /* MaxPooling1D(2) of the legacy tower      v1/layers.py:154-207*/
+  JG_OP_FRAMESUM = 9   /* legacy frame Add                         v1/layers.py:399-423*/
+} jg_op_kind;
+
+typedef enum {
+  JG_ST_NONE = 0,
+  JG_ST_BIAS = 1,    /* + bias[c]                         p0=bias                       */
+  JG_ST_BN = 2,      /* g*((x-mu)*inv_std)+b              p0=mu p1=inv_std p2=g p3=b    */
+  JG_ST_DYT = 3,     /* tanh(alpha*x)*g+b (*mask)         f0=alpha p2=g p3=b arg=use mask*/
+  JG_ST_ADD = 4,     /* + other[buf arg] (residual add)   arg=activation buffer slot    */
+  JG_ST_ACT = 5,     /* activation                        arg=jg_act                    */
+  JG_ST_NMD = 6,     /* tap: partial masked channel sums  arg=partial-sum slot          */
+  JG_ST_MASKMUL = 7, /* * out mask                                                      */
+  JG_ST_LN = 8       /* MaskedLayerNormalization (eltwise op only) p2=g p3=b f0=eps     */
+} jg_stage_kind;
+
+typedef enum {
+  JG_ACT_NONE = 0,
+  JG_ACT_GELU_TANH = 1,  /* tf.nn.gelu(approximate=True) layers.py:29 */
+  JG_ACT_GELU_ERF = 2,   /* legacy exact GELU v1/layers.py:72-79 */
+  JG_ACT_RELU = 3,
+  JG_ACT_TANH = 4,
+  JG_ACT_SIGMOID = 5
+} jg_act;
+
+typedef enum { JG_MASK_ANY = 0, JG_MASK_MAJORITY = 1, JG_MASK_STRICT = 2 } jg_mask_mode;
+typedef enum { JG_PAD_VALID = 0, JG_PAD_SAME = 1 } jg_padding;
+typedef enum { JG_POOL_MAX = 0, JG_POOL_AVG = 1, JG_POOL_MAX_NOMASK = 2 } jg_pool_kind;
+
+/* buffer slot constants */
+#define JG_BUF_NONE (-1)
+#define JG_BUF_IDS (-2) /* conv input = embedding gather of the id tensor; mask = ids != 0 */
+
+typedef struct {
+  int32_t kind;   /* jg_stage_kind */
+  int32_t arg;
+  int64_t p0, p1, p2, p3; /* offsets (in floats) into the weight blob, -1 = unused */
+  float f0;
+  int32_t pad_;
+} jg_stage;
+
+typedef struct {
+  int32_t kind;                 /* jg_op_kind */
+  int32_t in_buf, out_buf;      /* activation slots (JG_BUF_IDS allowed for in_buf) */
+  int32_t in_mask, out_mask;    /* mask slots, JG_BUF_NONE = no mask, JG_BUF_IDS = ids != 0 */
+  int32_t k, cin, cout;         /* conv: taps, in/out channels; dense: cin->cout */
+  int32_t stride, dilation;
+  int32_t padding;              /* jg_padding */
+  int32_t mask_mode;            /* jg_mask_mode */
+  int32_t in_vec, out_vec;      /* vector slots (pool out, dense in/out, nmd out) */
+  int32_t vec_off;              /* column offset inside out_vec (nmd concat) */
+  int32_t arg;                  /* pool kind / dense activation / nmd partial slot */
+  int64_t w_off;                /* conv/dense kernel offset (floats) */
+  int64_t b_off;                /* dense bias / embedding table / nmd moving_mean offset */
+  float f0;                     /* eps */
+  int32_t n_stages;
+  jg_stage stages[JG_MAX_STAGES];
+} jg_op;
+
+typedef struct jg_engine jg_engine; /* opaque, one per GPU */
+typedef struct jg_model jg_model;   /* opaque, weights + op program on one engine */
+
+/* ---- lifecycle ---------------------------------------------------------- */
+/* Replaces the TF device / strategy setup of commands/predict.py:583-664. */
+int jg_abi_version(void);
+/* sizeof(jg_op) (which=0) / sizeof(jg_stage) (which=1): lets a binding check its struct layout */
+int jg_sizeof(int which);
+const char *jg_last_error(void);
+int jg_engine_create(int device_id, jg_engine **out);
+int jg_engine_destroy(jg_engine *e);
+int jg_engine_sync(jg_engine *e);
+
+/* Replaces tf.saved_model.load + serving_default (nnlib/inference.py:307-325):
+ * `ops` is the layer plan compiled by jaeger_amd/program.py, `weights` one f32
+ * blob (host) the op offsets index into. */
+int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const float *weights,
+                    int64_t n_weights, int32_t vocab, jg_model **out);
+int jg_model_destroy(jg_model *m);
+
+/* ---- hot path ----------------------------------------------------------- */
+/* Replaces fragment_generator's per-window slice + 4x str.count
+ * (seqops/io.py:119-133) and process_string_inference (seqops/encode.py:228-302)
+ * for input_type="translated", ngram_width=3, seq_onehot=False:
+ *   bases      concatenated contig bytes (ASCII), dev/host
+ *   win_start  n_win byte offsets of the windows into `bases`
+ *   win_len    n_win window lengths (<= fsize; shorter = whole-contig window)
+ *   fsize      crop_size the frame offset is derived from (encode.py:232-236)
+ *   lut65      65-byte table: entry 16*b0+4*b1+b2 (TCAG=0..3) -> codon_id+1; [64] unused
+ *   soft_mask  0: upper-case before lookup/counting (masking=False, dustmask off)
+ *   l_pad      codons per frame row in the output (>= frame length of fsize)
+ * outputs (device or host per out_loc):
+ *   ids        (n_win, 6, l_pad) u8, rows f1,f2,f3,r1,r2,r3, 0 = invalid / padding
+ *   counts     (n_win, 4) i32 upper-case G,C,A,T counts of each window
+ */
+int jg_encode(jg_engine *e, const uint8_t *bases, int64_t n_bases, int bases_loc,
+              const int64_t *win_start, const int32_t *win_len, int win_loc, int64_t n_win,
+              int32_t fsize, const uint8_t *lut65, int32_t soft_mask, int32_t l_pad,
+              uint8_t *ids, int32_t *counts, int out_loc, void *stream);
+
+/* Replaces InferModel.predict's per-batch serving_default call
+ * (nnlib/inference.py:355-363): ids (n_win, 6, l) u8 -> per-window outputs.
+ * Any output pointer may be NULL.  Output widths are those of the program
+ * (jg_model_vec_width).  `chunk` = windows per launch group (0 = default). */
+int jg_forward(jg_model *m, const uint8_t *ids, int ids_loc, int64_t n_win, int32_t l,
+               float *prediction, float *reliability, float *embedding, float *nmd,
+               int out_loc, int32_t chunk, void *stream);
+
+/* encode + forward on device-resident bases in one call (no id tensor round trip). */
+int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_bases, int bases_loc,
+                       const int64_t *win_start, const int32_t *win_len, int win_loc,
+                       int64_t n_win, int32_t fsize, const uint8_t *lut65, int32_t soft_mask,
+                       int32_t l_pad, float *prediction, float *reliability, float *embedding,
+                       float *nmd, int32_t *counts, int out_loc, int32_t chunk, void *stream);
+
+/* widths of the named outputs: which = 0 prediction, 1 reliability, 2 embedding, 3 nmd */
+int jg_model_vec_width(const jg_model *m, int which);
+/* algorithmic conv FLOPs of one window at l codons per frame */
+double jg_model_flops_per_window(const jg_model *m, int32_t l);
+
+/* ---- device memory helpers (so callers need no other GPU runtime) ------- */
+int jg_dev_alloc(jg_engine *e, int64_t bytes, void **out);
+int jg_dev_free(jg_engine *e, void *p);
+int jg_memcpy_h2d(jg_engine *e, void *dst, const void *src, int64_t bytes);
+int jg_memcpy_d2h(jg_engine *e, void *dst, const void *src, int64_t bytes);
+
+/* ---- measurement (bench.py): HIP-event timing on the engine's stream ---- */
+int jg_timer_start(jg_engine *e, void *stream);
+int jg_timer_stop_ms(jg_engine *e, void *stream, float *ms);
+/* accumulated HIP-event time and launch count of the dominant (conv) kernel since reset;
+ * enabled by jg_profile_enable(e, 1), which inserts events around every conv launch */
+int jg_profile_enable(jg_engine *e, int on);
+int jg_profile_read(jg_engine *e, double *conv_ms, int64_t *conv_launches, double *conv_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JAEGER_HIP_H */

@@ -1,0 +1,798 @@
+// C-ABI of libjaeger_hip.so (see include/jaeger_hip.h): engine / model lifecycle,
+// the op-program interpreter that sequences the gfx950 kernels, and the timing
+// hooks bench.py uses.  Host logic only - kernels live in jg_kernels.hip.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "jg_common.h"
+
+static thread_local char g_err[1024] = "";
+
+void jg_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *jg_last_error(void) { return g_err; }
+extern "C" int jg_abi_version(void) { return JG_ABI_VERSION; }
+extern "C" int jg_sizeof(int which) {
+  return which == 0 ? (int)sizeof(jg_op) : (which == 1 ? (int)sizeof(jg_stage) : -1);
+}
+
+// ---------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------
+extern "C" int jg_engine_create(int device_id, jg_engine **out) {
+  JG_REQUIRE(out != nullptr, JG_ERR_INVALID, "jg_engine_create: out is NULL");
+  int n_dev = 0;
+  JG_HIP(hipGetDeviceCount(&n_dev));
+  JG_REQUIRE(device_id >= 0 && device_id < n_dev, JG_ERR_INVALID,
+             "jg_engine_create: device %d not present (%d visible)", device_id, n_dev);
+  JG_HIP(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  JG_HIP(hipGetDeviceProperties(&prop, device_id));
+  JG_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, JG_ERR_UNSUPPORTED,
+             "jg_engine_create: device %d is %s; this library targets gfx950 (MI355X) only",
+             device_id, prop.gcnArchName);
+  jg_engine *e = new jg_engine();
+  e->dev = device_id;
+  e->n_cu = prop.multiProcessorCount;
+  JG_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  JG_HIP(hipEventCreate(&e->t0));
+  JG_HIP(hipEventCreate(&e->t1));
+  *out = e;
+  return JG_OK;
+}
+
+extern "C" int jg_engine_destroy(jg_engine *e) {
+  if (e == nullptr) return JG_OK;
+  (void)hipSetDevice(e->dev);
+  (void)hipStreamSynchronize(e->stream);
+  for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto ev : e->pool) (void)hipEventDestroy(ev);
+  (void)hipEventDestroy(e->t0);
+  (void)hipEventDestroy(e->t1);
+  (void)hipStreamDestroy(e->stream);
+  delete e;
+  return JG_OK;
+}
+
+extern "C" int jg_engine_sync(jg_engine *e) {
+  JG_REQUIRE(e != nullptr, JG_ERR_INVALID, "jg_engine_sync: NULL engine");
+  JG_HIP(hipSetDevice(e->dev));
+  JG_HIP(hipStreamSynchronize(e->stream));
+  return JG_OK;
+}
+
+static hipStream_t pick_stream(jg_engine *e, void *stream) {
+  return stream != nullptr ? reinterpret_cast<hipStream_t>(stream) : e->stream;
+}
+
+extern "C" int jg_dev_alloc(jg_engine *e, int64_t bytes, void **out) {
+  JG_REQUIRE(e != nullptr && out != nullptr && bytes >= 0, JG_ERR_INVALID, "jg_dev_alloc: bad args");
+  JG_HIP(hipSetDevice(e->dev));
+  *out = nullptr;
+  if (bytes == 0) return JG_OK;
+  hipError_t err = hipMalloc(out, (size_t)bytes);
+  if (err != hipSuccess) {
+    jg_set_error("jg_dev_alloc: hipMalloc(%lld) -> %s", (long long)bytes, hipGetErrorString(err));
+    return JG_ERR_NOMEM;
+  }
+  return JG_OK;
+}
+
+extern "C" int jg_dev_free(jg_engine *e, void *p) {
+  JG_REQUIRE(e != nullptr, JG_ERR_INVALID, "jg_dev_free: NULL engine");
+  JG_HIP(hipSetDevice(e->dev));
+  if (p != nullptr) JG_HIP(hipFree(p));
+  return JG_OK;
+}
+
+extern "C" int jg_memcpy_h2d(jg_engine *e, void *dst, const void *src, int64_t bytes) {
+  JG_REQUIRE(e != nullptr, JG_ERR_INVALID, "jg_memcpy_h2d: NULL engine");
+  JG_HIP(hipSetDevice(e->dev));
+  if (bytes > 0) {
+    JG_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, e->stream));
+    JG_HIP(hipStreamSynchronize(e->stream));
+  }
+  return JG_OK;
+}
+
+extern "C" int jg_memcpy_d2h(jg_engine *e, void *dst, const void *src, int64_t bytes) {
+  JG_REQUIRE(e != nullptr, JG_ERR_INVALID, "jg_memcpy_d2h: NULL engine");
+  JG_HIP(hipSetDevice(e->dev));
+  if (bytes > 0) {
+    JG_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, e->stream));
+    JG_HIP(hipStreamSynchronize(e->stream));
+  }
+  return JG_OK;
+}
+
+extern "C" int jg_timer_start(jg_engine *e, void *stream) {
+  JG_REQUIRE(e != nullptr, JG_ERR_INVALID, "jg_timer_start: NULL engine");
+  JG_HIP(hipSetDevice(e->dev));
+  JG_HIP(hipEventRecord(e->t0, pick_stream(e, stream)));
+  return JG_OK;
+}
+
+extern "C" int jg_timer_stop_ms(jg_engine *e, void *stream, float *ms) {
+  JG_REQUIRE(e != nullptr && ms != nullptr, JG_ERR_INVALID, "jg_timer_stop_ms: bad args");
+  JG_HIP(hipSetDevice(e->dev));
+  JG_HIP(hipEventRecord(e->t1, pick_stream(e, stream)));
+  JG_HIP(hipEventSynchronize(e->t1));
+  JG_HIP(hipEventElapsedTime(ms, e->t0, e->t1));
+  return JG_OK;
+}
+
+extern "C" int jg_profile_enable(jg_engine *e, int on) {
+  JG_REQUIRE(e != nullptr, JG_ERR_INVALID, "jg_profile_enable: NULL engine");
+  e->profile = on != 0;
+  e->conv_ms = 0.0;
+  e->conv_flops = 0.0;
+  e->conv_launches = 0;
+  return JG_OK;
+}
+
+static int drain_profile(jg_engine *e) {
+  for (auto &p : e->pending) {
+    JG_HIP(hipEventSynchronize(p.b));
+    float ms = 0.f;
+    JG_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+    e->conv_ms += ms;
+    e->conv_flops += p.flops;
+    e->conv_launches += 1;
+    e->pool.push_back(p.a);
+    e->pool.push_back(p.b);
+  }
+  e->pending.clear();
+  return JG_OK;
+}
+
+extern "C" int jg_profile_read(jg_engine *e, double *conv_ms, int64_t *conv_launches,
+                               double *conv_flops) {
+  JG_REQUIRE(e != nullptr, JG_ERR_INVALID, "jg_profile_read: NULL engine");
+  JG_HIP(hipSetDevice(e->dev));
+  int rc = drain_profile(e);
+  if (rc != JG_OK) return rc;
+  if (conv_ms) *conv_ms = e->conv_ms;
+  if (conv_launches) *conv_launches = e->conv_launches;
+  if (conv_flops) *conv_flops = e->conv_flops;
+  return JG_OK;
+}
+
+static int prof_event(jg_engine *e, hipEvent_t *ev) {
+  if (!e->pool.empty()) {
+    *ev = e->pool.back();
+    e->pool.pop_back();
+    return JG_OK;
+  }
+  JG_HIP(hipEventCreate(ev));
+  return JG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------
+struct Shape {
+  int frames = 0, L = 0, C = 0;
+};
+
+static void conv_geometry(int L_in, int k, int stride, int dil, int padding, int *L_out,
+                          int *pad_left) {
+  if (padding == JG_PAD_SAME) {
+    // TF 'SAME': L_out = ceil(L/s); pad_left = pad_total // 2
+    const int lo = (L_in + stride - 1) / stride;
+    int total = (lo - 1) * stride + (k - 1) * dil + 1 - L_in;
+    if (total < 0) total = 0;
+    *L_out = lo;
+    *pad_left = total / 2;
+  } else {
+    const int span = dil * (k - 1) + 1;
+    *L_out = L_in >= span ? (L_in - span) / stride + 1 : 0;
+    *pad_left = 0;
+  }
+}
+
+static int validate_program(const jg_model *m) {
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    const jg_op &op = m->ops[i];
+    auto slot_ok = [](int s, bool allow_ids) {
+      return (s >= 0 && s < JG_MAX_BUFS) || s == JG_BUF_NONE || (allow_ids && s == JG_BUF_IDS);
+    };
+    JG_REQUIRE(op.kind >= JG_OP_CONV && op.kind <= JG_OP_FRAMESUM, JG_ERR_INVALID,
+               "op %zu: unknown kind %d", i, op.kind);
+    JG_REQUIRE(slot_ok(op.in_buf, true) && slot_ok(op.out_buf, false) && slot_ok(op.in_mask, true) &&
+                   slot_ok(op.out_mask, false),
+               JG_ERR_INVALID, "op %zu: buffer slot out of range", i);
+    JG_REQUIRE(op.in_vec >= -1 && op.in_vec < JG_MAX_VECS && op.out_vec >= -1 &&
+                   op.out_vec < JG_MAX_VECS,
+               JG_ERR_INVALID, "op %zu: vector slot out of range", i);
+    JG_REQUIRE(op.n_stages >= 0 && op.n_stages <= JG_MAX_STAGES, JG_ERR_INVALID,
+               "op %zu: %d stages", i, op.n_stages);
+    auto off_ok = [&](int64_t off, int64_t n) { return off >= 0 && off + n <= m->n_w; };
+    if (op.kind == JG_OP_CONV) {
+      JG_REQUIRE(op.k >= 1 && op.cin >= 1 && op.cout >= 1 && op.stride >= 1 && op.dilation >= 1,
+                 JG_ERR_INVALID, "op %zu: bad conv geometry", i);
+      const int64_t cin_pad = (op.cin + 1) & ~1, cout_pad = (op.cout + 31) / 32 * 32;
+      JG_REQUIRE(off_ok(op.w_off, (int64_t)op.k * cin_pad * cout_pad), JG_ERR_INVALID,
+                 "op %zu: conv kernel outside the weight blob", i);
+      if (op.in_buf == JG_BUF_IDS)
+        JG_REQUIRE(off_ok(op.b_off, (int64_t)m->vocab * op.cin), JG_ERR_INVALID,
+                   "op %zu: embedding table outside the weight blob", i);
+    }
+    if (op.kind == JG_OP_DENSE) {
+      JG_REQUIRE(off_ok(op.w_off, (int64_t)op.cin * op.cout), JG_ERR_INVALID,
+                 "op %zu: dense kernel outside the weight blob", i);
+      JG_REQUIRE(op.b_off < 0 || off_ok(op.b_off, op.cout), JG_ERR_INVALID,
+                 "op %zu: dense bias outside the weight blob", i);
+    }
+    for (int s = 0; s < op.n_stages; ++s) {
+      const jg_stage &st = op.stages[s];
+      const int64_t c = op.cout;
+      switch (st.kind) {
+        case JG_ST_BIAS:
+          JG_REQUIRE(off_ok(st.p0, c), JG_ERR_INVALID, "op %zu stage %d: bias offset", i, s);
+          break;
+        case JG_ST_BN:
+          JG_REQUIRE(off_ok(st.p0, c) && off_ok(st.p1, c) && off_ok(st.p2, c) && off_ok(st.p3, c),
+                     JG_ERR_INVALID, "op %zu stage %d: batchnorm offsets", i, s);
+          break;
+        case JG_ST_DYT:
+          JG_REQUIRE(off_ok(st.p2, c) && off_ok(st.p3, c), JG_ERR_INVALID,
+                     "op %zu stage %d: dyt offsets", i, s);
+          break;
+        case JG_ST_ADD:
+          JG_REQUIRE(st.arg >= 0 && st.arg < JG_MAX_BUFS, JG_ERR_INVALID,
+                     "op %zu stage %d: add slot", i, s);
+          break;
+        case JG_ST_NMD:
+          JG_REQUIRE(st.arg >= 0 && st.arg < JG_MAX_BUFS, JG_ERR_INVALID,
+                     "op %zu stage %d: nmd partial slot", i, s);
+          break;
+        case JG_ST_ACT:
+        case JG_ST_MASKMUL:
+          break;
+        default:
+          jg_set_error("op %zu stage %d: stage kind %d is not implemented", i, s, st.kind);
+          return JG_ERR_UNSUPPORTED;
+      }
+    }
+  }
+  return JG_OK;
+}
+
+// Dry-run the program at `l` codons per frame: per-slot element counts (per
+// window) and vector widths.  Also used to validate that shapes line up.
+static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
+                       int64_t msk_elems[JG_MAX_BUFS], int64_t nmd_elems[JG_MAX_BUFS],
+                       int vec_w[JG_MAX_VECS], double *flops) {
+  Shape sh[JG_MAX_BUFS];
+  int mlen[JG_MAX_BUFS] = {};   // positions per window of each mask slot
+  for (int i = 0; i < JG_MAX_BUFS; ++i) act_elems[i] = msk_elems[i] = nmd_elems[i] = 0;
+  for (int i = 0; i < JG_MAX_VECS; ++i) vec_w[i] = 0;
+  double fl = 0.0;
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    const jg_op &op = m->ops[i];
+    switch (op.kind) {
+      case JG_OP_CONV: {
+        Shape in;
+        if (op.in_buf == JG_BUF_IDS) { in.frames = 6; in.L = l; in.C = op.cin; }
+        else in = sh[op.in_buf];
+        JG_REQUIRE(in.C == op.cin, JG_ERR_INVALID, "op %zu: conv expects %d channels, input has %d",
+                   i, op.cin, in.C);
+        int lo, pl;
+        conv_geometry(in.L, op.k, op.stride, op.dilation, op.padding, &lo, &pl);
+        JG_REQUIRE(lo > 0, JG_ERR_INVALID,
+                   "op %zu: conv output is empty at %d codons per frame (window too short)", i, in.L);
+        JG_REQUIRE(op.out_buf >= 0, JG_ERR_INVALID, "op %zu: conv needs an output slot", i);
+        sh[op.out_buf] = Shape{in.frames, lo, op.cout};
+        act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)in.frames * lo * op.cout);
+        fl += 2.0 * op.k * op.cin * op.cout * (double)in.frames * lo;
+        const int tiles = (lo + 127) / 128;
+        for (int s = 0; s < op.n_stages; ++s)
+          if (op.stages[s].kind == JG_ST_NMD)
+            nmd_elems[op.stages[s].arg] = std::max<int64_t>(nmd_elems[op.stages[s].arg],
+                                                           (int64_t)in.frames * tiles * op.cout);
+      } break;
+      case JG_OP_MASK: {
+        const int L_in = op.in_mask == JG_BUF_IDS ? l : (mlen[op.in_mask] / 6);
+        int lo, pl;
+        conv_geometry(L_in, op.k, op.stride, op.dilation, op.padding, &lo, &pl);
+        JG_REQUIRE(op.out_mask >= 0 && lo > 0, JG_ERR_INVALID, "op %zu: bad mask op", i);
+        mlen[op.out_mask] = 6 * lo;
+        msk_elems[op.out_mask] = std::max<int64_t>(msk_elems[op.out_mask], (int64_t)6 * lo);
+      } break;
+      case JG_OP_ELTWISE: {
+        const Shape in = sh[op.in_buf];
+        JG_REQUIRE(in.C == op.cout, JG_ERR_INVALID, "op %zu: eltwise channel mismatch", i);
+        sh[op.out_buf] = in;
+        act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)in.frames * in.L * in.C);
+      } break;
+      case JG_OP_MAXPOOL1D: {
+        const Shape in = sh[op.in_buf];
+        const int lo = in.L / 2;
+        JG_REQUIRE(lo > 0, JG_ERR_INVALID, "op %zu: maxpool output empty", i);
+        sh[op.out_buf] = Shape{in.frames, lo, in.C};
+        act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)in.frames * lo * in.C);
+      } break;
+      case JG_OP_FRAMESUM: {
+        const Shape in = sh[op.in_buf];
+        sh[op.out_buf] = Shape{1, in.L, in.C};
+        act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)in.L * in.C);
+      } break;
+      case JG_OP_POOL: {
+        const Shape in = sh[op.in_buf];
+        JG_REQUIRE(op.out_vec >= 0, JG_ERR_INVALID, "op %zu: pool needs an output vector", i);
+        vec_w[op.out_vec] = std::max(vec_w[op.out_vec], op.vec_off + in.C);
+      } break;
+      case JG_OP_DENSE:
+        JG_REQUIRE(op.in_vec >= 0 && op.out_vec >= 0, JG_ERR_INVALID, "op %zu: dense vectors", i);
+        JG_REQUIRE(vec_w[op.in_vec] >= op.cin, JG_ERR_INVALID,
+                   "op %zu: dense expects %d inputs, vector %d has %d", i, op.cin, op.in_vec,
+                   vec_w[op.in_vec]);
+        vec_w[op.out_vec] = std::max(vec_w[op.out_vec], op.vec_off + op.cout);
+        break;
+      case JG_OP_NMD_FINAL:
+        JG_REQUIRE(op.out_vec >= 0, JG_ERR_INVALID, "op %zu: nmd needs an output vector", i);
+        vec_w[op.out_vec] = std::max(vec_w[op.out_vec], op.vec_off + op.cout);
+        break;
+      case JG_OP_OODSIG:
+        JG_REQUIRE(op.out_vec >= 0, JG_ERR_INVALID, "op %zu: oodsig needs an output vector", i);
+        vec_w[op.out_vec] = std::max(vec_w[op.out_vec], op.vec_off + op.cout);
+        break;
+      default:
+        break;
+    }
+  }
+  for (int i = 0; i < JG_MAX_VECS; ++i) vec_w[i] = (vec_w[i] + 3) & ~3;  // float4-aligned rows
+  if (flops) *flops = fl;
+  return JG_OK;
+}
+
+extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const float *weights,
+                               int64_t n_weights, int32_t vocab, jg_model **out) {
+  JG_REQUIRE(e != nullptr && ops != nullptr && n_ops > 0 && weights != nullptr && n_weights > 0 &&
+                 out != nullptr,
+             JG_ERR_INVALID, "jg_model_create: bad arguments");
+  JG_HIP(hipSetDevice(e->dev));
+  jg_model *m = new jg_model();
+  m->e = e;
+  m->ops.assign(ops, ops + n_ops);
+  m->n_w = n_weights;
+  m->vocab = vocab;
+  int rc = validate_program(m);
+  if (rc != JG_OK) { delete m; return rc; }
+  hipError_t err = hipMalloc(&m->d_w, (size_t)n_weights * sizeof(float));
+  if (err != hipSuccess) {
+    jg_set_error("jg_model_create: weights hipMalloc -> %s", hipGetErrorString(err));
+    delete m;
+    return JG_ERR_NOMEM;
+  }
+  JG_HIP(hipMemcpy(m->d_w, weights, (size_t)n_weights * sizeof(float), hipMemcpyHostToDevice));
+  JG_HIP(hipMalloc(&m->d_lut, 80));
+  *out = m;
+  return JG_OK;
+}
+
+static void free_workspace(jg_model *m) {
+  for (int i = 0; i < JG_MAX_BUFS; ++i) {
+    if (m->act[i]) (void)hipFree(m->act[i]);
+    if (m->msk[i]) (void)hipFree(m->msk[i]);
+    if (m->nmd_part[i]) (void)hipFree(m->nmd_part[i]);
+    m->act[i] = nullptr; m->msk[i] = nullptr; m->nmd_part[i] = nullptr;
+  }
+  for (int i = 0; i < JG_MAX_VECS; ++i) {
+    if (m->vec[i]) (void)hipFree(m->vec[i]);
+    m->vec[i] = nullptr;
+  }
+  m->cap_chunk = 0;
+  m->cap_l = 0;
+}
+
+extern "C" int jg_model_destroy(jg_model *m) {
+  if (m == nullptr) return JG_OK;
+  (void)hipSetDevice(m->e->dev);
+  (void)hipStreamSynchronize(m->e->stream);
+  free_workspace(m);
+  if (m->d_w) (void)hipFree(m->d_w);
+  if (m->d_ids) (void)hipFree(m->d_ids);
+  if (m->d_counts) (void)hipFree(m->d_counts);
+  if (m->d_win) (void)hipFree(m->d_win);
+  if (m->d_lut) (void)hipFree(m->d_lut);
+  delete m;
+  return JG_OK;
+}
+
+static int ensure_workspace(jg_model *m, int64_t chunk, int l) {
+  if (chunk <= m->cap_chunk && l == m->cap_l) return JG_OK;
+  JG_HIP(hipStreamSynchronize(m->e->stream));
+  free_workspace(m);
+  int64_t nmd_elems[JG_MAX_BUFS];
+  int rc = plan_shapes(m, l, m->act_elems, m->msk_elems, nmd_elems, m->vec_w, nullptr);
+  if (rc != JG_OK) return rc;
+  for (int i = 0; i < JG_MAX_BUFS; ++i) {
+    m->nmd_part_elems[i] = nmd_elems[i];
+    if (m->act_elems[i] > 0)
+      JG_HIP(hipMalloc(&m->act[i], (size_t)(chunk * m->act_elems[i]) * sizeof(float)));
+    if (m->msk_elems[i] > 0) JG_HIP(hipMalloc(&m->msk[i], (size_t)(chunk * m->msk_elems[i])));
+    if (nmd_elems[i] > 0)
+      JG_HIP(hipMalloc(&m->nmd_part[i], (size_t)(chunk * nmd_elems[i]) * sizeof(float)));
+  }
+  for (int i = 0; i < JG_MAX_VECS; ++i)
+    if (m->vec_w[i] > 0) {
+      JG_HIP(hipMalloc(&m->vec[i], (size_t)(chunk * m->vec_w[i]) * sizeof(float)));
+      JG_HIP(hipMemsetAsync(m->vec[i], 0, (size_t)(chunk * m->vec_w[i]) * sizeof(float),
+                            m->e->stream));
+    }
+  m->cap_chunk = chunk;
+  m->cap_l = l;
+  return JG_OK;
+}
+
+static void resolve_stages(const jg_model *m, const jg_op &op, StageArg *dst, int *n) {
+  *n = op.n_stages;
+  for (int s = 0; s < op.n_stages; ++s) {
+    const jg_stage &st = op.stages[s];
+    StageArg &g = dst[s];
+    g.kind = st.kind;
+    g.arg = st.arg;
+    g.f0 = st.f0;
+    g.pad_ = 0;
+    auto wp = [&](int64_t off) -> const float * { return off >= 0 ? m->d_w + off : nullptr; };
+    g.p0 = wp(st.p0); g.p1 = wp(st.p1); g.p2 = wp(st.p2); g.p3 = wp(st.p3);
+    if (st.kind == JG_ST_ADD) g.p0 = m->act[st.arg];
+    if (st.kind == JG_ST_NMD) g.p0 = m->nmd_part[st.arg];
+  }
+}
+
+// Run the op program over `nw` windows whose ids (nw, 6, l) are on the device.
+static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream_t s) {
+  jg_engine *e = m->e;
+  Shape sh[JG_MAX_BUFS];
+  int mlen[JG_MAX_BUFS] = {};
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    const jg_op &op = m->ops[i];
+    int rc = JG_OK;
+    switch (op.kind) {
+      case JG_OP_CONV: {
+        Shape in;
+        if (op.in_buf == JG_BUF_IDS) { in.frames = 6; in.L = l; in.C = op.cin; }
+        else in = sh[op.in_buf];
+        int lo, pl;
+        conv_geometry(in.L, op.k, op.stride, op.dilation, op.padding, &lo, &pl);
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = op.in_buf == JG_BUF_IDS ? nullptr : m->act[op.in_buf];
+        a.ids = op.in_buf == JG_BUF_IDS ? d_ids : nullptr;
+        a.emb = op.in_buf == JG_BUF_IDS ? m->d_w + op.b_off : nullptr;
+        a.mask_from_ids = op.in_mask == JG_BUF_IDS;
+        a.mask_in = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
+        a.mask_out = op.out_mask >= 0 ? m->msk[op.out_mask] : nullptr;
+        a.w = m->d_w + op.w_off;
+        a.y = m->act[op.out_buf];
+        a.rows = nw * in.frames;
+        a.L_in = in.L; a.L_out = lo;
+        a.cin = op.cin; a.cin_pad = (op.cin + 1) & ~1;
+        a.cout = op.cout; a.cout_pad = (op.cout + 31) / 32 * 32;
+        a.k = op.k; a.stride = op.stride; a.dil = op.dilation; a.pad_left = pl;
+        a.tiles_m = (lo + 127) / 128;
+        resolve_stages(m, op, a.st, &a.n_stages);
+        ProfEvent pe;
+        if (e->profile) {
+          if ((rc = prof_event(e, &pe.a)) != JG_OK || (rc = prof_event(e, &pe.b)) != JG_OK) return rc;
+          pe.flops = 2.0 * op.k * op.cin * op.cout * (double)a.rows * lo;
+          JG_HIP(hipEventRecord(pe.a, s));
+        }
+        rc = jg_launch_conv(e, a, s);
+        if (e->profile && rc == JG_OK) {
+          JG_HIP(hipEventRecord(pe.b, s));
+          e->pending.push_back(pe);
+        }
+        sh[op.out_buf] = Shape{in.frames, lo, op.cout};
+      } break;
+      case JG_OP_MASK: {
+        const int L_in = op.in_mask == JG_BUF_IDS ? l : mlen[op.in_mask] / 6;
+        int lo, pl;
+        conv_geometry(L_in, op.k, op.stride, op.dilation, op.padding, &lo, &pl);
+        const uint8_t *src = op.in_mask == JG_BUF_IDS ? d_ids : m->msk[op.in_mask];
+        rc = jg_launch_mask(src, nw * 6, L_in, lo, op.k, op.stride, op.dilation, pl, op.mask_mode,
+                            m->msk[op.out_mask], s);
+        mlen[op.out_mask] = 6 * lo;
+      } break;
+      case JG_OP_ELTWISE: {
+        const Shape in = sh[op.in_buf];
+        EltArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = m->act[op.in_buf];
+        a.y = m->act[op.out_buf];
+        a.mask = op.out_mask >= 0 ? m->msk[op.out_mask] : nullptr;
+        a.n_pos = (int64_t)nw * in.frames * in.L;
+        a.c = in.C;
+        resolve_stages(m, op, a.st, &a.n_stages);
+        rc = jg_launch_eltwise(a, s);
+        sh[op.out_buf] = in;
+      } break;
+      case JG_OP_MAXPOOL1D: {
+        const Shape in = sh[op.in_buf];
+        const int lo = in.L / 2;
+        rc = jg_launch_maxpool1d(m->act[op.in_buf], nullptr, nw * in.frames, in.L, lo, in.C,
+                                 m->act[op.out_buf], nullptr, s);
+        sh[op.out_buf] = Shape{in.frames, lo, in.C};
+      } break;
+      case JG_OP_FRAMESUM: {
+        const Shape in = sh[op.in_buf];
+        rc = jg_launch_framesum(m->act[op.in_buf], nw, in.frames, (int64_t)in.L * in.C,
+                                m->act[op.out_buf], s);
+        sh[op.out_buf] = Shape{1, in.L, in.C};
+      } break;
+      case JG_OP_POOL: {
+        const Shape in = sh[op.in_buf];
+        const uint8_t *mk = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
+        rc = jg_launch_pool(m->act[op.in_buf], mk, nw, in.frames * in.L, in.C, op.arg,
+                            m->vec[op.out_vec] + op.vec_off, m->vec_w[op.out_vec], s);
+      } break;
+      case JG_OP_DENSE:
+        rc = jg_launch_dense(m->vec[op.in_vec], m->vec_w[op.in_vec], m->d_w + op.w_off,
+                             op.b_off >= 0 ? m->d_w + op.b_off : nullptr, nw, op.cin, op.cout,
+                             op.arg, m->vec[op.out_vec] + op.vec_off, m->vec_w[op.out_vec], s);
+        break;
+      case JG_OP_NMD_FINAL: {
+        // op.arg = partial slot, in_mask = mask the tap used, cout = channels,
+        // in_buf = activation slot whose shape gives the position count
+        const Shape in = sh[op.in_buf];
+        const int tiles = (in.L + 127) / 128;
+        const uint8_t *mk = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
+        rc = jg_launch_nmd_final(m->nmd_part[op.arg], in.frames * tiles, mk, in.frames * in.L,
+                                 m->d_w + op.b_off, op.f0, nw, op.cout, m->vec[op.out_vec],
+                                 m->vec_w[op.out_vec], op.vec_off, s);
+      } break;
+      case JG_OP_OODSIG:
+        // in_vec = logits (cin classes), op.k = nmd vector slot (width op.stride), arg = order
+        rc = jg_launch_oodsig(m->vec[op.in_vec], op.cin, m->vec[op.k], m->vec_w[op.k], nw,
+                              (unsigned)op.arg, op.f0, m->vec[op.out_vec], m->vec_w[op.out_vec],
+                              op.vec_off, s);
+        break;
+      default:
+        jg_set_error("op %zu: kind %d not implemented", i, op.kind);
+        return JG_ERR_UNSUPPORTED;
+    }
+    if (rc != JG_OK) return rc;
+  }
+  return JG_OK;
+}
+
+extern "C" int jg_model_vec_width(const jg_model *m, int which) {
+  if (m == nullptr || which < 0 || which > 3) return 0;
+  // slot convention: 0 embedding, 1 nmd, 2 prediction, 3 reliability
+  static const int slot_of[4] = {2, 3, 0, 1};
+  int64_t a[JG_MAX_BUFS], b[JG_MAX_BUFS], c[JG_MAX_BUFS];
+  int vw[JG_MAX_VECS];
+  // unpadded widths: recompute from the ops
+  int width = 0;
+  const int slot = slot_of[which];
+  for (const jg_op &op : m->ops) {
+    if (op.out_vec != slot) continue;
+    int wd = 0;
+    if (op.kind == JG_OP_DENSE || op.kind == JG_OP_NMD_FINAL)
+      wd = op.vec_off + op.cout;
+    else if (op.kind == JG_OP_POOL)
+      wd = op.vec_off + op.cout;
+    width = std::max(width, wd);
+  }
+  (void)a; (void)b; (void)c; (void)vw;
+  return width;
+}
+
+extern "C" double jg_model_flops_per_window(const jg_model *m, int32_t l) {
+  if (m == nullptr) return 0.0;
+  int64_t a[JG_MAX_BUFS], b[JG_MAX_BUFS], c[JG_MAX_BUFS];
+  int vw[JG_MAX_VECS];
+  double fl = 0.0;
+  if (plan_shapes(const_cast<jg_model *>(m), l, a, b, c, vw, &fl) != JG_OK) return 0.0;
+  return fl;
+}
+
+static int copy_out(jg_model *m, int slot, int width, float *dst, int64_t row0, int nw, int out_loc,
+                    hipStream_t s) {
+  if (dst == nullptr || width <= 0) return JG_OK;
+  JG_REQUIRE(m->vec[slot] != nullptr, JG_ERR_INVALID,
+             "output requested but the model does not produce vector slot %d", slot);
+  const hipMemcpyKind kind = out_loc == JG_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  JG_HIP(hipMemcpy2DAsync(dst + row0 * width, (size_t)width * sizeof(float), m->vec[slot],
+                          (size_t)m->vec_w[slot] * sizeof(float), (size_t)width * sizeof(float),
+                          (size_t)nw, kind, s));
+  return JG_OK;
+}
+
+static int forward_device_ids(jg_model *m, const uint8_t *d_ids, int64_t n_win, int l,
+                              float *prediction, float *reliability, float *embedding, float *nmd,
+                              int out_loc, int chunk, hipStream_t s) {
+  if (chunk <= 0) chunk = 256;
+  if (chunk > n_win) chunk = (int)std::max<int64_t>(n_win, 1);
+  JG_REQUIRE((int64_t)chunk * 6 <= 0x7fffffff / 8, JG_ERR_INVALID, "chunk too large");
+  int rc = ensure_workspace(m, chunk, l);
+  if (rc != JG_OK) return rc;
+  const int w_pred = jg_model_vec_width(m, 0), w_rel = jg_model_vec_width(m, 1);
+  const int w_emb = jg_model_vec_width(m, 2), w_nmd = jg_model_vec_width(m, 3);
+  for (int64_t w0 = 0; w0 < n_win; w0 += chunk) {
+    const int nw = (int)std::min<int64_t>(chunk, n_win - w0);
+    rc = run_chunk(m, d_ids + w0 * 6 * (int64_t)l, nw, l, s);
+    if (rc != JG_OK) return rc;
+    if ((rc = copy_out(m, 2, w_pred, prediction, w0, nw, out_loc, s)) != JG_OK) return rc;
+    if ((rc = copy_out(m, 3, w_rel, reliability, w0, nw, out_loc, s)) != JG_OK) return rc;
+    if ((rc = copy_out(m, 0, w_emb, embedding, w0, nw, out_loc, s)) != JG_OK) return rc;
+    if ((rc = copy_out(m, 1, w_nmd, nmd, w0, nw, out_loc, s)) != JG_OK) return rc;
+  }
+  return JG_OK;
+}
+
+template <typename T>
+static int grow(T **p, int64_t *cap, int64_t need_bytes) {
+  if (need_bytes <= *cap) return JG_OK;
+  if (*p) JG_HIP(hipFree(*p));
+  *p = nullptr;
+  JG_HIP(hipMalloc(reinterpret_cast<void **>(p), (size_t)need_bytes));
+  *cap = need_bytes;
+  return JG_OK;
+}
+
+extern "C" int jg_forward(jg_model *m, const uint8_t *ids, int ids_loc, int64_t n_win, int32_t l,
+                          float *prediction, float *reliability, float *embedding, float *nmd,
+                          int out_loc, int32_t chunk, void *stream) {
+  JG_REQUIRE(m != nullptr && ids != nullptr && n_win >= 0 && l > 0, JG_ERR_INVALID,
+             "jg_forward: bad arguments");
+  if (n_win == 0) return JG_OK;
+  jg_engine *e = m->e;
+  JG_HIP(hipSetDevice(e->dev));
+  hipStream_t s = pick_stream(e, stream);
+  const uint8_t *d_ids = ids;
+  if (ids_loc == JG_PTR_HOST) {
+    const int64_t bytes = n_win * 6 * (int64_t)l;
+    int rc = grow(&m->d_ids, &m->d_ids_cap, bytes);
+    if (rc != JG_OK) return rc;
+    JG_HIP(hipMemcpyAsync(m->d_ids, ids, (size_t)bytes, hipMemcpyHostToDevice, s));
+    d_ids = m->d_ids;
+  }
+  int rc = forward_device_ids(m, d_ids, n_win, l, prediction, reliability, embedding, nmd, out_loc,
+                              chunk, s);
+  if (rc != JG_OK) return rc;
+  if (out_loc == JG_PTR_HOST || ids_loc == JG_PTR_HOST) JG_HIP(hipStreamSynchronize(s));
+  return JG_OK;
+}
+
+static int frame_len(int nt) {
+  if (nt < 3) return 0;
+  const int off = (nt % 3 == 0) ? -2 : ((nt % 3 == 1) ? -1 : 0);
+  const int usable = nt - 5 + off;
+  return usable > 0 ? (usable + 2) / 3 : 0;
+}
+
+// shared by jg_encode / jg_predict_windows: stage host-side window tables and
+// run the encoder into a device id tensor
+static int encode_common(jg_engine *e, jg_model *scratch_owner, const uint8_t *bases, int64_t n_bases,
+                         int bases_loc, const int64_t *win_start, const int32_t *win_len, int win_loc,
+                         int64_t n_win, int32_t fsize, const uint8_t *lut65, int32_t flags,
+                         int32_t l_pad, uint8_t *d_ids, int32_t *d_counts, uint8_t *d_lut,
+                         std::vector<void *> &to_free, hipStream_t s) {
+  (void)scratch_owner;
+  JG_REQUIRE(fsize >= 3 && l_pad >= frame_len(fsize), JG_ERR_INVALID,
+             "encode: l_pad=%d is smaller than the %d codons a %d-nt window yields", l_pad,
+             frame_len(fsize), fsize);
+  const uint8_t *d_bases = bases;
+  if (bases_loc == JG_PTR_HOST) {
+    void *p = nullptr;
+    JG_HIP(hipMalloc(&p, (size_t)std::max<int64_t>(n_bases, 1)));
+    to_free.push_back(p);
+    JG_HIP(hipMemcpyAsync(p, bases, (size_t)n_bases, hipMemcpyHostToDevice, s));
+    d_bases = static_cast<const uint8_t *>(p);
+  }
+  const int64_t *d_start = win_start;
+  const int32_t *d_len = win_len;
+  if (win_loc == JG_PTR_HOST) {
+    // validate on the host: every window must lie inside the base buffer
+    for (int64_t i = 0; i < n_win; ++i)
+      JG_REQUIRE(win_start[i] >= 0 && win_len[i] >= 0 && win_start[i] + win_len[i] <= n_bases,
+                 JG_ERR_INVALID, "encode: window %lld [%lld, +%d) outside the %lld-byte base buffer",
+                 (long long)i, (long long)win_start[i], win_len[i], (long long)n_bases);
+    void *p = nullptr;
+    JG_HIP(hipMalloc(&p, (size_t)n_win * 12));
+    to_free.push_back(p);
+    JG_HIP(hipMemcpyAsync(p, win_start, (size_t)n_win * 8, hipMemcpyHostToDevice, s));
+    JG_HIP(hipMemcpyAsync(static_cast<char *>(p) + n_win * 8, win_len, (size_t)n_win * 4,
+                          hipMemcpyHostToDevice, s));
+    d_start = static_cast<const int64_t *>(p);
+    d_len = reinterpret_cast<const int32_t *>(static_cast<char *>(p) + n_win * 8);
+  }
+  JG_HIP(hipMemcpyAsync(d_lut, lut65, 65, hipMemcpyHostToDevice, s));
+  return jg_launch_encode(d_bases, d_start, d_len, n_win, fsize, d_lut, flags, l_pad, d_ids,
+                          d_counts, s);
+}
+
+extern "C" int jg_encode(jg_engine *e, const uint8_t *bases, int64_t n_bases, int bases_loc,
+                         const int64_t *win_start, const int32_t *win_len, int win_loc,
+                         int64_t n_win, int32_t fsize, const uint8_t *lut65, int32_t soft_mask,
+                         int32_t l_pad, uint8_t *ids, int32_t *counts, int out_loc, void *stream) {
+  JG_REQUIRE(e != nullptr && bases != nullptr && win_start != nullptr && win_len != nullptr &&
+                 lut65 != nullptr && ids != nullptr && n_win >= 0,
+             JG_ERR_INVALID, "jg_encode: bad arguments");
+  if (n_win == 0) return JG_OK;
+  JG_HIP(hipSetDevice(e->dev));
+  hipStream_t s = pick_stream(e, stream);
+  std::vector<void *> to_free;
+  uint8_t *d_ids = ids;
+  int32_t *d_counts = counts;
+  const int64_t id_bytes = n_win * 6 * (int64_t)l_pad;
+  void *d_lut = nullptr;
+  JG_HIP(hipMalloc(&d_lut, 80));
+  to_free.push_back(d_lut);
+  if (out_loc == JG_PTR_HOST) {
+    void *p = nullptr;
+    JG_HIP(hipMalloc(&p, (size_t)id_bytes));
+    to_free.push_back(p);
+    d_ids = static_cast<uint8_t *>(p);
+    if (counts != nullptr) {
+      JG_HIP(hipMalloc(&p, (size_t)n_win * 16));
+      to_free.push_back(p);
+      d_counts = static_cast<int32_t *>(p);
+    }
+  }
+  int rc = encode_common(e, nullptr, bases, n_bases, bases_loc, win_start, win_len, win_loc, n_win,
+                         fsize, lut65, soft_mask, l_pad, d_ids, d_counts,
+                         static_cast<uint8_t *>(d_lut), to_free, s);
+  if (rc == JG_OK && out_loc == JG_PTR_HOST) {
+    hipError_t err = hipMemcpyAsync(ids, d_ids, (size_t)id_bytes, hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess && counts != nullptr)
+      err = hipMemcpyAsync(counts, d_counts, (size_t)n_win * 16, hipMemcpyDeviceToHost, s);
+    if (err != hipSuccess) {
+      jg_set_error("jg_encode: D2H copy -> %s", hipGetErrorString(err));
+      rc = JG_ERR_HIP;
+    }
+  }
+  if (!to_free.empty() || out_loc == JG_PTR_HOST) (void)hipStreamSynchronize(s);
+  for (void *p : to_free) (void)hipFree(p);
+  return rc;
+}
+
+extern "C" int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_bases, int bases_loc,
+                                  const int64_t *win_start, const int32_t *win_len, int win_loc,
+                                  int64_t n_win, int32_t fsize, const uint8_t *lut65,
+                                  int32_t soft_mask, int32_t l_pad, float *prediction,
+                                  float *reliability, float *embedding, float *nmd, int32_t *counts,
+                                  int out_loc, int32_t chunk, void *stream) {
+  JG_REQUIRE(m != nullptr && bases != nullptr && win_start != nullptr && win_len != nullptr &&
+                 lut65 != nullptr && n_win >= 0,
+             JG_ERR_INVALID, "jg_predict_windows: bad arguments");
+  if (n_win == 0) return JG_OK;
+  jg_engine *e = m->e;
+  JG_HIP(hipSetDevice(e->dev));
+  hipStream_t s = pick_stream(e, stream);
+  std::vector<void *> to_free;
+  int rc = grow(&m->d_ids, &m->d_ids_cap, n_win * 6 * (int64_t)l_pad);
+  if (rc != JG_OK) return rc;
+  int32_t *d_counts = counts;
+  if (counts != nullptr && out_loc == JG_PTR_HOST) {
+    rc = grow(&m->d_counts, &m->d_counts_cap, n_win * 16);
+    if (rc != JG_OK) return rc;
+    d_counts = m->d_counts;
+  }
+  rc = encode_common(e, m, bases, n_bases, bases_loc, win_start, win_len, win_loc, n_win, fsize,
+                     lut65, soft_mask, l_pad, m->d_ids, d_counts, m->d_lut, to_free, s);
+  if (rc == JG_OK)
+    rc = forward_device_ids(m, m->d_ids, n_win, l_pad, prediction, reliability, embedding, nmd,
+                            out_loc, chunk, s);
+  if (rc == JG_OK && counts != nullptr && out_loc == JG_PTR_HOST) {
+    hipError_t err = hipMemcpyAsync(counts, d_counts, (size_t)n_win * 16, hipMemcpyDeviceToHost, s);
+    if (err != hipSuccess) {
+      jg_set_error("jg_predict_windows: counts D2H -> %s", hipGetErrorString(err));
+      rc = JG_ERR_HIP;
+    }
+  }
+  if (!to_free.empty() || out_loc == JG_PTR_HOST) (void)hipStreamSynchronize(s);
+  for (void *p : to_free) (void)hipFree(p);
+  return rc;
+}

@@ -1,0 +1,130 @@
+// Internal declarations shared by the HIP translation units of libjaeger_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "jaeger_hip.h"
+
+void jg_set_error(const char *fmt, ...);
+
+#define JG_HIP(call)                                                                 \
+  do {                                                                               \
+    hipError_t err_ = (call);                                                        \
+    if (err_ != hipSuccess) {                                                        \
+      jg_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(err_)); \
+      return JG_ERR_HIP;                                                             \
+    }                                                                                \
+  } while (0)
+
+#define JG_REQUIRE(cond, code, ...)  \
+  do {                               \
+    if (!(cond)) {                   \
+      jg_set_error(__VA_ARGS__);     \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+// ---- device-side argument blocks (passed by value as kernargs) -------------
+struct StageArg {
+  int kind;
+  int arg;
+  const float *p0, *p1, *p2, *p3;
+  float f0;
+  int pad_;
+};
+
+struct ConvArgs {
+  const float *x;          // (rows, L_in, cin) or null when ids != null
+  const uint8_t *ids;      // (rows, L_in) embedding-gather source
+  const float *emb;        // (vocab, cin)
+  const uint8_t *mask_in;  // (rows, L_in) or null
+  const uint8_t *mask_out; // (rows, L_out) or null
+  const float *w;          // (k, cin_pad, cout_pad)
+  float *y;                // (rows, L_out, cout)
+  int rows, L_in, L_out;
+  int cin, cin_pad, cout, cout_pad;
+  int k, stride, dil, pad_left;
+  int tiles_m;
+  int mask_from_ids; // conv input multiplied by (ids != 0)
+  int n_stages;
+  StageArg st[JG_MAX_STAGES];
+};
+
+struct EltArgs {
+  const float *x;
+  float *y;
+  const uint8_t *mask; // (rows*L) or null
+  int64_t n_pos;       // rows * L
+  int c;
+  int n_stages;
+  StageArg st[JG_MAX_STAGES];
+};
+
+struct ProfEvent {
+  hipEvent_t a, b;
+  double flops;
+};
+
+struct jg_engine {
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool profile = false;
+  std::vector<ProfEvent> pending; // conv launches awaiting readout
+  std::vector<hipEvent_t> pool;   // recycled events
+  double conv_ms = 0.0, conv_flops = 0.0;
+  int64_t conv_launches = 0;
+  int n_cu = 256;
+};
+
+struct jg_model {
+  jg_engine *e = nullptr;
+  std::vector<jg_op> ops;
+  float *d_w = nullptr;
+  int64_t n_w = 0;
+  int vocab = 0;
+  // workspace (grown on demand)
+  int64_t cap_chunk = 0;
+  int cap_l = 0;
+  float *act[JG_MAX_BUFS] = {};
+  int64_t act_elems[JG_MAX_BUFS] = {}; // per window
+  uint8_t *msk[JG_MAX_BUFS] = {};
+  int64_t msk_elems[JG_MAX_BUFS] = {};
+  float *vec[JG_MAX_VECS] = {};
+  int vec_w[JG_MAX_VECS] = {};
+  float *nmd_part[JG_MAX_BUFS] = {};
+  int64_t nmd_part_elems[JG_MAX_BUFS] = {};
+  uint8_t *d_ids = nullptr;
+  int64_t d_ids_cap = 0;
+  int32_t *d_counts = nullptr;
+  int64_t d_counts_cap = 0;
+  void *d_win = nullptr;
+  int64_t d_win_cap = 0;
+  uint8_t *d_lut = nullptr;
+};
+
+// ---- kernel launchers (defined in jg_kernels.hip) ---------------------------
+int jg_launch_conv(jg_engine *e, const ConvArgs &a, hipStream_t s);
+int jg_launch_mask(const uint8_t *in, int rows, int L_in, int L_out, int k, int stride, int dil,
+                   int pad_left, int mode, uint8_t *out, hipStream_t s);
+int jg_launch_pool(const float *x, const uint8_t *mask, int n_win, int positions, int c, int kind,
+                   float *out, int out_ld, hipStream_t s);
+int jg_launch_dense(const float *in, int in_ld, const float *w, const float *b, int n_win, int cin,
+                    int cout, int act, float *out, int out_ld, hipStream_t s);
+int jg_launch_nmd_final(const float *part, int parts_per_win, const uint8_t *mask, int positions,
+                        const float *moving_mean, float eps, int n_win, int c, float *out,
+                        int out_ld, int out_off, hipStream_t s);
+int jg_launch_eltwise(const EltArgs &a, hipStream_t s);
+int jg_launch_encode(const uint8_t *bases, const int64_t *win_start, const int32_t *win_len,
+                     int64_t n_win, int fsize, const uint8_t *lut, int flags, int l_pad,
+                     uint8_t *ids, int32_t *counts, hipStream_t s);
+int jg_launch_oodsig(const float *logits, int n_cls, const float *nmd, int nmd_w, int n_win,
+                     unsigned signal_bits, float eps, float *out, int out_ld, int out_off,
+                     hipStream_t s);
+int jg_launch_maxpool1d(const float *x, const uint8_t *mask_in, int rows, int L_in, int L_out, int c,
+                        float *y, uint8_t *mask_out, hipStream_t s);
+int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,
+                       hipStream_t s);
+int jg_conv_tile_m(int cout);

@@ -1,0 +1,707 @@
+// gfx950 (MI355X / CDNA4) kernels of the Jaeger predict hot path.
+//
+//   encode_kernel   window bytes -> 6-frame codon ids + G/C/A/T counts
+//                   (seqops/io.py:119-133, seqops/encode.py:228-302)
+//   mask_kernel     MaskedConv1D output-mask rule (nnlib/v2/layers.py:1226-1255)
+//   conv_f32_kernel MaskedConv1D as an implicit-im2col GEMM on the exact-f32
+//                   matrix cores (v_mfma_f32_32x32x2_f32) with the following
+//                   norm / activation / residual-add / NMD tap fused behind it
+//                   (layers.py:1217-1280, :918-938, :431-444, :1882-1915; nmd.py:52-77)
+//   pool/dense/nmd  masked global pools, Dense heads, NMD finalisation
+//                   (layers.py:455-538, builder.py:589-613, nmd.py:66-77)
+//
+// Written for 64-lane wavefronts; no other target is supported.
+#include <math.h>
+
+#include "jg_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float jg_apply_act(float v, int act) {
+  switch (act) {
+    case JG_ACT_GELU_TANH: {
+      // tf.nn.gelu(approximate=True): 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))
+      const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+      return 0.5f * v * (1.0f + tanhf(u));
+    }
+    case JG_ACT_GELU_ERF:
+      return 0.5f * v * erfcf(-v * 0.70710678118654752f);
+    case JG_ACT_RELU:
+      return fmaxf(v, 0.0f);
+    case JG_ACT_TANH:
+      return tanhf(v);
+    case JG_ACT_SIGMOID:
+      return 1.0f / (1.0f + expf(-v));
+    default:
+      return v;
+  }
+}
+
+// Apply the fused stage list to 4 consecutive channels n..n+3 of one position.
+// `o` = flat element offset of channel n in the (rows, L_out, cout) output,
+// `mk` = output mask of the position (1 when the op carries no mask).
+__device__ __forceinline__ float4 jg_apply_stages(float4 v, const StageArg *st, int n_stages, int n,
+                                                  size_t o, float mk, float4 *nmd_acc) {
+  for (int s = 0; s < n_stages; ++s) {
+    const StageArg &g = st[s];
+    switch (g.kind) {
+      case JG_ST_BIAS: {
+        const float4 b = *reinterpret_cast<const float4 *>(g.p0 + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      } break;
+      case JG_ST_BN: {
+        // MaskedBatchNorm inference (layers.py:928-935): gamma*((x-mu)*inv_std)+beta
+        const float4 mu = *reinterpret_cast<const float4 *>(g.p0 + n);
+        const float4 is = *reinterpret_cast<const float4 *>(g.p1 + n);
+        const float4 ga = *reinterpret_cast<const float4 *>(g.p2 + n);
+        const float4 be = *reinterpret_cast<const float4 *>(g.p3 + n);
+        v.x = ga.x * ((v.x - mu.x) * is.x) + be.x;
+        v.y = ga.y * ((v.y - mu.y) * is.y) + be.y;
+        v.z = ga.z * ((v.z - mu.z) * is.z) + be.z;
+        v.w = ga.w * ((v.w - mu.w) * is.w) + be.w;
+      } break;
+      case JG_ST_DYT: {
+        // MaskedDYT (layers.py:431-444): tanh(alpha*x)*gamma+beta, then *mask
+        const float4 ga = *reinterpret_cast<const float4 *>(g.p2 + n);
+        const float4 be = *reinterpret_cast<const float4 *>(g.p3 + n);
+        const float al = g.f0;
+        const float mm = g.arg ? mk : 1.0f;
+        v.x = (tanhf(al * v.x) * ga.x + be.x) * mm;
+        v.y = (tanhf(al * v.y) * ga.y + be.y) * mm;
+        v.z = (tanhf(al * v.z) * ga.z + be.z) * mm;
+        v.w = (tanhf(al * v.w) * ga.w + be.w) * mm;
+      } break;
+      case JG_ST_ADD: {
+        const float4 r = *reinterpret_cast<const float4 *>(g.p0 + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      } break;
+      case JG_ST_ACT:
+        v.x = jg_apply_act(v.x, g.arg);
+        v.y = jg_apply_act(v.y, g.arg);
+        v.z = jg_apply_act(v.z, g.arg);
+        v.w = jg_apply_act(v.w, g.arg);
+        break;
+      case JG_ST_NMD:
+        nmd_acc->x += v.x * mk; nmd_acc->y += v.y * mk;
+        nmd_acc->z += v.z * mk; nmd_acc->w += v.w * mk;
+        break;
+      case JG_ST_MASKMUL:
+        v.x *= mk; v.y *= mk; v.z *= mk; v.w *= mk;
+        break;
+      default:
+        break;
+    }
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// encoder
+// ---------------------------------------------------------------------------
+// One workgroup per window.  The window's bytes are scanned once from HBM
+// (coalesced), reduced to 2-bit codes (T,C,A,G = 0..3, anything else = 4) in
+// LDS, and every (frame, codon slot) is then a 3-code LDS read + one lookup in
+// the LDS-resident 64-entry codon table.  flags bit0: bytes are already cased
+// (lower case = soft-masked: not counted); bit1: ids are case sensitive
+// (string_processor.masking = true, encode.py:259-261).
+__global__ __launch_bounds__(256) void encode_kernel(const uint8_t *__restrict__ bases,
+                                                     const int64_t *__restrict__ win_start,
+                                                     const int32_t *__restrict__ win_len, int fsize,
+                                                     const uint8_t *__restrict__ lut, int flags,
+                                                     int l_pad, uint8_t *__restrict__ ids,
+                                                     int32_t *__restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
+  uint8_t *code = sm;                 // fsize bytes (padded to 16)
+  uint8_t *slut = sm + ((fsize + 15) & ~15);
+  int *scnt = reinterpret_cast<int *>(slut + 64);
+  const int64_t w = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t start = win_start[w];
+  int n = win_len[w];
+  n = n < fsize ? n : fsize;           // forward_strand[:crop_size], encode.py:234
+  if (tid < 64) slut[tid] = lut[tid];
+  if (tid < 4) scnt[tid] = 0;
+  __syncthreads();
+  int cg = 0, cc = 0, ca = 0, ct = 0;
+  for (int i = tid; i < n; i += 256) {
+    uint8_t ch = bases[start + i];
+    uint8_t up = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch;
+    const uint8_t cnt_ch = (flags & 1) ? ch : up;  // io.py:104 upper() unless pre-cased
+    const uint8_t id_ch = (flags & 2) ? cnt_ch : up;
+    cg += cnt_ch == 'G'; cc += cnt_ch == 'C'; ca += cnt_ch == 'A'; ct += cnt_ch == 'T';
+    uint8_t cd = 4;
+    if (id_ch == 'T') cd = 0;
+    else if (id_ch == 'C') cd = 1;
+    else if (id_ch == 'A') cd = 2;
+    else if (id_ch == 'G') cd = 3;
+    code[i] = cd;
+  }
+  // wave reduction of the counts, then one LDS atomic per wave
+  for (int off = 32; off > 0; off >>= 1) {
+    cg += __shfl_down(cg, off); cc += __shfl_down(cc, off);
+    ca += __shfl_down(ca, off); ct += __shfl_down(ct, off);
+  }
+  if ((tid & 63) == 0) {
+    atomicAdd(&scnt[0], cg); atomicAdd(&scnt[1], cc);
+    atomicAdd(&scnt[2], ca); atomicAdd(&scnt[3], ct);
+  }
+  __syncthreads();
+  if (counts != nullptr && tid < 4) counts[w * 4 + tid] = scnt[tid];
+  // frame length: ceil((n-5+off)/3), off from crop_size % 3 (encode.py:232-236, :279-284)
+  const int off3 = (fsize % 3 == 0) ? -2 : ((fsize % 3 == 1) ? -1 : 0);
+  const int usable = n - 5 + off3;
+  const int lw = usable > 0 ? (usable + 2) / 3 : 0;
+  uint8_t *out = ids + w * 6 * (int64_t)l_pad;
+  for (int idx = tid; idx < 6 * l_pad; idx += 256) {
+    const int f = idx / l_pad, i = idx - f * l_pad;
+    uint8_t v = 0;
+    if (i < lw) {
+      const int j = f >= 3 ? f - 3 : f;
+      int b0, b1, b2;
+      if (f < 3) {
+        const int p = j + 3 * i;
+        b0 = code[p]; b1 = code[p + 1]; b2 = code[p + 2];
+      } else {
+        // reverse strand: rev[q] = complement(fwd[n-1-q]); T<->A, C<->G is code^2
+        const int p = n - 1 - j - 3 * i;
+        b0 = code[p] ^ 2; b1 = code[p - 1] ^ 2; b2 = code[p - 2] ^ 2;
+      }
+      if ((b0 | b1 | b2) < 4) v = slut[16 * b0 + 4 * b1 + b2];
+    }
+    out[idx] = v;
+  }
+}
+
+int jg_launch_encode(const uint8_t *bases, const int64_t *win_start, const int32_t *win_len,
+                     int64_t n_win, int fsize, const uint8_t *lut, int flags, int l_pad,
+                     uint8_t *ids, int32_t *counts, hipStream_t s) {
+  if (n_win == 0) return JG_OK;
+  const size_t smem = ((fsize + 15) & ~15) + 64 + 16;
+  JG_REQUIRE(smem <= 160 * 1024, JG_ERR_UNSUPPORTED, "encode: fsize %d exceeds the LDS window", fsize);
+  if (smem > 48 * 1024)
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encode_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(encode_kernel, dim3((unsigned)n_win), dim3(256), smem, s, bases, win_start,
+                     win_len, fsize, lut, flags, l_pad, ids, counts);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// conv output mask
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_kernel(const uint8_t *__restrict__ in, int64_t total,
+                                                   int L_in, int L_out, int k, int stride, int dil,
+                                                   int pad_left, int mode,
+                                                   uint8_t *__restrict__ out) {
+  const int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t row = idx / L_out;
+  const int m = (int)(idx - row * L_out);
+  const uint8_t *r = in + row * L_in;
+  int cnt = 0;
+  for (int t = 0; t < k; ++t) {
+    const int p = m * stride - pad_left + t * dil;
+    if (p >= 0 && p < L_in) cnt += r[p] != 0;
+  }
+  uint8_t v;
+  if (mode == JG_MASK_ANY) v = cnt > 0;
+  else if (mode == JG_MASK_MAJORITY) v = cnt >= (k + 1) / 2;
+  else v = cnt == k;
+  out[idx] = v;
+}
+
+int jg_launch_mask(const uint8_t *in, int rows, int L_in, int L_out, int k, int stride, int dil,
+                   int pad_left, int mode, uint8_t *out, hipStream_t s) {
+  const int64_t total = (int64_t)rows * L_out;
+  if (total == 0) return JG_OK;
+  hipLaunchKernelGGL(mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, total,
+                     L_in, L_out, k, stride, dil, pad_left, mode, out);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// conv: implicit-im2col GEMM on exact-f32 MFMA
+// ---------------------------------------------------------------------------
+// One workgroup computes a BM x BN tile of one (window, frame) row:
+//   out[m, n] = sum_{t, c} x[m*stride - pad_left + t*dil, c] * w[t, c, n]
+// The (BM-1)*stride + (k-1)*dil + 1 input positions it touches are staged once
+// in LDS (mask multiply / embedding gather fused into the staging), row pitch
+// cin_pad+1 floats so the 32 rows an MFMA A-fragment reads fall in 32 banks.
+// B fragments (2 x 32 consecutive output channels per k-step) stream from
+// the weight blob, which is L2-resident (<= 460 KB per layer).
+// Accumulators go through LDS once so the epilogue runs on float4 channel
+// quads with fully coalesced stores.
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+  constexpr int LDC = BN + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid - wm * WN;
+  const int row = blockIdx.x / a.tiles_m;
+  const int tile = blockIdx.x - row * a.tiles_m;
+  const int n_blk = blockIdx.y * BN;
+  const int m0 = tile * BM;
+  const int ldr = a.cin_pad + 1;
+  const int rows_in = (BM - 1) * a.stride + (a.k - 1) * a.dil + 1;
+  const int p0 = m0 * a.stride - a.pad_left;
+
+  // ---- stage the input rows ------------------------------------------------
+  {
+    const int c4 = a.cin >> 2;
+    const int total = rows_in * c4;
+    for (int idx = tid; idx < total; idx += NT) {
+      const int r = idx / c4, cq = idx - r * c4;
+      const int p = p0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p >= 0 && p < a.L_in) {
+        const size_t pos = (size_t)row * a.L_in + p;
+        if (a.ids != nullptr) {
+          const int id = a.ids[pos];
+          if (id != 0 || !a.mask_from_ids)
+            v = *reinterpret_cast<const float4 *>(a.emb + (size_t)id * a.cin + cq * 4);
+        } else if (a.mask_in == nullptr || a.mask_in[pos] != 0) {
+          v = *reinterpret_cast<const float4 *>(a.x + pos * a.cin + cq * 4);
+        }
+      }
+      float *d = smem + r * ldr + cq * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    if (a.cin_pad != a.cin) {  // zero K padding (cin not a multiple of the k-step)
+      for (int r = tid; r < rows_in; r += NT)
+        for (int c = a.cin; c < a.cin_pad; ++c) smem[r * ldr + c] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- MFMA main loop --------------------------------------------------------
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int i = lane & 31, h = lane >> 5;
+  const float *wcol = a.w + n_blk + wn * (TN * 32) + i;
+  for (int t = 0; t < a.k; ++t) {
+    const float *arow = smem + ((wm * (TM * 32) + i) * a.stride + t * a.dil) * ldr + h;
+    const float *wt = wcol + ((size_t)t * a.cin_pad + h) * a.cout_pad;
+#pragma unroll 4
+    for (int c = 0; c < a.cin_pad; c += 2) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) av[tm] = arow[(tm * 32 * a.stride) * ldr + c];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) bv[tn] = wt[(size_t)c * a.cout_pad + tn * 32];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // every wave is done reading the input rows
+
+  // ---- accumulators -> LDS C tile ---------------------------------------------
+  // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int nl = (wn * TN + tn) * 32 + i;
+        smem[ml * LDC + nl] = acc[tm][tn][r];
+      }
+  __syncthreads();
+
+  // ---- fused epilogue on channel quads ------------------------------------------
+  constexpr int QN = BN / 4;          // channel quads per tile row
+  constexpr int RSTEP = NT / QN;      // rows advanced per iteration
+  const int q = tid % QN, r0 = tid / QN;
+  const int n = n_blk + q * 4;
+  float4 nmd_acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n < a.cout) {
+    for (int ml = r0; ml < BM; ml += RSTEP) {
+      const int m = m0 + ml;
+      if (m >= a.L_out) break;
+      const size_t pos = (size_t)row * a.L_out + m;
+      const float mk = a.mask_out != nullptr ? (a.mask_out[pos] != 0 ? 1.f : 0.f) : 1.f;
+      const size_t o = pos * a.cout + n;
+      float4 v = *reinterpret_cast<const float4 *>(smem + ml * LDC + q * 4);
+      v = jg_apply_stages(v, a.st, a.n_stages, n, o, mk, &nmd_acc);
+      *reinterpret_cast<float4 *>(a.y + o) = v;
+    }
+  }
+  // NMD tap: deterministic in-block reduction over the RSTEP row groups, one
+  // partial per (row, tile) written to the stage's partial-sum buffer.
+  bool has_nmd = false;
+  float *nmd_out = nullptr;
+  for (int s = 0; s < a.n_stages; ++s)
+    if (a.st[s].kind == JG_ST_NMD) {
+      has_nmd = true;
+      nmd_out = const_cast<float *>(a.st[s].p0);
+    }
+  if (has_nmd) {
+    __syncthreads();
+    float4 *red = reinterpret_cast<float4 *>(smem);
+    red[r0 * QN + q] = nmd_acc;
+    __syncthreads();
+    if (r0 == 0 && n < a.cout) {
+      float4 sacc = red[q];
+      for (int g = 1; g < RSTEP; ++g) {
+        const float4 t4 = red[g * QN + q];
+        sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w;
+      }
+      *reinterpret_cast<float4 *>(nmd_out + ((size_t)row * a.tiles_m + tile) * a.cout + n) = sacc;
+    }
+  }
+}
+
+int jg_conv_tile_m(int cout) {
+  (void)cout;
+  return 128;
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_conv_t(const ConvArgs &a, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const int rows_in = (BM - 1) * a.stride + (a.k - 1) * a.dil + 1;
+  size_t lds_a = (size_t)rows_in * (a.cin_pad + 1) * sizeof(float);
+  size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+  size_t smem = lds_a > lds_c ? lds_a : lds_c;
+  smem = (smem + 15) & ~(size_t)15;
+  JG_REQUIRE(smem <= 160 * 1024, JG_ERR_UNSUPPORTED,
+             "conv: k=%d cin=%d stride=%d dil=%d needs %zu B of LDS (>160 KiB)", a.k, a.cin,
+             a.stride, a.dil, smem);
+  auto kern = conv_f32_kernel<WM, WN, TM, TN>;
+  static size_t attr_set = 0;
+  if (smem > attr_set) {
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = 160 * 1024;
+  }
+  dim3 grid((unsigned)((size_t)a.rows * a.tiles_m), (unsigned)((a.cout + BN - 1) / BN));
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, a);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+int jg_launch_conv(jg_engine *e, const ConvArgs &a, hipStream_t s) {
+  (void)e;
+  JG_REQUIRE(a.cin % 4 == 0 && a.cout % 4 == 0, JG_ERR_UNSUPPORTED,
+             "conv: cin=%d / cout=%d must be multiples of 4", a.cin, a.cout);
+  if (a.rows == 0 || a.L_out <= 0) return JG_OK;
+  if (a.cout_pad % 128 == 0) return launch_conv_t<2, 2, 2, 2>(a, s);
+  if (a.cout_pad % 64 == 0) return launch_conv_t<2, 2, 2, 1>(a, s);
+  return launch_conv_t<4, 1, 1, 1>(a, s);
+}
+
+// ---------------------------------------------------------------------------
+// standalone elementwise stages (norm / activation not preceded by a conv)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eltwise_kernel(EltArgs a) {
+  const int cq = a.c >> 2;
+  const int64_t total = a.n_pos * cq;
+  float4 dummy = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int64_t pos = idx / cq;
+    const int n = (int)(idx - pos * cq) * 4;
+    const float mk = a.mask != nullptr ? (a.mask[pos] != 0 ? 1.f : 0.f) : 1.f;
+    const size_t o = (size_t)pos * a.c + n;
+    float4 v = *reinterpret_cast<const float4 *>(a.x + o);
+    v = jg_apply_stages(v, a.st, a.n_stages, n, o, mk, &dummy);
+    *reinterpret_cast<float4 *>(a.y + o) = v;
+  }
+}
+
+int jg_launch_eltwise(const EltArgs &a, hipStream_t s) {
+  JG_REQUIRE(a.c % 4 == 0, JG_ERR_UNSUPPORTED, "eltwise: c=%d must be a multiple of 4", a.c);
+  const int64_t total = a.n_pos * (a.c >> 2);
+  if (total == 0) return JG_OK;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(eltwise_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// masked global pooling over (frames, length): one workgroup per window
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ x,
+                                                   const uint8_t *__restrict__ mask, int positions,
+                                                   int c, int kind, float *__restrict__ out,
+                                                   int out_ld) {
+  __shared__ float4 red[256];
+  __shared__ float redc[256];
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const int cq = c >> 2;
+  const int groups = 256 / cq;
+  const int q = tid % cq, g = tid / cq;
+  const bool is_max = kind != JG_POOL_AVG;
+  float4 acc = is_max ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+  float cnt = 0.f;
+  if (g < groups) {
+    const float *xb = x + (size_t)w * positions * c + q * 4;
+    const uint8_t *mb = mask != nullptr ? mask + (size_t)w * positions : nullptr;
+    for (int p = g; p < positions; p += groups) {
+      const bool keep = mb == nullptr || mb[p] != 0;
+      if (!keep) continue;
+      const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)p * c);
+      cnt += 1.f;
+      if (is_max) {
+        acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y);
+        acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w);
+      } else {
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+  }
+  red[tid] = acc;
+  redc[tid] = cnt;
+  __syncthreads();
+  if (g == 0) {
+    for (int gg = 1; gg < groups; ++gg) {
+      const float4 t = red[gg * cq + q];
+      cnt += redc[gg * cq + q];
+      if (is_max) {
+        acc.x = fmaxf(acc.x, t.x); acc.y = fmaxf(acc.y, t.y);
+        acc.z = fmaxf(acc.z, t.z); acc.w = fmaxf(acc.w, t.w);
+      } else {
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      }
+    }
+    float4 r;
+    if (is_max) {
+      // layers.py:517-529: masked positions lose to the -1e9 sentinel; a window
+      // with no valid position pools to zeros.  Without a mask: plain max.
+      if (mask == nullptr) {
+        r = acc;
+      } else if (cnt <= 0.f) {
+        r = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (cnt < (float)positions) {
+        r = make_float4(fmaxf(acc.x, -1.0e9f), fmaxf(acc.y, -1.0e9f), fmaxf(acc.z, -1.0e9f),
+                        fmaxf(acc.w, -1.0e9f));
+      } else {
+        r = acc;
+      }
+    } else {
+      // layers.py:460-480: sum(x*m) / max(sum(m), 1e-7); plain mean without a mask
+      const float d = mask != nullptr ? fmaxf(cnt, 1e-7f) : (float)positions;
+      r = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
+    }
+    *reinterpret_cast<float4 *>(out + (size_t)w * out_ld + q * 4) = r;
+  }
+}
+
+int jg_launch_pool(const float *x, const uint8_t *mask, int n_win, int positions, int c, int kind,
+                   float *out, int out_ld, hipStream_t s) {
+  JG_REQUIRE(c % 4 == 0 && c / 4 <= 256, JG_ERR_UNSUPPORTED, "pool: c=%d unsupported", c);
+  JG_REQUIRE(out_ld % 4 == 0, JG_ERR_UNSUPPORTED, "pool: out_ld=%d must be a multiple of 4", out_ld);
+  if (n_win == 0) return JG_OK;
+  hipLaunchKernelGGL(pool_kernel, dim3((unsigned)n_win), dim3(256), 0, s, x, mask, positions, c,
+                     kind, out, out_ld);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Dense head layer: out[w, o] = act(sum_i in[w, i] * W[i, o] + b[o])
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ in, int in_ld,
+                                                    const float *__restrict__ w,
+                                                    const float *__restrict__ b, int64_t total,
+                                                    int cin, int cout, int act,
+                                                    float *__restrict__ out, int out_ld) {
+  const int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t win = idx / cout;
+  const int o = (int)(idx - win * cout);
+  const float *xi = in + win * in_ld;
+  float acc = 0.f;
+  for (int i = 0; i < cin; ++i) acc = fmaf(xi[i], w[(size_t)i * cout + o], acc);
+  if (b != nullptr) acc += b[o];
+  out[win * out_ld + o] = jg_apply_act(acc, act);
+}
+
+int jg_launch_dense(const float *in, int in_ld, const float *w, const float *b, int n_win, int cin,
+                    int cout, int act, float *out, int out_ld, hipStream_t s) {
+  const int64_t total = (int64_t)n_win * cout;
+  if (total == 0) return JG_OK;
+  hipLaunchKernelGGL(dense_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, in_ld,
+                     w, b, total, cin, cout, act, out, out_ld);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// NMD finalisation: sum partials, divide by (sum(mask)+eps), subtract moving mean
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nmd_final_kernel(const float *__restrict__ part,
+                                                        int parts_per_win,
+                                                        const uint8_t *__restrict__ mask,
+                                                        int positions,
+                                                        const float *__restrict__ moving_mean,
+                                                        float eps, int c, float *__restrict__ out,
+                                                        int out_ld, int out_off) {
+  __shared__ float scount[256];
+  const int w = blockIdx.x, tid = threadIdx.x;
+  float cnt = 0.f;
+  if (mask != nullptr) {
+    const uint8_t *mb = mask + (size_t)w * positions;
+    for (int p = tid; p < positions; p += 256) cnt += mb[p] != 0 ? 1.f : 0.f;
+  }
+  scount[tid] = cnt;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) scount[tid] += scount[tid + st];
+    __syncthreads();
+  }
+  // nmd.py:60-69: masked -> sum/(count+eps); unmasked -> reduce_mean
+  const float denom = mask != nullptr ? scount[0] + eps : (float)positions;
+  for (int ch = tid; ch < c; ch += 256) {
+    const float *pb = part + (size_t)w * parts_per_win * c + ch;
+    float sacc = 0.f;
+    for (int j = 0; j < parts_per_win; ++j) sacc += pb[(size_t)j * c];
+    out[(size_t)w * out_ld + out_off + ch] = sacc / denom - moving_mean[ch];
+  }
+}
+
+int jg_launch_nmd_final(const float *part, int parts_per_win, const uint8_t *mask, int positions,
+                        const float *moving_mean, float eps, int n_win, int c, float *out,
+                        int out_ld, int out_off, hipStream_t s) {
+  if (n_win == 0) return JG_OK;
+  hipLaunchKernelGGL(nmd_final_kernel, dim3((unsigned)n_win), dim3(256), 0, s, part, parts_per_win,
+                     mask, positions, moving_mean, eps, c, out, out_ld, out_off);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// OODSignalLayer (layers.py:1632-1667): one thread per window
+// bits: 1 max_prob, 2 entropy, 4 energy, 8 margin, 16 nmd_norm (emitted in the
+// order of the model's `signals` list, which the host encodes in `order`).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void oodsig_kernel(const float *__restrict__ logits, int n_cls,
+                                                     const float *__restrict__ nmd, int nmd_w,
+                                                     int n_win, unsigned order, float eps,
+                                                     float *__restrict__ out, int out_ld,
+                                                     int out_off) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_win) return;
+  const float *lg = logits + (size_t)w * n_cls;
+  float mx = -INFINITY;
+  for (int i = 0; i < n_cls; ++i) mx = fmaxf(mx, lg[i]);
+  float se = 0.f;
+  for (int i = 0; i < n_cls; ++i) se += expf(lg[i] - mx);
+  float p1 = 0.f, p2 = 0.f, ent = 0.f;
+  for (int i = 0; i < n_cls; ++i) {
+    const float p = expf(lg[i] - mx) / se;
+    if (p > p1) { p2 = p1; p1 = p; } else if (p > p2) p2 = p;
+    const float sp = fmaxf(p, eps);
+    ent -= sp * logf(sp);
+  }
+  int col = 0;
+  for (int sidx = 0; sidx < 5; ++sidx) {
+    const unsigned code = (order >> (4 * sidx)) & 0xF;
+    if (code == 0) break;
+    float v = 0.f;
+    if (code == 1) v = p1;
+    else if (code == 2) v = ent;
+    else if (code == 3) v = mx + logf(se);
+    else if (code == 4) v = p1 - p2;
+    else if (code == 5) {
+      float ss = 0.f;
+      for (int i = 0; i < nmd_w; ++i) { const float t = nmd[(size_t)w * nmd_w + i]; ss += t * t; }
+      v = sqrtf(ss);
+    }
+    out[(size_t)w * out_ld + out_off + col] = v;
+    ++col;
+  }
+}
+
+int jg_launch_oodsig(const float *logits, int n_cls, const float *nmd, int nmd_w, int n_win,
+                     unsigned signal_bits, float eps, float *out, int out_ld, int out_off,
+                     hipStream_t s) {
+  if (n_win == 0) return JG_OK;
+  hipLaunchKernelGGL(oodsig_kernel, dim3((unsigned)((n_win + 255) / 256)), dim3(256), 0, s, logits,
+                     n_cls, nmd, nmd_w, n_win, signal_bits, eps, out, out_ld, out_off);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// legacy tower helpers: MaxPooling1D(pool 2, stride 2, VALID) and the frame sum
+// (nnlib/v1/layers.py:154-207, :399-423)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool1d_kernel(const float *__restrict__ x, int64_t total,
+                                                        int L_in, int L_out, int c,
+                                                        float *__restrict__ y) {
+  const int cq = c >> 2;
+  for (int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int q = (int)(idx % cq);
+    const int64_t pos = idx / cq;
+    const int64_t row = pos / L_out;
+    const int m = (int)(pos - row * L_out);
+    const float *s0 = x + ((size_t)(row * L_in + 2 * m)) * c + q * 4;
+    const float4 a = *reinterpret_cast<const float4 *>(s0);
+    const float4 b = *reinterpret_cast<const float4 *>(s0 + c);
+    *reinterpret_cast<float4 *>(y + (size_t)pos * c + q * 4) =
+        make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+  }
+}
+
+int jg_launch_maxpool1d(const float *x, const uint8_t *mask_in, int rows, int L_in, int L_out, int c,
+                        float *y, uint8_t *mask_out, hipStream_t s) {
+  (void)mask_in; (void)mask_out;
+  JG_REQUIRE(c % 4 == 0, JG_ERR_UNSUPPORTED, "maxpool1d: c=%d must be a multiple of 4", c);
+  const int64_t total = (int64_t)rows * L_out * (c >> 2);
+  if (total == 0) return JG_OK;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(maxpool1d_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, total, L_in, L_out,
+                     c, y);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+__global__ __launch_bounds__(256) void framesum_kernel(const float *__restrict__ x, int64_t total4,
+                                                       int frames, int64_t per_frame4,
+                                                       float *__restrict__ y) {
+  for (int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x; idx < total4;
+       idx += (int64_t)gridDim.x * 256) {
+    const int64_t w = idx / per_frame4, r = idx - w * per_frame4;
+    const float4 *src = reinterpret_cast<const float4 *>(x) + w * frames * per_frame4 + r;
+    float4 acc = src[0];
+    for (int f = 1; f < frames; ++f) {
+      const float4 t = src[(size_t)f * per_frame4];
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    reinterpret_cast<float4 *>(y)[idx] = acc;
+  }
+}
+
+int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,
+                       hipStream_t s) {
+  JG_REQUIRE(per_frame % 4 == 0, JG_ERR_UNSUPPORTED, "framesum: L*C must be a multiple of 4");
+  const int64_t total4 = (int64_t)n_win * (per_frame / 4);
+  if (total4 == 0) return JG_OK;
+  int64_t blocks = (total4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(framesum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, total4, frames,
+                     per_frame / 4, y);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}

@@ -1,0 +1,283 @@
+"""Python face of the MI355X engine: the reference's inference-engine duck type.
+
+``JaegerHipEngine`` provides what ``commands/predict.py:745-841`` expects of an
+engine (``InferModel``, ``nnlib/inference.py:300-483``): ``class_map``,
+``string_processor_config`` and ``predict(dataset) -> dict[str, np.ndarray]``
+- plus the fused entry points that move the fragmenter's per-window work and
+the encoder onto the GPU (``predict_windows``).  All compute goes through the
+C-ABI in ``include/jaeger_hip.h``; there is no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from collections import defaultdict
+from pathlib import Path
+from typing import Any, Iterable
+
+import numpy as np
+import yaml
+
+from . import _lib as L
+from .plan import ModelPlan, build_plan
+from .program import Program, compile_plan
+
+
+def frame_length(nucleotides: int) -> int:
+    """Codons per frame of a ``nucleotides``-long crop (seqops/crop.py:44-61)."""
+    nt = int(nucleotides)
+    if nt < 3:
+        return 0
+    usable = nt - 5 + (-2, -1, 0)[nt % 3]
+    return 0 if usable <= 0 else -(-usable // 3)
+
+
+def codon_lut(codon_id: list[int]) -> np.ndarray:
+    """65-byte table for ``jg_encode``: 16*b0+4*b1+b2 over TCAG=0..3 -> codon_id+1."""
+    from .maps import CODONS
+    index = {c: i for i, c in enumerate(CODONS)}
+    lut = np.zeros(65, np.uint8)
+    alpha = "TCAG"
+    for i0, a in enumerate(alpha):
+        for i1, b in enumerate(alpha):
+            for i2, c in enumerate(alpha):
+                lut[16 * i0 + 4 * i1 + i2] = codon_id[index[a + b + c]] + 1
+    return lut
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class HipDevice:
+    """One ``jg_engine`` (one GPU, one HIP stream)."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = L.load()
+        self.handle = C.c_void_p()
+        L.check(self.lib.jg_engine_create(int(device_id), C.byref(self.handle)), "jg_engine_create")
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.jg_engine_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def sync(self):
+        L.check(self.lib.jg_engine_sync(self.handle), "jg_engine_sync")
+
+    # raw device memory -------------------------------------------------------
+    def alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        L.check(self.lib.jg_dev_alloc(self.handle, int(nbytes), C.byref(p)), "jg_dev_alloc")
+        return p.value or 0
+
+    def free(self, ptr: int):
+        if ptr:
+            L.check(self.lib.jg_dev_free(self.handle, C.c_void_p(ptr)), "jg_dev_free")
+
+    def upload(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(max(arr.nbytes, 1))
+        L.check(self.lib.jg_memcpy_h2d(self.handle, C.c_void_p(p), _ptr(arr), arr.nbytes), "jg_memcpy_h2d")
+        return p
+
+    def download(self, ptr: int, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        L.check(self.lib.jg_memcpy_d2h(self.handle, _ptr(out), C.c_void_p(ptr), out.nbytes), "jg_memcpy_d2h")
+        return out
+
+    # timing --------------------------------------------------------------------
+    def timer_start(self):
+        L.check(self.lib.jg_timer_start(self.handle, None))
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_float()
+        L.check(self.lib.jg_timer_stop_ms(self.handle, None, C.byref(ms)))
+        return float(ms.value)
+
+    def profile_enable(self, on: bool = True):
+        L.check(self.lib.jg_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_read(self) -> dict:
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        L.check(self.lib.jg_profile_read(self.handle, C.byref(ms), C.byref(n), C.byref(fl)))
+        return {"conv_ms": ms.value, "conv_launches": n.value, "conv_flops": fl.value}
+
+    def encode(self, bases: np.ndarray, win_start: np.ndarray, win_len: np.ndarray, fsize: int,
+               lut: np.ndarray, flags: int = 0, l_pad: int | None = None):
+        """``jg_encode`` with host buffers -> (ids (W,6,l_pad) u8, counts (W,4) i32)."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        ws = np.ascontiguousarray(win_start, np.int64)
+        wl = np.ascontiguousarray(win_len, np.int32)
+        n = ws.size
+        l_pad = frame_length(fsize) if l_pad is None else int(l_pad)
+        ids = np.zeros((n, 6, l_pad), np.uint8)
+        counts = np.zeros((n, 4), np.int32)
+        lut = np.ascontiguousarray(lut, np.uint8)
+        L.check(self.lib.jg_encode(self.handle, _ptr(bases), bases.size, L.JG_PTR_HOST, _ptr(ws), _ptr(wl),
+                                   L.JG_PTR_HOST, n, int(fsize), _ptr(lut), int(flags), l_pad,
+                                   _ptr(ids), _ptr(counts), L.JG_PTR_HOST, None), "jg_encode")
+        return ids, counts
+
+
+class HipModel:
+    """A compiled :class:`Program` resident on one :class:`HipDevice`."""
+
+    def __init__(self, device: HipDevice, program: Program):
+        self.dev, self.program, self.lib = device, program, device.lib
+        self.handle = C.c_void_p()
+        ops = program.op_array()
+        blob = np.ascontiguousarray(program.blob, np.float32)
+        L.check(self.lib.jg_model_create(device.handle, ops, len(program.ops), _ptr(blob), blob.size,
+                                         program.vocab, C.byref(self.handle)), "jg_model_create")
+        self.widths = {name: self.lib.jg_model_vec_width(self.handle, i)
+                       for i, name in enumerate(("prediction", "reliability", "embedding", "nmd"))}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.jg_model_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def flops_per_window(self, l: int) -> float:
+        return float(self.lib.jg_model_flops_per_window(self.handle, int(l)))
+
+    def _host_outputs(self, n: int, want: Iterable[str]):
+        outs = {}
+        for name in ("prediction", "reliability", "embedding", "nmd"):
+            w = self.widths[name]
+            outs[name] = np.zeros((n, w), np.float32) if (w > 0 and name in want) else None
+        return outs
+
+    def forward(self, ids: np.ndarray, chunk: int = 0,
+                want=("prediction", "reliability", "embedding", "nmd")) -> dict[str, np.ndarray]:
+        """ids (W, 6, L) u8 on the host -> dict of host arrays (``jg_forward``)."""
+        ids = np.ascontiguousarray(ids, np.uint8)
+        n, six, l = ids.shape
+        assert six == 6
+        o = self._host_outputs(n, want)
+        L.check(self.lib.jg_forward(self.handle, _ptr(ids), L.JG_PTR_HOST, n, l, _ptr(o["prediction"]),
+                                    _ptr(o["reliability"]), _ptr(o["embedding"]), _ptr(o["nmd"]),
+                                    L.JG_PTR_HOST, int(chunk), None), "jg_forward")
+        return {k: v for k, v in o.items() if v is not None}
+
+    def predict_windows(self, bases, n_bases: int, win_start, win_len, n_win: int, fsize: int, lut,
+                        flags: int = 0, l_pad: int | None = None, chunk: int = 0, device_inputs=False,
+                        want=("prediction", "reliability", "embedding", "nmd"), counts=True):
+        """``jg_predict_windows``.  With ``device_inputs`` the base / window buffers
+        are raw device pointers (ints); outputs always land in host arrays."""
+        l_pad = frame_length(fsize) if l_pad is None else int(l_pad)
+        o = self._host_outputs(n_win, want)
+        cnt = np.zeros((n_win, 4), np.int32) if counts else None
+        loc = L.JG_PTR_DEVICE if device_inputs else L.JG_PTR_HOST
+        lut = np.ascontiguousarray(lut, np.uint8)
+        L.check(self.lib.jg_predict_windows(
+            self.handle, _ptr(bases), int(n_bases), loc, _ptr(win_start), _ptr(win_len), loc, int(n_win),
+            int(fsize), _ptr(lut), int(flags), l_pad, _ptr(o["prediction"]), _ptr(o["reliability"]),
+            _ptr(o["embedding"]), _ptr(o["nmd"]), _ptr(cnt), L.JG_PTR_HOST, int(chunk), None),
+            "jg_predict_windows")
+        res = {k: v for k, v in o.items() if v is not None}
+        if cnt is not None:
+            res["counts"] = cnt
+        return res
+
+
+class JaegerHipEngine:
+    """Drop-in for ``InferModel`` (nnlib/inference.py:300-483) on one MI355X.
+
+    ``path_dict`` keys as produced by ``AvailableModels`` (utils/misc.py:346-392):
+    ``classes`` (yaml), ``project`` (yaml), ``weights`` (h5) and ``graph`` (dir;
+    only used for weight recovery when no ``weights`` file is present).
+    Alternatively pass ``model_cfg`` + ``weights`` (canonical-name dict) directly.
+    """
+
+    def __init__(self, path_dict: dict | None = None, *, model_cfg: dict | None = None,
+                 weights: dict[str, np.ndarray] | None = None, device_id: int = 0,
+                 use_xla: bool = False, return_embedding: bool = False, chunk: int = 0):
+        self.use_xla = use_xla                      # accepted for signature parity; no-op
+        self.return_embedding = return_embedding
+        self.chunk = chunk
+        self.class_map = None
+        if path_dict is not None:
+            self.class_map = self._load_class_map(path_dict.get("classes"))
+            project = path_dict.get("project")
+            if project is None:
+                raise ValueError("JaegerHipEngine needs the model's *_project.yaml (layer plan source)")
+            cfg = yaml.safe_load(Path(project).read_text()) or {}
+            model_cfg = cfg.get("model")
+            if weights is None:
+                from .weights import load_weights
+                weights = load_weights(path_dict, build_plan(model_cfg))
+        if model_cfg is None or weights is None:
+            raise ValueError("JaegerHipEngine: provide path_dict or model_cfg + weights")
+        self.plan: ModelPlan = build_plan(model_cfg)
+        sp = self.plan.string_processor
+        if sp.get("shuffle") or sp.get("mutate"):
+            # commands/predict.py:229-231 forwards these into the inference encoder,
+            # which makes the reference's own output random; parity is undefined.
+            import warnings
+            warnings.warn("project.yaml sets string_processor.shuffle/mutate: the reference would "
+                          "randomise the windows at inference; jaeger_amd runs deterministically "
+                          "with both disabled", stacklevel=2)
+        self.string_processor_config = sp
+        if self.class_map is None and self.plan.class_label_map:
+            cm = self.plan.class_label_map
+            self.class_map = {"num_classes": len(cm), "class": [i["class"] for i in cm],
+                              "index": [i["label"] for i in cm]}
+        self.program = compile_plan(self.plan, weights)
+        self.device = HipDevice(device_id)
+        self.model = HipModel(self.device, self.program)
+        if return_embedding and self.model.widths["embedding"] == 0:
+            raise ValueError("The selected model does not expose an 'embedding' output.")
+        self.lut = codon_lut(sp["codon_id"])
+        self.encode_flags = 2 if sp.get("masking") else 0
+
+    @staticmethod
+    def _load_class_map(path):
+        """inference.py:411-421."""
+        if path is None:
+            return None
+        with open(path) as f:
+            cm = yaml.safe_load(f)["classes"]
+        return {"num_classes": len(cm), "class": [i["class"] for i in cm], "index": [i["label"] for i in cm]}
+
+    # -- InferModel.predict -----------------------------------------------------
+    def predict(self, dataset, no_progress: bool = False) -> dict[str, np.ndarray]:
+        """``dataset`` yields ``(inputs_dict, meta0..meta9)`` batches like the reference's
+        tf.data pipeline (inference.py:341-373); ``inputs_dict["translated"]`` is the
+        (B, 6, L) id tensor (float or int, 0 = invalid)."""
+        acc: dict[str, list] = defaultdict(list)
+        key = self.string_processor_config.get("input_type", "translated")
+        for inputs, *meta in dataset:
+            ids = np.asarray(inputs.get(key))
+            if ids.ndim != 3:
+                raise ValueError("JaegerHipEngine.predict expects (B, 6, L) id tensors (seq_onehot=False)")
+            out = self.model.forward(ids.astype(np.uint8), chunk=self.chunk)
+            for k, v in out.items():
+                acc[k].append(v)
+            for idx, m in enumerate(meta):
+                acc[f"meta_{idx}"].append(np.asarray(m))
+        return {k: np.concatenate(v, axis=0) for k, v in acc.items()}
+
+    # -- fused path ---------------------------------------------------------------
+    def predict_windows(self, bases: np.ndarray, win_start: np.ndarray, win_len: np.ndarray, fsize: int,
+                        l_pad: int | None = None, pre_cased: bool = False) -> dict[str, np.ndarray]:
+        """Encode + forward for windows given as (start, length) into ``bases``."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        ws = np.ascontiguousarray(win_start, np.int64)
+        wl = np.ascontiguousarray(win_len, np.int32)
+        flags = self.encode_flags | (1 if pre_cased else 0)
+        return self.model.predict_windows(bases, bases.size, ws, wl, ws.size, fsize, self.lut, flags,
+                                          l_pad, self.chunk)
+
+    def close(self):
+        self.model.close()
+        self.device.close()

@@ -1,0 +1,329 @@
+"""``*_project.yaml`` -> explicit layer plan.
+
+The reference turns the ``model:`` section of a project YAML into a Keras graph
+in ``nnlib/builder.py`` (``build_fragment_classifier`` :442-838,
+``_build_embedding`` :844-894, ``_build_block`` :982-1193, ``_get_pooler``
+:1697-1714).  This module resolves the same section into a flat, fully
+defaulted plan (every default below cites the constructor it comes from) that
+``program.py`` compiles for the MI355X engine.  Layers outside the conv family
+(attention, LSTM, Hyena, gated pooling ...) raise :class:`UnsupportedLayer`.
+
+Canonical weight names (shared with the loaders in ``weights.py``):
+``embedding/embeddings``; ``rep/<i>/{kernel,bias,gamma,beta,moving_mean,
+moving_variance,alpha}`` for the i-th ``hidden_layers`` entry;
+``rep/<i>/block<j>/{conv1,conv2,conv3,bn1,bn2,bn3}/<var>`` inside a
+``residual_block``; ``classifier/<i>/...`` and ``reliability/<i>/...`` for the heads.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Any
+
+from . import maps
+
+_ACT_ALIASES = ("relu", "gelu", "sigmoid", "softmax", "tanh")
+_NORMS = ("masked_batchnorm", "masked_dyt", "masked_layernorm")
+_DEFAULT_SIGNALS = ["max_prob", "entropy", "energy", "margin", "nmd_norm"]
+
+
+class UnsupportedLayer(ValueError):
+    """A layer / option of the project YAML that the MI355X engine does not implement."""
+
+
+@dataclass
+class Conv:
+    name: str                      # weight prefix
+    kernel_size: int
+    cin: int
+    filters: int
+    strides: int = 1               # layers.py:1154
+    padding: str = "valid"         # layers.py:1156 (MaskedConv1D default!)
+    dilation_rate: int = 1         # layers.py:1157
+    use_bias: bool = True          # layers.py:1159
+    activation: str | None = None  # layers.py:1158
+    use_masking: bool = True       # layers.py:1163
+    mask_mode: str = "any"         # layers.py:1164
+
+
+@dataclass
+class Norm:
+    name: str
+    kind: str                      # masked_batchnorm | masked_dyt | masked_layernorm
+    channels: int
+    epsilon: float = 1e-5          # MaskedBatchNorm layers.py:804; LN 1e-3 layers.py:306
+    use_masking: bool = True
+
+
+@dataclass
+class Act:
+    kind: str
+
+
+@dataclass
+class Nmd:
+    name: str
+    channels: int
+    epsilon: float = 1e-5          # nmd.py:19
+
+
+@dataclass
+class ResBlock:
+    """One ResidualBlock (layers.py:1774-1915)."""
+    name: str
+    conv1: Conv
+    bn1: Norm
+    conv2: Conv
+    bn2: Norm
+    conv3: Conv | None
+    bn3: Norm | None
+    activation: str = "gelu"       # layers.py:1781
+    use_masking: bool = True
+
+
+@dataclass
+class Dense:
+    name: str
+    cin: int
+    units: int
+    use_bias: bool = True
+    activation: str | None = None
+
+
+@dataclass
+class ModelPlan:
+    vocab: int
+    embedding_dim: int
+    rep: list[Any]
+    pooling: str                   # "max" | "average"
+    rep_channels: int
+    classifier: list[Any]
+    n_classes: int
+    nmd_dims: list[int] = field(default_factory=list)
+    reliability: list[Any] | None = None
+    reliability_mode: str = "nmd"
+    reliability_signals: list[str] = field(default_factory=list)
+    use_masking: bool = True
+    string_processor: dict = field(default_factory=dict)
+    class_label_map: list[dict] = field(default_factory=list)
+
+    @property
+    def nmd_dim(self) -> int:
+        return sum(self.nmd_dims)
+
+
+def _norm(name: str, kind: str, channels: int, cfg: dict, use_masking: bool) -> Norm:
+    if cfg.get("return_nmd"):
+        raise UnsupportedLayer(f"{name}: return_nmd=True norms are not supported; use an 'nmd' layer")
+    eps = {"masked_batchnorm": 1e-5, "masked_layernorm": 1e-3, "masked_dyt": 0.0}[kind]
+    return Norm(name, kind, channels, float(cfg.get("epsilon", eps)), use_masking)
+
+
+def _block(layers: list[dict], prefix: str, cin: int, use_masking_default: bool,
+           nmd_dims: list[int] | None):
+    """builder.py:982-1158: walk one ``hidden_layers`` list."""
+    out: list[Any] = []
+    for i, layer in enumerate(layers):
+        name = str(layer.get("name", "")).lower()
+        cfg = dict(layer.get("config", {}) or {})
+        p = f"{prefix}/{i}"
+        if name == "masked_conv1d":
+            um = bool(cfg.get("use_masking", use_masking_default))   # builder.py:1019-1020
+            mode = cfg.get("mask_mode", "any")
+            if mode not in ("any", "majority", "strict"):
+                raise ValueError(f"{p}: invalid mask_mode {mode!r}")
+            out.append(Conv(p, int(cfg["kernel_size"]), cin, int(cfg["filters"]),
+                            int(cfg.get("strides", 1)), str(cfg.get("padding", "valid")).lower(),
+                            int(cfg.get("dilation_rate", 1)), bool(cfg.get("use_bias", True)),
+                            cfg.get("activation"), um, mode))
+            cin = int(cfg["filters"])
+        elif name in _NORMS:
+            um = bool(cfg.get("use_masking", use_masking_default)) if name == "masked_batchnorm" else True
+            out.append(_norm(p, name, cin, cfg, um))
+        elif name == "nmd":
+            if nmd_dims is None:
+                raise UnsupportedLayer(f"{p}: nmd layer outside the representation learner")
+            out.append(Nmd(p, cin, float(cfg.get("epsilon", 1e-5))))
+            nmd_dims.append(cin)
+        elif name == "activation" or name in _ACT_ALIASES:
+            kind = name if name in _ACT_ALIASES else cfg.get("activation")   # builder.py:1022-1023
+            out.append(Act(str(kind).lower()))
+        elif name == "residual_block":
+            if cfg.get("return_nmd"):
+                raise UnsupportedLayer(f"{p}: return_nmd residual blocks are not supported")
+            um = bool(cfg.get("use_masking", use_masking_default))
+            filters = int(cfg["filters"])
+            k = int(cfg.get("kernel_size", 3))                 # layers.py:1788
+            stride = int(cfg.get("strides", 1))
+            pad = str(cfg.get("padding", "same")).lower()      # layers.py:1790
+            dil = int(cfg.get("dilation_rate", 1))
+            bias = bool(cfg.get("use_bias", True))
+            nt = str(cfg.get("norm_type", "masked_batchnorm")).lower()
+            if nt not in _NORMS:
+                raise UnsupportedLayer(f"{p}: norm_type {nt!r}")
+            act = cfg.get("activation", "gelu")
+            for j in range(int(cfg.get("block_size", 1))):
+                bp = f"{p}/block{j}"
+                # use_1x1conv only reaches the first block (layers.py:2677-2679)
+                bypass = (bool(cfg.get("use_1x1conv", False)) and j == 0) or stride > 1
+                c1 = Conv(f"{bp}/conv1", k, cin, filters, stride, pad, dil, bias, None, um, "any")
+                c2 = Conv(f"{bp}/conv2", k, filters, filters, 1, pad, dil, bias, None, um, "any")
+                c3 = b3 = None
+                if bypass:
+                    c3 = Conv(f"{bp}/conv3", 1, cin, filters, stride, pad, dil, bias, None, um, "any")
+                    b3 = _norm(f"{bp}/bn3", nt, filters, {}, um)
+                out.append(ResBlock(bp, c1, _norm(f"{bp}/bn1", nt, filters, {}, um), c2,
+                                    _norm(f"{bp}/bn2", nt, filters, {}, um), c3, b3, act, um))
+                cin = filters
+        elif name == "dense":
+            out.append(Dense(p, cin, int(cfg["units"]), bool(cfg.get("use_bias", True)),
+                             cfg.get("activation")))
+            cin = int(cfg["units"])
+        elif name == "dropout":
+            continue                                            # identity at inference
+        else:
+            raise UnsupportedLayer(
+                f"{p}: layer {name!r} is outside the Conv1D -> norm -> pool -> dense family "
+                "the MI355X engine implements")
+    return out, cin
+
+
+def resolve_string_processor(model_cfg: dict) -> dict:
+    """``InferModel._load_string_processor_config`` (nnlib/inference.py:423-483)."""
+    cfg = dict(model_cfg.get("embedding", {}) or {})
+    cfg.update(model_cfg.get("string_processor", {}) or {})
+    cfg["input_type"] = cfg.get("type", "translated")          # inference.py:443-444
+    if cfg.get("codon") is not None and cfg.get("codon_id") is not None:
+        codon_name, id_name = cfg["codon"], cfg["codon_id"]
+        cfg["codon"] = maps.NAMED_MAPS.get(codon_name)
+        cfg["codon_id"] = maps.NAMED_MAPS.get(id_name)
+        if cfg["codon"] is None or cfg["codon_id"] is None:
+            raise UnsupportedLayer(f"codon map {codon_name!r}/{id_name!r} is not supported")
+        cfg["codon_depth"] = max(cfg["codon_id"]) + 1
+        cfg["vocab_size"] = len(cfg["codon_id"]) + 1
+        cfg["ngram_width"] = int(math.log(len(cfg["codon"]), 4))
+        shape = (model_cfg.get("embedding", {}) or {}).get("input_shape")
+        if cfg.get("seq_onehot") is None and shape is not None:
+            cfg["seq_onehot"] = len(shape) == 3 and shape[-1] is not None and shape[-1] > 1
+        cfg["seq_onehot"] = cfg.get("seq_onehot", False)
+        if cfg["seq_onehot"] is False:
+            cfg["codon_depth"] = 1
+    if "crop_size" in cfg:
+        size = cfg["crop_size"]
+        units = cfg.setdefault("crop_units", "nucleotide" if cfg["input_type"] == "nucleotide" else "codon")
+        if cfg["input_type"] == "nucleotide":
+            cfg["crop_size_nt"] = int(size)
+        elif units == "codon":                                  # seqops/crop.py:70-89
+            cfg["crop_size_codons"], cfg["crop_size_nt"] = int(size), 3 * int(size) + 5
+        else:
+            cfg["crop_size_codons"], cfg["crop_size_nt"] = (int(size) - 5) // 3, int(size)
+    return cfg
+
+
+def build_plan(model_cfg: dict) -> ModelPlan:
+    """Resolve the ``model:`` section of a project YAML into a :class:`ModelPlan`."""
+    sp = resolve_string_processor(model_cfg)
+    emb = model_cfg.get("embedding")
+    if emb is None:
+        raise ValueError("Missing 'embedding' section in config")   # builder.py:476
+    if sp["input_type"] != "translated":
+        raise UnsupportedLayer(f"input_type {sp['input_type']!r}: only 'translated' models are supported")
+    if sp.get("ngram_width", 3) != 3:
+        raise UnsupportedLayer("dicodon (ngram_width 6) encodings are not supported")
+    if not emb.get("use_embedding_layer", False) or sp.get("seq_onehot"):
+        raise UnsupportedLayer("only use_embedding_layer=true / seq_onehot=false models are supported")
+    if emb.get("use_positional_embeddings", False):
+        raise UnsupportedLayer("positional embeddings are not supported")
+    for section in ("representation_learner", "classifier"):
+        if "branch" in (model_cfg.get(section) or {}):
+            raise UnsupportedLayer(f"branched {section} is not supported")
+    if "projection" in model_cfg:
+        pass  # training-only head, not part of the serving graph outputs
+    use_masking = bool(model_cfg.get("use_masking", True))          # builder.py:259
+    e = int(emb.get("embedding_size", 4))
+    nmd_dims: list[int] = []
+    rep_cfg = model_cfg["representation_learner"]
+    rep, rep_c = _block(rep_cfg.get("hidden_layers", []), "rep", e, use_masking, nmd_dims)
+    pooling = str(rep_cfg.get("pooling", "")).lower()
+    pooling = {"masked_max": "max", "masked_average": "average"}.get(pooling, pooling)
+    if pooling not in ("max", "average"):
+        raise UnsupportedLayer(f"pooling {pooling!r} is not supported (max / average only)")
+    cls, n_cls = _block(model_cfg["classifier"].get("hidden_layers", []), "classifier", rep_c,
+                        use_masking, None)
+    plan = ModelPlan(vocab=sp["vocab_size"], embedding_dim=e, rep=rep, pooling=pooling,
+                     rep_channels=rep_c, classifier=cls, n_classes=n_cls, nmd_dims=nmd_dims,
+                     use_masking=use_masking, string_processor=sp,
+                     class_label_map=list(model_cfg.get("class_label_map", []) or []))
+    rel = model_cfg.get("reliability_model")
+    if rel is not None and nmd_dims:
+        merge = rel.get("merge") or {}
+        if len(nmd_dims) > 1 and merge.get("mode", "concat") != "concat":
+            raise UnsupportedLayer("NMDMerge modes other than concat are not supported")
+        mode = rel.get("mode", "nmd")
+        if mode not in ("nmd", "nmd_plus_signals"):
+            raise ValueError(f"Unsupported reliability_model.mode: {mode!r}")   # builder.py:628-632
+        sig = list(rel.get("signals", _DEFAULT_SIGNALS)) if mode == "nmd_plus_signals" else []
+        rin = sum(nmd_dims) + len(sig)
+        expected = rel.get("input_shape")
+        if expected is not None and expected != rin:
+            raise ValueError(f"reliability_model.input_shape ({expected}) does not match computed "
+                             f"reliability input dimension ({rin})")              # builder.py:662-667
+        plan.reliability, _ = _block(rel.get("hidden_layers", []), "reliability", rin, use_masking, None)
+        plan.reliability_mode = mode
+        plan.reliability_signals = sig
+    elif rel is not None:
+        raise ValueError("reliability_model is configured but the representation learner "
+                         "produced no NMD tensor")                                # builder.py:636-641
+    return plan
+
+
+def weight_shapes(plan: ModelPlan) -> dict[str, tuple]:
+    """Canonical variable names -> shapes."""
+    out: dict[str, tuple] = {"embedding/embeddings": (plan.vocab, plan.embedding_dim)}
+
+    def norm(n: Norm):
+        vars_ = {"masked_batchnorm": ("gamma", "beta", "moving_mean", "moving_variance"),
+                 "masked_dyt": ("alpha", "gamma", "beta"),
+                 "masked_layernorm": ("gamma", "beta")}[n.kind]
+        for v in vars_:
+            out[f"{n.name}/{v}"] = (1,) if v == "alpha" else (n.channels,)
+
+    def conv(c: Conv):
+        out[f"{c.name}/kernel"] = (c.kernel_size, c.cin, c.filters)
+        if c.use_bias:
+            out[f"{c.name}/bias"] = (c.filters,)
+
+    for seq in (plan.rep, plan.classifier, plan.reliability or []):
+        for layer in seq:
+            if isinstance(layer, Conv):
+                conv(layer)
+            elif isinstance(layer, Norm):
+                norm(layer)
+            elif isinstance(layer, Nmd):
+                out[f"{layer.name}/moving_mean"] = (layer.channels,)
+            elif isinstance(layer, ResBlock):
+                for c in (layer.conv1, layer.conv2, layer.conv3):
+                    if c is not None:
+                        conv(c)
+                for n in (layer.bn1, layer.bn2, layer.bn3):
+                    if n is not None:
+                        norm(n)
+            elif isinstance(layer, Dense):
+                out[f"{layer.name}/kernel"] = (layer.cin, layer.units)
+                if layer.use_bias:
+                    out[f"{layer.name}/bias"] = (layer.units,)
+    return out
+
+
+def conv_flops_per_position(plan: ModelPlan) -> list[tuple[str, int, int, int, str, int]]:
+    """(name, k, cin, cout, padding, stride) of every conv, in execution order."""
+    rows = []
+    for layer in plan.rep:
+        if isinstance(layer, Conv):
+            rows.append((layer.name, layer.kernel_size, layer.cin, layer.filters, layer.padding, layer.strides))
+        elif isinstance(layer, ResBlock):
+            for c in (layer.conv1, layer.conv2, layer.conv3):
+                if c is not None:
+                    rows.append((c.name, c.kernel_size, c.cin, c.filters, c.padding, c.strides))
+    return rows

@@ -1,0 +1,360 @@
+"""Layer plan -> op program + weight blob for ``libjaeger_hip.so``.
+
+Fuses what the reference runs as separate Keras layers (``nnlib/builder.py:982-1193``
+``_build_block``; ``nnlib/v2/layers.py:1882-1915`` ``ResidualBlock.call``) into
+conv launches with epilogue stages:
+
+* ``masked_conv1d -> [nmd] -> norm -> activation``            one conv op
+* ``ResidualBlock``: ``conv1 -> bn1 -> act`` one conv op; ``conv2 -> bn2 -> (+ shortcut)
+  -> act [-> nmd -> norm -> activation that follow the stack]`` one conv op;
+  optional ``conv3 -> bn3`` bypass one conv op
+* each conv with masking gets one tiny mask op (``layers.py:1226-1255``).
+
+Pure host logic (numpy + ctypes structs): unit-tested on CPU.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+from .plan import Act, Conv, Dense, ModelPlan, Nmd, Norm, ResBlock, UnsupportedLayer, weight_shapes
+
+_ACT_CODE = {None: L.ACT_NONE, "linear": L.ACT_NONE, "gelu": L.ACT_GELU_TANH, "gelu_erf": L.ACT_GELU_ERF,
+             "relu": L.ACT_RELU, "tanh": L.ACT_TANH, "sigmoid": L.ACT_SIGMOID}
+_MASK_MODE = {"any": L.MASK_ANY, "majority": L.MASK_MAJORITY, "strict": L.MASK_STRICT}
+_SIGNAL_CODE = {"max_prob": 1, "entropy": 2, "energy": 3, "margin": 4, "nmd_norm": 5}
+
+
+def act_code(name) -> int:
+    key = name.lower() if isinstance(name, str) else name
+    if key not in _ACT_CODE:
+        raise UnsupportedLayer(f"activation {name!r} is not supported by the MI355X engine")
+    return _ACT_CODE[key]
+
+
+class _Blob:
+    """Flat f32 weight blob; every tensor starts on a 16-byte boundary."""
+
+    def __init__(self):
+        self.parts: list[np.ndarray] = []
+        self.size = 0
+
+    def add(self, arr) -> int:
+        a = np.ascontiguousarray(arr, dtype=np.float32).ravel()
+        off = self.size
+        pad = (-a.size) % 4
+        self.parts.append(a)
+        if pad:
+            self.parts.append(np.zeros(pad, np.float32))
+        self.size += a.size + pad
+        return off
+
+    def finish(self) -> np.ndarray:
+        return np.concatenate(self.parts) if self.parts else np.zeros(4, np.float32)
+
+
+class _Slots:
+    def __init__(self, n: int, what: str):
+        self.free = list(range(n))
+        self.what = what
+
+    def take(self) -> int:
+        if not self.free:
+            raise UnsupportedLayer(f"program needs more than {L.JG_MAX_BUFS} {self.what} buffers")
+        return self.free.pop(0)
+
+    def give(self, s: int) -> None:
+        if s is not None and s >= 0 and s not in self.free:
+            self.free.append(s)
+            self.free.sort()
+
+
+def pack_conv_kernel(kernel: np.ndarray) -> np.ndarray:
+    """(k, cin, cout) -> (k, cin_pad, cout_pad) zero padded (cin to even, cout to x32)."""
+    k, cin, cout = kernel.shape
+    cin_pad, cout_pad = (cin + 1) & ~1, (cout + 31) // 32 * 32
+    out = np.zeros((k, cin_pad, cout_pad), np.float32)
+    out[:, :cin, :cout] = kernel
+    return out
+
+
+@dataclass
+class Program:
+    ops: list            # list[L.JgOp]
+    blob: np.ndarray     # float32
+    vocab: int
+    n_classes: int
+    has_reliability: bool
+    nmd_dim: int
+    embedding_dim: int
+
+    def op_array(self):
+        arr = (L.JgOp * len(self.ops))()
+        for i, op in enumerate(self.ops):
+            arr[i] = op
+        return arr
+
+    def describe(self) -> list[str]:
+        kinds = {v: k for k, v in vars(L).items() if k.startswith("OP_")}
+        stk = {v: k[3:] for k, v in vars(L).items() if k.startswith("ST_")}
+        rows = []
+        for op in self.ops:
+            st = "+".join(stk[op.stages[s].kind] for s in range(op.n_stages))
+            rows.append(f"{kinds[op.kind][3:]:9s} in={op.in_buf} out={op.out_buf} m={op.in_mask}->{op.out_mask} "
+                        f"k={op.k} c={op.cin}->{op.cout} s={op.stride} d={op.dilation} [{st}]")
+        return rows
+
+
+class _Compiler:
+    def __init__(self, plan: ModelPlan, weights: dict[str, np.ndarray]):
+        self.plan, self.w = plan, weights
+        missing = [n for n in weight_shapes(plan) if n not in weights]
+        if missing:
+            raise KeyError(f"weights missing for: {missing[:6]}{'...' if len(missing) > 6 else ''}")
+        for n, shp in weight_shapes(plan).items():
+            if tuple(weights[n].shape) != tuple(shp):
+                raise ValueError(f"weight {n}: shape {tuple(weights[n].shape)} != expected {shp}")
+        self.blob = _Blob()
+        self.ops: list = []
+        self.bufs = _Slots(L.JG_MAX_BUFS, "activation")
+        self.masks = _Slots(L.JG_MAX_BUFS, "mask")
+        self.parts = _Slots(L.JG_MAX_BUFS, "nmd partial")
+        self.nmd_off = 0
+
+    # ---- helpers -----------------------------------------------------------
+    def _op(self, kind, **kw):
+        op = L.JgOp()
+        op.kind = kind
+        for f in ("in_buf", "out_buf", "in_mask", "out_mask", "in_vec", "out_vec"):
+            setattr(op, f, -1)
+        op.w_off = op.b_off = -1
+        op.stride = op.dilation = 1
+        for k, v in kw.items():
+            setattr(op, k, v)
+        return op
+
+    @staticmethod
+    def _stage(kind, arg=0, p0=-1, p1=-1, p2=-1, p3=-1, f0=0.0):
+        st = L.JgStage()
+        st.kind, st.arg, st.p0, st.p1, st.p2, st.p3, st.f0 = kind, arg, p0, p1, p2, p3, f0
+        return st
+
+    def _norm_stage(self, n: Norm, has_mask: bool):
+        w = self.w
+        if n.kind == "masked_batchnorm":
+            var = w[f"{n.name}/moving_variance"].astype(np.float32)
+            inv_std = (np.float32(1.0) / np.sqrt(var + np.float32(n.epsilon))).astype(np.float32)
+            return self._stage(L.ST_BN, p0=self.blob.add(w[f"{n.name}/moving_mean"]), p1=self.blob.add(inv_std),
+                               p2=self.blob.add(w[f"{n.name}/gamma"]), p3=self.blob.add(w[f"{n.name}/beta"]))
+        if n.kind == "masked_dyt":
+            return self._stage(L.ST_DYT, arg=1 if has_mask else 0, f0=float(w[f"{n.name}/alpha"].ravel()[0]),
+                               p2=self.blob.add(w[f"{n.name}/gamma"]), p3=self.blob.add(w[f"{n.name}/beta"]))
+        raise UnsupportedLayer(f"{n.name}: {n.kind} is not supported by the MI355X engine yet")
+
+    def _emit_conv(self, c: Conv, in_buf: int, in_mask: int, stages: list, out_mask: int, out_buf: int):
+        if len(stages) > L.JG_MAX_STAGES:
+            raise UnsupportedLayer(f"{c.name}: more than {L.JG_MAX_STAGES} fused epilogue stages")
+        op = self._op(L.OP_CONV, in_buf=in_buf, out_buf=out_buf,
+                      in_mask=in_mask if c.use_masking else L.JG_BUF_NONE, out_mask=out_mask,
+                      k=c.kernel_size, cin=c.cin, cout=c.filters, stride=c.strides, dilation=c.dilation_rate,
+                      padding=L.PAD_SAME if c.padding == "same" else L.PAD_VALID,
+                      mask_mode=_MASK_MODE[c.mask_mode],
+                      w_off=self.blob.add(pack_conv_kernel(self.w[f"{c.name}/kernel"])))
+        if in_buf == L.JG_BUF_IDS:
+            op.b_off = self.emb_off
+        op.n_stages = len(stages)
+        for i, st in enumerate(stages):
+            op.stages[i] = st
+        self.ops.append(op)
+
+    def _conv_mask(self, c: Conv, in_mask: int) -> int:
+        """Emit the mask op of a conv; returns the output mask slot (or NONE)."""
+        if not c.use_masking or in_mask == L.JG_BUF_NONE:
+            return L.JG_BUF_NONE
+        if c.padding not in ("same", "valid"):
+            raise ValueError(f"{c.name}: Invalid padding type {c.padding!r}")
+        out = self.masks.take()
+        self.ops.append(self._op(L.OP_MASK, in_mask=in_mask, out_mask=out, k=c.kernel_size, stride=c.strides,
+                                 dilation=c.dilation_rate, mask_mode=_MASK_MODE[c.mask_mode],
+                                 padding=L.PAD_SAME if c.padding == "same" else L.PAD_VALID))
+        return out
+
+    def _base_stages(self, c: Conv) -> list:
+        st = []
+        if c.use_bias:
+            st.append(self._stage(L.ST_BIAS, p0=self.blob.add(self.w[f"{c.name}/bias"])))
+        if c.activation is not None:
+            st.append(self._stage(L.ST_ACT, arg=act_code(c.activation)))
+        return st
+
+    def _fuse_tail(self, layers: list, i: int, stages: list, mask: int, channels: int, pending_nmd: list):
+        """Greedily fuse following nmd / norm / activation layers as epilogue stages."""
+        while i < len(layers) and len(stages) < L.JG_MAX_STAGES:
+            nxt = layers[i]
+            if isinstance(nxt, Nmd):
+                slot = self.parts.take()
+                stages.append(self._stage(L.ST_NMD, arg=slot))
+                pending_nmd.append((nxt, slot, mask))
+            elif isinstance(nxt, Norm) and nxt.kind in ("masked_batchnorm", "masked_dyt"):
+                stages.append(self._norm_stage(nxt, mask != L.JG_BUF_NONE))
+                if nxt.kind == "masked_batchnorm" and not nxt.use_masking:
+                    mask = L.JG_BUF_NONE          # supports_masking False drops the mask (layers.py:816)
+            elif isinstance(nxt, Act):
+                stages.append(self._stage(L.ST_ACT, arg=act_code(nxt.kind)))
+            else:
+                break
+            i += 1
+        return i, mask
+
+    def _flush_nmd(self, pending: list, buf: int):
+        for nmd, slot, mask in pending:
+            self.ops.append(self._op(L.OP_NMD_FINAL, in_buf=buf, in_mask=mask, cout=nmd.channels, arg=slot,
+                                     out_vec=L.VEC_NMD, vec_off=self.nmd_off, f0=nmd.epsilon,
+                                     b_off=self.blob.add(self.w[f"{nmd.name}/moving_mean"])))
+            self.nmd_off += nmd.channels
+            self.parts.give(slot)
+        pending.clear()
+
+    # ---- representation learner ----------------------------------------------
+    def _rep(self):
+        plan = self.plan
+        layers = plan.rep
+        self.emb_off = self.blob.add(self.w["embedding/embeddings"])
+        buf, mask = L.JG_BUF_IDS, L.JG_BUF_IDS      # Embedding(mask_zero=True), builder.py:858-867
+        i = 0
+        while i < len(layers):
+            layer = layers[i]
+            pending: list = []
+            if isinstance(layer, Conv):
+                om = self._conv_mask(layer, mask)
+                stages = self._base_stages(layer)
+                i, om2 = self._fuse_tail(layers, i + 1, stages, om, layer.filters, pending)
+                out = self.bufs.take()
+                self._emit_conv(layer, buf, mask, stages, om, out)
+                self._flush_nmd(pending, out)
+                self.bufs.give(buf)
+                if mask != om:
+                    self.masks.give(mask)
+                buf, mask = out, om2
+            elif isinstance(layer, ResBlock):
+                blk = layer
+                in_mask = mask if blk.use_masking else L.JG_BUF_NONE
+                m1 = self._conv_mask(blk.conv1, in_mask)
+                b1 = self.bufs.take()
+                st1 = self._base_stages(blk.conv1) + [self._norm_stage(blk.bn1, m1 != L.JG_BUF_NONE),
+                                                      self._stage(L.ST_ACT, arg=act_code(blk.activation))]
+                self._emit_conv(blk.conv1, buf, in_mask, st1, m1, b1)
+                shortcut = buf
+                b3 = None
+                if blk.conv3 is not None:
+                    m3 = self._conv_mask(blk.conv3, in_mask)
+                    b3 = self.bufs.take()
+                    st3 = self._base_stages(blk.conv3) + [self._norm_stage(blk.bn3, m3 != L.JG_BUF_NONE)]
+                    self._emit_conv(blk.conv3, buf, in_mask, st3, m3, b3)
+                    self.masks.give(m3)
+                    shortcut = b3
+                if shortcut == L.JG_BUF_IDS:
+                    raise UnsupportedLayer(f"{blk.name}: a residual block cannot be the first layer")
+                m2 = self._conv_mask(blk.conv2, m1)
+                b2 = self.bufs.take()
+                st2 = self._base_stages(blk.conv2) + [self._norm_stage(blk.bn2, m2 != L.JG_BUF_NONE),
+                                                      self._stage(L.ST_ADD, arg=shortcut),
+                                                      self._stage(L.ST_ACT, arg=act_code(blk.activation))]
+                i, m2b = self._fuse_tail(layers, i + 1, st2, m2, blk.conv2.filters, pending)
+                self._emit_conv(blk.conv2, b1, m1, st2, m2, b2)
+                self._flush_nmd(pending, b2)
+                for s in (buf, b1, b3):
+                    self.bufs.give(s)
+                for s in (mask, m1):
+                    if s != m2:
+                        self.masks.give(s)
+                buf, mask = b2, m2b
+            elif isinstance(layer, (Norm, Act)):
+                if buf == L.JG_BUF_IDS:
+                    raise UnsupportedLayer("a norm / activation directly on the embedding is not supported")
+                stages: list = []
+                i, mask2 = self._fuse_tail(layers, i, stages, mask, 0, pending)
+                if pending:
+                    raise UnsupportedLayer("an nmd layer must directly follow a conv or residual block")
+                if not stages:
+                    raise UnsupportedLayer(f"{getattr(layer, 'name', layer)}: unsupported standalone layer")
+                channels = self._channels_before(layers, i)
+                op = self._op(L.OP_ELTWISE, in_buf=buf, out_buf=buf, out_mask=mask, cout=channels)
+                op.n_stages = len(stages)
+                for j, st in enumerate(stages):
+                    op.stages[j] = st
+                self.ops.append(op)
+                mask = mask2
+            elif isinstance(layer, Nmd):
+                raise UnsupportedLayer("an nmd layer must directly follow a conv or residual block")
+            else:
+                raise UnsupportedLayer(f"layer {layer!r} is not supported in the representation learner")
+        if buf == L.JG_BUF_IDS:
+            raise UnsupportedLayer("the representation learner has no conv layer")
+        kind = L.POOL_MAX if plan.pooling == "max" else L.POOL_AVG
+        self.ops.append(self._op(L.OP_POOL, in_buf=buf, in_mask=mask, out_vec=L.VEC_EMBEDDING, vec_off=0,
+                                 cout=plan.rep_channels, arg=kind))
+
+    def _channels_before(self, layers, i) -> int:
+        c = self.plan.embedding_dim
+        for layer in layers[:i]:
+            if isinstance(layer, Conv):
+                c = layer.filters
+            elif isinstance(layer, ResBlock):
+                c = layer.conv2.filters
+        return c
+
+    # ---- heads -----------------------------------------------------------------
+    def _head(self, layers: list, in_vec: int, out_vec: int, scratch0: int) -> None:
+        dense_idx = [j for j, l in enumerate(layers) if isinstance(l, Dense)]
+        if not dense_idx:
+            raise UnsupportedLayer("a head needs at least one dense layer")
+        cur, scratch = in_vec, scratch0
+        j = 0
+        while j < len(layers):
+            layer = layers[j]
+            if not isinstance(layer, Dense):
+                raise UnsupportedLayer(f"head layer {layer!r} must follow a dense layer")
+            act = layer.activation
+            if j + 1 < len(layers) and isinstance(layers[j + 1], Act):
+                if act is not None:
+                    raise UnsupportedLayer("dense activation followed by another activation")
+                act = layers[j + 1].kind
+                j += 1
+            last = not any(isinstance(l, Dense) for l in layers[j + 1:])
+            dst = out_vec if last else scratch
+            if not last:
+                scratch += 1
+                if scratch >= L.JG_MAX_VECS:
+                    raise UnsupportedLayer("head too deep for the vector slots")
+            b_off = self.blob.add(self.w[f"{layer.name}/bias"]) if layer.use_bias else -1
+            self.ops.append(self._op(L.OP_DENSE, in_vec=cur, out_vec=dst, vec_off=0, cin=layer.cin,
+                                     cout=layer.units, arg=act_code(act),
+                                     w_off=self.blob.add(self.w[f"{layer.name}/kernel"]), b_off=b_off))
+            cur = dst
+            j += 1
+
+    def compile(self) -> Program:
+        plan = self.plan
+        self._rep()
+        self._head(plan.classifier, L.VEC_EMBEDDING, L.VEC_PREDICTION, L.VEC_SCRATCH0)
+        if plan.reliability is not None:
+            if plan.reliability_signals:
+                order = 0
+                for idx, s in enumerate(plan.reliability_signals):
+                    if s not in _SIGNAL_CODE:
+                        raise ValueError(f"Unsupported signal(s): {s!r}")       # layers.py:1626-1630
+                    order |= _SIGNAL_CODE[s] << (4 * idx)
+                self.ops.append(self._op(L.OP_OODSIG, in_vec=L.VEC_PREDICTION, k=L.VEC_NMD, cin=plan.n_classes,
+                                         cout=len(plan.reliability_signals), out_vec=L.VEC_NMD,
+                                         vec_off=plan.nmd_dim, arg=order, f0=1e-10, stride=plan.nmd_dim))
+            self._head(plan.reliability, L.VEC_NMD, L.VEC_RELIABILITY, L.VEC_SCRATCH0 + 4)
+        return Program(self.ops, self.blob.finish(), plan.vocab, plan.n_classes,
+                       plan.reliability is not None, plan.nmd_dim, plan.rep_channels)
+
+
+def compile_plan(plan: ModelPlan, weights: dict[str, np.ndarray]) -> Program:
+    return _Compiler(plan, weights).compile()

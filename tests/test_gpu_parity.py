@@ -1,0 +1,154 @@
+"""GPU parity: HIP path (through the C-ABI) vs the CPU oracle on identical inputs.
+
+Encoder / counts / masks: bit-exact.  Logits and the other float outputs:
+max-abs-err <= 1e-4 (BASELINE.json north_star tolerance) against the f32 oracle.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_model_cfg
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _random_dna(rng, n, n_frac=0.0, lower_frac=0.0):
+    seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n).copy()
+    if n_frac > 0:
+        # N runs of length 1..20 (BASELINE.md config 2 variant)
+        n_runs = max(1, int(n * n_frac / 10))
+        for s in rng.integers(0, n, n_runs):
+            seq[s:s + rng.integers(1, 21)] = ord("N")
+    if lower_frac > 0:
+        idx = rng.random(n) < lower_frac
+        seq[idx] |= 0x20
+    return seq
+
+
+@pytest.fixture(scope="module")
+def device():
+    from jaeger_amd.engine import HipDevice
+    dev = HipDevice(0)
+    yield dev
+    dev.close()
+
+
+@pytest.mark.parametrize("fsize", [1500, 2000, 500, 1501, 1502])
+def test_encoder_bit_exact(device, fsize):
+    from jaeger_amd.engine import codon_lut, frame_length
+    from jaeger_amd.maps import CODON_ID
+    from oracle import encoder as oenc
+    rng = np.random.Generator(np.random.PCG64(fsize))
+    n_win = 37
+    seq = _random_dna(rng, fsize * n_win + 11, n_frac=0.01, lower_frac=0.05)
+    starts = rng.integers(0, seq.size - fsize, n_win).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    lens[::5] = rng.integers(5, fsize, lens[::5].size)       # short whole-contig windows
+    lens[3] = 4                                               # yields no codon at all
+    ids, counts = device.encode(seq, starts, lens, fsize, codon_lut(CODON_ID))
+    windows = [seq[s:s + n].tobytes() for s, n in zip(starts, lens)]
+    ref = oenc.encode_windows(windows, fsize, pad_to=frame_length(fsize))
+    assert ids.shape == ref.shape
+    np.testing.assert_array_equal(ids, ref)
+    # literal (string-op) restatement on a few windows
+    for wi in (0, 5, 10):
+        lit = oenc.encode_window_literal(windows[wi].decode(), fsize)
+        np.testing.assert_array_equal(ids[wi, :, :lit.shape[1]], lit.astype(np.uint8))
+        assert not ids[wi, :, lit.shape[1]:].any()
+    ref_counts = np.array([oenc.window_counts(w.upper()) for w in windows], np.int32)
+    np.testing.assert_array_equal(counts, ref_counts)
+
+
+def test_encoder_case_flags_and_id_maps(device):
+    from jaeger_amd.engine import codon_lut, frame_length
+    from jaeger_amd.maps import AA_ID
+    from oracle import encoder as oenc
+    rng = np.random.Generator(np.random.PCG64(99))
+    fsize, n_win = 600, 9
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.02, lower_frac=0.2)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    windows = [seq[s:s + fsize].tobytes() for s in starts]
+    # masking=True: lower case survives -> invalid codons; counts upper-case only (flags 1|2)
+    ids, counts = device.encode(seq, starts, lens, fsize, codon_lut(AA_ID), flags=3)
+    ref = oenc.encode_windows(windows, fsize, codon_id=AA_ID, masking=True, pad_to=frame_length(fsize))
+    np.testing.assert_array_equal(ids, ref)
+    np.testing.assert_array_equal(counts, np.array([oenc.window_counts(w) for w in windows], np.int32))
+    lit = oenc.encode_window_literal(windows[2].decode(), fsize, codon_id=AA_ID, masking=True)
+    np.testing.assert_array_equal(ids[2], lit.astype(np.uint8))
+
+
+def _forward_case(name, fsize, n_win, seed, n_frac, chunk=0, short=False):
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = load_model_cfg(name)
+    weights = ofwd.random_weights(cfg, seed=38341)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    seq = _random_dna(rng, fsize * n_win, n_frac=n_frac)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    if short:
+        lens[1::3] = rng.integers(fsize // 2, fsize, lens[1::3].size)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, chunk=chunk)
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    windows = [seq[s:s + n].tobytes() for s, n in zip(starts, lens)]
+    ids = oenc.encode_windows(windows, fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    # the id-tensor entry point must agree with the fused one bit for bit
+    got2 = eng.model.forward(ids, chunk=chunk)
+    eng.close()
+    errs = {}
+    for k, r in ref.items():
+        assert got[k].shape == r.shape, k
+        errs[k] = float(np.abs(got[k] - r).max())
+        np.testing.assert_array_equal(got[k], got2[k])
+    print(name, fsize, {k: f"{v:.2e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v <= TOL, (k, v)
+    ref_counts = np.array([oenc.window_counts(w) for w in windows], np.int32)
+    np.testing.assert_array_equal(got["counts"], ref_counts)
+
+
+def test_forward_brain_1500():
+    _forward_case("brain", 1500, 10, 1, n_frac=0.0)
+
+
+def test_forward_brain_1500_with_n_runs_chunked():
+    _forward_case("brain", 1500, 11, 2, n_frac=0.03, chunk=4)
+
+
+def test_forward_brain_2000_short_windows():
+    _forward_case("brain", 2000, 7, 3, n_frac=0.01, short=True)
+
+
+def test_forward_zeus_dyt():
+    _forward_case("zeus", 1500, 6, 4, n_frac=0.01)
+
+
+def test_forward_baseline500():
+    _forward_case("baseline500", 500, 64, 5, n_frac=0.02)
+
+
+def test_forward_all_masked_window():
+    """A window of only N: every position invalid -> max pool emits zeros (layers.py:523-528)."""
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = load_model_cfg("brain")
+    weights = ofwd.random_weights(cfg, seed=38341)
+    fsize = 1500
+    rng = np.random.Generator(np.random.PCG64(11))
+    seq = _random_dna(rng, fsize * 3)
+    seq[fsize:2 * fsize] = ord("N")
+    starts = (np.arange(3) * fsize).astype(np.int64)
+    lens = np.full(3, fsize, np.int32)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights)
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    eng.close()
+    ids = oenc.encode_windows([seq[s:s + fsize].tobytes() for s in starts], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    assert not got["embedding"][1].any()
+    for k, r in ref.items():
+        assert np.abs(got[k] - r).max() <= TOL, k
