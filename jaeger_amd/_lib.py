@@ -103,6 +103,13 @@ def load():
             f"{path} not found: the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C jaeger_amd/csrc`). "
             "jaeger_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; importing it first makes the loader
+    # resolve our DT_NEEDED to that same copy, so torch tensors, RCCL and this library
+    # share ONE HIP runtime in the process (torch is plumbing here, never compute).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(path))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)            # AttributeError if the .so misses a declared symbol

@@ -190,6 +190,21 @@ class HipModel:
         return res
 
 
+    def predict_windows_raw(self, bases_ptr: int, n_bases: int, win_start_ptr: int, win_len_ptr: int,
+                            n_win: int, fsize: int, lut, flags: int, l_pad: int, out_ptrs: dict,
+                            counts_ptr: int = 0, chunk: int = 0) -> None:
+        """``jg_predict_windows`` on raw DEVICE pointers for inputs and outputs (no host
+        round trip); asynchronous on the engine stream - call ``HipDevice.sync()``."""
+        lut = np.ascontiguousarray(lut, np.uint8)
+        g = lambda k: C.c_void_p(out_ptrs[k]) if out_ptrs.get(k) else None  # noqa: E731
+        L.check(self.lib.jg_predict_windows(
+            self.handle, C.c_void_p(bases_ptr), int(n_bases), L.JG_PTR_DEVICE, C.c_void_p(win_start_ptr),
+            C.c_void_p(win_len_ptr), L.JG_PTR_DEVICE, int(n_win), int(fsize), _ptr(lut), int(flags),
+            int(l_pad), g("prediction"), g("reliability"), g("embedding"), g("nmd"),
+            C.c_void_p(counts_ptr) if counts_ptr else None, L.JG_PTR_DEVICE, int(chunk), None),
+            "jg_predict_windows")
+
+
 class JaegerHipEngine:
     """Drop-in for ``InferModel`` (nnlib/inference.py:300-483) on one MI355X.
 

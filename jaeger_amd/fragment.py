@@ -1,0 +1,143 @@
+"""Host side of the fragmenter: FASTA records -> window table + metadata.
+
+The reference's ``fragment_generator`` (``seqops/io.py:74-147``) materialises one
+Python string per window (slice + 4x ``str.count`` + f-string).  Here the host
+only computes *where* the windows are (``_window_indices``, ``io.py:38-71``,
+vectorised over contigs); slicing, base counting and encoding happen on the GPU
+(``jg_encode`` / ``jg_predict_windows``), and the ten metadata fields the
+post-processing needs (``postprocess/collect.py:259-327``) are produced as numpy
+arrays in the reference's field order.
+"""
+
+from __future__ import annotations
+
+import gzip
+import math
+from dataclasses import dataclass
+from typing import Iterable, Iterator
+
+import numpy as np
+
+
+def read_fasta(path: str) -> Iterator[tuple[str, bytes]]:
+    """(name, sequence bytes); name = header up to the first whitespace
+    (``pyfastx.Fasta(build_index=False)`` semantics, io.py:98-103)."""
+    opener = gzip.open if str(path).endswith(".gz") else open
+    name, chunks = None, []
+    with opener(path, "rb") as fh:
+        for line in fh:
+            line = line.rstrip(b"\r\n")
+            if line.startswith(b">"):
+                if name is not None:
+                    yield name, b"".join(chunks)
+                fields = line[1:].split()
+                name = fields[0].decode() if fields else ""
+                chunks = []
+            elif name is not None:
+                chunks.append(line.strip())
+    if name is not None:
+        yield name, b"".join(chunks)
+
+
+def window_indices(seqlen: int, fragsize: int, stride: int | None, dynamic_stride: bool = False,
+                   dynamic_stride_threshold: float = 10.0) -> list[int]:
+    """Window starts of one contig (io.py:38-71)."""
+    if dynamic_stride and seqlen < dynamic_stride_threshold * fragsize:
+        n = max(1, math.ceil(seqlen / fragsize))
+        if n == 1:
+            return [0]
+        raw = (seqlen - fragsize) / (n - 1)
+        starts = [int(round(i * raw)) for i in range(n)]
+        starts[-1] = seqlen - fragsize
+        return list(dict.fromkeys(starts))
+    step = fragsize if stride is None else stride
+    return list(range(0, seqlen - (fragsize - 1), step))
+
+
+@dataclass
+class WindowTable:
+    """Windows of a set of contigs, in the reference's emission order."""
+    contig: np.ndarray      # (W,) index into the record list
+    start: np.ndarray       # (W,) offset inside the contig            (meta_1 "index")
+    length: np.ndarray      # (W,) window length (< fsize: whole-contig window)
+    is_last: np.ndarray     # (W,) 1 on the last window of a contig    (meta_2)
+    ordinal: np.ndarray     # (W,) window number inside the contig     (meta_3)
+    seqlen: np.ndarray      # (W,) contig length                       (meta_4)
+
+    def __len__(self) -> int:
+        return int(self.contig.size)
+
+
+def build_window_table(lengths: Iterable[int], fragsize: int, stride: int | None = None,
+                       dynamic_stride: bool = False, dynamic_stride_threshold: float = 10.0,
+                       min_len: int | None = None, max_len: int | None = None) -> WindowTable:
+    """Vectorised ``fragment_generator`` control flow (io.py:110-145) over contig lengths."""
+    lengths = np.asarray(list(lengths) if not isinstance(lengths, np.ndarray) else lengths, np.int64)
+    if min_len is None:
+        min_len = fragsize
+    step = fragsize if stride is None else stride
+    keep = np.ones(lengths.size, bool)
+    if max_len is not None:
+        keep &= lengths <= max_len                                   # io.py:110-111
+    long_ = keep & (lengths >= fragsize)
+    short = keep & (lengths < fragsize) & (lengths >= min_len)       # io.py:134
+    n_win = np.zeros(lengths.size, np.int64)
+    n_win[long_] = (lengths[long_] - fragsize) // step + 1
+    n_win[short] = 1
+    dyn = np.zeros(lengths.size, bool)
+    dyn_starts: dict[int, list[int]] = {}
+    if dynamic_stride:
+        dyn = long_ & (lengths < dynamic_stride_threshold * fragsize)
+        for ci in np.nonzero(dyn)[0]:
+            s = window_indices(int(lengths[ci]), fragsize, stride, True, dynamic_stride_threshold)
+            dyn_starts[int(ci)] = s
+            n_win[ci] = len(s)
+    total = int(n_win.sum())
+    contig = np.repeat(np.arange(lengths.size, dtype=np.int64), n_win)
+    first = np.cumsum(n_win) - n_win
+    ordinal = np.arange(total, dtype=np.int64) - np.repeat(first, n_win)
+    start = ordinal * step
+    for ci, s in dyn_starts.items():
+        start[first[ci]:first[ci] + n_win[ci]] = s
+    seqlen = lengths[contig]
+    length = np.minimum(seqlen, fragsize).astype(np.int32)
+    start[short[contig]] = 0
+    is_last = (ordinal == n_win[contig] - 1).astype(np.int32)
+    return WindowTable(contig, start, length, is_last, ordinal, seqlen)
+
+
+def concat_records(seqs: list[bytes]) -> tuple[np.ndarray, np.ndarray]:
+    """One contiguous base buffer + per-contig offsets (the layout ``jg_encode`` scans)."""
+    lengths = np.fromiter((len(s) for s in seqs), np.int64, len(seqs))
+    offsets = np.zeros(len(seqs) + 1, np.int64)
+    np.cumsum(lengths, out=offsets[1:])
+    buf = np.empty(int(offsets[-1]), np.uint8)
+    for s, o in zip(seqs, offsets[:-1]):
+        buf[o:o + len(s)] = np.frombuffer(s, np.uint8)
+    return buf, offsets
+
+
+def safe_divide(numerator, denominator):
+    """utils/misc.py:117-123 on arrays: round(n/d, 2), 0 where d == 0."""
+    n = np.asarray(numerator, np.float64)
+    d = np.asarray(denominator, np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = np.where(d != 0, np.round(n / np.where(d != 0, d, 1.0), 2), 0.0)
+    return out
+
+
+def window_metadata(table: WindowTable, headers: list[str], counts: np.ndarray) -> dict[str, np.ndarray]:
+    """meta_0..meta_9 as ``InferModel.predict`` returns them (inference.py:365-367):
+    header, index, contig_end, i, seqlen, g, c, a, t, gc_skew (io.py:128-133)."""
+    hdr = np.array([h.strip().replace(",", "___") for h in headers], dtype=object)   # io.py:109
+    g, c, a, t = (counts[:, i].astype(np.int64) for i in range(4))
+    skew = safe_divide(g - c, g + c)
+    return {
+        "meta_0": hdr[table.contig].astype(str) if len(table) else np.array([], dtype=str),
+        "meta_1": table.start.astype(np.int64),
+        "meta_2": table.is_last.astype(np.int32),
+        "meta_3": table.ordinal.astype(np.int64),
+        "meta_4": table.seqlen.astype(np.int64),
+        "meta_5": g, "meta_6": c, "meta_7": a, "meta_8": t,
+        "meta_9": skew,
+    }
