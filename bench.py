@@ -26,6 +26,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table: v_mfma_f32_32x32x2_f32
+F16_MFMA_PEAK_TFLOPS = 2500.0     # dense f16/bf16 MFMA peak (same table); split-f16 issues 3 MFMAs/product
 
 
 def synth_contigs(rng: np.random.Generator, n_contigs: int, lo: int = 1500, hi: int = 200_000):
@@ -45,35 +46,39 @@ def cpu_baseline(cfg, weights, bases, offsets, table, fsize, target_s: float = 1
     from oracle import forward as ofwd
     from oracle import fragmenter as ofrag
 
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 64))       # beyond ~64 threads the batch-96 GEMMs stop scaling
     torch.set_num_threads(cores)
-    # sample: leading contigs until ~n windows; calibrate n on a first small batch
-    def run(n_contigs):
-        recs = [(f"c{i}", bases[offsets[i]:offsets[i + 1]].tobytes().decode()) for i in range(n_contigs)]
+    n_contigs_all = len(offsets) - 1
+    win_per_contig = np.array([(offsets[i + 1] - offsets[i]) // fsize for i in range(min(n_contigs_all, 4000))])
+    cum = np.cumsum(win_per_contig)
+
+    def run(n_windows):
+        n_c = int(np.searchsorted(cum, n_windows) + 1)
+        recs = [(f"c{i}", bases[offsets[i]:offsets[i + 1]].tobytes().decode()) for i in range(n_c)]
         t0 = time.perf_counter()
-        frags = list(ofrag.fragment_strings(recs, fsize, fsize))
-        wins = [f.split(",", 1)[0] for f in frags]
+        wins = []
+        for frag in ofrag.fragment_strings(recs, fsize, fsize):
+            wins.append(frag.split(",", 1)[0])
+            if len(wins) >= n_windows:
+                break
         ids = oenc.encode_windows(wins, fsize)
         n = 0
         for i in range(0, len(wins), 96):                       # reference default --batch 96
-            out = ofwd.forward(cfg, weights, ids[i:i + 96])
-            n += out["prediction"].shape[0]
-        dt = time.perf_counter() - t0
-        return n, dt
+            n += ofwd.forward(cfg, weights, ids[i:i + 96])["prediction"].shape[0]
+        return n, time.perf_counter() - t0
 
-    # contigs are log-uniform; take contigs until >= 48 windows for calibration
-    cum = np.cumsum([(offsets[i + 1] - offsets[i]) // fsize for i in range(min(len(offsets) - 1, 2000))])
-    n_cal = int(np.searchsorted(cum, 48) + 1)
-    run(1)                                                       # warm-up (thread pools, oneDNN)
-    n_w, dt = run(n_cal)
-    rate = n_w / dt
-    want = int(max(96, min(rate * target_s, 4000)))
-    n_big = int(np.searchsorted(cum, want) + 1)
-    n_w, dt = run(n_big)
+    run(8)                                                       # warm-up (thread pools, BLAS)
+    n_w, dt = run(24)
+    want = int(max(96, min(n_w / dt * target_s, 20000)))
+    n_w, dt = run(want)
     return {"value": round(n_w * fsize / dt / 1e6, 5), "unit": "Mbp/s", "cores": cores, "kind": "port",
-            "sample": f"{n_w} windows x {fsize} bp (first {n_big} contigs of the workload), oracle: python "
-                      f"fragmenter + numpy encoder + torch-CPU f32 forward, batch 96, {cores} threads, "
-                      f"{dt:.1f} s"}
+            "sample": f"first {n_w} windows x {fsize} bp of the workload; oracle = python fragmenter + "
+                      f"numpy encoder + torch-CPU f32 forward, batch 96, {cores} threads "
+                      f"({avail} cores visible), {dt:.1f} s"}
 
 
 def main():
@@ -84,6 +89,7 @@ def main():
     ap.add_argument("--contigs", type=int, default=10_000)
     ap.add_argument("--fsize", type=int, default=1500)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -111,7 +117,9 @@ def main():
     weights = ofwd.random_weights(cfg, seed=38341)
     import warnings
     warnings.simplefilter("ignore")
-    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=local_rank, chunk=args.chunk)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=local_rank, chunk=args.chunk,
+                          precision=args.precision)
+    mode = eng.model.precision
 
     fsize = args.fsize
     l_pad = frame_length(fsize)
@@ -179,19 +187,23 @@ def main():
         value = bp_total * steps / dt_max / 1e6
         conv_s = prof["conv_ms"] / 1e3
         ach = prof["conv_flops"] / conv_s / 1e12 if conv_s > 0 else 0.0
+        # roofline: algorithmic (f32-equivalent) conv FLOP/s against the matrix-core peak the kernel
+        # can reach: exact-f32 MFMA, or the f16 MFMA peak / 3 for the split-f16 scheme
+        peak = F32_MFMA_PEAK_TFLOPS if mode == "f32" else F16_MFMA_PEAK_TFLOPS / 3.0
         line = {
             "metric": "Mbp/s classified (1500bp frags)", "value": round(value, 3), "unit": "Mbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if mode == "f32" else "f16x3 (split-f16, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"jaeger_38341_1.4M_fragment stand-in (nn_config_1500bp_nmd_merge_6_class_brain "
                                    f"architecture, seeded random weights), {fsize}bp windows stride {fsize}, "
                                    f"{args.contigs} synthetic contigs/GPU log-uniform 1.5-200 kb",
                        "windows_per_gpu": int(win_total / world), "bp_per_gpu": int(bp_total / world),
                        "parallelism": f"contig-sharded x{world}, final RCCL gather"},
-            "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv_f32_kernel", "launches": int(prof["conv_launches"]),
+            "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1),
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                         "kernel": "conv_f32_kernel" if mode == "f32" else "conv_f16x3_kernel", "launches": int(prof["conv_launches"]),
                          "avg_launch_ms": round(prof["conv_ms"] / max(prof["conv_launches"], 1), 4)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -128,6 +128,13 @@ int jg_engine_sync(jg_engine *e);
 int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const float *weights,
                     int64_t n_weights, int32_t vocab, jg_model **out);
 int jg_model_destroy(jg_model *m);
+/* Arithmetic of the conv stack: 0 = exact-f32 MFMA, 1 = split-f16 ("f16x3": each f32 operand
+ * as an f16 hi/lo pair, three f16 MFMAs per product, f32 accumulate; ~f32 accuracy).  A model
+ * starts in mode 1 when every conv is eligible (128 output channels, stride 1), else 0; mode 1
+ * falls back to 0 by itself if an activation ever leaves the f16 range.  Replaces the
+ * --precision switch of commands/predict.py:604-613 (which trades accuracy; this one does not). */
+int jg_model_set_precision(jg_model *m, int mode);
+int jg_model_get_precision(const jg_model *m);
 
 /* ---- hot path ----------------------------------------------------------- */
 /* Replaces fragment_generator's per-window slice + 4x str.count

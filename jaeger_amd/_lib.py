@@ -72,6 +72,8 @@ SYMBOLS = {
     "jg_engine_sync": (C.c_int, [_vp]),
     "jg_model_create": (C.c_int, [_vp, C.POINTER(JgOp), C.c_int, _vp, C.c_int64, C.c_int32, C.POINTER(_vp)]),
     "jg_model_destroy": (C.c_int, [_vp]),
+    "jg_model_set_precision": (C.c_int, [_vp, C.c_int]),
+    "jg_model_get_precision": (C.c_int, [_vp]),
     "jg_encode": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_int, C.c_int64, C.c_int32, _vp,
                             C.c_int32, C.c_int32, _vp, _vp, C.c_int, _vp]),
     "jg_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, C.c_int,

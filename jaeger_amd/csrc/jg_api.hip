@@ -293,7 +293,7 @@ static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
         sh[op.out_buf] = Shape{in.frames, lo, op.cout};
         act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)in.frames * lo * op.cout);
         fl += 2.0 * op.k * op.cin * op.cout * (double)in.frames * lo;
-        const int tiles = (lo + 127) / 128;
+        const int tiles = std::max((lo + 127) / 128, 4 * ((lo + 255) / 256));
         for (int s = 0; s < op.n_stages; ++s)
           if (op.stages[s].kind == JG_ST_NMD)
             nmd_elems[op.stages[s].arg] = std::max<int64_t>(nmd_elems[op.stages[s].arg],
@@ -354,6 +354,121 @@ static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
   return JG_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// split-f16 operand preparation (host): see jg_conv_f16.hip for the layouts
+// ---------------------------------------------------------------------------
+static inline uint16_t f16_bits(float x) {
+  _Float16 h = (_Float16)x;
+  uint16_t b;
+  memcpy(&b, &h, 2);
+  return b;
+}
+static inline float f16_value(float x) { return (float)(_Float16)x; }
+
+// which later op needs slot `buf` (written by op `i`) in plain f32?
+static bool slot_needs_f32(const jg_model *m, size_t i, int buf) {
+  for (size_t j = i + 1; j < m->ops.size(); ++j) {
+    const jg_op &o = m->ops[j];
+    if ((o.kind == JG_OP_POOL || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D ||
+         o.kind == JG_OP_FRAMESUM) && o.in_buf == buf)
+      return true;
+    if ((o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D ||
+         o.kind == JG_OP_FRAMESUM) && o.out_buf == buf)
+      return false;   // overwritten
+  }
+  return false;
+}
+
+static int prepare_f16(jg_model *m, const float *weights) {
+  m->hprep.assign(m->ops.size(), ConvHPrep());
+  m->f16_eligible = true;
+  m->f16_reason.clear();
+  auto fail = [&](const char *why) { m->f16_eligible = false; m->f16_reason = why; };
+  bool f32_fmt[JG_MAX_BUFS] = {};   // current format of each slot while walking the program
+  for (size_t i = 0; i < m->ops.size() && m->f16_eligible; ++i) {
+    const jg_op &op = m->ops[i];
+    if (op.kind == JG_OP_ELTWISE || op.kind == JG_OP_MAXPOOL1D || op.kind == JG_OP_FRAMESUM) {
+      fail("program has standalone elementwise / pooling ops");
+      break;
+    }
+    if (op.kind != JG_OP_CONV) continue;
+    if (op.stride != 1) { fail("strided conv"); break; }
+    if (op.cout % 16 != 0 || (op.cout + 31) / 32 * 32 != 128) { fail("conv width is not 128 channels"); break; }
+    if ((jg_conv_f16_tile_m() + 4 * op.dilation) * 4 > 3 * 512) { fail("dilation too large"); break; }
+    if (op.in_buf >= 0 && f32_fmt[op.in_buf]) { fail("conv input produced in f32"); break; }
+    for (int s = 0; s < op.n_stages; ++s)
+      if (op.stages[s].kind == JG_ST_ADD && f32_fmt[op.stages[s].arg]) fail("shortcut produced in f32");
+    if (!m->f16_eligible) break;
+    ConvHPrep &hp = m->hprep[i];
+    hp.out_f16s = !slot_needs_f32(m, i, op.out_buf);
+    f32_fmt[op.out_buf] = !hp.out_f16s;
+    const int cin16 = (op.cin + 15) / 16 * 16, cin_pad = (op.cin + 1) & ~1, cout_pad = 128;
+    hp.cc_in = cin16 / 16;
+    const float *w = weights + op.w_off;   // (k, cin_pad, cout_pad32) f32
+    const int cout_pad32 = (op.cout + 31) / 32 * 32;
+    float maxabs = 0.f;
+    for (int64_t q = 0; q < (int64_t)op.k * cin_pad * cout_pad32; ++q) maxabs = std::max(maxabs, fabsf(w[q]));
+    int sexp = 0;
+    if (maxabs > 0.f) {
+      int e2;
+      frexpf(maxabs, &e2);            // maxabs = f * 2^e2, f in [0.5, 1)
+      sexp = 3 - e2;                  // scaled max in [4, 8)
+    }
+    const float wscale = ldexpf(1.f, sexp);
+    hp.acc_scale = ldexpf(1.f, -sexp);
+    const int kc_total = cin16 / 8;
+    const size_t n_items = (size_t)2 * op.k * kc_total * cout_pad;
+    std::vector<uint16_t> wh(n_items * 8, 0);
+    for (int t = 0; t < op.k; ++t)
+      for (int c = 0; c < op.cin; ++c)
+        for (int n = 0; n < op.cout; ++n) {
+          const float v = w[((size_t)t * cin_pad + c) * cout_pad32 + n] * wscale;
+          const float hi = f16_value(v);
+          const size_t item = (((size_t)0 * op.k + t) * kc_total + c / 8) * cout_pad + n;
+          const size_t item_lo = (((size_t)1 * op.k + t) * kc_total + c / 8) * cout_pad + n;
+          wh[item * 8 + c % 8] = f16_bits(hi);
+          wh[item_lo * 8 + c % 8] = f16_bits(v - hi);
+        }
+    JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_wh), n_items * 16));
+    JG_HIP(hipMemcpy(hp.d_wh, wh.data(), n_items * 16, hipMemcpyHostToDevice));
+    if (op.in_buf == JG_BUF_IDS) {
+      const float *emb = weights + op.b_off;   // (vocab, cin)
+      const size_t e_items = (size_t)m->vocab * hp.cc_in * 4;
+      std::vector<uint16_t> eh(e_items * 8, 0);
+      for (int id = 0; id < m->vocab; ++id)
+        for (int c = 0; c < op.cin; ++c) {
+          const float v = emb[(size_t)id * op.cin + c];
+          const float hi = f16_value(v);
+          if (!(fabsf(v) <= 65000.f)) fail("embedding value outside the f16 range");
+          const int cc = c / 16, hh = (c % 16) / 8, j = c % 8;
+          eh[(((size_t)id * hp.cc_in + cc) * 4 + 0 * 2 + hh) * 8 + j] = f16_bits(hi);
+          eh[(((size_t)id * hp.cc_in + cc) * 4 + 1 * 2 + hh) * 8 + j] = f16_bits(v - hi);
+        }
+      JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_embh), e_items * 16));
+      JG_HIP(hipMemcpy(hp.d_embh, eh.data(), e_items * 16, hipMemcpyHostToDevice));
+    }
+  }
+  return JG_OK;
+}
+
+extern "C" int jg_model_set_precision(jg_model *m, int mode) {
+  JG_REQUIRE(m != nullptr && (mode == 0 || mode == 1), JG_ERR_INVALID, "jg_model_set_precision: bad args");
+  if (mode == 1 && !m->f16_eligible) {
+    jg_set_error("split-f16 path unavailable for this model: %s", m->f16_reason.c_str());
+    return JG_ERR_UNSUPPORTED;
+  }
+  if (mode != m->precision) {
+    JG_HIP(hipSetDevice(m->e->dev));
+    JG_HIP(hipStreamSynchronize(m->e->stream));
+    m->precision = mode;
+  }
+  return JG_OK;
+}
+
+extern "C" int jg_model_get_precision(const jg_model *m) { return m ? m->precision : -1; }
+
+extern "C" int jg_model_destroy(jg_model *m);
 extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const float *weights,
                                int64_t n_weights, int32_t vocab, jg_model **out) {
   JG_REQUIRE(e != nullptr && ops != nullptr && n_ops > 0 && weights != nullptr && n_weights > 0 &&
@@ -375,6 +490,11 @@ extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const 
   }
   JG_HIP(hipMemcpy(m->d_w, weights, (size_t)n_weights * sizeof(float), hipMemcpyHostToDevice));
   JG_HIP(hipMalloc(&m->d_lut, 80));
+  JG_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_overflow), sizeof(int)));
+  JG_HIP(hipMemset(m->d_overflow, 0, sizeof(int)));
+  rc = prepare_f16(m, weights);
+  if (rc != JG_OK) { jg_model_destroy(m); return rc; }
+  m->precision = m->f16_eligible ? 1 : 0;
   *out = m;
   return JG_OK;
 }
@@ -404,6 +524,11 @@ extern "C" int jg_model_destroy(jg_model *m) {
   if (m->d_counts) (void)hipFree(m->d_counts);
   if (m->d_win) (void)hipFree(m->d_win);
   if (m->d_lut) (void)hipFree(m->d_lut);
+  if (m->d_overflow) (void)hipFree(m->d_overflow);
+  for (auto &hp : m->hprep) {
+    if (hp.d_wh) (void)hipFree(hp.d_wh);
+    if (hp.d_embh) (void)hipFree(hp.d_embh);
+  }
   delete m;
   return JG_OK;
 }
@@ -465,30 +590,58 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         else in = sh[op.in_buf];
         int lo, pl;
         conv_geometry(in.L, op.k, op.stride, op.dilation, op.padding, &lo, &pl);
-        ConvArgs a;
-        memset(&a, 0, sizeof(a));
-        a.x = op.in_buf == JG_BUF_IDS ? nullptr : m->act[op.in_buf];
-        a.ids = op.in_buf == JG_BUF_IDS ? d_ids : nullptr;
-        a.emb = op.in_buf == JG_BUF_IDS ? m->d_w + op.b_off : nullptr;
-        a.mask_from_ids = op.in_mask == JG_BUF_IDS;
-        a.mask_in = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
-        a.mask_out = op.out_mask >= 0 ? m->msk[op.out_mask] : nullptr;
-        a.w = m->d_w + op.w_off;
-        a.y = m->act[op.out_buf];
-        a.rows = nw * in.frames;
-        a.L_in = in.L; a.L_out = lo;
-        a.cin = op.cin; a.cin_pad = (op.cin + 1) & ~1;
-        a.cout = op.cout; a.cout_pad = (op.cout + 31) / 32 * 32;
-        a.k = op.k; a.stride = op.stride; a.dil = op.dilation; a.pad_left = pl;
-        a.tiles_m = (lo + 127) / 128;
-        resolve_stages(m, op, a.st, &a.n_stages);
         ProfEvent pe;
         if (e->profile) {
           if ((rc = prof_event(e, &pe.a)) != JG_OK || (rc = prof_event(e, &pe.b)) != JG_OK) return rc;
-          pe.flops = 2.0 * op.k * op.cin * op.cout * (double)a.rows * lo;
+          pe.flops = 2.0 * op.k * op.cin * op.cout * (double)nw * in.frames * lo;
           JG_HIP(hipEventRecord(pe.a, s));
         }
-        rc = jg_launch_conv(e, a, s);
+        if (m->precision == 1) {
+          const ConvHPrep &hp = m->hprep[i];
+          ConvHArgs a;
+          memset(&a, 0, sizeof(a));
+          a.xh = op.in_buf == JG_BUF_IDS ? nullptr : reinterpret_cast<const uint4 *>(m->act[op.in_buf]);
+          a.ids = op.in_buf == JG_BUF_IDS ? d_ids : nullptr;
+          a.embh = hp.d_embh;
+          a.mask_from_ids = op.in_mask == JG_BUF_IDS;
+          a.mask_in = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
+          a.mask_out = op.out_mask >= 0 ? m->msk[op.out_mask] : nullptr;
+          a.wh = hp.d_wh;
+          a.y = m->act[op.out_buf];
+          a.overflow = m->d_overflow;
+          a.rows = nw * in.frames;
+          a.L_in = in.L; a.L_out = lo;
+          a.cc_in = hp.cc_in; a.cout = op.cout; a.cout_pad = 128;
+          a.k = op.k; a.dil = op.dilation; a.pad_left = pl;
+          a.tiles_m = (lo + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m();
+          a.out_f16s = hp.out_f16s ? 1 : 0;
+          a.acc_scale = hp.acc_scale;
+          resolve_stages(m, op, a.st, &a.n_stages);
+          for (int q = 0; q < a.n_stages; ++q) {
+            if (a.st[q].kind == JG_ST_ADD) a.addh = reinterpret_cast<const uint4 *>(a.st[q].p0);
+            if (a.st[q].kind == JG_ST_NMD) a.nmd_out = const_cast<float *>(a.st[q].p0);
+          }
+          rc = jg_launch_conv_f16(e, a, s);
+        } else {
+          ConvArgs a;
+          memset(&a, 0, sizeof(a));
+          a.x = op.in_buf == JG_BUF_IDS ? nullptr : m->act[op.in_buf];
+          a.ids = op.in_buf == JG_BUF_IDS ? d_ids : nullptr;
+          a.emb = op.in_buf == JG_BUF_IDS ? m->d_w + op.b_off : nullptr;
+          a.mask_from_ids = op.in_mask == JG_BUF_IDS;
+          a.mask_in = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
+          a.mask_out = op.out_mask >= 0 ? m->msk[op.out_mask] : nullptr;
+          a.w = m->d_w + op.w_off;
+          a.y = m->act[op.out_buf];
+          a.rows = nw * in.frames;
+          a.L_in = in.L; a.L_out = lo;
+          a.cin = op.cin; a.cin_pad = (op.cin + 1) & ~1;
+          a.cout = op.cout; a.cout_pad = (op.cout + 31) / 32 * 32;
+          a.k = op.k; a.stride = op.stride; a.dil = op.dilation; a.pad_left = pl;
+          a.tiles_m = (lo + 127) / 128;
+          resolve_stages(m, op, a.st, &a.n_stages);
+          rc = jg_launch_conv(e, a, s);
+        }
         if (e->profile && rc == JG_OK) {
           JG_HIP(hipEventRecord(pe.b, s));
           e->pending.push_back(pe);
@@ -545,9 +698,11 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         // op.arg = partial slot, in_mask = mask the tap used, cout = channels,
         // in_buf = activation slot whose shape gives the position count
         const Shape in = sh[op.in_buf];
-        const int tiles = (in.L + 127) / 128;
+        const int parts = m->precision == 1
+                              ? 4 * ((in.L + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m())
+                              : (in.L + 127) / 128;
         const uint8_t *mk = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
-        rc = jg_launch_nmd_final(m->nmd_part[op.arg], in.frames * tiles, mk, in.frames * in.L,
+        rc = jg_launch_nmd_final(m->nmd_part[op.arg], in.frames * parts, mk, in.frames * in.L,
                                  m->d_w + op.b_off, op.f0, nw, op.cout, m->vec[op.out_vec],
                                  m->vec_w[op.out_vec], op.vec_off, s);
       } break;
@@ -619,14 +774,26 @@ static int forward_device_ids(jg_model *m, const uint8_t *d_ids, int64_t n_win, 
   if (rc != JG_OK) return rc;
   const int w_pred = jg_model_vec_width(m, 0), w_rel = jg_model_vec_width(m, 1);
   const int w_emb = jg_model_vec_width(m, 2), w_nmd = jg_model_vec_width(m, 3);
-  for (int64_t w0 = 0; w0 < n_win; w0 += chunk) {
-    const int nw = (int)std::min<int64_t>(chunk, n_win - w0);
-    rc = run_chunk(m, d_ids + w0 * 6 * (int64_t)l, nw, l, s);
-    if (rc != JG_OK) return rc;
-    if ((rc = copy_out(m, 2, w_pred, prediction, w0, nw, out_loc, s)) != JG_OK) return rc;
-    if ((rc = copy_out(m, 3, w_rel, reliability, w0, nw, out_loc, s)) != JG_OK) return rc;
-    if ((rc = copy_out(m, 0, w_emb, embedding, w0, nw, out_loc, s)) != JG_OK) return rc;
-    if ((rc = copy_out(m, 1, w_nmd, nmd, w0, nw, out_loc, s)) != JG_OK) return rc;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int64_t w0 = 0; w0 < n_win; w0 += chunk) {
+      const int nw = (int)std::min<int64_t>(chunk, n_win - w0);
+      rc = run_chunk(m, d_ids + w0 * 6 * (int64_t)l, nw, l, s);
+      if (rc != JG_OK) return rc;
+      if ((rc = copy_out(m, 2, w_pred, prediction, w0, nw, out_loc, s)) != JG_OK) return rc;
+      if ((rc = copy_out(m, 3, w_rel, reliability, w0, nw, out_loc, s)) != JG_OK) return rc;
+      if ((rc = copy_out(m, 0, w_emb, embedding, w0, nw, out_loc, s)) != JG_OK) return rc;
+      if ((rc = copy_out(m, 1, w_nmd, nmd, w0, nw, out_loc, s)) != JG_OK) return rc;
+    }
+    if (m->precision != 1) break;
+    // split-f16 range guard: an activation beyond the f16 range poisons the fast path;
+    // fall back to the exact-f32 kernels for this and every later call of the model.
+    int flag = 0;
+    JG_HIP(hipMemcpyAsync(&flag, m->d_overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+    JG_HIP(hipStreamSynchronize(s));
+    if (flag == 0) break;
+    JG_HIP(hipMemsetAsync(m->d_overflow, 0, sizeof(int), s));
+    m->precision = 0;
+    m->f16_reason = "an activation left the f16 range at run time";
   }
   return JG_OK;
 }

@@ -52,6 +52,28 @@ struct ConvArgs {
   StageArg st[JG_MAX_STAGES];
 };
 
+// split-f16 conv (jg_conv_f16.hip); uint4 = one 16-byte item of 8 halfs
+struct ConvHArgs {
+  const uint4 *xh;         // F16S input [rows][cc_in][4][L_in] or null when ids != null
+  const uint8_t *ids;      // (rows, L_in) embedding-gather source
+  const uint4 *embh;       // pre-split table [vocab][cc_in][4]
+  const uint8_t *mask_in;  // (rows, L_in) or null
+  const uint8_t *mask_out; // (rows, L_out) or null
+  const uint4 *wh;         // [2 planes][k][cc_in*2][cout_pad]
+  void *y;                 // F16S [rows][cout_pad/16][4][L_out] items, or f32 (rows, L_out, cout)
+  const uint4 *addh;       // residual shortcut in F16S (same geometry as y) or null
+  float *nmd_out;          // NMD partial sums [rows][tiles_m][4][cout] or null
+  int *overflow;           // set to 1 when an output leaves the f16 range
+  int rows, L_in, L_out;
+  int cc_in, cout, cout_pad;
+  int k, dil, pad_left, tiles_m;
+  int mask_from_ids, out_f16s;
+  float acc_scale;         // 2^-s undoing the weight pre-scale
+  int dbg;                 // ablation switches (JG_DBG env, timing experiments only)
+  int n_stages;
+  StageArg st[JG_MAX_STAGES];
+};
+
 struct EltArgs {
   const float *x;
   float *y;
@@ -79,9 +101,22 @@ struct jg_engine {
   int n_cu = 256;
 };
 
+struct ConvHPrep {          // per CONV op: split-f16 operands (built at model creation)
+  uint4 *d_wh = nullptr;    // weights [2][k][cin16/8][cout_pad]
+  uint4 *d_embh = nullptr;  // embedding table [vocab][cin16/16][4] (conv on ids only)
+  float acc_scale = 1.f;
+  int cc_in = 0;
+  bool out_f16s = false;
+};
+
 struct jg_model {
   jg_engine *e = nullptr;
   std::vector<jg_op> ops;
+  std::vector<ConvHPrep> hprep;   // parallel to ops
+  int precision = 0;              // 0 = exact f32 MFMA, 1 = split-f16 (f16x3)
+  bool f16_eligible = false;
+  std::string f16_reason;         // why the fast path is unavailable
+  int *d_overflow = nullptr;
   float *d_w = nullptr;
   int64_t n_w = 0;
   int vocab = 0;
@@ -128,3 +163,6 @@ int jg_launch_maxpool1d(const float *x, const uint8_t *mask_in, int rows, int L_
 int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,
                        hipStream_t s);
 int jg_conv_tile_m(int cout);
+int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s);
+int jg_conv_f16_lds_bytes(int dil);
+int jg_conv_f16_tile_m(void);

@@ -147,6 +147,15 @@ class HipModel:
 
     __del__ = close
 
+    @property
+    def precision(self) -> str:
+        return "f16x3" if self.lib.jg_model_get_precision(self.handle) == 1 else "f32"
+
+    def set_precision(self, mode: str) -> None:
+        """"f32" = exact-f32 MFMA kernels, "f16x3" = split-f16 fast path (f32-accurate)."""
+        L.check(self.lib.jg_model_set_precision(self.handle, {"f32": 0, "f16x3": 1}[mode]),
+                "jg_model_set_precision")
+
     def flops_per_window(self, l: int) -> float:
         return float(self.lib.jg_model_flops_per_window(self.handle, int(l)))
 
@@ -216,7 +225,8 @@ class JaegerHipEngine:
 
     def __init__(self, path_dict: dict | None = None, *, model_cfg: dict | None = None,
                  weights: dict[str, np.ndarray] | None = None, device_id: int = 0,
-                 use_xla: bool = False, return_embedding: bool = False, chunk: int = 0):
+                 use_xla: bool = False, return_embedding: bool = False, chunk: int = 0,
+                 precision: str | None = None):
         self.use_xla = use_xla                      # accepted for signature parity; no-op
         self.return_embedding = return_embedding
         self.chunk = chunk
@@ -250,6 +260,8 @@ class JaegerHipEngine:
         self.program = compile_plan(self.plan, weights)
         self.device = HipDevice(device_id)
         self.model = HipModel(self.device, self.program)
+        if precision is not None:
+            self.model.set_precision(precision)
         if return_embedding and self.model.widths["embedding"] == 0:
             raise ValueError("The selected model does not expose an 'embedding' output.")
         self.lut = codon_lut(sp["codon_id"])

@@ -72,15 +72,24 @@ def same_pad(length: int, k: int, stride: int, dilation: int) -> tuple[int, int,
 
 
 def conv1d_nwc(x, kernel, stride, padding, dilation):
-    """tf.nn.conv1d on (N, L, Cin) with a (k, Cin, Cout) kernel."""
-    k = kernel.shape[0]
-    xt = x.transpose(1, 2)                                   # (N, Cin, L)
+    """tf.nn.conv1d on (N, L, Cin) with a (k, Cin, Cout) kernel, written as k shifted
+    GEMMs (y[:, m] = sum_t x[:, m*s + t*d - pad_left] @ W[t]) so the CPU baseline runs
+    on the BLAS sgemm path like TensorFlow's oneDNN/Eigen conv does."""
+    k, cin, cout = kernel.shape
+    n, length, _ = x.shape
     if padding == "SAME":
-        _, pl, pr = same_pad(x.shape[1], k, stride, dilation)
-        xt = F.pad(xt, (pl, pr))
-    w = kernel.permute(2, 1, 0).contiguous()                 # (Cout, Cin, k)
-    y = F.conv1d(xt, w, None, stride=stride, dilation=dilation)
-    return y.transpose(1, 2)                                 # (N, L_out, Cout)
+        l_out, pl, pr = same_pad(length, k, stride, dilation)
+        x = F.pad(x, (0, 0, pl, pr))
+    else:
+        span = dilation * (k - 1) + 1
+        l_out = (length - span) // stride + 1 if length >= span else 0
+    y = None
+    for t in range(k):
+        start = t * dilation
+        xs = x[:, start:start + (l_out - 1) * stride + 1:stride, :]
+        term = xs.reshape(-1, cin) @ kernel[t]
+        y = term if y is None else y + term
+    return y.reshape(n, l_out, cout)
 
 
 def masked_conv1d(x, mask, w: dict, *, kernel_size, strides=1, padding="valid",

@@ -79,7 +79,7 @@ def test_encoder_case_flags_and_id_maps(device):
     np.testing.assert_array_equal(ids[2], lit.astype(np.uint8))
 
 
-def _forward_case(name, fsize, n_win, seed, n_frac, chunk=0, short=False):
+def _forward_case(name, fsize, n_win, seed, n_frac, chunk=0, short=False, precision=None):
     from jaeger_amd.engine import JaegerHipEngine, frame_length
     from oracle import encoder as oenc
     from oracle import forward as ofwd
@@ -91,47 +91,73 @@ def _forward_case(name, fsize, n_win, seed, n_frac, chunk=0, short=False):
     lens = np.full(n_win, fsize, np.int32)
     if short:
         lens[1::3] = rng.integers(fsize // 2, fsize, lens[1::3].size)
-    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, chunk=chunk)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, chunk=chunk, precision=precision)
+    if precision is not None:
+        assert eng.model.precision == precision
     got = eng.predict_windows(seq, starts, lens, fsize)
     windows = [seq[s:s + n].tobytes() for s, n in zip(starts, lens)]
     ids = oenc.encode_windows(windows, fsize, pad_to=frame_length(fsize))
     ref = ofwd.forward(cfg, weights, ids)
     # the id-tensor entry point must agree with the fused one bit for bit
     got2 = eng.model.forward(ids, chunk=chunk)
+    mode = eng.model.precision
     eng.close()
     errs = {}
     for k, r in ref.items():
         assert got[k].shape == r.shape, k
         errs[k] = float(np.abs(got[k] - r).max())
         np.testing.assert_array_equal(got[k], got2[k])
-    print(name, fsize, {k: f"{v:.2e}" for k, v in errs.items()})
+    print(name, fsize, mode, {k: f"{v:.2e}" for k, v in errs.items()})
     for k, v in errs.items():
-        assert v <= TOL, (k, v)
+        # the 1e-4 gate is on the logits; wide-range side outputs scale with their magnitude
+        tol = TOL if k in ("prediction", "reliability") else TOL * max(1.0, float(np.abs(ref[k]).max()) / 8)
+        assert v <= tol, (k, v, tol)
     ref_counts = np.array([oenc.window_counts(w) for w in windows], np.int32)
     np.testing.assert_array_equal(got["counts"], ref_counts)
 
 
-def test_forward_brain_1500():
-    _forward_case("brain", 1500, 10, 1, n_frac=0.0)
+PRECISIONS = ["f32", "f16x3"]
 
 
-def test_forward_brain_1500_with_n_runs_chunked():
-    _forward_case("brain", 1500, 11, 2, n_frac=0.03, chunk=4)
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_brain_1500(precision):
+    _forward_case("brain", 1500, 10, 1, n_frac=0.0, precision=precision)
 
 
-def test_forward_brain_2000_short_windows():
-    _forward_case("brain", 2000, 7, 3, n_frac=0.01, short=True)
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_brain_1500_with_n_runs_chunked(precision):
+    _forward_case("brain", 1500, 11, 2, n_frac=0.03, chunk=4, precision=precision)
 
 
-def test_forward_zeus_dyt():
-    _forward_case("zeus", 1500, 6, 4, n_frac=0.01)
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_brain_2000_short_windows(precision):
+    _forward_case("brain", 2000, 7, 3, n_frac=0.01, short=True, precision=precision)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_zeus_dyt(precision):
+    _forward_case("zeus", 1500, 6, 4, n_frac=0.01, precision=precision)
+
+
+def test_default_precision_is_f16x3_when_eligible():
+    from jaeger_amd.engine import JaegerHipEngine
+    from oracle import forward as ofwd
+    for name, want in (("brain", "f16x3"), ("baseline500", "f32")):
+        cfg = load_model_cfg(name)
+        eng = JaegerHipEngine(model_cfg=cfg, weights=ofwd.random_weights(cfg))
+        assert eng.model.precision == want
+        if want == "f32":
+            with pytest.raises(Exception):
+                eng.model.set_precision("f16x3")
+        eng.close()
 
 
 def test_forward_baseline500():
     _forward_case("baseline500", 500, 64, 5, n_frac=0.02)
 
 
-def test_forward_all_masked_window():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_all_masked_window(precision):
     """A window of only N: every position invalid -> max pool emits zeros (layers.py:523-528)."""
     from jaeger_amd.engine import JaegerHipEngine, frame_length
     from oracle import encoder as oenc
@@ -144,7 +170,7 @@ def test_forward_all_masked_window():
     seq[fsize:2 * fsize] = ord("N")
     starts = (np.arange(3) * fsize).astype(np.int64)
     lens = np.full(3, fsize, np.int32)
-    eng = JaegerHipEngine(model_cfg=cfg, weights=weights)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, precision=precision)
     got = eng.predict_windows(seq, starts, lens, fsize)
     eng.close()
     ids = oenc.encode_windows([seq[s:s + fsize].tobytes() for s in starts], fsize, pad_to=frame_length(fsize))
