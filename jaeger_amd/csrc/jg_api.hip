@@ -293,7 +293,7 @@ static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
         sh[op.out_buf] = Shape{in.frames, lo, op.cout};
         act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)in.frames * lo * op.cout);
         fl += 2.0 * op.k * op.cin * op.cout * (double)in.frames * lo;
-        const int tiles = std::max((lo + 127) / 128, 4 * ((lo + 255) / 256));
+        const int tiles = std::max((lo + 127) / 128, 8 * ((lo + 255) / 256));
         for (int s = 0; s < op.n_stages; ++s)
           if (op.stages[s].kind == JG_ST_NMD)
             nmd_elems[op.stages[s].arg] = std::max<int64_t>(nmd_elems[op.stages[s].arg],
@@ -394,8 +394,8 @@ static int prepare_f16(jg_model *m, const float *weights) {
     }
     if (op.kind != JG_OP_CONV) continue;
     if (op.stride != 1) { fail("strided conv"); break; }
+    if (!jg_conv_f16_supports(op.k, op.dilation)) { fail("taps / dilation outside the split-f16 tiling"); break; }
     if (op.cout % 16 != 0 || (op.cout + 31) / 32 * 32 != 128) { fail("conv width is not 128 channels"); break; }
-    if ((jg_conv_f16_tile_m() + 4 * op.dilation) * 4 > 3 * 512) { fail("dilation too large"); break; }
     if (op.in_buf >= 0 && f32_fmt[op.in_buf]) { fail("conv input produced in f32"); break; }
     for (int s = 0; s < op.n_stages; ++s)
       if (op.stages[s].kind == JG_ST_ADD && f32_fmt[op.stages[s].arg]) fail("shortcut produced in f32");
@@ -447,6 +447,69 @@ static int prepare_f16(jg_model *m, const float *weights) {
         }
       JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_embh), e_items * 16));
       JG_HIP(hipMemcpy(hp.d_embh, eh.data(), e_items * 16, hipMemcpyHostToDevice));
+    }
+    // compact epilogue: fold acc un-scale, bias and batch-norm chains into per-channel affines
+    {
+      std::vector<float> tab;                       // [n_hst][2][128]
+      std::vector<double> sc(128, (double)hp.acc_scale), sh(128, 0.0);
+      bool pending = true;                          // an affine (the un-scale) is always pending first
+      hp.n_hst = 0;
+      auto flush = [&]() {
+        if (!pending) return;
+        HStageArg h{JG_HST_AFFINE, 0, 0.f, 0};
+        hp.hst[hp.n_hst++] = h;
+        for (int n = 0; n < 128; ++n) tab.push_back((float)sc[n]);
+        for (int n = 0; n < 128; ++n) tab.push_back((float)sh[n]);
+        std::fill(sc.begin(), sc.end(), 1.0);
+        std::fill(sh.begin(), sh.end(), 0.0);
+        pending = false;
+      };
+      for (int q = 0; q < op.n_stages && m->f16_eligible; ++q) {
+        const jg_stage &st = op.stages[q];
+        auto vecp = [&](int64_t off) { return weights + off; };
+        if (st.kind == JG_ST_BIAS) {
+          for (int n = 0; n < op.cout; ++n) sh[n] += (double)vecp(st.p0)[n];
+          pending = true;
+          continue;
+        }
+        if (st.kind == JG_ST_BN) {   // g*((x-mu)*is)+b on top of x = v*sc+sh
+          for (int n = 0; n < op.cout; ++n) {
+            const double mu = vecp(st.p0)[n], is = vecp(st.p1)[n], g = vecp(st.p2)[n], b = vecp(st.p3)[n];
+            sc[n] = sc[n] * is * g;
+            sh[n] = (sh[n] - mu) * is * g + b;
+          }
+          pending = true;
+          continue;
+        }
+        flush();
+        if (hp.n_hst >= JG_MAX_STAGES) { fail("epilogue too long"); break; }
+        HStageArg h{0, st.arg, st.f0, 0};
+        switch (st.kind) {
+          case JG_ST_DYT:
+            h.kind = JG_HST_DYT;
+            for (int n = 0; n < 128; ++n) tab.push_back(n < op.cout ? vecp(st.p2)[n] : 0.f);
+            for (int n = 0; n < 128; ++n) tab.push_back(n < op.cout ? vecp(st.p3)[n] : 0.f);
+            break;
+          case JG_ST_ADD: h.kind = JG_HST_ADD; hp.add_slot = st.arg; break;
+          case JG_ST_ACT:
+            h.kind = JG_HST_ACT;
+            if (st.arg == JG_ACT_GELU_ERF) fail("exact-erf GELU is only implemented on the f32 path");
+            break;
+          case JG_ST_NMD: h.kind = JG_HST_NMD; hp.nmd_slot = st.arg; break;
+          case JG_ST_MASKMUL: h.kind = JG_HST_MASKMUL; break;
+          default: fail("epilogue stage not supported by the split-f16 kernel"); break;
+        }
+        if (h.kind != JG_HST_DYT) tab.resize(tab.size() + 256, 0.f);
+        hp.hst[hp.n_hst++] = h;
+      }
+      if (m->f16_eligible) {
+        if (pending && hp.n_hst >= JG_MAX_STAGES) fail("epilogue too long");
+        else flush();
+      }
+      if (m->f16_eligible) {
+        JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_epi), tab.size() * sizeof(float)));
+        JG_HIP(hipMemcpy(hp.d_epi, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+      }
     }
   }
   return JG_OK;
@@ -528,6 +591,7 @@ extern "C" int jg_model_destroy(jg_model *m) {
   for (auto &hp : m->hprep) {
     if (hp.d_wh) (void)hipFree(hp.d_wh);
     if (hp.d_embh) (void)hipFree(hp.d_embh);
+    if (hp.d_epi) (void)hipFree(hp.d_epi);
   }
   delete m;
   return JG_OK;
@@ -615,12 +679,11 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           a.k = op.k; a.dil = op.dilation; a.pad_left = pl;
           a.tiles_m = (lo + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m();
           a.out_f16s = hp.out_f16s ? 1 : 0;
-          a.acc_scale = hp.acc_scale;
-          resolve_stages(m, op, a.st, &a.n_stages);
-          for (int q = 0; q < a.n_stages; ++q) {
-            if (a.st[q].kind == JG_ST_ADD) a.addh = reinterpret_cast<const uint4 *>(a.st[q].p0);
-            if (a.st[q].kind == JG_ST_NMD) a.nmd_out = const_cast<float *>(a.st[q].p0);
-          }
+          a.n_hst = hp.n_hst;
+          a.epi = hp.d_epi;
+          for (int q = 0; q < hp.n_hst; ++q) a.hst[q] = hp.hst[q];
+          if (hp.add_slot >= 0) a.addh = reinterpret_cast<const uint4 *>(m->act[hp.add_slot]);
+          if (hp.nmd_slot >= 0) a.nmd_out = m->nmd_part[hp.nmd_slot];
           rc = jg_launch_conv_f16(e, a, s);
         } else {
           ConvArgs a;
@@ -699,7 +762,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         // in_buf = activation slot whose shape gives the position count
         const Shape in = sh[op.in_buf];
         const int parts = m->precision == 1
-                              ? 4 * ((in.L + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m())
+                              ? 8 * ((in.L + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m())
                               : (in.L + 127) / 128;
         const uint8_t *mk = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
         rc = jg_launch_nmd_final(m->nmd_part[op.arg], in.frames * parts, mk, in.frames * in.L,

@@ -52,6 +52,16 @@ struct ConvArgs {
   StageArg st[JG_MAX_STAGES];
 };
 
+// compact epilogue of the split-f16 conv: bias / batch-norm chains are folded into one
+// per-channel affine on the host (f64), parameters live in a (stage, 2, 128) f32 table
+enum { JG_HST_AFFINE = 1, JG_HST_DYT = 2, JG_HST_ADD = 3, JG_HST_ACT = 4, JG_HST_NMD = 5, JG_HST_MASKMUL = 6 };
+struct HStageArg {
+  int kind;
+  int arg;
+  float f0;
+  int pad_;
+};
+
 // split-f16 conv (jg_conv_f16.hip); uint4 = one 16-byte item of 8 halfs
 struct ConvHArgs {
   const uint4 *xh;         // F16S input [rows][cc_in][4][L_in] or null when ids != null
@@ -68,10 +78,10 @@ struct ConvHArgs {
   int cc_in, cout, cout_pad;
   int k, dil, pad_left, tiles_m;
   int mask_from_ids, out_f16s;
-  float acc_scale;         // 2^-s undoing the weight pre-scale
   int dbg;                 // ablation switches (JG_DBG env, timing experiments only)
-  int n_stages;
-  StageArg st[JG_MAX_STAGES];
+  int n_hst;
+  const float *epi;        // [n_hst][2][128] epilogue parameters
+  HStageArg hst[JG_MAX_STAGES];
 };
 
 struct EltArgs {
@@ -107,6 +117,10 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   float acc_scale = 1.f;
   int cc_in = 0;
   bool out_f16s = false;
+  float *d_epi = nullptr;   // compact epilogue parameter table
+  int n_hst = 0;
+  HStageArg hst[JG_MAX_STAGES] = {};
+  int add_slot = -1, nmd_slot = -1;
 };
 
 struct jg_model {
@@ -164,5 +178,6 @@ int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame,
                        hipStream_t s);
 int jg_conv_tile_m(int cout);
 int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s);
-int jg_conv_f16_lds_bytes(int dil);
+int jg_conv_f16_lds_bytes(int k, int dil);
+bool jg_conv_f16_supports(int k, int dil);
 int jg_conv_f16_tile_m(void);

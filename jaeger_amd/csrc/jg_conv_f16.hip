@@ -3,7 +3,7 @@
 //
 // Every f32 operand is carried as an f16 pair  x = hi + lo  (hi = f16(x),
 // lo = f16(x - hi), 22 significant bits together) and each logical product is
-// three MFMAs accumulating in f32:  a.w ~= hi_a*hi_w + lo_a*hi_w + hi_a*lo_w
+// three MFMAs accumulating in f32:  x.w ~= hi_x*hi_w + lo_x*hi_w + hi_x*lo_w
 // (the dropped lo*lo term is 2^-22 relative).  v_mfma_f32_32x32x16_f16 runs at
 // 16x the rate of the exact-f32 MFMA, so the scheme nets ~5.3x the f32 roof
 // while keeping the logits inside the 1e-4 gate (tests/test_gpu_parity.py).
@@ -12,384 +12,543 @@
 //   F16S activations, per (window, frame) row block of L positions and C = 16*CC
 //     channels:  [cc][plane hi|lo][h][L][8 halfs]   (16-byte items; channel
 //     c = 16*cc + 8*h + j).  Same 4 B/element as f32, but a tile's operand slice
-//     for one 16-channel chunk is 4 contiguous runs - coalesced 16-B loads in,
+//     for one 16-channel chunk is 4 contiguous runs - coalesced 16-B DMA in,
 //     conflict-free ds_read_b128 MFMA fragments out.
 //   weights  [plane][tap][kc = cin/8][cout_pad][8 halfs], pre-scaled by 2^s so
 //     the lo parts stay out of the f16 subnormal range (undone in the epilogue).
 //
-// One persistent workgroup (8 waves, 4(M) x 2(N), 64x64 outputs per wave) walks
-// 256 x 128 output tiles.  The K loop is cut into stages = (16-channel chunk,
-// group of <= 5 taps); stage s+1's operands are fetched into registers while
-// stage s runs on the matrix cores from the other LDS buffer (one barrier per
-// stage).  Mask multiply, zero padding and the embedding gather happen while
-// staging; bias / norm / residual add / activation / NMD tap run in the epilogue.
+// Work decomposition.  One persistent workgroup (8 waves, 4 x 2, each wave 64
+// positions x 64 channels of a tile) walks PAIRS of 256-position x 128-channel
+// output tiles that share every weight slice.  The K loop runs in steps = (16-
+// channel chunk, tap): a step needs one 8 KB weight slice and the chunk's two
+// activation slices.  Everything moves global->LDS by DMA (global_load_lds with
+// an SGPR base + per-lane 32-bit offset, no register staging): weight slices
+// K-2 steps ahead into a ring with one slot per tap, activation slices one chunk
+// ahead into a double buffer.  Steps wait with COUNTED s_waitcnt vmcnt, so the
+// DMA queue never drains; zero padding / mask multiply are applied by zero-
+// filling the affected 16-byte pieces after the DMA has landed (rare), the
+// embedding gather of the first conv is a DMA from the pre-split table.
+// The MFMAs take the WEIGHTS as their A operand, so an accumulator register
+// holds one channel and a lane holds one position: the fused epilogue (folded
+// bias/batch-norm affine, residual add, GELU, NMD tap, f16 re-split) needs no
+// cross-lane transpose and reads its per-channel parameters from LDS.
 #include <stdlib.h>
 
 #include "jg_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int HM = 256;       // tile rows (positions)
 constexpr int HN = 128;       // tile cols (output channels)
 constexpr int HT = 512;       // threads
-constexpr int TGMAX = 5;      // taps per stage
-constexpr int A_ITERS = 3;    // 16-B A pieces per thread per stage (<= 4*384/512)
-constexpr int B_ITERS = TGMAX;
+constexpr int NT = 2;         // tiles per workgroup pass (share the weight slices)
+constexpr int A_ITERS = 5;    // 16-B activation pieces per thread per chunk (NT*4*rows_a <= 2560)
+constexpr int W_ITEMS = 2 * 2 * HN;           // 16-B items of one weight slice (chunk, tap): 8 KB
 
+// GELU (tanh form) as x * sigmoid(2u), u = sqrt(2/pi)(x + 0.044715 x^3): one v_exp_f32 and
+// one v_rcp_f32 (~1 ulp each) instead of a libm tanhf; abs error < 1e-6 * |x|.
+__device__ __forceinline__ float fast_gelu(float v) {
+  const float t = v * (-2.3022082f - 0.10294324f * v * v);   // -2u * log2(e)
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+}
+__device__ __forceinline__ float fast_tanh(float v) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853901f * v));
+}
 __device__ __forceinline__ float jg_act(float v, int act) {
   switch (act) {
-    case JG_ACT_GELU_TANH: {
-      const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-      return 0.5f * v * (1.0f + tanhf(u));
-    }
-    case JG_ACT_GELU_ERF: return 0.5f * v * erfcf(-v * 0.70710678118654752f);
+    case JG_ACT_GELU_TANH: return fast_gelu(v);
     case JG_ACT_RELU: return fmaxf(v, 0.0f);
-    case JG_ACT_TANH: return tanhf(v);
-    case JG_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case JG_ACT_TANH: return fast_tanh(v);
+    case JG_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950f * v));
     default: return v;
   }
 }
 
-// stages on 4 consecutive channels; ADD takes the already-loaded shortcut values
-__device__ __forceinline__ float4 apply4(float4 v, const StageArg *st, int n_stages, int n,
-                                         float4 addv, float mk, float4 &nmd) {
-  for (int s = 0; s < n_stages; ++s) {
-    const StageArg &g = st[s];
-    switch (g.kind) {
-      case JG_ST_BIAS: {
-        const float4 b = *reinterpret_cast<const float4 *>(g.p0 + n);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-      } break;
-      case JG_ST_BN: {
-        const float4 mu = *reinterpret_cast<const float4 *>(g.p0 + n);
-        const float4 is = *reinterpret_cast<const float4 *>(g.p1 + n);
-        const float4 ga = *reinterpret_cast<const float4 *>(g.p2 + n);
-        const float4 be = *reinterpret_cast<const float4 *>(g.p3 + n);
-        v.x = ga.x * ((v.x - mu.x) * is.x) + be.x;
-        v.y = ga.y * ((v.y - mu.y) * is.y) + be.y;
-        v.z = ga.z * ((v.z - mu.z) * is.z) + be.z;
-        v.w = ga.w * ((v.w - mu.w) * is.w) + be.w;
-      } break;
-      case JG_ST_DYT: {
-        const float4 ga = *reinterpret_cast<const float4 *>(g.p2 + n);
-        const float4 be = *reinterpret_cast<const float4 *>(g.p3 + n);
-        const float al = g.f0, mm = g.arg ? mk : 1.0f;
-        v.x = (tanhf(al * v.x) * ga.x + be.x) * mm;
-        v.y = (tanhf(al * v.y) * ga.y + be.y) * mm;
-        v.z = (tanhf(al * v.z) * ga.z + be.z) * mm;
-        v.w = (tanhf(al * v.w) * ga.w + be.w) * mm;
-      } break;
-      case JG_ST_ADD:
-        v.x += addv.x; v.y += addv.y; v.z += addv.z; v.w += addv.w;
-        break;
-      case JG_ST_ACT:
-        v.x = jg_act(v.x, g.arg); v.y = jg_act(v.y, g.arg);
-        v.z = jg_act(v.z, g.arg); v.w = jg_act(v.w, g.arg);
-        break;
-      case JG_ST_NMD:
-        nmd.x += v.x * mk; nmd.y += v.y * mk; nmd.z += v.z * mk; nmd.w += v.w * mk;
-        break;
-      case JG_ST_MASKMUL:
-        v.x *= mk; v.y *= mk; v.z *= mk; v.w *= mk;
-        break;
-      default: break;
-    }
-  }
-  return v;
+// 16-byte-per-lane global -> LDS DMA: global address = SGPR base + per-lane 32-bit byte offset,
+// LDS address = wave-uniform base (M0) + lane*16.  Issued from inline asm on purpose: hipcc
+// serialises the builtin form behind vmcnt(0) waits (one per DMA, and again before the first
+// ds_read), which forbids any overlap with the matrix cores.  The kernel tracks the DMA queue
+// itself with counted s_waitcnt vmcnt(N).
+__device__ __forceinline__ void glds16(const void *sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ void split8(const float *v, uint4 &hi, uint4 &lo, bool &ovf) {
-  half8 h, l;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const _Float16 hh = (_Float16)v[j];
-    h[j] = hh;
-    l[j] = (_Float16)(v[j] - (float)hh);
-    ovf |= !(fabsf(v[j]) <= 65000.0f);
-  }
-  hi = *reinterpret_cast<uint4 *>(&h);
-  lo = *reinterpret_cast<uint4 *>(&l);
-}
-
-__device__ __forceinline__ void join8(const uint4 &hi, const uint4 &lo, float *v) {
-  const half8 h = *reinterpret_cast<const half8 *>(&hi);
-  const half8 l = *reinterpret_cast<const half8 *>(&lo);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (float)h[j] + (float)l[j];
-}
-
-struct Stage {   // one pipeline stage of one tile
-  int rowblk, m0, cc, t0, nt;
+struct Tile {
+  int rowblk, m0, valid;
 };
 
+template <int K>
 __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
+  constexpr int WA = K - 2;                  // weight slices in flight ahead of the matrix cores
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
   const int i = lane & 31, h = lane >> 5;
   // LDS carve (16-byte units)
-  const int rows_a = HM + (TGMAX - 1) * a.dil;            // rows of one A stage buffer (max)
-  uint4 *Abuf = lds;                                       // [2][4][rows_a]
-  uint4 *Bbuf = lds + 2 * 4 * rows_a;                      // [2][2 planes][TGMAX][2 h][HN]
-  float *scratch = reinterpret_cast<float *>(Bbuf + 2 * 2 * TGMAX * 2 * HN) + wid * (32 * 33);
+  const int rows_a = HM + (K - 1) * a.dil;                 // rows of one activation slice
+  const int a_items = NT * 4 * rows_a;                      // [NT][4 ph][rows_a]
+  uint4 *Abuf = lds;                                        // [2 bufs][a_items]
+  uint4 *Wbuf = lds + 2 * a_items;                          // [K slots][2 planes][2 h][HN]
+  float *epiL = reinterpret_cast<float *>(Wbuf + K * W_ITEMS);
+  for (int q = tid; q < a.n_hst * 2 * HN; q += HT) epiL[q] = a.epi[q];   // visible after the first barrier
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+  // wave-uniform LDS byte addresses of this wave's DMA destinations
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);                       // + buf*a_items*16 + it*8192
+  const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + wid * 1024);   // + slot*8192
 
-  const int n_tg = (a.k + TGMAX - 1) / TGMAX;
-  const int stages_per_tile = a.cc_in * n_tg;
-  const int n_tiles = a.rows * a.tiles_m;                  // BN = cout_pad = 128: one N block
-  int my_tiles = 0;
-  if ((int)blockIdx.x < n_tiles) my_tiles = (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
-  const int total_stages = my_tiles * stages_per_tile;
-  if (total_stages == 0) return;
+  const int n_tiles = a.rows * a.tiles_m;
+  const int n_pairs = (n_tiles + NT - 1) / NT;
+  int my_pairs = 0;
+  if ((int)blockIdx.x < n_pairs) my_pairs = (n_pairs - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+  if (my_pairs == 0) return;
 
-  auto stage_of = [&](int s) {
-    Stage st;
-    const int tl = s / stages_per_tile, r = s - tl * stages_per_tile;
-    const int T = blockIdx.x + tl * gridDim.x;
-    st.rowblk = T / a.tiles_m;
-    st.m0 = (T - st.rowblk * a.tiles_m) * HM;
-    st.cc = r / n_tg;
-    const int tg = r - st.cc * n_tg;
-    st.t0 = tg * TGMAX;
-    st.nt = min(TGMAX, a.k - st.t0);
-    return st;
+  // per-thread activation piece coordinates: q -> (tile u, plane/half ph, row r)
+  // packed as (u << 20) | (ph << 16) | r to keep the register footprint small
+  unsigned a_pk[A_ITERS];
+#pragma unroll
+  for (int it = 0; it < A_ITERS; ++it) {
+    const int q = tid + it * HT;
+    const int u = q / (4 * rows_a);     // >= NT: no piece
+    const int rem = q - u * 4 * rows_a;
+    const int ph = rem / rows_a;
+    a_pk[it] = ((unsigned)u << 20) | ((unsigned)ph << 16) | (unsigned)(rem - ph * rows_a);
+  }
+  // weight slice: one item per thread, [plane][h][n] -> byte offset inside the tap-major blob
+  const unsigned w_voff = (unsigned)((((tid >> 8) * K * a.cc_in * 2 + ((tid >> 7) & 1)) * HN + (tid & (HN - 1))) * 16);
+
+  auto tiles_of = [&](int pass, Tile *t) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int T = (blockIdx.x + pass * gridDim.x) * NT + u;
+      const int Tc = min(T, n_tiles - 1);
+      t[u].rowblk = Tc / a.tiles_m;
+      t[u].m0 = (Tc - t[u].rowblk * a.tiles_m) * HM;
+      t[u].valid = T < n_tiles;
+    }
   };
 
-  uint4 ra[A_ITERS], rb[B_ITERS];
-
-  // ---- fetch one stage's operands into registers ---------------------------------
-  auto fetch = [&](const Stage &st) {
-    const int rows_g = HM + (st.nt - 1) * a.dil;          // rows this tap group touches
-    const int pbase = st.m0 - a.pad_left + st.t0 * a.dil; // input position of LDS row 0
+  // ---- per-pass piece table --------------------------------------------------------------
+  // A piece's source offset and validity depend on its input position only (in range, mask
+  // byte / codon id non-zero), not on the channel chunk: per pass each thread keeps 5 byte
+  // offsets (relative to the chunk's SGPR base) and 5 validity bits.  The position bytes are
+  // read one pass ahead (raw[]), so no step ever waits on a dependent load.
+  const uint8_t *bsrc = a.ids != nullptr ? a.ids : a.mask_in;
+  unsigned char raw[A_ITERS];
+  unsigned x_voff[A_ITERS];
+  unsigned x_ok = 0;
+  auto piece_pos = [&](const Tile *tl2, int it, int &pc, bool &inr) -> int {
+    const int a_u = (int)(a_pk[it] >> 20), a_r = (int)(a_pk[it] & 0xffff);
+    const int u = min(a_u, NT - 1);
+    const int m0 = u == 0 ? tl2[0].m0 : tl2[1].m0;
+    const int rb = u == 0 ? tl2[0].rowblk : tl2[1].rowblk;
+    const int vd = u == 0 ? tl2[0].valid : tl2[1].valid;
+    const int p = m0 - a.pad_left + a_r;
+    pc = min(max(p, 0), a.L_in - 1);
+    inr = a_u < NT && vd && p >= 0 && p < a.L_in;
+    return rb;
+  };
+  auto load_bytes = [&](const Tile *tl2) {
+    if (bsrc != nullptr) {
 #pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      const int q = tid + it * HT;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      const int ph = q / rows_g;
-      if (ph < 4) {
-        const int r = q - ph * rows_g;
-        const int p = pbase + r;
-        if (p >= 0 && p < a.L_in) {
-          const size_t pos = (size_t)st.rowblk * a.L_in + p;
-          if (a.ids != nullptr) {
-            const int id = a.ids[pos];
-            if (id != 0 || !a.mask_from_ids)
-              v = a.embh[((size_t)id * a.cc_in + st.cc) * 4 + ph];
-          } else if (a.mask_in == nullptr || a.mask_in[pos] != 0) {
-            v = a.xh[(((size_t)st.rowblk * a.cc_in + st.cc) * 4 + ph) * a.L_in + p];
-          }
-        }
+      for (int it = 0; it < A_ITERS; ++it) {
+        int pc; bool inr;
+        const int rb = piece_pos(tl2, it, pc, inr);
+        raw[it] = bsrc[(size_t)rb * a.L_in + pc];
       }
-      ra[it] = v;
-    }
-    // weights: [plane][tap][kc][cout_pad][8]; stage slice = planes x taps x h x HN items
-    const int kc_total = a.cc_in * 2;
+    } else {
 #pragma unroll
-    for (int it = 0; it < B_ITERS; ++it) {
-      const int q = tid + it * HT;               // = ((plane*TGMAX + tl)*2 + hh)*HN + n
-      const int n = q & (HN - 1);
-      const int blk = q >> 7;                    // HN == 128
-      const int hh = blk & 1;
-      const int tl = (blk >> 1) % TGMAX;
-      const int plane = (blk >> 1) / TGMAX;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (tl < st.nt)
-        v = a.wh[(((size_t)plane * a.k + (st.t0 + tl)) * kc_total + (st.cc * 2 + hh)) * a.cout_pad + n];
-      rb[it] = v;
+      for (int it = 0; it < A_ITERS; ++it) raw[it] = 1;
     }
   };
-
-  auto commit = [&](const Stage &st, int buf) {
-    const int rows_g = HM + (st.nt - 1) * a.dil;
-    uint4 *A = Abuf + buf * 4 * rows_a;
+  auto build_pieces = [&](const Tile *tl2) {     // consumes raw[] (loaded a pass ago)
+    x_ok = 0;
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
-      const int q = tid + it * HT;
-      const int ph = q / rows_g;
-      if (ph < 4) A[ph * rows_a + (q - ph * rows_g)] = ra[it];
+      int pc; bool inr;
+      const int rb = piece_pos(tl2, it, pc, inr);
+      const unsigned ph = (a_pk[it] >> 16) & 3;
+      const unsigned byte = raw[it];
+      bool keep;
+      if (a.ids != nullptr) {       // embedding gather (first conv): byte = codon id
+        x_voff[it] = (byte * a.cc_in * 4 + ph) * 16;
+        keep = byte != 0 || !a.mask_from_ids;
+      } else {
+        x_voff[it] = (unsigned)(((rb * a.cc_in * 4 + (int)ph) * a.L_in + pc) * 16);
+        keep = byte != 0;
+      }
+      if (inr && keep) x_ok |= 1u << it;
     }
-    uint4 *B = Bbuf + buf * (2 * TGMAX * 2 * HN);
+  };
+  const char *x_base = a.ids != nullptr ? reinterpret_cast<const char *>(a.embh)
+                                        : reinterpret_cast<const char *>(a.xh);
+  const unsigned x_cc_stride = a.ids != nullptr ? 4u * 16u : 4u * (unsigned)a.L_in * 16u;   // bytes per chunk
+
+  // ---- DMA issue ---------------------------------------------------------------------------
+  auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
+    if (a.dbg & 16) return;
+    glds16(reinterpret_cast<const char *>(a.wh) + ((size_t)(t * a.cc_in * 2 + cc * 2) * HN) * 16, w_voff,
+           ldsW + t * (W_ITEMS * 16));
+  };
+  auto issue_x = [&](int cc, int buf) {      // both tiles' activation slices of chunk cc
+    if (a.dbg & 8) return;
+    const char *sb = x_base + (size_t)cc * x_cc_stride;
+    const unsigned dst = ldsA + buf * (a_items * 16);
 #pragma unroll
-    for (int it = 0; it < B_ITERS; ++it) B[tid + it * HT] = rb[it];
+    for (int it = 0; it < A_ITERS; ++it)
+      if ((a_pk[it] >> 20) < NT) glds16(sb, x_voff[it], dst + it * (HT * 16));
+  };
+  // after a slice's DMA has landed: overwrite padding / masked-out pieces with zeros (by the
+  // lanes that fetched them); the step barrier then publishes the slice
+  auto zero_fill = [&](int buf) {
+    uint4 *A = Abuf + buf * a_items;
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it)
+      if ((a_pk[it] >> 20) < NT && !((x_ok >> it) & 1u)) A[tid + it * HT] = make_uint4(0u, 0u, 0u, 0u);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[NT][2][2];     // [tile][tm: position block][tn: channel block]
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int u = 0; u < NT; ++u)
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
+      for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[u][tm][tn][r] = 0.f;
   };
   zero_acc();
 
-  Stage cur = stage_of(0);
-  fetch(cur);
-  for (int s = 0; s < total_stages; ++s) {
-    const int buf = s & 1;
-    commit(cur, buf);
-    __syncthreads();
-    Stage nxt = cur;
-    if (s + 1 < total_stages) {
-      nxt = stage_of(s + 1);
-      if (!(a.dbg & 4)) fetch(nxt);
-    }
-    // ---- matrix-core work of this stage ---------------------------------------------
-    {
-      const uint4 *A = Abuf + buf * 4 * rows_a;
-      const uint4 *B = Bbuf + buf * (2 * TGMAX * 2 * HN);
-      const int arow = wm * 64 + i;
-      const int bcol = wn * 64 + i;
-      for (int tl = 0; tl < ((a.dbg & 2) ? 0 : cur.nt); ++tl) {
-        half8 ah[2], al[2], bh[2], bl[2];
+  // LDS fragment addresses (16-byte items): weights [plane][h][n], activations [u][plane][h][row]
+  const int w_frag = h * HN + wn * 64 + i;                  // + plane*2*HN + tn*32 (+ slot*W_ITEMS)
+  const int x_frag = h * rows_a + wm * 64 + i;              // + (u*4 + plane*2)*rows_a + tm*32 + t*dil
+
+  // ---- software pipeline -----------------------------------------------------------------
+  // step (cc, t): weights of step +WA are issued into slot (t+WA)%K, whose last reader was step
+  // -2; the next chunk's activations are issued at tap 0 into the other buffer.  A step may
+  // leave outstanding only what was issued after its own weight slice: WA-1 weight DMAs, plus
+  // the A_ITERS activation DMAs when those went out in between (taps 1..WA).
+  Tile cur[NT], np[NT];            // tiles of this pass / of the next pass
+  tiles_of(0, cur);
+  load_bytes(cur);
+  build_pieces(cur);               // the only exposed byte-load latency of the launch
+  tiles_of(1, np);
+  load_bytes(np);
+  issue_x(0, 0);
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-          const int r = arow + tm * 32 + tl * a.dil;
-          const uint4 vh = A[(0 * 2 + h) * rows_a + r];
-          const uint4 vl = A[(1 * 2 + h) * rows_a + r];
-          ah[tm] = *reinterpret_cast<const half8 *>(&vh);
-          al[tm] = *reinterpret_cast<const half8 *>(&vl);
+  for (int t = 0; t < WA; ++t) issue_w(0, t);
+  int xc = 0;                      // running chunk count: activation buffer parity
+  for (int pass = 0; pass < my_pairs; ++pass) {
+    for (int cc = 0; cc < a.cc_in; ++cc) {
+      const int abuf = xc & 1;
+      const bool last_chunk = cc == a.cc_in - 1;
+      const bool tail = last_chunk && pass == my_pairs - 1;     // nothing is issued behind this chunk
+      const uint4 *A = Abuf + abuf * a_items + x_frag;
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        // -- wait for this step's operands, publish them ---------------------------------------
+        if (tail) wait_vm<0>();
+        else if (t >= 1 && t <= WA) wait_vm<WA - 1 + A_ITERS>();
+        else wait_vm<WA - 1>();
+        if (t == 0) zero_fill(abuf);
+        __syncthreads();
+        // -- keep the DMA queue full --------------------------------------------------------------
+        if (t + WA < K) {
+          issue_w(cc, t + WA);
+        } else if (!tail) {
+          issue_w(last_chunk ? 0 : cc + 1, t + WA - K);
         }
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          const uint4 vh = B[((0 * TGMAX + tl) * 2 + h) * HN + bcol + tn * 32];
-          const uint4 vl = B[((1 * TGMAX + tl) * 2 + h) * HN + bcol + tn * 32];
-          bh[tn] = *reinterpret_cast<const half8 *>(&vh);
-          bl[tn] = *reinterpret_cast<const half8 *>(&vl);
+        if (t == 0 && !tail) {
+          if (last_chunk) build_pieces(np);        // the next pass's pieces take over from here
+          issue_x(last_chunk ? 0 : cc + 1, abuf ^ 1);
         }
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        // -- matrix-core work: one tap of one 16-channel chunk ----------------------------------
+        if (!(a.dbg & 2)) {
+          const uint4 *B = Wbuf + t * W_ITEMS + w_frag;
+          half8 wh[2], wl[2];
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn) {
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            const uint4 vh = B[tn * 32];
+            const uint4 vl = B[2 * HN + tn * 32];
+            wh[tn] = *reinterpret_cast<const half8 *>(&vh);
+            wl[tn] = *reinterpret_cast<const half8 *>(&vl);
           }
-      }
-    }
-    // ---- tile finished: fused epilogue (per wave, through a private LDS transposer) ----
-    const bool tile_end = ((s + 1) % stages_per_tile) == 0;
-    if (tile_end && (a.dbg & 1)) {
-      if (acc[0][0][0] + acc[1][1][3] + acc[0][1][7] + acc[1][0][9] == 12345.678f) a.overflow[0] = 2;
-      zero_acc();
-    } else if (tile_end) {
-      bool ovf = false;
-      const int m_l = lane & 31;               // position inside the 32-row block
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        float4 nmd0[2], nmd1[2];               // NMD partials of this lane's channel groups
+          for (int u = 0; u < NT; ++u) {
+            half8 xh[2], xl[2];
 #pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-          nmd0[g2] = make_float4(0.f, 0.f, 0.f, 0.f);
-          nmd1[g2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+            for (int tm = 0; tm < 2; ++tm) {
+              const uint4 vh = A[(u * 4) * rows_a + tm * 32 + t * a.dil];
+              const uint4 vl = A[(u * 4 + 2) * rows_a + tm * 32 + t * a.dil];
+              xh[tm] = *reinterpret_cast<const half8 *>(&vh);
+              xl[tm] = *reinterpret_cast<const half8 *>(&vl);
+            }
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-          // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            scratch[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + i] = acc[tm][tn][r] * a.acc_scale;
-          // wave-private scratch: LDS ops of one wave execute in order, so only the
-          // compiler has to be kept from reordering across the exchange
-          __builtin_amdgcn_wave_barrier();
-          const int m = cur.m0 + (wm * 2 + tm) * 32 + m_l;
-          const bool mvalid = m < a.L_out;
-          const size_t pos = (size_t)cur.rowblk * a.L_out + (mvalid ? m : 0);
-          const float mk = (a.mask_out != nullptr && mvalid) ? (a.mask_out[pos] != 0 ? 1.f : 0.f) : 1.f;
-#pragma unroll
-          for (int g2 = 0; g2 < 2; ++g2) {
-            const int g = h + 2 * g2;                          // 8-channel group inside the 32-col block
-            const int n = (wn * 2 + tn) * 32 + g * 8;          // first output channel
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = scratch[m_l * 33 + g * 8 + j];
-            if (g2 == 1) __builtin_amdgcn_wave_barrier();
-            if (mvalid && n < a.cout) {
-              const int G = n >> 3;                            // global 8-channel group
-              const size_t item = (((size_t)cur.rowblk * (a.cout_pad >> 4) + (G >> 1)) * 4 + (G & 1)) *
-                                      a.L_out + m;             // hi plane item; lo = + 2*L_out
-              float sc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-              if (a.addh != nullptr) join8(a.addh[item], a.addh[item + 2 * (size_t)a.L_out], sc);
-              float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
-              v0 = apply4(v0, a.st, a.n_stages, n, make_float4(sc[0], sc[1], sc[2], sc[3]), mk, nmd0[g2]);
-              v1 = apply4(v1, a.st, a.n_stages, n + 4, make_float4(sc[4], sc[5], sc[6], sc[7]), mk, nmd1[g2]);
-              if (a.out_f16s) {
-                const float o8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                uint4 hi, lo;
-                split8(o8, hi, lo, ovf);
-                uint4 *yh = reinterpret_cast<uint4 *>(a.y);
-                yh[item] = hi;
-                yh[item + 2 * (size_t)a.L_out] = lo;
-              } else {
-                float *yf = reinterpret_cast<float *>(a.y) + pos * a.cout + n;
-                *reinterpret_cast<float4 *>(yf) = v0;
-                *reinterpret_cast<float4 *>(yf + 4) = v1;
+              for (int tn = 0; tn < 2; ++tn) {
+                // weights are the MFMA A operand: acc rows = channels, cols = positions
+                acc[u][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xl[tm], acc[u][tm][tn], 0, 0, 0);
+                acc[u][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[tn], xh[tm], acc[u][tm][tn], 0, 0, 0);
+                acc[u][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xh[tm], acc[u][tm][tn], 0, 0, 0);
               }
-            }
-          }
-        }
-        // NMD partial: reduce the 32 positions of this lane half, one row per (tile, wm)
-        if (a.nmd_out != nullptr) {
-#pragma unroll
-          for (int g2 = 0; g2 < 2; ++g2) {
-            float vals[8] = {nmd0[g2].x, nmd0[g2].y, nmd0[g2].z, nmd0[g2].w,
-                             nmd1[g2].x, nmd1[g2].y, nmd1[g2].z, nmd1[g2].w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float x = vals[j];
-#pragma unroll
-              for (int off = 16; off > 0; off >>= 1) x += __shfl_xor(x, off, 32);
-              vals[j] = x;
-            }
-            const int n = (wn * 2 + tn) * 32 + (h + 2 * g2) * 8;
-            if (m_l == 0 && n < a.cout) {
-              const int tile = cur.m0 / HM;
-              float *dst = a.nmd_out + (((size_t)cur.rowblk * a.tiles_m + tile) * 4 + wm) * a.cout + n;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) dst[j] = vals[j];
-            }
           }
         }
       }
-      if (ovf && a.overflow != nullptr) atomicOr(a.overflow, 1);
-      zero_acc();
+      ++xc;
     }
-    cur = nxt;
+
+    // ---- pass finished: fused epilogue straight from the accumulators ----------------------
+    if (a.dbg & 1) {
+      if (acc[0][0][0][0] + acc[1][1][1][3] + acc[0][0][1][7] + acc[1][1][0][9] == 12345.678f) a.overflow[0] = 2;
+    } else {
+      float vmax = 0.f;             // running max |output|: f16-range guard
+      // what a block needs from memory, fetched one block ahead so the loads of block b+1
+      // fly under the arithmetic of block b
+      struct Pre {
+        uint2 sh[4], sl[4];
+        unsigned char mkb;
+      };
+      // lanes i and i+32 hold channels 0-3 / 4-7 of the same 8-channel F16S item: a
+      // v_permlane32_swap per dword turns two 8-byte accesses per lane into one 16-byte access
+      // (lane half h then owns the whole item of group 2j+h)
+      auto swap32 = [](unsigned &lo_half_keeps, unsigned &hi_half_keeps) {
+        const auto r = __builtin_amdgcn_permlane32_swap(lo_half_keeps, hi_half_keeps, false, false);
+        lo_half_keeps = r[0];
+        hi_half_keeps = r[1];
+      };
+      auto item4 = [&](const Tile &tile, int mc, int nb, int j) -> unsigned {
+        // hi-plane item of group 2j + h (uint4 units); lo plane = + 2*L_out
+        const int G = (nb >> 3) + 2 * j + h;
+        return (unsigned)(((tile.rowblk * (a.cout_pad >> 4) + (G >> 1)) * 4 + (G & 1)) * a.L_out + mc);
+      };
+      auto item2 = [&](const Tile &tile, int mc, int nb, int g) -> unsigned {
+        // this lane's 8-byte half (channels 4h..4h+3) of group g's hi-plane F16S item, uint2 units
+        const int G = (nb >> 3) + g;
+        return (unsigned)((((tile.rowblk * (a.cout_pad >> 4) + (G >> 1)) * 4 + (G & 1)) * a.L_out + mc) * 2 + h);
+      };
+      auto prefetch = [&](Pre &p, const Tile &tile, int tm, int tn) {
+        const int nb = (wn * 2 + tn) * 32;
+        const int m = tile.m0 + (wm * 2 + tm) * 32 + i;
+        const int mc = m < a.L_out ? m : 0;
+        p.mkb = a.mask_out != nullptr ? a.mask_out[(size_t)tile.rowblk * a.L_out + mc] : (unsigned char)1;
+        if (a.addh != nullptr && !(a.dbg & 128)) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const unsigned it4 = item4(tile, mc, nb, j);
+            uint4 vh = a.addh[it4];                        // whole item of group 2j+h
+            uint4 vl = a.addh[it4 + 2u * (unsigned)a.L_out];
+            // give each lane back its own 4 channels of groups 2j and 2j+1
+            swap32(vh.x, vh.z); swap32(vh.y, vh.w);
+            swap32(vl.x, vl.z); swap32(vl.y, vl.w);
+            p.sh[2 * j] = make_uint2(vh.x, vh.y);  p.sh[2 * j + 1] = make_uint2(vh.z, vh.w);
+            p.sl[2 * j] = make_uint2(vl.x, vl.y);  p.sl[2 * j + 1] = make_uint2(vl.z, vl.w);
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) p.sh[g] = p.sl[g] = make_uint2(0u, 0u);
+        }
+      };
+      // one 32-channel x 32-position accumulator block, processed in place (static register
+      // indices only).  C/D layout: col = lane&31 -> position, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+      // -> channel
+      auto epi_block = [&](f32x16 &x, const Tile &tile, int tm, int tn) {
+        Pre p;
+        prefetch(p, tile, tm, tn);
+        const int nb = (wn * 2 + tn) * 32;
+        const int m = tile.m0 + (wm * 2 + tm) * 32 + i;
+        const bool live = m < a.L_out && tile.valid;
+        const int mc = m < a.L_out ? m : 0;
+        const float mk = p.mkb != 0 ? 1.f : 0.f;
+        for (int q = 0; q < ((a.dbg & 32) ? 0 : a.n_hst); ++q) {
+          const HStageArg st = a.hst[q];
+          const float *pr = epiL + (q * 2) * HN + nb + 4 * h;
+          switch (st.kind) {
+            case JG_HST_AFFINE:
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const float4 sc = *reinterpret_cast<const float4 *>(pr + 8 * g);
+                const float4 of = *reinterpret_cast<const float4 *>(pr + HN + 8 * g);
+                x[4 * g + 0] = fmaf(x[4 * g + 0], sc.x, of.x);
+                x[4 * g + 1] = fmaf(x[4 * g + 1], sc.y, of.y);
+                x[4 * g + 2] = fmaf(x[4 * g + 2], sc.z, of.z);
+                x[4 * g + 3] = fmaf(x[4 * g + 3], sc.w, of.w);
+              }
+              break;
+            case JG_HST_DYT: {
+              const float mm = st.arg ? mk : 1.0f;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const float4 ga = *reinterpret_cast<const float4 *>(pr + 8 * g);
+                const float4 be = *reinterpret_cast<const float4 *>(pr + HN + 8 * g);
+                x[4 * g + 0] = (fast_tanh(st.f0 * x[4 * g + 0]) * ga.x + be.x) * mm;
+                x[4 * g + 1] = (fast_tanh(st.f0 * x[4 * g + 1]) * ga.y + be.y) * mm;
+                x[4 * g + 2] = (fast_tanh(st.f0 * x[4 * g + 2]) * ga.z + be.z) * mm;
+                x[4 * g + 3] = (fast_tanh(st.f0 * x[4 * g + 3]) * ga.w + be.w) * mm;
+              }
+            } break;
+            case JG_HST_ADD:
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const half4 hh4 = *reinterpret_cast<const half4 *>(&p.sh[g]);
+                const half4 ll4 = *reinterpret_cast<const half4 *>(&p.sl[g]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[4 * g + j] += (float)hh4[j] + (float)ll4[j];
+              }
+              break;
+            case JG_HST_ACT:
+#pragma unroll
+              for (int r = 0; r < 16; ++r) x[r] = jg_act(x[r], st.arg);
+              break;
+            case JG_HST_NMD: {
+              // masked channel sums over this block's 32 positions (one partial row per
+              // (tile, wm, tm)), reduced across the 32 lanes of the half right away
+              float part[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                float v = live ? x[r] * mk : 0.f;
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+                part[r] = v;
+              }
+              if (i == 0 && tile.valid) {
+                const int tileno = tile.m0 / HM;
+                float *dst = a.nmd_out + ((((size_t)tile.rowblk * a.tiles_m + tileno) * 4 + wm) * 2 + tm) * a.cout + nb + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                  if (nb + 8 * g + 4 * h < a.cout)
+                    *reinterpret_cast<float4 *>(dst + 8 * g) =
+                        make_float4(part[4 * g], part[4 * g + 1], part[4 * g + 2], part[4 * g + 3]);
+              }
+            } break;
+            case JG_HST_MASKMUL:
+#pragma unroll
+              for (int r = 0; r < 16; ++r) x[r] *= mk;
+              break;
+            default: break;
+          }
+        }
+        if (live && !(a.dbg & 64)) {
+          if (a.out_f16s) {
+            uint4 *yh = reinterpret_cast<uint4 *>(a.y);
+            uint2 ph[4], pl[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              half4 hh4, ll4;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float v = x[4 * g + j];
+                const _Float16 hv = (_Float16)v;
+                hh4[j] = hv;
+                ll4[j] = (_Float16)(v - (float)hv);
+                vmax = fmaxf(vmax, fabsf(v));
+              }
+              ph[g] = *reinterpret_cast<uint2 *>(&hh4);
+              pl[g] = *reinterpret_cast<uint2 *>(&ll4);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              uint4 vh = make_uint4(ph[2 * j].x, ph[2 * j].y, ph[2 * j + 1].x, ph[2 * j + 1].y);
+              uint4 vl = make_uint4(pl[2 * j].x, pl[2 * j].y, pl[2 * j + 1].x, pl[2 * j + 1].y);
+              swap32(vh.x, vh.z); swap32(vh.y, vh.w);      // -> whole item of group 2j+h
+              swap32(vl.x, vl.z); swap32(vl.y, vl.w);
+              const unsigned it4 = item4(tile, mc, nb, j);
+              yh[it4] = vh;
+              yh[it4 + 2u * (unsigned)a.L_out] = vl;
+            }
+          } else {
+            float *yf = reinterpret_cast<float *>(a.y) + ((size_t)tile.rowblk * a.L_out + mc) * a.cout + nb + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              if (nb + 8 * g + 4 * h < a.cout)
+                *reinterpret_cast<float4 *>(yf + 8 * g) =
+                    make_float4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+          }
+        }
+      };
+      epi_block(acc[0][0][0], cur[0], 0, 0);
+      epi_block(acc[0][1][0], cur[0], 1, 0);
+      epi_block(acc[0][0][1], cur[0], 0, 1);
+      epi_block(acc[0][1][1], cur[0], 1, 1);
+      epi_block(acc[1][0][0], cur[1], 0, 0);
+      epi_block(acc[1][1][0], cur[1], 1, 0);
+      epi_block(acc[1][0][1], cur[1], 0, 1);
+      epi_block(acc[1][1][1], cur[1], 1, 1);
+      if (!(vmax <= 65000.0f) && a.overflow != nullptr) atomicOr(a.overflow, 1);
+    }
+    zero_acc();
+#pragma unroll
+    for (int u = 0; u < NT; ++u) cur[u] = np[u];
+    tiles_of(pass + 2, np);
+    load_bytes(np);                // position bytes of the pass after next
   }
+}
+
+template <int K>
+int launch_k(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  const int smem = jg_conv_f16_lds_bytes(K, a.dil);
+  static bool attr_set = false;
+  if (!attr_set) {
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<K>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int n_tiles = a.rows * a.tiles_m;
+  const int n_pairs = (n_tiles + NT - 1) / NT;
+  int grid = e->n_cu;
+  if (grid > n_pairs) grid = n_pairs;
+  hipLaunchKernelGGL(conv_f16x3_kernel<K>, dim3((unsigned)grid), dim3(HT), (size_t)smem, s, a);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
 }
 
 }  // namespace
 
-int jg_conv_f16_lds_bytes(int dil) {
-  const int rows_a = HM + (TGMAX - 1) * dil;
-  return (2 * 4 * rows_a + 2 * 2 * TGMAX * 2 * HN) * 16 + 8 * 32 * 33 * 4;
+int jg_conv_f16_lds_bytes(int k, int dil) {
+  const int rows_a = HM + (k - 1) * dil;
+  return (2 * NT * 4 * rows_a + k * W_ITEMS) * 16 + JG_MAX_STAGES * 2 * HN * 4;
+}
+
+// taps / dilation the kernel's tiling can hold: instantiated tap counts, activation slice
+// <= A_ITERS pieces per thread, LDS <= 160 KiB
+bool jg_conv_f16_supports(int k, int dil) {
+  return (k == 5 || k == 7 || k == 9) && NT * 4 * (HM + (k - 1) * dil) <= A_ITERS * HT &&
+         jg_conv_f16_lds_bytes(k, dil) <= 160 * 1024;
 }
 
 int jg_conv_f16_tile_m(void) { return HM; }
 
 int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
-  JG_REQUIRE(a.cout_pad == HN, JG_ERR_UNSUPPORTED, "conv_f16x3: cout_pad=%d (needs 128)", a.cout_pad);
-  JG_REQUIRE((HM + (TGMAX - 1) * a.dil) * 4 <= A_ITERS * HT, JG_ERR_UNSUPPORTED,
-             "conv_f16x3: dilation %d too large", a.dil);
+  JG_REQUIRE(a.cout_pad == HN && a.cout % 16 == 0, JG_ERR_UNSUPPORTED,
+             "conv_f16x3: cout=%d (needs 128 padded, multiple of 16)", a.cout);
+  JG_REQUIRE(jg_conv_f16_supports(a.k, a.dil), JG_ERR_UNSUPPORTED,
+             "conv_f16x3: k=%d dilation=%d outside the kernel's tiling", a.k, a.dil);
+  // DMA offsets are 32-bit: the activation tensor of one launch must stay below 4 GiB
+  JG_REQUIRE((double)a.rows * a.cc_in * 4.0 * a.L_in * 16.0 < 4.0e9, JG_ERR_UNSUPPORTED,
+             "conv_f16x3: activation tensor of %d rows exceeds the 32-bit DMA offset range", a.rows);
   if (a.rows == 0 || a.L_out <= 0) return JG_OK;
-  const int smem = jg_conv_f16_lds_bytes(a.dil);
-  JG_REQUIRE(smem <= 160 * 1024, JG_ERR_UNSUPPORTED, "conv_f16x3: needs %d B of LDS", smem);
-  static bool attr_set = false;
-  if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  const int n_tiles = a.rows * a.tiles_m;
   static int dbg = -1;
   if (dbg < 0) { const char *ev = getenv("JG_DBG"); dbg = ev ? atoi(ev) : 0; }
   const_cast<ConvHArgs &>(a).dbg = dbg;
-  int grid = e->n_cu;
-  if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL(conv_f16x3_kernel, dim3((unsigned)grid), dim3(HT), (size_t)smem, s, a);
-  JG_HIP(hipGetLastError());
-  return JG_OK;
+  switch (a.k) {
+    case 5: return launch_k<5>(e, a, s);
+    case 7: return launch_k<7>(e, a, s);
+    case 9: return launch_k<9>(e, a, s);
+    default: break;
+  }
+  jg_set_error("conv_f16x3: k=%d has no instantiation", a.k);
+  return JG_ERR_UNSUPPORTED;
 }
