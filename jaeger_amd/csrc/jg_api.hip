@@ -454,9 +454,10 @@ static int prepare_f16(jg_model *m, const float *weights) {
       std::vector<double> sc(128, (double)hp.acc_scale), sh(128, 0.0);
       bool pending = true;                          // an affine (the un-scale) is always pending first
       hp.n_hst = 0;
+      hp.n_epi_rows = 0;
       auto flush = [&]() {
         if (!pending) return;
-        HStageArg h{JG_HST_AFFINE, 0, 0.f, 0};
+        HStageArg h{JG_HST_AFFINE, 0, 0.f, hp.n_epi_rows++};
         hp.hst[hp.n_hst++] = h;
         for (int n = 0; n < 128; ++n) tab.push_back((float)sc[n]);
         for (int n = 0; n < 128; ++n) tab.push_back((float)sh[n]);
@@ -487,6 +488,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
         switch (st.kind) {
           case JG_ST_DYT:
             h.kind = JG_HST_DYT;
+            h.pad_ = hp.n_epi_rows++;
             for (int n = 0; n < 128; ++n) tab.push_back(n < op.cout ? vecp(st.p2)[n] : 0.f);
             for (int n = 0; n < 128; ++n) tab.push_back(n < op.cout ? vecp(st.p3)[n] : 0.f);
             break;
@@ -499,12 +501,35 @@ static int prepare_f16(jg_model *m, const float *weights) {
           case JG_ST_MASKMUL: h.kind = JG_HST_MASKMUL; break;
           default: fail("epilogue stage not supported by the split-f16 kernel"); break;
         }
-        if (h.kind != JG_HST_DYT) tab.resize(tab.size() + 256, 0.f);
         hp.hst[hp.n_hst++] = h;
       }
       if (m->f16_eligible) {
         if (pending && hp.n_hst >= JG_MAX_STAGES) fail("epilogue too long");
         else flush();
+      }
+      if (hp.n_epi_rows > JG_EPI_ROWS) fail("more norm stages than the split-f16 epilogue table holds");
+      // match the stage list against the compiled pattern
+      //   affine [nmd] [norm1] [add] [gelu] [nmd] [norm2] [gelu]
+      {
+        unsigned ep = 0;
+        int q = 0;
+        const int n = hp.n_hst;
+        auto is = [&](int kind) { return q < n && hp.hst[q].kind == kind; };
+        bool ok = is(JG_HST_AFFINE);
+        if (ok) {
+          ++q;
+          if (is(JG_HST_NMD)) { ep |= JG_EP_NMD1; ++q; }
+          if (is(JG_HST_AFFINE)) { ep |= JG_EP_NORM1_AFF; ++q; }
+          else if (is(JG_HST_DYT)) { ep |= JG_EP_NORM1_DYT; hp.alpha1 = hp.hst[q].f0; hp.dytmask1 = hp.hst[q].arg; ++q; }
+          if (is(JG_HST_ADD)) { ep |= JG_EP_ADD; ++q; }
+          if (is(JG_HST_ACT) && hp.hst[q].arg == JG_ACT_GELU_TANH) { ep |= JG_EP_ACT1; ++q; }
+          if (is(JG_HST_NMD)) { ep |= JG_EP_NMD2; ++q; }
+          if (is(JG_HST_AFFINE)) { ep |= JG_EP_NORM2_AFF; ++q; }
+          else if (is(JG_HST_DYT)) { ep |= JG_EP_NORM2_DYT; hp.alpha2 = hp.hst[q].f0; hp.dytmask2 = hp.hst[q].arg; ++q; }
+          if (is(JG_HST_ACT) && hp.hst[q].arg == JG_ACT_GELU_TANH) { ep |= JG_EP_ACT2; ++q; }
+          ok = q == n;
+        }
+        hp.ep = ok ? ep : JG_EP_GENERIC;
       }
       if (m->f16_eligible) {
         JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_epi), tab.size() * sizeof(float)));
@@ -680,6 +705,10 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           a.tiles_m = (lo + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m();
           a.out_f16s = hp.out_f16s ? 1 : 0;
           a.n_hst = hp.n_hst;
+          a.ep = hp.ep;
+          a.alpha1 = hp.alpha1; a.alpha2 = hp.alpha2;
+          a.dytmask1 = hp.dytmask1; a.dytmask2 = hp.dytmask2;
+          a.n_epi_rows = hp.n_epi_rows;
           a.epi = hp.d_epi;
           for (int q = 0; q < hp.n_hst; ++q) a.hst[q] = hp.hst[q];
           if (hp.add_slot >= 0) a.addh = reinterpret_cast<const uint4 *>(m->act[hp.add_slot]);
@@ -830,7 +859,12 @@ static int copy_out(jg_model *m, int slot, int width, float *dst, int64_t row0, 
 static int forward_device_ids(jg_model *m, const uint8_t *d_ids, int64_t n_win, int l,
                               float *prediction, float *reliability, float *embedding, float *nmd,
                               int out_loc, int chunk, hipStream_t s) {
-  if (chunk <= 0) chunk = 256;
+  if (chunk <= 0) chunk = 1024;     // windows per launch group: amortises launch + pipeline fill
+  // split-f16 DMA offsets are 32-bit: keep one activation tensor (6 frames x l x 512 B) < 3.5 GB
+  if (m->precision == 1) {
+    const int64_t cap = (int64_t)(3.5e9 / (6.0 * l * 512.0));
+    if (chunk > cap) chunk = (int)std::max<int64_t>(cap, 1);
+  }
   if (chunk > n_win) chunk = (int)std::max<int64_t>(n_win, 1);
   JG_REQUIRE((int64_t)chunk * 6 <= 0x7fffffff / 8, JG_ERR_INVALID, "chunk too large");
   int rc = ensure_workspace(m, chunk, l);

@@ -54,6 +54,18 @@ struct ConvArgs {
 
 // compact epilogue of the split-f16 conv: bias / batch-norm chains are folded into one
 // per-channel affine on the host (f64), parameters live in a (stage, 2, 128) f32 table
+// compiled epilogue pattern of the split-f16 conv: affine [nmd] [norm1] [add] [gelu] [nmd] [norm2] [gelu]
+#define JG_EP_NMD1 0x001u
+#define JG_EP_NORM1_AFF 0x002u
+#define JG_EP_NORM1_DYT 0x004u
+#define JG_EP_ADD 0x008u
+#define JG_EP_ACT1 0x010u
+#define JG_EP_NMD2 0x020u
+#define JG_EP_NORM2_AFF 0x040u
+#define JG_EP_NORM2_DYT 0x080u
+#define JG_EP_ACT2 0x100u
+#define JG_EP_GENERIC 0xffffu
+#define JG_EPI_ROWS 4   /* parameter rows (affine / dyt stages) of a split-f16 epilogue */
 enum { JG_HST_AFFINE = 1, JG_HST_DYT = 2, JG_HST_ADD = 3, JG_HST_ACT = 4, JG_HST_NMD = 5, JG_HST_MASKMUL = 6 };
 struct HStageArg {
   int kind;
@@ -79,8 +91,13 @@ struct ConvHArgs {
   int k, dil, pad_left, tiles_m;
   int mask_from_ids, out_f16s;
   int dbg;                 // ablation switches (JG_DBG env, timing experiments only)
+  int stagger;             // shader cycles the second half of the grid waits before starting
+  unsigned ep;             // JG_EP_* pattern of the stage list (JG_EP_GENERIC: interpret hst[])
+  float alpha1, alpha2;    // DyT alphas of norm1 / norm2
+  int dytmask1, dytmask2;
   int n_hst;
-  const float *epi;        // [n_hst][2][128] epilogue parameters
+  int n_epi_rows;
+  const float *epi;        // [n_epi_rows][2][128] epilogue parameters (HStageArg.pad_ = row)
   HStageArg hst[JG_MAX_STAGES];
 };
 
@@ -118,9 +135,12 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   int cc_in = 0;
   bool out_f16s = false;
   float *d_epi = nullptr;   // compact epilogue parameter table
-  int n_hst = 0;
+  int n_hst = 0, n_epi_rows = 0;
   HStageArg hst[JG_MAX_STAGES] = {};
   int add_slot = -1, nmd_slot = -1;
+  unsigned ep = JG_EP_GENERIC;
+  float alpha1 = 0.f, alpha2 = 0.f;
+  int dytmask1 = 0, dytmask2 = 0;
 };
 
 struct jg_model {

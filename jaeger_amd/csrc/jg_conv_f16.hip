@@ -44,9 +44,11 @@ namespace {
 
 constexpr int HM = 256;       // tile rows (positions)
 constexpr int HN = 128;       // tile cols (output channels)
-constexpr int HT = 512;       // threads
-constexpr int NT = 2;         // tiles per workgroup pass (share the weight slices)
-constexpr int A_ITERS = 5;    // 16-B activation pieces per thread per chunk (NT*4*rows_a <= 2560)
+constexpr int HT = 256;       // threads: 4 waves, 2 (positions) x 2 (channels), 128 x 64 outputs each
+constexpr int NT = 1;         // tiles per workgroup pass
+constexpr int A_ITERS = 5;    // 16-B activation pieces per thread per chunk (4*rows_a <= 1280)
+constexpr int W_ITERS = 2;    // 16-B weight items per thread per slice
+constexpr int TM = 4;         // 32-position blocks per wave
 constexpr int W_ITEMS = 2 * 2 * HN;           // 16-B items of one weight slice (chunk, tap): 8 KB
 
 // GELU (tanh form) as x * sigmoid(2u), u = sqrt(2/pi)(x + 0.044715 x^3): one v_exp_f32 and
@@ -89,7 +91,7 @@ struct Tile {
   int rowblk, m0, valid;
 };
 
-template <int K>
+template <int K, unsigned EP>
 __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
   constexpr int WA = K - 2;                  // weight slices in flight ahead of the matrix cores
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
@@ -103,11 +105,11 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
   uint4 *Abuf = lds;                                        // [2 bufs][a_items]
   uint4 *Wbuf = lds + 2 * a_items;                          // [K slots][2 planes][2 h][HN]
   float *epiL = reinterpret_cast<float *>(Wbuf + K * W_ITEMS);
-  for (int q = tid; q < a.n_hst * 2 * HN; q += HT) epiL[q] = a.epi[q];   // visible after the first barrier
+  for (int q = tid; q < a.n_epi_rows * 2 * HN; q += HT) epiL[q] = a.epi[q];   // visible after the first barrier
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
   // wave-uniform LDS byte addresses of this wave's DMA destinations
-  const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);                       // + buf*a_items*16 + it*8192
-  const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + wid * 1024);   // + slot*8192
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);                       // + buf*a_items*16 + it*4096
+  const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + wid * 1024);   // + slot*8192 + it*4096
 
   const int n_tiles = a.rows * a.tiles_m;
   const int n_pairs = (n_tiles + NT - 1) / NT;
@@ -121,13 +123,16 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
   for (int it = 0; it < A_ITERS; ++it) {
     const int q = tid + it * HT;
-    const int u = q / (4 * rows_a);     // >= NT: no piece
-    const int rem = q - u * 4 * rows_a;
-    const int ph = rem / rows_a;
-    a_pk[it] = ((unsigned)u << 20) | ((unsigned)ph << 16) | (unsigned)(rem - ph * rows_a);
+    const int ph = q / rows_a;          // >= 4: no piece
+    a_pk[it] = ((unsigned)(ph >> 2) << 20) | ((unsigned)(ph & 3) << 16) | (unsigned)(q - ph * rows_a);
   }
   // weight slice: one item per thread, [plane][h][n] -> byte offset inside the tap-major blob
-  const unsigned w_voff = (unsigned)((((tid >> 8) * K * a.cc_in * 2 + ((tid >> 7) & 1)) * HN + (tid & (HN - 1))) * 16);
+  unsigned w_voff[W_ITERS];
+#pragma unroll
+  for (int it = 0; it < W_ITERS; ++it) {
+    const int q = tid + it * HT;          // [plane][h][n]
+    w_voff[it] = (unsigned)((((q >> 8) * K * a.cc_in * 2 + ((q >> 7) & 1)) * HN + (q & (HN - 1))) * 16);
+  }
 
   auto tiles_of = [&](int pass, Tile *t) {
 #pragma unroll
@@ -151,10 +156,7 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
   unsigned x_ok = 0;
   auto piece_pos = [&](const Tile *tl2, int it, int &pc, bool &inr) -> int {
     const int a_u = (int)(a_pk[it] >> 20), a_r = (int)(a_pk[it] & 0xffff);
-    const int u = min(a_u, NT - 1);
-    const int m0 = u == 0 ? tl2[0].m0 : tl2[1].m0;
-    const int rb = u == 0 ? tl2[0].rowblk : tl2[1].rowblk;
-    const int vd = u == 0 ? tl2[0].valid : tl2[1].valid;
+    const int m0 = tl2[0].m0, rb = tl2[0].rowblk, vd = tl2[0].valid;
     const int p = m0 - a.pad_left + a_r;
     pc = min(max(p, 0), a.L_in - 1);
     inr = a_u < NT && vd && p >= 0 && p < a.L_in;
@@ -199,8 +201,9 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
   // ---- DMA issue ---------------------------------------------------------------------------
   auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
     if (a.dbg & 16) return;
-    glds16(reinterpret_cast<const char *>(a.wh) + ((size_t)(t * a.cc_in * 2 + cc * 2) * HN) * 16, w_voff,
-           ldsW + t * (W_ITEMS * 16));
+    const char *sb = reinterpret_cast<const char *>(a.wh) + ((size_t)(t * a.cc_in * 2 + cc * 2) * HN) * 16;
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) glds16(sb, w_voff[it], ldsW + t * (W_ITEMS * 16) + it * (HT * 16));
   };
   auto issue_x = [&](int cc, int buf) {      // both tiles' activation slices of chunk cc
     if (a.dbg & 8) return;
@@ -219,22 +222,28 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
       if ((a_pk[it] >> 20) < NT && !((x_ok >> it) & 1u)) A[tid + it * HT] = make_uint4(0u, 0u, 0u, 0u);
   };
 
-  f32x16 acc[NT][2][2];     // [tile][tm: position block][tn: channel block]
+  f32x16 acc[TM][2];        // [tm: position block][tn: channel block]
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int u = 0; u < NT; ++u)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[u][tm][tn][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
   };
   zero_acc();
 
   // LDS fragment addresses (16-byte items): weights [plane][h][n], activations [u][plane][h][row]
   const int w_frag = h * HN + wn * 64 + i;                  // + plane*2*HN + tn*32 (+ slot*W_ITEMS)
-  const int x_frag = h * rows_a + wm * 64 + i;              // + (u*4 + plane*2)*rows_a + tm*32 + t*dil
+  const int x_frag = h * rows_a + wm * (TM * 32) + i;       // + plane*2*rows_a + tm*32 + t*dil
+
+  // The two workgroups sharing a CU would otherwise run in lockstep (same program, same work)
+  // and reach their VALU-only epilogues together; delaying the second-dispatched half of the
+  // grid by about half a pass lets one workgroup's epilogue run under the other's MFMA steps.
+  if (a.stagger > 0 && blockIdx.x >= gridDim.x / 2) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(32);
+  }
 
   // ---- software pipeline -----------------------------------------------------------------
   // step (cc, t): weights of step +WA are issued into slot (t+WA)%K, whose last reader was step
@@ -261,8 +270,8 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
       for (int t = 0; t < K; ++t) {
         // -- wait for this step's operands, publish them ---------------------------------------
         if (tail) wait_vm<0>();
-        else if (t >= 1 && t <= WA) wait_vm<WA - 1 + A_ITERS>();
-        else wait_vm<WA - 1>();
+        else if (t >= 1 && t <= WA) wait_vm<(WA - 1) * W_ITERS + A_ITERS>();
+        else wait_vm<(WA - 1) * W_ITERS>();
         if (t == 0) zero_fill(abuf);
         __syncthreads();
         // -- keep the DMA queue full --------------------------------------------------------------
@@ -287,23 +296,24 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
             wl[tn] = *reinterpret_cast<const half8 *>(&vl);
           }
 #pragma unroll
-          for (int u = 0; u < NT; ++u) {
+          for (int tp = 0; tp < TM / 2; ++tp) {           // two position blocks at a time
             half8 xh[2], xl[2];
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-              const uint4 vh = A[(u * 4) * rows_a + tm * 32 + t * a.dil];
-              const uint4 vl = A[(u * 4 + 2) * rows_a + tm * 32 + t * a.dil];
-              xh[tm] = *reinterpret_cast<const half8 *>(&vh);
-              xl[tm] = *reinterpret_cast<const half8 *>(&vl);
+            for (int tq = 0; tq < 2; ++tq) {
+              const uint4 vh = A[(tp * 2 + tq) * 32 + t * a.dil];
+              const uint4 vl = A[2 * rows_a + (tp * 2 + tq) * 32 + t * a.dil];
+              xh[tq] = *reinterpret_cast<const half8 *>(&vh);
+              xl[tq] = *reinterpret_cast<const half8 *>(&vl);
             }
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
               for (int tn = 0; tn < 2; ++tn) {
                 // weights are the MFMA A operand: acc rows = channels, cols = positions
-                acc[u][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xl[tm], acc[u][tm][tn], 0, 0, 0);
-                acc[u][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[tn], xh[tm], acc[u][tm][tn], 0, 0, 0);
-                acc[u][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xh[tm], acc[u][tm][tn], 0, 0, 0);
+                f32x16 &c = acc[tp * 2 + tq][tn];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xl[tq], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[tn], xh[tq], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xh[tq], c, 0, 0, 0);
               }
           }
         }
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
 
     // ---- pass finished: fused epilogue straight from the accumulators ----------------------
     if (a.dbg & 1) {
-      if (acc[0][0][0][0] + acc[1][1][1][3] + acc[0][0][1][7] + acc[1][1][0][9] == 12345.678f) a.overflow[0] = 2;
+      if (acc[0][0][0] + acc[1][1][3] + acc[2][1][7] + acc[3][0][9] == 12345.678f) a.overflow[0] = 2;
     } else {
       float vmax = 0.f;             // running max |output|: f16-range guard
       // what a block needs from memory, fetched one block ahead so the loads of block b+1
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
       };
       auto prefetch = [&](Pre &p, const Tile &tile, int tm, int tn) {
         const int nb = (wn * 2 + tn) * 32;
-        const int m = tile.m0 + (wm * 2 + tm) * 32 + i;
+        const int m = tile.m0 + (wm * TM + tm) * 32 + i;
         const int mc = m < a.L_out ? m : 0;
         p.mkb = a.mask_out != nullptr ? a.mask_out[(size_t)tile.rowblk * a.L_out + mc] : (unsigned char)1;
         if (a.addh != nullptr && !(a.dbg & 128)) {
@@ -369,105 +379,153 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
         Pre p;
         prefetch(p, tile, tm, tn);
         const int nb = (wn * 2 + tn) * 32;
-        const int m = tile.m0 + (wm * 2 + tm) * 32 + i;
+        const int m = tile.m0 + (wm * TM + tm) * 32 + i;
         const bool live = m < a.L_out && tile.valid;
         const int mc = m < a.L_out ? m : 0;
         const float mk = p.mkb != 0 ? 1.f : 0.f;
-        for (int q = 0; q < ((a.dbg & 32) ? 0 : a.n_hst); ++q) {
-          const HStageArg st = a.hst[q];
-          const float *pr = epiL + (q * 2) * HN + nb + 4 * h;
-          switch (st.kind) {
-            case JG_HST_AFFINE:
+        // ---- stage primitives on this lane's 16 channels of one position -----------------
+        auto st_affine = [&](int row) {
+          const float *pr = epiL + (row * 2) * HN + nb + 4 * h;
 #pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const float4 sc = *reinterpret_cast<const float4 *>(pr + 8 * g);
-                const float4 of = *reinterpret_cast<const float4 *>(pr + HN + 8 * g);
-                x[4 * g + 0] = fmaf(x[4 * g + 0], sc.x, of.x);
-                x[4 * g + 1] = fmaf(x[4 * g + 1], sc.y, of.y);
-                x[4 * g + 2] = fmaf(x[4 * g + 2], sc.z, of.z);
-                x[4 * g + 3] = fmaf(x[4 * g + 3], sc.w, of.w);
-              }
-              break;
-            case JG_HST_DYT: {
-              const float mm = st.arg ? mk : 1.0f;
+          for (int g = 0; g < 4; ++g) {
+            const float4 sc = *reinterpret_cast<const float4 *>(pr + 8 * g);
+            const float4 of = *reinterpret_cast<const float4 *>(pr + HN + 8 * g);
+            x[4 * g + 0] = fmaf(x[4 * g + 0], sc.x, of.x);
+            x[4 * g + 1] = fmaf(x[4 * g + 1], sc.y, of.y);
+            x[4 * g + 2] = fmaf(x[4 * g + 2], sc.z, of.z);
+            x[4 * g + 3] = fmaf(x[4 * g + 3], sc.w, of.w);
+          }
+        };
+        auto st_dyt = [&](int row, float alpha, int use_mask) {
+          const float *pr = epiL + (row * 2) * HN + nb + 4 * h;
+          const float mm = use_mask ? mk : 1.0f;
 #pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const float4 ga = *reinterpret_cast<const float4 *>(pr + 8 * g);
-                const float4 be = *reinterpret_cast<const float4 *>(pr + HN + 8 * g);
-                x[4 * g + 0] = (fast_tanh(st.f0 * x[4 * g + 0]) * ga.x + be.x) * mm;
-                x[4 * g + 1] = (fast_tanh(st.f0 * x[4 * g + 1]) * ga.y + be.y) * mm;
-                x[4 * g + 2] = (fast_tanh(st.f0 * x[4 * g + 2]) * ga.z + be.z) * mm;
-                x[4 * g + 3] = (fast_tanh(st.f0 * x[4 * g + 3]) * ga.w + be.w) * mm;
-              }
-            } break;
-            case JG_HST_ADD:
+          for (int g = 0; g < 4; ++g) {
+            const float4 ga = *reinterpret_cast<const float4 *>(pr + 8 * g);
+            const float4 be = *reinterpret_cast<const float4 *>(pr + HN + 8 * g);
+            x[4 * g + 0] = (fast_tanh(alpha * x[4 * g + 0]) * ga.x + be.x) * mm;
+            x[4 * g + 1] = (fast_tanh(alpha * x[4 * g + 1]) * ga.y + be.y) * mm;
+            x[4 * g + 2] = (fast_tanh(alpha * x[4 * g + 2]) * ga.z + be.z) * mm;
+            x[4 * g + 3] = (fast_tanh(alpha * x[4 * g + 3]) * ga.w + be.w) * mm;
+          }
+        };
+        auto st_add = [&]() {
 #pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const half4 hh4 = *reinterpret_cast<const half4 *>(&p.sh[g]);
-                const half4 ll4 = *reinterpret_cast<const half4 *>(&p.sl[g]);
+          for (int g = 0; g < 4; ++g) {
+            const half4 hh4 = *reinterpret_cast<const half4 *>(&p.sh[g]);
+            const half4 ll4 = *reinterpret_cast<const half4 *>(&p.sl[g]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) x[4 * g + j] += (float)hh4[j] + (float)ll4[j];
-              }
-              break;
-            case JG_HST_ACT:
+            for (int j = 0; j < 4; ++j) x[4 * g + j] += (float)hh4[j] + (float)ll4[j];
+          }
+        };
+        auto st_gelu = [&]() {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) x[r] = jg_act(x[r], st.arg);
-              break;
-            case JG_HST_NMD: {
-              // masked channel sums over this block's 32 positions (one partial row per
-              // (tile, wm, tm)), reduced across the 32 lanes of the half right away
-              float part[16];
+          for (int r = 0; r < 16; ++r) x[r] = fast_gelu(x[r]);
+        };
+        auto st_nmd = [&]() {
+          // masked channel sums over this block's 32 positions (one partial row per
+          // (tile, wm, tm)), reduced across the 32 lanes of the half right away
+          float part[16];
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                float v = live ? x[r] * mk : 0.f;
+          for (int r = 0; r < 16; ++r) {
+            float v = live ? x[r] * mk : 0.f;
 #pragma unroll
-                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
-                part[r] = v;
-              }
-              if (i == 0 && tile.valid) {
-                const int tileno = tile.m0 / HM;
-                float *dst = a.nmd_out + ((((size_t)tile.rowblk * a.tiles_m + tileno) * 4 + wm) * 2 + tm) * a.cout + nb + 4 * h;
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+            part[r] = v;
+          }
+          if (i == 0 && tile.valid) {
+            const int tileno = tile.m0 / HM;
+            float *dst = a.nmd_out + ((((size_t)tile.rowblk * a.tiles_m + tileno) * 2 + wm) * TM + tm) * a.cout + nb + 4 * h;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                  if (nb + 8 * g + 4 * h < a.cout)
-                    *reinterpret_cast<float4 *>(dst + 8 * g) =
-                        make_float4(part[4 * g], part[4 * g + 1], part[4 * g + 2], part[4 * g + 3]);
-              }
-            } break;
-            case JG_HST_MASKMUL:
+            for (int g = 0; g < 4; ++g)
+              if (nb + 8 * g + 4 * h < a.cout)
+                *reinterpret_cast<float4 *>(dst + 8 * g) =
+                    make_float4(part[4 * g], part[4 * g + 1], part[4 * g + 2], part[4 * g + 3]);
+          }
+        };
+        if constexpr (EP == JG_EP_GENERIC) {
+          // any stage list: interpreted at run time (slow path: the accumulators bounce through
+          // the interpreter's switch); the model families in-tree all hit a compiled pattern
+          for (int q = 0; q < ((a.dbg & 32) ? 0 : a.n_hst); ++q) {
+            const HStageArg st = a.hst[q];
+            switch (st.kind) {
+              case JG_HST_AFFINE: st_affine(st.pad_); break;
+              case JG_HST_DYT: st_dyt(st.pad_, st.f0, st.arg); break;
+              case JG_HST_ADD: st_add(); break;
+              case JG_HST_ACT:
 #pragma unroll
-              for (int r = 0; r < 16; ++r) x[r] *= mk;
-              break;
-            default: break;
+                for (int r = 0; r < 16; ++r) x[r] = jg_act(x[r], st.arg);
+                break;
+              case JG_HST_NMD: st_nmd(); break;
+              case JG_HST_MASKMUL:
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] *= mk;
+                break;
+              default: break;
+            }
+          }
+        } else if (!(a.dbg & 32)) {
+          // compiled pattern: affine [nmd] [norm1] [add] [gelu] [nmd] [norm2] [gelu], straight line
+          constexpr int N1 = (EP >> 1) & 3, N2 = (EP >> 6) & 3;
+          st_affine(0);
+          if constexpr (EP & JG_EP_NMD1) st_nmd();
+          if constexpr (N1 == 1) st_affine(1);
+          if constexpr (N1 == 2) st_dyt(1, a.alpha1, a.dytmask1);
+          if constexpr (EP & JG_EP_ADD) st_add();
+          if constexpr (EP & JG_EP_ACT1) st_gelu();
+          if constexpr (EP & JG_EP_NMD2) st_nmd();
+          if constexpr (N2 == 1) st_affine(N1 ? 2 : 1);
+          if constexpr (N2 == 2) st_dyt(N1 ? 2 : 1, a.alpha2, a.dytmask2);
+          if constexpr (EP & JG_EP_ACT2) st_gelu();
+        }
+        // results stay in the block's registers (F16S: re-split, lane-pair swapped and bit-cast,
+        // dword 4j..4j+3 = hi item, 8+4j.. = lo item of group 2j+h); stored by store_block() once
+        // every block's loads are done - no load ever queues behind a store
+        if (a.out_f16s) {
+          uint2 ph[4], pl[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            half4 hh4, ll4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float v = x[4 * g + j];
+              const _Float16 hv = (_Float16)v;
+              hh4[j] = hv;
+              ll4[j] = (_Float16)(v - (float)hv);
+              vmax = fmaxf(vmax, live ? fabsf(v) : 0.f);
+            }
+            ph[g] = *reinterpret_cast<uint2 *>(&hh4);
+            pl[g] = *reinterpret_cast<uint2 *>(&ll4);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            unsigned h0 = ph[2 * j].x, h1 = ph[2 * j].y, h2 = ph[2 * j + 1].x, h3 = ph[2 * j + 1].y;
+            unsigned l0 = pl[2 * j].x, l1 = pl[2 * j].y, l2 = pl[2 * j + 1].x, l3 = pl[2 * j + 1].y;
+            swap32(h0, h2); swap32(h1, h3);      // -> whole item of group 2j+h
+            swap32(l0, l2); swap32(l1, l3);
+            x[4 * j + 0] = __uint_as_float(h0); x[4 * j + 1] = __uint_as_float(h1);
+            x[4 * j + 2] = __uint_as_float(h2); x[4 * j + 3] = __uint_as_float(h3);
+            x[8 + 4 * j + 0] = __uint_as_float(l0); x[8 + 4 * j + 1] = __uint_as_float(l1);
+            x[8 + 4 * j + 2] = __uint_as_float(l2); x[8 + 4 * j + 3] = __uint_as_float(l3);
           }
         }
+      };
+      auto store_block = [&](const f32x16 &x, const Tile &tile, int tm, int tn) {
+        const int nb = (wn * 2 + tn) * 32;
+        const int m = tile.m0 + (wm * TM + tm) * 32 + i;
+        const bool live = m < a.L_out && tile.valid;
+        const int mc = m < a.L_out ? m : 0;
         if (live && !(a.dbg & 64)) {
           if (a.out_f16s) {
             uint4 *yh = reinterpret_cast<uint4 *>(a.y);
-            uint2 ph[4], pl[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              half4 hh4, ll4;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const float v = x[4 * g + j];
-                const _Float16 hv = (_Float16)v;
-                hh4[j] = hv;
-                ll4[j] = (_Float16)(v - (float)hv);
-                vmax = fmaxf(vmax, fabsf(v));
-              }
-              ph[g] = *reinterpret_cast<uint2 *>(&hh4);
-              pl[g] = *reinterpret_cast<uint2 *>(&ll4);
-            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-              uint4 vh = make_uint4(ph[2 * j].x, ph[2 * j].y, ph[2 * j + 1].x, ph[2 * j + 1].y);
-              uint4 vl = make_uint4(pl[2 * j].x, pl[2 * j].y, pl[2 * j + 1].x, pl[2 * j + 1].y);
-              swap32(vh.x, vh.z); swap32(vh.y, vh.w);      // -> whole item of group 2j+h
-              swap32(vl.x, vl.z); swap32(vl.y, vl.w);
               const unsigned it4 = item4(tile, mc, nb, j);
-              yh[it4] = vh;
-              yh[it4 + 2u * (unsigned)a.L_out] = vl;
+              yh[it4] = make_uint4(__float_as_uint(x[4 * j]), __float_as_uint(x[4 * j + 1]),
+                                   __float_as_uint(x[4 * j + 2]), __float_as_uint(x[4 * j + 3]));
+              yh[it4 + 2u * (unsigned)a.L_out] =
+                  make_uint4(__float_as_uint(x[8 + 4 * j]), __float_as_uint(x[8 + 4 * j + 1]),
+                             __float_as_uint(x[8 + 4 * j + 2]), __float_as_uint(x[8 + 4 * j + 3]));
             }
           } else {
             float *yf = reinterpret_cast<float *>(a.y) + ((size_t)tile.rowblk * a.L_out + mc) * a.cout + nb + 4 * h;
@@ -479,15 +537,17 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
           }
         }
       };
-      epi_block(acc[0][0][0], cur[0], 0, 0);
-      epi_block(acc[0][1][0], cur[0], 1, 0);
-      epi_block(acc[0][0][1], cur[0], 0, 1);
-      epi_block(acc[0][1][1], cur[0], 1, 1);
-      epi_block(acc[1][0][0], cur[1], 0, 0);
-      epi_block(acc[1][1][0], cur[1], 1, 0);
-      epi_block(acc[1][0][1], cur[1], 0, 1);
-      epi_block(acc[1][1][1], cur[1], 1, 1);
-      if (!(vmax <= 65000.0f) && a.overflow != nullptr) atomicOr(a.overflow, 1);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        epi_block(acc[tm][0], cur[0], tm, 0);
+        epi_block(acc[tm][1], cur[0], tm, 1);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        store_block(acc[tm][0], cur[0], tm, 0);
+        store_block(acc[tm][1], cur[0], tm, 1);
+      }
+      if (!(vmax <= 65000.0f) && a.overflow != nullptr && a.dbg == 0) atomicOr(a.overflow, 1);
     }
     zero_acc();
 #pragma unroll
@@ -497,29 +557,56 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
   }
 }
 
-template <int K>
-int launch_k(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+template <int K, unsigned EP>
+int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   const int smem = jg_conv_f16_lds_bytes(K, a.dil);
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<K>),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<K, EP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const int n_tiles = a.rows * a.tiles_m;
   const int n_pairs = (n_tiles + NT - 1) / NT;
-  int grid = e->n_cu;
+  // two 4-wave workgroups per CU when their LDS fits (<= 80 KB each): the two run out of phase,
+  // so one's epilogue and stores overlap the other's matrix-core steps
+  int grid = (smem <= 80 * 1024 ? 2 : 1) * e->n_cu;
   if (grid > n_pairs) grid = n_pairs;
-  hipLaunchKernelGGL(conv_f16x3_kernel<K>, dim3((unsigned)grid), dim3(HT), (size_t)smem, s, a);
+  ConvHArgs b = a;
+  static int stag = -1;
+  // JG_STAGGER: experiment switch (measured: no gain on MI355X), off by default
+  if (stag < 0) { const char *ev = getenv("JG_STAGGER"); stag = ev ? atoi(ev) : 0; }
+  // half a pass of matrix-core time (cycles): cc_in*K steps of 24 MFMAs x 32 cycles, two waves per SIMD
+  b.stagger = (stag && grid > e->n_cu && n_pairs >= 2 * grid) ? a.cc_in * K * 24 * 32 * stag : 0;
+  hipLaunchKernelGGL((conv_f16x3_kernel<K, EP>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, b);
   JG_HIP(hipGetLastError());
   return JG_OK;
+}
+
+// compiled epilogue patterns (see jg_common.h JG_EP_*); everything else runs the interpreter
+template <int K>
+int launch_k(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  switch (a.ep) {
+#define JG_CASE(ep) case (ep): return launch_ke<K, (ep)>(e, a, s);
+    JG_CASE(JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_AFF | JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ACT1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2)
+    JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1)
+    JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1)
+#undef JG_CASE
+    default: return launch_ke<K, JG_EP_GENERIC>(e, a, s);
+  }
 }
 
 }  // namespace
 
 int jg_conv_f16_lds_bytes(int k, int dil) {
   const int rows_a = HM + (k - 1) * dil;
-  return (2 * NT * 4 * rows_a + k * W_ITEMS) * 16 + JG_MAX_STAGES * 2 * HN * 4;
+  return (2 * NT * 4 * rows_a + k * W_ITEMS) * 16 + JG_EPI_ROWS * 2 * HN * 4;
 }
 
 // taps / dilation the kernel's tiling can hold: instantiated tap counts, activation slice
