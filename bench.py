@@ -111,10 +111,11 @@ def main():
     from jaeger_amd.engine import JaegerHipEngine, frame_length
     from jaeger_amd.fragment import build_window_table
     from jaeger_amd import dist as jdist
-    from oracle import forward as ofwd          # weights generator + cpu_baseline only
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import random_weights
 
     cfg = yaml.safe_load((ROOT / "tests" / "golden" / "brain_project.yaml").read_text())["model"]
-    weights = ofwd.random_weights(cfg, seed=38341)
+    weights = random_weights(build_plan(cfg), seed=38341)
     import warnings
     warnings.simplefilter("ignore")
     eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=local_rank, chunk=args.chunk,

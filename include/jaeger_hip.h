@@ -146,7 +146,8 @@ int jg_model_get_precision(const jg_model *m);
  *   fsize      crop_size the frame offset is derived from (encode.py:232-236)
  *   lut65      65-byte table: entry 16*b0+4*b1+b2 (TCAG=0..3) -> codon_id+1; [64] unused
  *   soft_mask  0: upper-case before lookup/counting (masking=False, dustmask off)
- *   l_pad      codons per frame row in the output (>= frame length of fsize)
+ *   l_pad      codons per frame row in the output (>= frame length of the longest window when the
+ *              window table is on the host, >= frame length of fsize when it is on the device)
  * outputs (device or host per out_loc):
  *   ids        (n_win, 6, l_pad) u8, rows f1,f2,f3,r1,r2,r3, 0 = invalid / padding
  *   counts     (n_win, 4) i32 upper-case G,C,A,T counts of each window

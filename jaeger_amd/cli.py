@@ -1,0 +1,70 @@
+"""``python -m jaeger_amd predict ...`` - the reference's ``jaeger predict`` flag surface
+(cli.py:122-370) in front of :func:`jaeger_amd.predict.run_core`.
+
+Flags that select machinery outside the MI355X hot path (``--cpu``, ``--onnx``, ``--quantized``,
+``--int8``, ``--prophage``, ``--crf``, ``--refine``, ``--getsequences``) are accepted so existing
+command lines parse, and rejected at run time with an explicit message - there is no silent
+fallback.  Extra flags: ``--exact-f32`` (disable the split-f16 conv path), ``--chunk``.
+"""
+
+from __future__ import annotations
+
+import click
+
+
+@click.group()
+def main():
+    """Jaeger predict path on AMD MI355X."""
+
+
+@main.command(context_settings=dict(ignore_unknown_options=True), help="Run jaeger inference pipeline on MI355X.")
+@click.option("-i", "--input", type=click.Path(exists=True), required=True, help="Path to input file")
+@click.option("-o", "--output", type=str, required=True, help="Path to output directory")
+@click.option("--fsize", type=int, default=2000, help="Length of the sliding window (value must be 2^n).")
+@click.option("--stride", type=int, default=1500, help="Stride of the sliding window.")
+@click.option("--dynamic-stride", is_flag=True, help="adaptive overlap per contig")
+@click.option("--dynamic-stride-threshold", type=float, default=10.0)
+@click.option("--crf", is_flag=True, help="[unsupported here]")
+@click.option("--crf-switch-cost", type=float, default=1.0)
+@click.option("--crf-smooth-sigma", type=float, default=0.0)
+@click.option("--crf-min-prob", type=float, default=0.5)
+@click.option("--dustmask/--no-dustmask", default=True, help="[DUST is not implemented: runs as --no-dustmask]")
+@click.option("--min-len", "min_len", type=int, default=None, help="Minimum contig length to process")
+@click.option("-m", "--model", type=str, default="default")
+@click.option("--model_path", type=click.Path(exists=True), default=None,
+              help="directory containing model/ with *_project.yaml, *_classes.yaml and weights")
+@click.option("--config", type=click.Path(exists=True), default=None)
+@click.option("-p", "--prophage", is_flag=True, help="[unsupported here]")
+@click.option("-s", "--sensitivity", type=float, default=1.5)
+@click.option("--lc", type=int, default=500000)
+@click.option("--plot-type", type=click.Choice(["circular", "linear"]), default="circular")
+@click.option("--rc", type=float, default=0.1, help="Minimum reliability score for the phage table")
+@click.option("--pc", type=int, default=3, help="Minimum phage score for the phage table")
+@click.option("--batch", type=int, default=96, help="batch of the short-contig padded pass")
+@click.option("--workers", type=int, default=4, help="accepted, unused (no host input pipeline)")
+@click.option("--window-scores", is_flag=True)
+@click.option("--getsequences", is_flag=True, help="[unsupported here]")
+@click.option("--cpu", is_flag=True, help="[rejected: no CPU fallback]")
+@click.option("--physicalid", type=int, default=0, help="GPU ordinal")
+@click.option("--mem", type=int, default=4, help="accepted, unused")
+@click.option("--getalllabels", is_flag=True)
+@click.option("-v", "--verbose", count=True, default=1)
+@click.option("-f", "--overwrite", is_flag=True)
+@click.option("--quantized", is_flag=True, help="[unsupported here]")
+@click.option("--precision", type=click.Choice(["fp32", "fp16", "bf16"]), default="fp32",
+              help="accepted; the engine always returns f32-accurate logits")
+@click.option("--xla", is_flag=True, help="accepted, no-op")
+@click.option("--onnx", is_flag=True, help="[unsupported here]")
+@click.option("--int8", is_flag=True, help="[unsupported here]")
+@click.option("--save-embedding", is_flag=True)
+@click.option("--save-nmd", is_flag=True)
+@click.option("--refine", is_flag=True, help="[unsupported here]")
+@click.option("--exact-f32", is_flag=True, help="run every convolution on the exact-f32 MFMA kernels")
+@click.option("--chunk", type=int, default=0, help="windows per device pass (0 = library default)")
+def predict(**kwargs):
+    from .predict import run_core
+    run_core(**kwargs)
+
+
+if __name__ == "__main__":
+    main()

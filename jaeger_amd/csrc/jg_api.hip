@@ -944,9 +944,19 @@ static int encode_common(jg_engine *e, jg_model *scratch_owner, const uint8_t *b
                          int32_t l_pad, uint8_t *d_ids, int32_t *d_counts, uint8_t *d_lut,
                          std::vector<void *> &to_free, hipStream_t s) {
   (void)scratch_owner;
-  JG_REQUIRE(fsize >= 3 && l_pad >= frame_len(fsize), JG_ERR_INVALID,
-             "encode: l_pad=%d is smaller than the %d codons a %d-nt window yields", l_pad,
-             frame_len(fsize), fsize);
+  // l_pad must hold the longest frame: known exactly for host-side window tables (the short-contig
+  // pass pads to the longest window of a batch, commands/predict.py:236-245), fsize-derived otherwise
+  int need = frame_len(fsize);
+  if (win_loc == JG_PTR_HOST && fsize >= 3) {
+    const int off3 = (fsize % 3 == 0) ? -2 : ((fsize % 3 == 1) ? -1 : 0);
+    int longest = 0;
+    for (int64_t i = 0; i < n_win; ++i) longest = std::max(longest, std::min(win_len[i], fsize));
+    const int usable = longest - 5 + off3;
+    need = usable > 0 ? (usable + 2) / 3 : 0;
+  }
+  JG_REQUIRE(fsize >= 3 && l_pad >= need && l_pad >= 1, JG_ERR_INVALID,
+             "encode: l_pad=%d is smaller than the %d codons the longest window yields (fsize %d)", l_pad,
+             need, fsize);
   const uint8_t *d_bases = bases;
   if (bases_loc == JG_PTR_HOST) {
     void *p = nullptr;

@@ -1,0 +1,330 @@
+"""``jaeger predict`` orchestration on the MI355X engine.
+
+Mirrors ``commands/predict.py:488-861`` (``run_core``) for the conv model family: model
+discovery, FASTA validation, output layout ``<output>/<model_id>/<stem>.tsv``, two-pass
+short-contig mode, auxiliary npz writers - with the tf.data pipeline
+(``_build_prediction_dataset`` :186-245) and ``InferModel.predict`` replaced by one window
+table + ``JaegerHipEngine.predict_windows`` call per pass.  Under ``torchrun`` (WORLD_SIZE > 1)
+contigs are sharded over the ranks and gathered on rank 0 (RCCL).
+"""
+
+from __future__ import annotations
+
+import json
+import logging
+import os
+import sys
+import time
+import traceback
+from collections import defaultdict
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+import pandas as pd
+
+from . import fragment as frag
+from .postprocess import pred_to_dict, write_output
+
+logger = logging.getLogger("Jaeger")
+
+
+# ---- model registry (utils/misc.py:334-396) ------------------------------------------------
+class AvailableModels:
+    """Scan ``model/`` directories for ``<name>_graph/``, ``<name>_classes.yaml``,
+    ``<name>_project.yaml`` and ``<name>.weights.h5`` / ``<name>.npz`` entries."""
+
+    def __init__(self, path):
+        self.paths = [Path(path)] if isinstance(path, (str, Path)) else [Path(p) for p in path]
+        self.info = self._scan()
+
+    def _scan(self):
+        models: dict[str, dict] = defaultdict(dict)
+        for path in self.paths:
+            dirs = [p for p in path.rglob("model") if p.is_dir()]
+            if path.name == "model" and path.is_dir():
+                dirs.append(path)
+            for d in dirs:
+                for e in d.iterdir():
+                    if e.is_dir() and e.name.endswith("_graph"):
+                        models[e.name.removesuffix("_graph")]["graph"] = e
+                    elif e.is_file():
+                        name = e.name
+                        if "_classes.yaml" in name:
+                            key = "classes"
+                        elif "_project.yaml" in name:
+                            key = "project"
+                        elif e.suffix == ".h5" and ".weights" in e.stem:
+                            key = "weights"
+                        elif e.suffix == ".npz" and ".weights" in e.stem:
+                            key = "weights_npz"           # canonical weights for the MI355X engine
+                        else:
+                            continue
+                        base = (name.replace("_classes.yaml", "").replace("_project.yaml", "")
+                                .replace(".weights.h5", "").replace(".weights.npz", ""))
+                        models[base][key] = e
+        return models
+
+
+def get_model_id(model: str) -> str:
+    """utils/misc.py:395-396: ``jaeger_38341_1.4M_fragment`` -> ``38341_1.4M``."""
+    return model.split("_", 1)[1].rsplit("_", 1)[0]
+
+
+def validate_fasta_entries(path: str, min_len: int) -> int:
+    """utils/fs.py:99-115: record count; raises when no record reaches ``min_len``."""
+    num = ok = 0
+    for _, seq in frag.read_fasta(path):
+        num += 1
+        ok += len(seq) >= min_len
+    logger.info(f"{ok}/{num} entries in {path}")
+    if ok == 0:
+        raise Exception(f"all records in {path} are < {min_len}bp")
+    return num
+
+
+def get_logger(out_dir: Path, log_file: Path, level: int = 1) -> logging.Logger:
+    """utils/logging.py:30-75: console + DEBUG file handler."""
+    lg = logging.getLogger("Jaeger")
+    lg.setLevel(logging.DEBUG)
+    for h in list(lg.handlers):
+        lg.removeHandler(h)
+    ch = logging.StreamHandler(sys.stderr)
+    ch.setLevel(logging.DEBUG if level and level > 1 else logging.INFO)
+    ch.setFormatter(logging.Formatter("%(asctime)s %(levelname)-8s [jaeger] %(message)s", "%Y-%m-%d %H:%M:%S"))
+    lg.addHandler(ch)
+    fh = logging.FileHandler(out_dir / f"{time.strftime('%m%d%Y_%H%M%S')}_{log_file}")
+    fh.setLevel(logging.DEBUG)
+    fh.setFormatter(ch.formatter)
+    lg.addHandler(fh)
+    return lg
+
+
+def _crop_length_warning(trained_codons, trained_nt, fsize: int) -> str | None:
+    """commands/predict.py:36-63."""
+    if trained_codons is not None:
+        runtime = (int(fsize) - 5) // 3
+        if runtime == trained_codons:
+            return None
+        hint = f" ({trained_nt} nt)" if trained_nt is not None else ""
+        return (f"runtime --fsize {fsize} maps to {runtime} codon frames, but the model was trained on "
+                f"{trained_codons} codons{hint}; prefer --fsize "
+                f"{trained_nt if trained_nt is not None else 'used at training'} for this model.")
+    if trained_nt is not None and int(fsize) != int(trained_nt):
+        return (f"runtime --fsize {fsize} differs from the model's trained fragment length ({trained_nt} nt).")
+    return None
+
+
+def _concat_predictions(a: dict, b: dict) -> dict:
+    """commands/predict.py:248-258."""
+    if not a:
+        return b
+    if not b:
+        return a
+    return {k: np.concatenate([a[k], b[k]], axis=0) for k in a}
+
+
+# ---- one prediction pass --------------------------------------------------------------------
+def predict_records(engine, names: list[str], seqs: list[bytes], fsize: int, stride: int | None,
+                    min_len: int | None = None, max_len: int | None = None, dynamic_stride: bool = False,
+                    dynamic_stride_threshold: float = 10.0, batch: int = 96,
+                    padded: bool = False) -> dict[str, np.ndarray]:
+    """Window table + GPU encode/forward for a set of records; returns the dict
+    ``InferModel.predict`` would (model outputs + ``meta_0..9``).  ``padded`` reproduces
+    ``padded_batch`` of the short-contig pass: windows are run in groups of ``batch`` padded to
+    the longest frame of the group (commands/predict.py:236-245)."""
+    from .engine import frame_length
+    lengths = np.fromiter((len(s) for s in seqs), np.int64, len(seqs))
+    table = frag.build_window_table(lengths, fsize, stride, dynamic_stride, dynamic_stride_threshold,
+                                    min_len, max_len)
+    if len(table) == 0:
+        return {}
+    bases, offsets = frag.concat_records(seqs)
+    starts = offsets[table.contig] + table.start
+    if not padded:
+        out = engine.predict_windows(bases, starts, table.length, fsize)
+    else:
+        off3 = (-2, -1, 0)[fsize % 3]
+        parts = []
+        for i in range(0, len(table), batch):
+            sl = slice(i, i + batch)
+            lmax = int(max(0, -(-(int(table.length[sl].max()) - 5 + off3) // 3)))
+            parts.append(engine.predict_windows(bases, starts[sl], table.length[sl], fsize, l_pad=max(lmax, 1)))
+        out = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+    counts = out.pop("counts")
+    out.update(frag.window_metadata(table, names, counts))
+    return out
+
+
+def _shard_records(names, seqs, fsize, stride, world, rank):
+    """Whole contigs to ranks, balanced by window count (LPT)."""
+    from .dist import lpt_partition
+    step = fsize if stride is None else stride
+    w = np.array([max(1, (len(s) - fsize) // step + 1) if len(s) >= fsize else 1 for s in seqs])
+    groups = lpt_partition(w, world)
+    mine = groups[rank]
+    return [names[i] for i in mine], [seqs[i] for i in mine], groups
+
+
+# ---- run_core ---------------------------------------------------------------------------------
+def run_core(**kwargs) -> int:
+    """Equivalent of ``commands/predict.py:run_core``; returns the number of table rows written."""
+    import yaml
+
+    from .engine import JaegerHipEngine
+
+    t_start = time.time()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(kwargs.get("physicalid", 0))))
+
+    model_path = kwargs.get("model_path")
+    if model_path:
+        info = AvailableModels(path=model_path).info
+        if not info:
+            print(f"No model found in {model_path}", file=sys.stderr)
+            sys.exit(1)
+        cands = {n: m for n, m in info.items() if m.get("project") is not None and m.get("classes") is not None}
+        if not cands:
+            print(f"No classification model found in {model_path}. Expected *_classes.yaml, *_project.yaml "
+                  "and *.weights.h5 / *.weights.npz files.", file=sys.stderr)
+            sys.exit(1)
+        non_emb = {n: m for n, m in cands.items() if not n.endswith("_embedding")}
+        cands = non_emb or cands
+        model_name = next(iter(cands))
+        model_info = cands[model_name]
+    else:
+        cfg_path = kwargs.get("config")
+        if not cfg_path:
+            print("jaeger_amd: pass --model_path <dir with model/> or --config <json with model_paths>",
+                  file=sys.stderr)
+            sys.exit(1)
+        paths = json.loads(Path(cfg_path).read_text()).get("model_paths", [])
+        info = AvailableModels(path=paths).info
+        model_name = kwargs.get("model")
+        if model_name not in info:
+            print(f"model {model_name!r} not found under {paths}", file=sys.stderr)
+            sys.exit(1)
+        model_info = info[model_name]
+    model_id = get_model_id(model_name)
+
+    input_path = Path(kwargs.get("input"))
+    file_base = input_path.stem
+    out_dir = Path(kwargs.get("output")) / model_id
+    out_dir.mkdir(parents=True, exist_ok=True)
+    lg = get_logger(out_dir, Path(f"{file_base}_jaeger.log"), kwargs.get("verbose", 1))
+    fsize, stride = kwargs.get("fsize", 2000), kwargs.get("stride", 1500)
+    user_min_len = kwargs.get("min_len")
+    min_len = user_min_len or fsize
+    try:
+        num = validate_fasta_entries(str(input_path), min_len=min_len)
+    except Exception as e:
+        lg.error(e)
+        sys.exit(1)
+    table_path, phage_path = out_dir / f"{file_base}.tsv", out_dir / f"{file_base}_phages.tsv"
+    if table_path.exists() and not kwargs.get("overwrite"):
+        lg.error("output file exists. enable --overwrite option to overwrite the output file.")
+        sys.exit(1)
+    for flag in ("prophage", "refine", "crf", "quantized", "onnx", "int8", "cpu", "getsequences"):
+        if kwargs.get(flag):
+            lg.error(f"--{flag} is not available on the MI355X predict path (jaeger_amd has no CPU / "
+                     "alternative-backend fallback; prophage / refinement / CRF post-processing is out of scope)")
+            sys.exit(1)
+    if kwargs.get("dustmask", True):
+        lg.warning("DUST low-complexity masking (pydustmasker) is not implemented on this path: running as "
+                   "--no-dustmask; G+C / N% columns can differ from a masked reference run")
+    lg.warning("terminal-repeat scan (parasail) is not implemented: terminal_repeats / repeat_length stay empty")
+
+    weights = None
+    wnpz = model_info.get("weights_npz")
+    if wnpz is not None:
+        from .weights import load_npz
+        weights = load_npz(wnpz)
+    precision = "f32" if kwargs.get("exact_f32") else None
+    try:
+        engine = JaegerHipEngine(model_info, weights=weights, device_id=local_rank, chunk=kwargs.get("chunk", 0),
+                                 precision=precision)
+    except Exception as e:
+        lg.debug(traceback.format_exc())
+        lg.error(f"could not set up the model on GPU {local_rank}: {e}")
+        sys.exit(1)
+    sp = engine.string_processor_config
+    lg.info(f"input file: {input_path.name}")
+    lg.info(f"outpath: {out_dir.resolve()}")
+    lg.info(f"fragment size: {fsize}  stride: {stride}  batch: {kwargs.get('batch', 96)}")
+    lg.info(f"model: {model_id}  arithmetic: {engine.model.precision}  device: MI355X #{local_rank} "
+            f"(rank {rank}/{world})")
+    msg = _crop_length_warning(sp.get("crop_size_codons"), sp.get("crop_size_nt"), fsize)
+    if msg:
+        lg.warning(msg)
+
+    records = list(frag.read_fasta(str(input_path)))
+    names, seqs = [r[0] for r in records], [r[1] for r in records]
+    groups = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl")
+        all_names = names
+        names, seqs, groups = _shard_records(names, seqs, fsize, stride, world, rank)
+    common = dict(dynamic_stride=kwargs.get("dynamic_stride", False),
+                  dynamic_stride_threshold=kwargs.get("dynamic_stride_threshold", 10.0),
+                  batch=kwargs.get("batch", 96))
+    try:
+        if user_min_len is not None and user_min_len < fsize:
+            lg.info(f"Two-pass prediction: long contigs (>= {fsize} bp) then short contigs "
+                    f"({user_min_len}-{fsize - 1} bp)")
+            y_long = predict_records(engine, names, seqs, fsize, stride, min_len=fsize, max_len=None, **common)
+            y_short = predict_records(engine, names, seqs, fsize, stride, min_len=user_min_len,
+                                      max_len=fsize - 1, padded=True, **common)
+            y_pred = _concat_predictions(y_long, y_short)
+        else:
+            y_pred = predict_records(engine, names, seqs, fsize, stride, min_len=min_len, max_len=None, **common)
+    except Exception as e:
+        lg.debug(traceback.format_exc())
+        lg.error(f"an error {e} occured during inference on MI355X #{local_rank}!")
+        sys.exit(1)
+
+    if world > 1:
+        import torch.distributed as dist
+        objs = [None] * world if rank == 0 else None
+        dist.gather_object(y_pred, objs, dst=0)
+        if rank != 0:
+            dist.barrier()
+            return 0
+        # restore the reference's emission order: FASTA order within each pass
+        blocks = {}
+        for yr in objs:
+            if not yr:
+                continue
+            ends = np.nonzero(np.asarray(yr["meta_2"]) == 1)[0] + 1
+            begins = np.concatenate(([0], ends[:-1]))
+            for b, e in zip(begins, ends):
+                blocks[(int(yr["meta_4"][b]) >= fsize, yr["meta_0"][b])] = (yr, b, e)
+        hdr = [n.strip().replace(",", "___") for n in all_names]
+        ordered = [blocks[(True, h)] for h in hdr if (True, h) in blocks] + \
+                  [blocks[(False, h)] for h in hdr if (False, h) in blocks]
+        keys = objs[0].keys() if objs[0] else next(o for o in objs if o).keys()
+        y_pred = {k: np.concatenate([yr[k][b:e] for yr, b, e in ordered], axis=0) for k in keys}
+        dist.barrier()
+
+    data, data_full = pred_to_dict(y_pred, class_map=engine.class_map, fsize=fsize, term_repeats=None)
+    n_written = write_output(data, labels=engine.class_map.get("class"), indices=engine.class_map.get("index"),
+                             output_table_path=table_path, output_phage_table_path=phage_path,
+                             reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))
+    lg.info(f"processed {n_written}/{num} sequences")
+    if kwargs.get("window_scores"):
+        np.savez(out_dir / f"{file_base}_window_scores.npz", headers=data_full["headers"],
+                 lengths=data_full["lengths"], predictions=np.array(data_full["predictions"], dtype=object),
+                 gc_skews=np.array(data_full["gc_skews"], dtype=object),
+                 gcs=np.array(data_full["gcs"], dtype=object))
+    headers = y_pred.get("meta_0", np.array([], dtype=object))
+    if kwargs.get("save_embedding") and "embedding" in y_pred:
+        np.savez(out_dir / f"{file_base}_embedding.npz", embedding=y_pred["embedding"], headers=headers)
+    if kwargs.get("save_nmd") and "nmd" in y_pred:
+        np.savez(out_dir / f"{file_base}_nmd.npz", embedding=y_pred["nmd"], headers=headers)   # legacy key name
+    lg.info(f"wall time(s) : {time.time() - t_start:.2f}  ({len(y_pred['meta_2'])} windows)")
+    engine.close()
+    return n_written

@@ -303,7 +303,7 @@ def random_weights(model_cfg: dict, seed: int = 38341) -> dict[str, np.ndarray]:
     kernels, BN gamma~U[0.5,1.5], beta/mu~N(0,0.1), var~U[0.5,1.5]."""
     rng = np.random.Generator(np.random.PCG64(seed))
     out = {}
-    for name, shp in weight_specs(model_cfg).items():
+    for name, shp in sorted(weight_specs(model_cfg).items()):
         leaf = name.rsplit("/", 1)[1]
         if leaf == "kernel":
             fan_in = int(np.prod(shp[:-1]))

@@ -22,3 +22,22 @@ def golden_dir():
 def load_model_cfg(name: str) -> dict:
     import yaml
     return yaml.safe_load((GOLDEN / f"{name}_project.yaml").read_text())["model"]
+
+
+def make_model_dir(root: Path, name: str = "brain", model_name: str = "jaeger_38341_1.4M_fragment",
+                   seed: int = 38341) -> Path:
+    """A model directory as ``AvailableModels`` expects it (utils/misc.py:346-392), with seeded
+    stand-in weights in the engine's canonical npz form."""
+    import shutil
+
+    import yaml
+
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import random_weights, save_npz
+    d = Path(root) / "model"
+    d.mkdir(parents=True, exist_ok=True)
+    shutil.copyfile(GOLDEN / f"{name}_project.yaml", d / f"{model_name}_project.yaml")
+    cfg = load_model_cfg(name)
+    (d / f"{model_name}_classes.yaml").write_text(yaml.safe_dump({"classes": cfg["class_label_map"]}))
+    save_npz(d / f"{model_name}.weights.npz", random_weights(build_plan(cfg), seed))
+    return Path(root)

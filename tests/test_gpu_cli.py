@@ -1,0 +1,128 @@
+"""End-to-end ``predict`` on the MI355X: FASTA -> TSV through the CLI, checked against the same
+pipeline assembled from the CPU oracle (fragmenter strings -> encoder -> forward) and the shared
+postprocess module (itself pinned to the reference's golden TSVs in test_postprocess.py)."""
+
+import numpy as np
+import pandas as pd
+import pytest
+from click.testing import CliRunner
+from conftest import GOLDEN, load_model_cfg, make_model_dir
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_pass(records, cfg, weights, fsize, stride, min_len, max_len, batch=None):
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    from oracle import fragmenter as ofr
+    rows = [r.split(",") for r in ofr.fragment_strings(records, fsize, stride, min_len=min_len, max_len=max_len)]
+    if not rows:
+        return {}
+    wins = [r[0] for r in rows]
+    if batch is None:
+        out = ofwd.forward(cfg, weights, oenc.encode_windows(wins, fsize, pad_to=oenc.frame_length(fsize)))
+    else:
+        parts = [ofwd.forward(cfg, weights, oenc.encode_windows(wins[i:i + batch], fsize))
+                 for i in range(0, len(wins), batch)]
+        out = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    out["meta_0"] = np.array([r[1] for r in rows])
+    for j, k in ((2, "meta_1"), (3, "meta_2"), (4, "meta_3"), (5, "meta_4"), (6, "meta_5"), (7, "meta_6"),
+                 (8, "meta_7"), (9, "meta_8")):
+        out[k] = np.array([int(r[j]) for r in rows])
+    out["meta_9"] = np.array([float(r[10]) for r in rows])
+    return out
+
+
+def _compare_tsv(got_path, exp_path):
+    got, exp = pd.read_csv(got_path, sep="\t"), pd.read_csv(exp_path, sep="\t")
+    assert list(got.columns) == list(exp.columns)
+    assert len(got) == len(exp)
+    for col in exp.columns:
+        if exp[col].dtype.kind == "f":
+            # per-contig statistics are stored as fp16 and printed with 3 decimals: a 1e-5 logit
+            # difference can move a value by one fp16 ulp
+            np.testing.assert_allclose(got[col].to_numpy(float), exp[col].to_numpy(float), rtol=2e-3, atol=2e-3,
+                                       equal_nan=True, err_msg=col)
+        else:
+            assert got[col].astype(str).tolist() == exp[col].astype(str).tolist(), col
+
+
+def _expected(tmp_path, records, cfg, weights, fsize, stride, min_len, batch):
+    from jaeger_amd.postprocess import pred_to_dict, write_output
+    from jaeger_amd.predict import _concat_predictions
+    if min_len is not None and min_len < fsize:
+        y = _concat_predictions(_oracle_pass(records, cfg, weights, fsize, stride, fsize, None),
+                                _oracle_pass(records, cfg, weights, fsize, stride, min_len, fsize - 1, batch))
+    else:
+        y = _oracle_pass(records, cfg, weights, fsize, stride, min_len or fsize, None)
+    classes = [c["class"] for c in cfg["class_label_map"]]
+    data, _ = pred_to_dict(y, class_map={"num_classes": len(classes)}, fsize=fsize, term_repeats=None)
+    exp, exp_ph = tmp_path / "expected.tsv", tmp_path / "expected_phages.tsv"
+    write_output(data, labels=classes, indices=[c["label"] for c in cfg["class_label_map"]], output_table_path=exp,
+                 output_phage_table_path=exp_ph, reliability_cutoff=0.1, phage_score=3)
+    return exp, exp_ph, y
+
+
+def test_cli_predict_bundled_contigs(tmp_path):
+    from jaeger_amd.cli import main
+    from jaeger_amd.fragment import read_fasta
+    from oracle import forward as ofwd
+    root = make_model_dir(tmp_path / "m")
+    cfg = load_model_cfg("brain")
+    weights = ofwd.random_weights(cfg, seed=38341)
+    fasta = GOLDEN / "test_contigs.fasta"
+    r = CliRunner().invoke(main, ["predict", "-i", str(fasta), "-o", str(tmp_path / "out"), "--model_path", str(root),
+                                  "--fsize", "1500", "--stride", "1500", "--no-dustmask", "--save-embedding",
+                                  "--save-nmd", "--window-scores"])
+    assert r.exit_code == 0, r.output
+    out = tmp_path / "out" / "38341_1.4M"
+    records = [(n, s.decode()) for n, s in read_fasta(str(fasta))]
+    exp, exp_ph, y = _expected(tmp_path, records, cfg, weights, 1500, 1500, None, 96)
+    _compare_tsv(out / "test_contigs.tsv", exp)
+    assert (out / "test_contigs_phages.tsv").exists() == exp_ph.exists()
+    emb = np.load(out / "test_contigs_embedding.npz", allow_pickle=True)
+    assert emb["embedding"].shape == y["embedding"].shape
+    assert list(emb["headers"]) == list(y["meta_0"])
+    tol = 1e-4 * max(1.0, float(np.abs(y["embedding"]).max()) / 8)
+    assert float(np.abs(emb["embedding"] - y["embedding"]).max()) <= tol
+    ws = np.load(out / "test_contigs_window_scores.npz", allow_pickle=True)
+    assert len(ws["headers"]) == 9
+    assert float(np.abs(np.concatenate(list(ws["predictions"])) - y["prediction"]).max()) <= 1e-4
+    # refuses to overwrite without -f
+    r = CliRunner().invoke(main, ["predict", "-i", str(fasta), "-o", str(tmp_path / "out"), "--model_path", str(root),
+                                  "--fsize", "1500"])
+    assert r.exit_code == 1
+
+
+def test_cli_two_pass_short_contigs(tmp_path):
+    """--min-len < --fsize: long pass, then the short contigs in padded groups of --batch
+    (commands/predict.py:741-798)."""
+    from jaeger_amd.cli import main
+    from oracle import forward as ofwd
+    rng = np.random.Generator(np.random.PCG64(77))
+    records = []
+    for i, n in enumerate([5200, 700, 1499, 3100, 650, 1203, 400, 1500, 999, 2999]):
+        seq = "".join(rng.choice(list("ACGT"), n))
+        if i == 2:
+            seq = seq[:300] + "N" * 40 + seq[340:]
+        records.append((f"ctg_{i} len={n}", seq))
+    fasta = tmp_path / "mixed.fasta"
+    with open(fasta, "w") as fh:
+        for n, s in records:
+            fh.write(f">{n}\n")
+            for j in range(0, len(s), 70):
+                fh.write(s[j:j + 70] + "\n")
+    root = make_model_dir(tmp_path / "m")
+    cfg = load_model_cfg("brain")
+    weights = ofwd.random_weights(cfg, seed=38341)
+    r = CliRunner().invoke(main, ["predict", "-i", str(fasta), "-o", str(tmp_path / "out"), "--model_path", str(root),
+                                  "--fsize", "1500", "--stride", "1500", "--no-dustmask", "--min-len", "600",
+                                  "--batch", "2"])
+    assert r.exit_code == 0, r.output
+    recs = [(n.split()[0], s) for n, s in records]
+    exp, _, y = _expected(tmp_path, recs, cfg, weights, 1500, 1500, 600, 2)
+    _compare_tsv(tmp_path / "out" / "38341_1.4M" / "mixed.tsv", exp)
+    got = pd.read_csv(tmp_path / "out" / "38341_1.4M" / "mixed.tsv", sep="\t")
+    assert "ctg_6" not in set(got["contig_id"])            # 400 bp < --min-len
+    # long pass first; contigs under 0.7 * fsize fall to the N% < 0.3 filter (collect.py:575)
+    assert list(got["contig_id"]) == ["ctg_0", "ctg_3", "ctg_7", "ctg_9", "ctg_2", "ctg_5"]

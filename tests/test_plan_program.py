@@ -1,0 +1,116 @@
+"""project.yaml -> layer plan -> op program (host logic, no GPU)."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import load_model_cfg
+
+
+def test_plan_defaults_follow_reference_constructors():
+    from jaeger_amd import plan as P
+    pl = P.build_plan(load_model_cfg("brain"))
+    conv0 = pl.rep[0]
+    assert isinstance(conv0, P.Conv) and conv0.padding == "valid"        # MaskedConv1D default (layers.py:1156)
+    assert conv0.mask_mode == "any" and conv0.kernel_size == 7 and conv0.cin == 128
+    blocks = [l for l in pl.rep if isinstance(l, P.ResBlock)]
+    assert len(blocks) == 6 and all(b.conv1.padding == "same" and b.conv1.dilation_rate == 3 for b in blocks)
+    assert all(b.conv3 is None for b in blocks)
+    assert pl.nmd_dims == [128] * 4 and pl.pooling == "max" and pl.n_classes == 6
+    assert pl.vocab == 65 and pl.string_processor["seq_onehot"] is False
+    assert pl.string_processor["input_type"] == "translated"
+    n_params = sum(int(np.prod(s)) for s in P.weight_shapes(pl).values())
+    assert n_params == 1121303
+
+
+def test_crop_resolution_and_seq_onehot_inference():
+    """nnlib/inference.py:452-482 (tests/unit/test_inference.py of the reference)."""
+    from jaeger_amd.plan import resolve_string_processor
+    cfg = load_model_cfg("baseline500")
+    sp = resolve_string_processor(cfg)
+    assert sp["crop_size_codons"] == 500 and sp["crop_size_nt"] == 1505     # crop_units defaults to codon
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["string_processor"].pop("seq_onehot")
+    cfg2["embedding"]["input_shape"] = [6, None, 64]
+    assert resolve_string_processor(cfg2)["seq_onehot"] is True
+    cfg2["embedding"]["input_shape"] = [6, None]
+    assert resolve_string_processor(cfg2)["seq_onehot"] is False
+    cfg3 = copy.deepcopy(cfg)
+    cfg3["string_processor"]["crop_units"] = "nucleotide"
+    cfg3["string_processor"]["crop_size"] = 1505
+    assert resolve_string_processor(cfg3)["crop_size_codons"] == 500
+
+
+def test_weight_names_agree_with_oracle():
+    from jaeger_amd import plan as P
+    from oracle import forward as F
+    for name in ("brain", "zeus", "baseline500"):
+        cfg = load_model_cfg(name)
+        assert P.weight_shapes(P.build_plan(cfg)) == F.weight_specs(cfg)
+
+
+def test_program_fuses_epilogues_and_fits_slots():
+    from jaeger_amd import _lib as L
+    from jaeger_amd import plan as P
+    from jaeger_amd import program as G
+    from oracle import forward as F
+    cfg = load_model_cfg("brain")
+    prog = G.compile_plan(P.build_plan(cfg), F.random_weights(cfg))
+    kinds = [op.kind for op in prog.ops]
+    assert kinds.count(L.OP_CONV) == 13 and kinds.count(L.OP_MASK) == 13
+    assert kinds.count(L.OP_NMD_FINAL) == 4 and kinds.count(L.OP_POOL) == 1 and kinds.count(L.OP_DENSE) == 3
+    convs = [op for op in prog.ops if op.kind == L.OP_CONV]
+    st = lambda op: [op.stages[i].kind for i in range(op.n_stages)]
+    assert st(convs[0]) == [L.ST_BIAS, L.ST_NMD, L.ST_BN, L.ST_ACT]
+    assert st(convs[1]) == [L.ST_BIAS, L.ST_BN, L.ST_ACT]
+    assert st(convs[2]) == [L.ST_BIAS, L.ST_BN, L.ST_ADD, L.ST_ACT]
+    assert st(convs[4]) == [L.ST_BIAS, L.ST_BN, L.ST_ADD, L.ST_ACT, L.ST_NMD, L.ST_BN, L.ST_ACT]
+    assert convs[0].in_buf == L.JG_BUF_IDS and convs[0].in_mask == L.JG_BUF_IDS
+    for op in prog.ops:
+        assert op.out_buf < L.JG_MAX_BUFS and op.out_mask < L.JG_MAX_BUFS
+    assert prog.blob.size % 4 == 0 and prog.nmd_dim == 512 and prog.has_reliability
+
+
+def test_use_masking_false_drops_masks():
+    from jaeger_amd import _lib as L
+    from jaeger_amd import plan as P
+    from jaeger_amd import program as G
+    from oracle import forward as F
+    cfg = load_model_cfg("baseline500")
+    cfg["use_masking"] = False                                     # legacy SavedModels (builder.py:259)
+    prog = G.compile_plan(P.build_plan(cfg), F.random_weights(cfg))
+    assert not any(op.kind == L.OP_MASK for op in prog.ops)
+    pool = [op for op in prog.ops if op.kind == L.OP_POOL][0]
+    assert pool.in_mask == L.JG_BUF_NONE
+
+
+def test_unsupported_layers_fail_loudly():
+    from jaeger_amd import plan as P
+    cfg = load_model_cfg("brain")
+    cfg["representation_learner"]["hidden_layers"].insert(1, {"name": "transformer_encoder", "config": {}})
+    with pytest.raises(P.UnsupportedLayer):
+        P.build_plan(cfg)
+    cfg = load_model_cfg("brain")
+    cfg["representation_learner"]["pooling"] = "gatedframe"
+    with pytest.raises(P.UnsupportedLayer):
+        P.build_plan(cfg)
+    cfg = load_model_cfg("brain")
+    cfg["reliability_model"]["input_shape"] = 100
+    with pytest.raises(ValueError):
+        P.build_plan(cfg)
+
+
+def test_missing_or_misshaped_weights_rejected():
+    from jaeger_amd import plan as P
+    from jaeger_amd import program as G
+    from oracle import forward as F
+    cfg = load_model_cfg("baseline500")
+    w = F.random_weights(cfg)
+    bad = dict(w)
+    bad.pop("rep/0/kernel")
+    with pytest.raises(KeyError):
+        G.compile_plan(P.build_plan(cfg), bad)
+    bad = dict(w)
+    bad["rep/0/kernel"] = bad["rep/0/kernel"][:, :, :16]
+    with pytest.raises(ValueError):
+        G.compile_plan(P.build_plan(cfg), bad)
