@@ -199,6 +199,8 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
   const unsigned x_cc_stride = a.ids != nullptr ? 4u * 16u : 4u * (unsigned)a.L_in * 16u;   // bytes per chunk
 
   // ---- DMA issue ---------------------------------------------------------------------------
+  // does this wave own pieces in the last (partial) activation iteration?
+  const bool x_last_wave = __builtin_amdgcn_readfirstlane((int)((A_ITERS - 1) * HT + wid * 64 < 4 * rows_a)) != 0;
   auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
     if (a.dbg & 16) return;
     const char *sb = reinterpret_cast<const char *>(a.wh) + ((size_t)(t * a.cc_in * 2 + cc * 2) * HN) * 16;
@@ -209,9 +211,14 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
     if (a.dbg & 8) return;
     const char *sb = x_base + (size_t)cc * x_cc_stride;
     const unsigned dst = ldsA + buf * (a_items * 16);
+    // Iterations 0..A_ITERS-2 are full (4*rows_a > 4*HT); the last one covers the halo remainder
+    // and exists only in the leading wave(s).  The branch around it is wave-uniform on purpose:
+    // the counted waits below must know exactly how many DMAs each wave has in flight.
 #pragma unroll
-    for (int it = 0; it < A_ITERS; ++it)
-      if ((a_pk[it] >> 20) < NT) glds16(sb, x_voff[it], dst + it * (HT * 16));
+    for (int it = 0; it < A_ITERS - 1; ++it) glds16(sb, x_voff[it], dst + it * (HT * 16));
+    if (x_last_wave) {
+      if ((a_pk[A_ITERS - 1] >> 20) < NT) glds16(sb, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
+    }
   };
   // after a slice's DMA has landed: overwrite padding / masked-out pieces with zeros (by the
   // lanes that fetched them); the step barrier then publishes the slice
@@ -270,7 +277,10 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
       for (int t = 0; t < K; ++t) {
         // -- wait for this step's operands, publish them ---------------------------------------
         if (tail) wait_vm<0>();
-        else if (t >= 1 && t <= WA) wait_vm<(WA - 1) * W_ITERS + A_ITERS>();
+        else if (t >= 1 && t <= WA) {
+          if (x_last_wave) wait_vm<(WA - 1) * W_ITERS + A_ITERS>();
+          else wait_vm<(WA - 1) * W_ITERS + A_ITERS - 1>();
+        }
         else wait_vm<(WA - 1) * W_ITERS>();
         if (t == 0) zero_fill(abuf);
         __syncthreads();

@@ -178,3 +178,26 @@ def test_forward_all_masked_window(precision):
     assert not got["embedding"][1].any()
     for k, r in ref.items():
         assert np.abs(got[k] - r).max() <= TOL, k
+
+
+@pytest.mark.parametrize("name,fsize,n_win", [("brain", 1500, 10), ("brain", 1500, 150), ("zeus", 1500, 24)])
+def test_f16x3_repeatable(name, fsize, n_win):
+    """The split-f16 conv tracks its DMA queue with counted waits; a miscounted wait shows up as
+    run-to-run differences.  40 repeats of the same forward must be bit-identical."""
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = load_model_cfg(name)
+    weights = ofwd.random_weights(cfg, seed=38341)
+    rng = np.random.Generator(np.random.PCG64(5))
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.01)
+    windows = [seq[i * fsize:(i + 1) * fsize].tobytes() for i in range(n_win)]
+    ids = oenc.encode_windows(windows, fsize, pad_to=frame_length(fsize))
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, precision="f16x3")
+    first = eng.model.forward(ids)
+    bad = 0
+    for rep in range(40):
+        again = eng.model.forward(ids, chunk=(0, 7, 64)[rep % 3])
+        bad += any(not np.array_equal(first[k], again[k]) for k in first)
+    eng.close()
+    assert bad == 0, f"{bad}/40 repeats differ"
