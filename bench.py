@@ -191,6 +191,15 @@ def main():
         # roofline: algorithmic (f32-equivalent) conv FLOP/s against the matrix-core peak the kernel
         # can reach: exact-f32 MFMA, or the f16 MFMA peak / 3 for the split-f16 scheme
         peak = F32_MFMA_PEAK_TFLOPS if mode == "f32" else F16_MFMA_PEAK_TFLOPS / 3.0
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (it cannot be
+        # read from inside the process); the committed summary applies to the default configuration only
+        traffic = None
+        try:
+            pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())["conv_f16x3_kernel"]
+            if mode == pmc["precision"] and fsize == pmc["fsize"] and args.chunk in (0, pmc["chunk"]):
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             "metric": "Mbp/s classified (1500bp frags)", "value": round(value, 3), "unit": "Mbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,7 +212,7 @@ def main():
                        "windows_per_gpu": int(win_total / world), "bp_per_gpu": int(bp_total / world),
                        "parallelism": f"contig-sharded x{world}, final RCCL gather"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1),
-                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                          "kernel": "conv_f32_kernel" if mode == "f32" else "conv_f16x3_kernel", "launches": int(prof["conv_launches"]),
                          "avg_launch_ms": round(prof["conv_ms"] / max(prof["conv_launches"], 1), 4)},
         }

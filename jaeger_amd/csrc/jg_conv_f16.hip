@@ -32,6 +32,7 @@
 // holds one channel and a lane holds one position: the fused epilogue (folded
 // bias/batch-norm affine, residual add, GELU, NMD tap, f16 re-split) needs no
 // cross-lane transpose and reads its per-channel parameters from LDS.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "jg_common.h"
@@ -91,8 +92,25 @@ struct Tile {
   int rowblk, m0, valid;
 };
 
+// -DJG_STAMP: experiment build that accumulates per-phase shader cycles of every wave
+// (wait / barrier / DMA issue / LDS+MFMA / epilogue / whole kernel) and prints them per launch.
+#ifdef JG_STAMP
+__device__ unsigned long long jg_stamp_acc[8];
+#define JG_ST_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime(); const unsigned long long st_t0 = st_t
+#define JG_ST(idx) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[idx] += n_ - st_t; st_t = n_; } while (0)
+#define JG_ST_END do { st_[5] = __builtin_amdgcn_s_memtime() - st_t0; if (lane == 0) { for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&jg_stamp_acc[q_], st_[q_]); } } while (0)
+#else
+#define JG_ST_DECL
+#define JG_ST(idx)
+#define JG_ST_END
+#endif
+
 template <int K, unsigned EP>
-__global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
+// K = 5 fits two workgroups per CU in LDS (<= 80 KB each): hold the register file to 256 per
+// lane so that both are really resident (without the bound hipcc takes ~340 and the second
+// workgroup of a CU only starts when the first has finished).
+__global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(K == 5 ? 2 : 1, 2)))
+void conv_f16x3_kernel(ConvHArgs a) {
   constexpr int WA = K - 2;                  // weight slices in flight ahead of the matrix cores
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -258,6 +276,7 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
   // leave outstanding only what was issued after its own weight slice: WA-1 weight DMAs, plus
   // the A_ITERS activation DMAs when those went out in between (taps 1..WA).
   Tile cur[NT], np[NT];            // tiles of this pass / of the next pass
+  JG_ST_DECL;
   tiles_of(0, cur);
   load_bytes(cur);
   build_pieces(cur);               // the only exposed byte-load latency of the launch
@@ -276,14 +295,17 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
       for (int t = 0; t < K; ++t) {
         // -- wait for this step's operands, publish them ---------------------------------------
+        JG_ST(6);
         if (tail) wait_vm<0>();
         else if (t >= 1 && t <= WA) {
           if (x_last_wave) wait_vm<(WA - 1) * W_ITERS + A_ITERS>();
           else wait_vm<(WA - 1) * W_ITERS + A_ITERS - 1>();
         }
         else wait_vm<(WA - 1) * W_ITERS>();
+        JG_ST(0);
         if (t == 0) zero_fill(abuf);
         __syncthreads();
+        JG_ST(1);
         // -- keep the DMA queue full --------------------------------------------------------------
         if (t + WA < K) {
           issue_w(cc, t + WA);
@@ -294,6 +316,7 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
           if (last_chunk) build_pieces(np);        // the next pass's pieces take over from here
           issue_x(last_chunk ? 0 : cc + 1, abuf ^ 1);
         }
+        JG_ST(2);
         // -- matrix-core work: one tap of one 16-channel chunk ----------------------------------
         if (!(a.dbg & 2)) {
           const uint4 *B = Wbuf + t * W_ITEMS + w_frag;
@@ -330,6 +353,7 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
       }
       ++xc;
     }
+    JG_ST(3);
 
     // ---- pass finished: fused epilogue straight from the accumulators ----------------------
     if (a.dbg & 1) {
@@ -564,7 +588,9 @@ __global__ __launch_bounds__(HT) void conv_f16x3_kernel(ConvHArgs a) {
     for (int u = 0; u < NT; ++u) cur[u] = np[u];
     tiles_of(pass + 2, np);
     load_bytes(np);                // position bytes of the pass after next
+    JG_ST(4);
   }
+  JG_ST_END;
 }
 
 template <int K, unsigned EP>
@@ -590,6 +616,17 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   b.stagger = (stag && grid > e->n_cu && n_pairs >= 2 * grid) ? a.cc_in * K * 24 * 32 * stag : 0;
   hipLaunchKernelGGL((conv_f16x3_kernel<K, EP>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, b);
   JG_HIP(hipGetLastError());
+#ifdef JG_STAMP
+  {
+    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    JG_HIP(hipStreamSynchronize(s));
+    JG_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(jg_stamp_acc), sizeof(h)));
+    JG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(jg_stamp_acc), z, sizeof(z)));
+    const double tot = (double)h[5];
+    fprintf(stderr, "STAMP k=%d ep=%u rows=%d grid=%d total_cyc/wave=%.0f wait=%.3f barrier=%.3f issue=%.3f lds_mfma=%.3f epilogue=%.3f\n",
+            K, EP, a.rows, grid, tot / (grid * 4.0), h[0] / tot, h[1] / tot, h[2] / tot, (h[3] + h[6]) / tot, h[4] / tot);
+  }
+#endif
   return JG_OK;
 }
 
