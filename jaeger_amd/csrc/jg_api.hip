@@ -535,6 +535,30 @@ static int prepare_f16(jg_model *m, const float *weights) {
         JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_epi), tab.size() * sizeof(float)));
         JG_HIP(hipMemcpy(hp.d_epi, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
       }
+      // first layer on ids: the conv is a sum of k table rows T_t[id] = E[id] . W_t (f64 on the
+      // host); the kernel's table variant then needs no matrix cores and no acc un-scale
+      static const bool no_lut = getenv("JG_NO_LUT") != nullptr;
+      if (m->f16_eligible && !no_lut && op.in_buf == JG_BUF_IDS &&
+          (op.in_mask == JG_BUF_IDS || op.in_mask < 0) && op.cout <= 128 &&
+          jg_conv_lut_supports(op.k, op.dilation, m->vocab)) {
+        const float *emb = weights + op.b_off;   // (vocab, cin)
+        const int vr = m->vocab + 1;             // + the all-zero padding row
+        std::vector<float> lut((size_t)2 * op.k * vr * 64, 0.f);
+        for (int t = 0; t < op.k; ++t)
+          for (int id = (op.in_mask == JG_BUF_IDS ? 1 : 0); id < m->vocab; ++id)   // id 0 is masked: zero row
+            for (int n = 0; n < op.cout; ++n) {
+              double acc = 0.0;
+              for (int c = 0; c < op.cin; ++c)
+                acc += (double)emb[(size_t)id * op.cin + c] * (double)w[((size_t)t * cin_pad + c) * cout_pad32 + n];
+              lut[(((size_t)(n >> 6) * op.k + t) * vr + id) * 64 + (n & 63)] = (float)acc;
+            }
+        std::vector<float> tab_lut(tab);
+        for (int n = 0; n < 128; ++n) tab_lut[n] = (float)((double)tab[n] / (double)hp.acc_scale);   // row 0 scale
+        JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_lut), lut.size() * sizeof(float)));
+        JG_HIP(hipMemcpy(hp.d_lut, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
+        JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_epi_lut), tab_lut.size() * sizeof(float)));
+        JG_HIP(hipMemcpy(hp.d_epi_lut, tab_lut.data(), tab_lut.size() * sizeof(float), hipMemcpyHostToDevice));
+      }
     }
   }
   return JG_OK;
@@ -617,6 +641,8 @@ extern "C" int jg_model_destroy(jg_model *m) {
     if (hp.d_wh) (void)hipFree(hp.d_wh);
     if (hp.d_embh) (void)hipFree(hp.d_embh);
     if (hp.d_epi) (void)hipFree(hp.d_epi);
+    if (hp.d_lut) (void)hipFree(hp.d_lut);
+    if (hp.d_epi_lut) (void)hipFree(hp.d_epi_lut);
   }
   delete m;
   return JG_OK;
@@ -713,6 +739,11 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           for (int q = 0; q < hp.n_hst; ++q) a.hst[q] = hp.hst[q];
           if (hp.add_slot >= 0) a.addh = reinterpret_cast<const uint4 *>(m->act[hp.add_slot]);
           if (hp.nmd_slot >= 0) a.nmd_out = m->nmd_part[hp.nmd_slot];
+          if (hp.d_lut != nullptr) {
+            a.lut = hp.d_lut;
+            a.lut_vocab = m->vocab;
+            a.epi = hp.d_epi_lut;
+          }
           rc = jg_launch_conv_f16(e, a, s);
         } else {
           ConvArgs a;

@@ -98,6 +98,8 @@ struct ConvHArgs {
   int n_hst;
   int n_epi_rows;
   const float *epi;        // [n_epi_rows][2][128] epilogue parameters (HStageArg.pad_ = row)
+  const float *lut;        // first-layer table [2 halves][k][lut_vocab + 1][64] f32 or null (matrix-core path)
+  int lut_vocab;
   HStageArg hst[JG_MAX_STAGES];
 };
 
@@ -135,6 +137,8 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   int cc_in = 0;
   bool out_f16s = false;
   float *d_epi = nullptr;   // compact epilogue parameter table
+  float *d_lut = nullptr;   // first-layer table E.W_t (conv on ids) and its epilogue table (no acc un-scale)
+  float *d_epi_lut = nullptr;
   int n_hst = 0, n_epi_rows = 0;
   HStageArg hst[JG_MAX_STAGES] = {};
   int add_slot = -1, nmd_slot = -1;
@@ -201,3 +205,5 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_lds_bytes(int k, int dil);
 bool jg_conv_f16_supports(int k, int dil);
 int jg_conv_f16_tile_m(void);
+int jg_conv_lut_lds_bytes(int k, int vocab);
+bool jg_conv_lut_supports(int k, int dil, int vocab);

@@ -51,6 +51,7 @@ constexpr int A_ITERS = 5;    // 16-B activation pieces per thread per chunk (4*
 constexpr int W_ITERS = 2;    // 16-B weight items per thread per slice
 constexpr int TM = 4;         // 32-position blocks per wave
 constexpr int W_ITEMS = 2 * 2 * HN;           // 16-B items of one weight slice (chunk, tap): 8 KB
+constexpr int LUT_RS = 68;    // floats per LDS row of the first-layer table (64 + 4: rows 16 apart share banks)
 
 // GELU (tanh form) as x * sigmoid(2u), u = sqrt(2/pi)(x + 0.044715 x^3): one v_exp_f32 and
 // one v_rcp_f32 (~1 ulp each) instead of a libm tanhf; abs error < 1e-6 * |x|.
@@ -105,7 +106,13 @@ __device__ unsigned long long jg_stamp_acc[8];
 #define JG_ST_END
 #endif
 
-template <int K, unsigned EP>
+// LUT = true is the first-layer variant: a convolution whose input is an embedding gather is linear
+// in one-hot ids, so y[p] = sum_t T_t[id[p + t]] with T_t = E . W_t (vocab x Cout, exact f32, built
+// on the host in f64).  The matrix-core loop is replaced by LDS row lookups (k rows of 64 channels per
+// output position); the epilogue is the same code.  A workgroup owns one 64-channel half of the
+// table (k * (vocab + 1) rows, row `vocab` = zeros for padding) and its four waves cover two
+// 256-position tiles: waves {0,1} the first, {2,3} the second.  K is unused (taps come from a.k).
+template <int K, unsigned EP, bool LUT = false>
 // K = 5 fits two workgroups per CU in LDS (<= 80 KB each): hold the register file to 256 per
 // lane so that both are really resident (without the bound hipcc takes ~340 and the second
 // workgroup of a CU only starts when the first has finished).
@@ -115,14 +122,22 @@ void conv_f16x3_kernel(ConvHArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = LUT ? (wid & 1) : (wid >> 1);
+  const int wn = LUT ? (int)(blockIdx.x & 1u) : (wid & 1);
   const int i = lane & 31, h = lane >> 5;
+  // virtual block index / grid / tiles per pass (LUT: two blocks = the two channel halves share one index)
+  const int vb = LUT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+  const int vgrid = LUT ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+  constexpr int TPER = LUT ? 2 : NT;
+  const int tsub = LUT ? (wid >> 1) : 0;
   // LDS carve (16-byte units)
   const int rows_a = HM + (K - 1) * a.dil;                 // rows of one activation slice
   const int a_items = NT * 4 * rows_a;                      // [NT][4 ph][rows_a]
   uint4 *Abuf = lds;                                        // [2 bufs][a_items]
   uint4 *Wbuf = lds + 2 * a_items;                          // [K slots][2 planes][2 h][HN]
-  float *epiL = reinterpret_cast<float *>(Wbuf + K * W_ITEMS);
+  const int lut_rows = a.k * (a.lut_vocab + 1);
+  float *epiL = LUT ? reinterpret_cast<float *>(lds) + lut_rows * LUT_RS
+                    : reinterpret_cast<float *>(Wbuf + K * W_ITEMS);
   for (int q = tid; q < a.n_epi_rows * 2 * HN; q += HT) epiL[q] = a.epi[q];   // visible after the first barrier
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
   // wave-uniform LDS byte addresses of this wave's DMA destinations
@@ -130,9 +145,9 @@ void conv_f16x3_kernel(ConvHArgs a) {
   const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + wid * 1024);   // + slot*8192 + it*4096
 
   const int n_tiles = a.rows * a.tiles_m;
-  const int n_pairs = (n_tiles + NT - 1) / NT;
+  const int n_pairs = (n_tiles + TPER - 1) / TPER;
   int my_pairs = 0;
-  if ((int)blockIdx.x < n_pairs) my_pairs = (n_pairs - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+  if (vb < n_pairs) my_pairs = (n_pairs - 1 - vb) / vgrid + 1;
   if (my_pairs == 0) return;
 
   // per-thread activation piece coordinates: q -> (tile u, plane/half ph, row r)
@@ -155,7 +170,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
   auto tiles_of = [&](int pass, Tile *t) {
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      const int T = (blockIdx.x + pass * gridDim.x) * NT + u;
+      const int T = (vb + pass * vgrid) * TPER + tsub + u;
       const int Tc = min(T, n_tiles - 1);
       t[u].rowblk = Tc / a.tiles_m;
       t[u].m0 = (Tc - t[u].rowblk * a.tiles_m) * HM;
@@ -278,16 +293,61 @@ void conv_f16x3_kernel(ConvHArgs a) {
   Tile cur[NT], np[NT];            // tiles of this pass / of the next pass
   JG_ST_DECL;
   tiles_of(0, cur);
-  load_bytes(cur);
-  build_pieces(cur);               // the only exposed byte-load latency of the launch
   tiles_of(1, np);
-  load_bytes(np);
-  issue_x(0, 0);
+  // ---- LUT variant: table half -> LDS once; per pass the wave stages the table-row index of
+  // each of its 128 + (k-1)*dil input positions in LDS (fetched one pass ahead) ----------------
+  unsigned char *stage = reinterpret_cast<unsigned char *>(epiL + JG_EPI_ROWS * 2 * HN) + wid * 256;
+  unsigned char nxt[4] = {0, 0, 0, 0};
+  auto lut_fetch = [&](const Tile &tl) {
 #pragma unroll
-  for (int t = 0; t < WA; ++t) issue_w(0, t);
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int p = tl.m0 + wm * (TM * 32) - a.pad_left + lane + 64 * q4;
+      const int pc = min(max(p, 0), a.L_in - 1);
+      const unsigned char b = a.ids[(size_t)tl.rowblk * a.L_in + pc];
+      nxt[q4] = (tl.valid && p >= 0 && p < a.L_in) ? b : (unsigned char)a.lut_vocab;   // row `vocab` = zeros
+    }
+  };
+  if constexpr (LUT) {
+    float4 *T4 = reinterpret_cast<float4 *>(lds);
+    const float4 *src = reinterpret_cast<const float4 *>(a.lut) + (size_t)wn * lut_rows * 16;
+    for (int q = tid; q < lut_rows * 16; q += HT) T4[(q >> 4) * (LUT_RS / 4) + (q & 15)] = src[q];
+    lut_fetch(cur[0]);
+    __syncthreads();
+  } else {
+    load_bytes(cur);
+    build_pieces(cur);               // the only exposed byte-load latency of the launch
+    load_bytes(np);
+    issue_x(0, 0);
+#pragma unroll
+    for (int t = 0; t < WA; ++t) issue_w(0, t);
+  }
   int xc = 0;                      // running chunk count: activation buffer parity
   for (int pass = 0; pass < my_pairs; ++pass) {
-    for (int cc = 0; cc < a.cc_in; ++cc) {
+    if constexpr (LUT) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) stage[lane + 64 * q4] = nxt[q4];
+      lut_fetch(np[0]);                                   // next pass's indices fly under this pass
+      __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the wave's own staging writes
+      __builtin_amdgcn_wave_barrier();
+      const float *Tl = reinterpret_cast<const float *>(lds) + 4 * h;
+      for (int t = 0; t < a.k; ++t) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int rowi = stage[tm * 32 + i + t * a.dil];
+          const float *r = Tl + (t * (a.lut_vocab + 1) + rowi) * LUT_RS;
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float4 v = *reinterpret_cast<const float4 *>(r + tn * 32 + 8 * g);
+              acc[tm][tn][4 * g + 0] += v.x; acc[tm][tn][4 * g + 1] += v.y;
+              acc[tm][tn][4 * g + 2] += v.z; acc[tm][tn][4 * g + 3] += v.w;
+            }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (!LUT) for (int cc = 0; cc < a.cc_in; ++cc) {
       const int abuf = xc & 1;
       const bool last_chunk = cc == a.cc_in - 1;
       const bool tail = last_chunk && pass == my_pairs - 1;     // nothing is issued behind this chunk
@@ -378,11 +438,6 @@ void conv_f16x3_kernel(ConvHArgs a) {
         // hi-plane item of group 2j + h (uint4 units); lo plane = + 2*L_out
         const int G = (nb >> 3) + 2 * j + h;
         return (unsigned)(((tile.rowblk * (a.cout_pad >> 4) + (G >> 1)) * 4 + (G & 1)) * a.L_out + mc);
-      };
-      auto item2 = [&](const Tile &tile, int mc, int nb, int g) -> unsigned {
-        // this lane's 8-byte half (channels 4h..4h+3) of group g's hi-plane F16S item, uint2 units
-        const int G = (nb >> 3) + g;
-        return (unsigned)((((tile.rowblk * (a.cout_pad >> 4) + (G >> 1)) * 4 + (G & 1)) * a.L_out + mc) * 2 + h);
       };
       auto prefetch = [&](Pre &p, const Tile &tile, int tm, int tn) {
         const int nb = (wn * 2 + tn) * 32;
@@ -587,7 +642,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
     for (int u = 0; u < NT; ++u) cur[u] = np[u];
     tiles_of(pass + 2, np);
-    load_bytes(np);                // position bytes of the pass after next
+    if constexpr (!LUT) load_bytes(np);   // position bytes of the pass after next
     JG_ST(4);
   }
   JG_ST_END;
@@ -630,6 +685,36 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   return JG_OK;
 }
 
+template <unsigned EP>
+int launch_lut_e(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  const int smem = jg_conv_lut_lds_bytes(a.k, a.lut_vocab);
+  static bool attr_set = false;
+  if (!attr_set) {
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<0, EP, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int n_tiles = a.rows * a.tiles_m;
+  const int n_pairs = (n_tiles + 1) / 2;
+  const int grid = 2 * (n_pairs < e->n_cu / 2 ? n_pairs : e->n_cu / 2);   // (tile pair, channel half); one per CU
+  hipLaunchKernelGGL((conv_f16x3_kernel<0, EP, true>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, a);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  switch (a.ep) {
+#define JG_CASE(ep) case (ep): return launch_lut_e<(ep)>(e, a, s);
+    JG_CASE(JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_AFF | JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ACT1)
+    JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1)
+    JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1)
+#undef JG_CASE
+    default: return launch_lut_e<JG_EP_GENERIC>(e, a, s);
+  }
+}
+
 // compiled epilogue patterns (see jg_common.h JG_EP_*); everything else runs the interpreter
 template <int K>
 int launch_k(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
@@ -651,6 +736,15 @@ int launch_k(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
 
 }  // namespace
 
+int jg_conv_lut_lds_bytes(int k, int vocab) {
+  return k * (vocab + 1) * LUT_RS * 4 + JG_EPI_ROWS * 2 * HN * 4 + 4 * 256;
+}
+
+// first-layer table variant: LDS holds k*(vocab+1) rows, a wave stages <= 256 positions
+bool jg_conv_lut_supports(int k, int dil, int vocab) {
+  return k >= 1 && (k - 1) * dil <= 128 && vocab <= 254 && jg_conv_lut_lds_bytes(k, vocab) <= 160 * 1024;
+}
+
 int jg_conv_f16_lds_bytes(int k, int dil) {
   const int rows_a = HM + (k - 1) * dil;
   return (2 * NT * 4 * rows_a + k * W_ITEMS) * 16 + JG_EPI_ROWS * 2 * HN * 4;
@@ -668,6 +762,15 @@ int jg_conv_f16_tile_m(void) { return HM; }
 int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   JG_REQUIRE(a.cout_pad == HN && a.cout % 16 == 0, JG_ERR_UNSUPPORTED,
              "conv_f16x3: cout=%d (needs 128 padded, multiple of 16)", a.cout);
+  if (a.lut != nullptr) {
+    JG_REQUIRE(a.ids != nullptr && jg_conv_lut_supports(a.k, a.dil, a.lut_vocab), JG_ERR_UNSUPPORTED,
+               "conv lut: k=%d dilation=%d vocab=%d outside the table variant's limits", a.k, a.dil, a.lut_vocab);
+    if (a.rows == 0 || a.L_out <= 0) return JG_OK;
+    static int dbg_l = -1;
+    if (dbg_l < 0) { const char *ev = getenv("JG_DBG"); dbg_l = ev ? atoi(ev) : 0; }
+    const_cast<ConvHArgs &>(a).dbg = dbg_l;
+    return launch_lut(e, a, s);
+  }
   JG_REQUIRE(jg_conv_f16_supports(a.k, a.dil), JG_ERR_UNSUPPORTED,
              "conv_f16x3: k=%d dilation=%d outside the kernel's tiling", a.k, a.dil);
   // DMA offsets are 32-bit: the activation tensor of one launch must stay below 4 GiB
