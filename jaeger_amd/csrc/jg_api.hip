@@ -822,7 +822,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         // in_buf = activation slot whose shape gives the position count
         const Shape in = sh[op.in_buf];
         const int parts = m->precision == 1
-                              ? 8 * ((in.L + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m())
+                              ? 2 * ((in.L + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m())
                               : (in.L + 127) / 128;
         const uint8_t *mk = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
         rc = jg_launch_nmd_final(m->nmd_part[op.arg], in.frames * parts, mk, in.frames * in.L,

@@ -420,6 +420,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
       if (acc[0][0][0] + acc[1][1][3] + acc[2][1][7] + acc[3][0][9] == 12345.678f) a.overflow[0] = 2;
     } else {
       float vmax = 0.f;             // running max |output|: f16-range guard
+      float nmd_acc[16];            // per-lane NMD sums of the current channel block
       // what a block needs from memory, fetched one block ahead so the loads of block b+1
       // fly under the arithmetic of block b
       struct Pre {
@@ -512,25 +513,11 @@ void conv_f16x3_kernel(ConvHArgs a) {
           for (int r = 0; r < 16; ++r) x[r] = fast_gelu(x[r]);
         };
         auto st_nmd = [&]() {
-          // masked channel sums over this block's 32 positions (one partial row per
-          // (tile, wm, tm)), reduced across the 32 lanes of the half right away
-          float part[16];
+          // masked channel sums: accumulated per lane over the wave's four position blocks of this
+          // channel block, reduced across lanes once (nmd_flush) - one partial row per 128 positions
+          const float mkl = live ? mk : 0.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = live ? x[r] * mk : 0.f;
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
-            part[r] = v;
-          }
-          if (i == 0 && tile.valid) {
-            const int tileno = tile.m0 / HM;
-            float *dst = a.nmd_out + ((((size_t)tile.rowblk * a.tiles_m + tileno) * 2 + wm) * TM + tm) * a.cout + nb + 4 * h;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              if (nb + 8 * g + 4 * h < a.cout)
-                *reinterpret_cast<float4 *>(dst + 8 * g) =
-                    make_float4(part[4 * g], part[4 * g + 1], part[4 * g + 2], part[4 * g + 3]);
-          }
+          for (int r = 0; r < 16; ++r) nmd_acc[r] = fmaf(x[r], mkl, nmd_acc[r]);
         };
         if constexpr (EP == JG_EP_GENERIC) {
           // any stage list: interpreted at run time (slow path: the accumulators bounce through
@@ -626,10 +613,47 @@ void conv_f16x3_kernel(ConvHArgs a) {
           }
         }
       };
+      // Cross-lane reduction of the NMD sums over a half's 32 lanes by register halving: at each
+      // step a lane keeps half of its registers and receives the partner's copy of that half (DPP
+      // within rows of 16, one bpermute across rows), so 16 registers cost 16 exchanges instead
+      // of 80.  Afterwards lane i holds channel register r = 8*b2 + 4*b1 + 2*b0 + b3 (bits of i).
+      auto nmd_flush = [&](const Tile &tile, int tn) {
+#define JG_DPP(v, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), (ctrl), 0xf, 0xf, false))
+        const bool b2 = (i & 4) != 0, b1 = (i & 2) != 0, b0 = (i & 1) != 0, b3 = (i & 8) != 0;
+        float s8[8], s4[4], s2[2];
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        epi_block(acc[tm][0], cur[0], tm, 0);
-        epi_block(acc[tm][1], cur[0], tm, 1);
+        for (int q = 0; q < 8; ++q) {        // partner i ^ 7 (row_half_mirror)
+          const float keep = b2 ? nmd_acc[8 + q] : nmd_acc[q], send = b2 ? nmd_acc[q] : nmd_acc[8 + q];
+          s8[q] = keep + JG_DPP(send, 0x141);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {        // partner i ^ 2 (quad_perm [2,3,0,1])
+          const float keep = b1 ? s8[4 + q] : s8[q], send = b1 ? s8[q] : s8[4 + q];
+          s4[q] = keep + JG_DPP(send, 0x4e);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {        // partner i ^ 1 (quad_perm [1,0,3,2])
+          const float keep = b0 ? s4[2 + q] : s4[q], send = b0 ? s4[q] : s4[2 + q];
+          s2[q] = keep + JG_DPP(send, 0xb1);
+        }
+        const float keep1 = b3 ? s2[1] : s2[0], send1 = b3 ? s2[0] : s2[1];
+        float v = keep1 + JG_DPP(send1, 0x128);   // partner i ^ 8 (row_ror:8)
+        v += __shfl_xor(v, 16, 32);                                           // partner i ^ 16
+        if (i < 16 && tile.valid) {
+          const int r = 8 * (int)b2 + 4 * (int)b1 + 2 * (int)b0 + (int)b3;
+          const int ch = (wn * 2 + tn) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+          const int tileno = tile.m0 / HM;
+          if (ch < a.cout) a.nmd_out[(((size_t)tile.rowblk * a.tiles_m + tileno) * 2 + wm) * a.cout + ch] = v;
+        }
+      };
+      const bool has_nmd = EP == JG_EP_GENERIC ? a.nmd_out != nullptr : (EP & (JG_EP_NMD1 | JG_EP_NMD2)) != 0;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nmd_acc[r] = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) epi_block(acc[tm][tn], cur[0], tm, tn);
+        if (has_nmd) nmd_flush(cur[0], tn);
       }
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
