@@ -61,8 +61,16 @@ def main():
 @click.option("--refine", is_flag=True, help="[unsupported here]")
 @click.option("--exact-f32", is_flag=True, help="run every convolution on the exact-f32 MFMA kernels")
 @click.option("--chunk", type=int, default=0, help="windows per device pass (0 = library default)")
+@click.option("--legacy-data", type=click.Path(exists=True), default=None,
+              help="reference data directory (config.json, models/default/) for -m default")
 def predict(**kwargs):
-    from .predict import run_core
+    # cli.py:375-410: --model_path wins; the `default` model goes through the legacy workflow
+    if not kwargs.get("model_path") and (kwargs.get("model") or "default") == "default" and not kwargs.get("config"):
+        click.echo(click.style("Warning: model 'default' uses the legacy prediction workflow and is deprecated.",
+                               fg="yellow"), err=True)
+        from .predict_legacy import run_core
+    else:
+        from .predict import run_core
     run_core(**kwargs)
 
 

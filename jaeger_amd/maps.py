@@ -58,6 +58,17 @@ def _ids_by_first_appearance(letters: list[str]) -> list[int]:
 #: (seqops/maps.py:137)
 AA_ID: list[int] = _ids_by_first_appearance(AA)
 
+
+
+def _v1_ids(letters: list[str]) -> list[int]:
+    order: dict[str, int] = {}
+    return [order.setdefault(a, len(order) + 1) for a in letters]
+
+
+#: legacy (v1) amino-acid ids 1..21 by first appearance, the stop codons share id 11; 0 is reserved
+#: for unknown trimers (preprocess/v1/maps.py TRIMER_INT, used by preprocess/v1/convert.py:18-21)
+V1_TRIMER_INT: list[int] = _v1_ids(AA)
+
 # Murphy-10 reduced alphabet, ids by first appearance of the group in codon
 # order (seqops/maps.py:408): {F,Y,W} {L,I,M,V} {S,T} {P} {A} {H} {Q,N,D,E}
 # {K,R} {C} {G}.

@@ -171,6 +171,66 @@ def main():
             "energy": np.asarray(data["energy"], np.float64).tolist(),
             "pred_sum": np.asarray(data["pred_sum"], np.float64).tolist(),
             "ood": None if data["ood"] is None else np.asarray(data["ood"], np.float64).tolist()}))
+    # ---- legacy `default` model (BASELINE config #1) -------------------------------------------
+    # data files the reference ships (weights, reliability model, batch statistics) + its config entry
+    import importlib.util
+    legacy = HERE / "legacy_data"
+    (legacy / "models" / "default").mkdir(parents=True, exist_ok=True)
+    for name in ("WRes_1024.h5", "LR_ood_4_class_default.pkl", "batch_means.npy", "batch_std.npy"):
+        shutil.copyfile(REF / "src/jaeger/data/models/default" / name, legacy / "models" / "default" / name)
+    cfg_all = json.loads((REF / "src/jaeger/data/config.json").read_text())
+    (legacy / "config.json").write_text(json.dumps({"default": cfg_all["default"]}, indent=1))
+    spec = importlib.util.spec_from_file_location("v1maps", REF / "src/jaeger/preprocess/v1/maps.py")
+    v1maps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(v1maps)
+    tables = json.loads((HERE / "maps.json").read_text())
+    tables["V1_TRIMERS"], tables["V1_TRIMER_INT"] = list(v1maps.TRIMERS), list(v1maps.TRIMER_INT)
+    (HERE / "maps.json").write_text(json.dumps(tables, indent=0))
+    # h5dump cross-check of the HDF5 reader's view of the weight file: per-dataset shape + sha256
+    sys.path.insert(0, str(HERE.parents[1]))
+    from jaeger_amd.hdf5_lite import read_datasets
+    import re
+    import subprocess
+    dsets = read_datasets(REF / "src/jaeger/data/models/default/WRes_1024.h5")
+    summary = {}
+    for key, arr in sorted(dsets.items()):
+        out = subprocess.run(["/opt/conda/bin/h5dump", "-d", key, "-y", "-w", "0", "-m", "%.9g",
+                              str(REF / "src/jaeger/data/models/default/WRes_1024.h5")],
+                             capture_output=True, text=True, check=True).stdout
+        body = out[out.index("DATA {") + 6:]
+        vals = np.array([float(x) for x in re.findall(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?", body)], np.float32)
+        assert vals.size == arr.size and np.array_equal(vals, arr.ravel()), key
+        summary[key] = {"shape": list(arr.shape), "sha256": hashlib.sha256(arr.tobytes()).hexdigest()}
+    (HERE / "legacy_h5_datasets.json").write_text(json.dumps(summary, indent=0))
+    # legacy postprocess on seeded synthetic outputs
+    import joblib
+    rng = np.random.Generator(np.random.PCG64(4321))
+    n_win = [2, 5, 1, 9]
+    n = sum(n_win)
+    yl = {"y_hat": {"output": rng.normal(0, 3, (n, 4)).astype(np.float32),
+                    "embedding": np.abs(rng.normal(0, 1, (n, 128))).astype(np.float32)},
+          "meta": [np.array(sum([[f"c{i}___y"] * k for i, k in enumerate(n_win)], [])),
+                   np.arange(n), np.array(sum([[0] * (k - 1) + [1] for k in n_win], [])), np.arange(n),
+                   np.array(sum([[2000 * k + 3] * k for k in n_win], [])),
+                   rng.integers(400, 500, n), rng.integers(400, 500, n), rng.integers(400, 500, n),
+                   rng.integers(400, 500, n), np.round(rng.normal(0, 0.1, n), 2)]}
+    yl["y_hat"]["output"][2:7, 1] += 9.0
+    np.savez(HERE / "postprocess_legacy_input.npz", output=yl["y_hat"]["output"], embedding=yl["y_hat"]["embedding"],
+             **{f"meta_{i}": m for i, m in enumerate(yl["meta"])})
+    conf = dict(cfg_all["default"])
+    conf["model"] = "default"
+    conf["labels"] = [v for _, v in conf["default_labels"].items()]
+    ood_params = {"type": "sklearn", "model": joblib.load(legacy / "models/default/LR_ood_4_class_default.pkl"),
+                  "batch_mean": np.load(legacy / "models/default/batch_means.npy"),
+                  "batch_std": np.load(legacy / "models/default/batch_std.npy")}
+    rep = pd.DataFrame({"contig_id": [f"c{i}___y" for i in range(len(n_win))],
+                        "terminal_repeats": [None, "ITR", None, None], "repeat_length": [np.nan, 77, np.nan, np.nan]})
+    data, _ = collect.pred_to_dict_legacy(conf, yl, model="default", fsize=2000, ood_params=ood_params,
+                                          term_repeats=rep)
+    collect.write_output_legacy(conf, data, output_table_path=HERE / "postprocess_legacy.tsv",
+                                output_phage_table_path=HERE / "postprocess_legacy_phages.tsv",
+                                reliability_cutoff=0.1, phage_score=3)
+    rep.to_csv(HERE / "postprocess_legacy_repeats.csv", index=False)
     print("golden vectors written to", HERE)
 
 
