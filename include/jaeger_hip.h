@@ -191,6 +191,18 @@ int jg_timer_stop_ms(jg_engine *e, void *stream, float *ms);
 int jg_profile_enable(jg_engine *e, int on);
 int jg_profile_read(jg_engine *e, double *conv_ms, int64_t *conv_launches, double *conv_flops);
 
+/* ---- FASTA ingest (host only; replaces the pyfastx iteration of seqops/io.py:98-103 and the
+ * per-record Python strings of utils/fs.py:99-115) ------------------------------------------
+ * jg_fasta_count : number of records (lines starting with '>') in a file image, and an upper bound of
+ *                  the bytes their names take
+ * jg_fasta_parse : bases (whitespace-stripped sequence lines joined; may alias `text` for in-place
+ *                  compaction), record offsets (max_records + 1 entries, offsets[i+1]-offsets[i] =
+ *                  length), names (header up to the first whitespace) back to back in `names` with
+ *                  name_off (max_records + 1 entries) */
+int jg_fasta_count(const uint8_t *text, int64_t n, int64_t *n_records, int64_t *name_bytes);
+int jg_fasta_parse(const uint8_t *text, int64_t n, int64_t max_records, uint8_t *bases, int64_t *offsets,
+                   uint8_t *names, int64_t *name_off, int64_t *n_records, int64_t *n_bases);
+
 #ifdef __cplusplus
 }
 #endif

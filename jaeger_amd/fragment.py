@@ -39,6 +39,53 @@ def read_fasta(path: str) -> Iterator[tuple[str, bytes]]:
         yield name, b"".join(chunks)
 
 
+@dataclass
+class FastaBatch:
+    """All records of a FASTA file in the layout the encoder scans."""
+    names: list[str]
+    bases: np.ndarray          # uint8, all sequences back to back
+    offsets: np.ndarray        # int64, len = n_records + 1
+
+    def __len__(self) -> int:
+        return len(self.names)
+
+    @property
+    def lengths(self) -> np.ndarray:
+        return np.diff(self.offsets)
+
+    def sequence(self, i: int) -> bytes:
+        return self.bases[self.offsets[i]:self.offsets[i + 1]].tobytes()
+
+
+def load_fasta(path) -> FastaBatch:
+    """Native one-pass ingest (``jg_fasta_parse``); same record rules as :func:`read_fasta`."""
+    import ctypes as C
+
+    from . import _lib as L
+    lib = L.load()
+    if str(path).endswith(".gz"):
+        with gzip.open(path, "rb") as fh:
+            text = np.frombuffer(fh.read(), np.uint8)
+    else:
+        text = np.fromfile(path, np.uint8)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    n_rec, name_bytes = C.c_int64(), C.c_int64()
+    L.check(lib.jg_fasta_count(ptr(text), text.size, C.byref(n_rec), C.byref(name_bytes)), "jg_fasta_count")
+    if not text.flags.writeable:
+        text = text.copy()
+    offsets = np.zeros(n_rec.value + 1, np.int64)
+    names_buf = np.zeros(max(name_bytes.value, 1), np.uint8)
+    name_off = np.zeros(n_rec.value + 1, np.int64)
+    got, nb = C.c_int64(), C.c_int64()
+    # in place: the base buffer is the file image itself, compacted
+    L.check(lib.jg_fasta_parse(ptr(text), text.size, n_rec.value, ptr(text), ptr(offsets), ptr(names_buf),
+                               ptr(name_off), C.byref(got), C.byref(nb)), "jg_fasta_parse")
+    raw = names_buf.tobytes()
+    no = name_off.tolist()
+    names = [raw[no[i]:no[i + 1]].decode() for i in range(got.value)]
+    return FastaBatch(names, text[:nb.value], offsets[:got.value + 1])
+
+
 def window_indices(seqlen: int, fragsize: int, stride: int | None, dynamic_stride: bool = False,
                    dynamic_stride_threshold: float = 10.0) -> list[int]:
     """Window starts of one contig (io.py:38-71)."""

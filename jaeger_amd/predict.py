@@ -71,15 +71,14 @@ def get_model_id(model: str) -> str:
     return model.split("_", 1)[1].rsplit("_", 1)[0]
 
 
-def validate_fasta_entries(path: str, min_len: int) -> int:
-    """utils/fs.py:99-115: record count; raises when no record reaches ``min_len``."""
-    num = ok = 0
-    for _, seq in frag.read_fasta(path):
-        num += 1
-        ok += len(seq) >= min_len
-    logger.info(f"{ok}/{num} entries in {path}")
+def validate_fasta_entries(path, min_len: int) -> int:
+    """utils/fs.py:99-115: record count; raises when no record reaches ``min_len``.  ``path`` may be
+    an already loaded :class:`~jaeger_amd.fragment.FastaBatch` (one ingest pass instead of three)."""
+    fa = path if isinstance(path, frag.FastaBatch) else frag.load_fasta(path)
+    num, ok = len(fa), int((fa.lengths >= min_len).sum())
+    logger.info(f"{ok}/{num} entries in {'input' if isinstance(path, frag.FastaBatch) else path}")
     if ok == 0:
-        raise Exception(f"all records in {path} are < {min_len}bp")
+        raise Exception(f"all records in {'input' if isinstance(path, frag.FastaBatch) else path} are < {min_len}bp")
     return num
 
 
@@ -125,45 +124,49 @@ def _concat_predictions(a: dict, b: dict) -> dict:
 
 
 # ---- one prediction pass --------------------------------------------------------------------
-def predict_records(engine, names: list[str], seqs: list[bytes], fsize: int, stride: int | None,
-                    min_len: int | None = None, max_len: int | None = None, dynamic_stride: bool = False,
-                    dynamic_stride_threshold: float = 10.0, batch: int = 96,
-                    padded: bool = False) -> dict[str, np.ndarray]:
-    """Window table + GPU encode/forward for a set of records; returns the dict
-    ``InferModel.predict`` would (model outputs + ``meta_0..9``).  ``padded`` reproduces
-    ``padded_batch`` of the short-contig pass: windows are run in groups of ``batch`` padded to
-    the longest frame of the group (commands/predict.py:236-245)."""
-    from .engine import frame_length
-    lengths = np.fromiter((len(s) for s in seqs), np.int64, len(seqs))
+def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None, min_len: int | None = None,
+                  max_len: int | None = None, dynamic_stride: bool = False,
+                  dynamic_stride_threshold: float = 10.0, batch: int = 96, padded: bool = False,
+                  subset=None) -> dict[str, np.ndarray]:
+    """Window table + GPU encode/forward for the records of ``fa`` (optionally only those listed in
+    ``subset``, kept in that order); returns the dict ``InferModel.predict`` would (model outputs +
+    ``meta_0..9``).  ``padded`` reproduces ``padded_batch`` of the short-contig pass: windows run in
+    groups of ``batch`` padded to the longest frame of the group (commands/predict.py:236-245)."""
+    idx = np.arange(len(fa)) if subset is None else np.asarray(subset, np.int64)
+    lengths = fa.lengths[idx]
+    names = [fa.names[i] for i in idx.tolist()] if subset is not None else fa.names
     table = frag.build_window_table(lengths, fsize, stride, dynamic_stride, dynamic_stride_threshold,
                                     min_len, max_len)
     if len(table) == 0:
         return {}
-    bases, offsets = frag.concat_records(seqs)
-    starts = offsets[table.contig] + table.start
+    starts = fa.offsets[idx][table.contig] + table.start
     if not padded:
-        out = engine.predict_windows(bases, starts, table.length, fsize)
+        out = engine.predict_windows(fa.bases, starts, table.length, fsize)
     else:
         off3 = (-2, -1, 0)[fsize % 3]
         parts = []
         for i in range(0, len(table), batch):
             sl = slice(i, i + batch)
             lmax = int(max(0, -(-(int(table.length[sl].max()) - 5 + off3) // 3)))
-            parts.append(engine.predict_windows(bases, starts[sl], table.length[sl], fsize, l_pad=max(lmax, 1)))
+            parts.append(engine.predict_windows(fa.bases, starts[sl], table.length[sl], fsize, l_pad=max(lmax, 1)))
         out = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
     counts = out.pop("counts")
     out.update(frag.window_metadata(table, names, counts))
     return out
 
 
-def _shard_records(names, seqs, fsize, stride, world, rank):
-    """Whole contigs to ranks, balanced by window count (LPT)."""
+def predict_records(engine, names: list[str], seqs: list[bytes], fsize: int, stride: int | None, **kw):
+    """:func:`predict_batch` for records given as Python lists."""
+    bases, offsets = frag.concat_records(seqs)
+    return predict_batch(engine, frag.FastaBatch(list(names), bases, offsets), fsize, stride, **kw)
+
+
+def _shard_records(lengths: np.ndarray, fsize: int, stride: int | None, world: int):
+    """Whole contigs to ranks, balanced by window count (LPT); returns one index list per rank."""
     from .dist import lpt_partition
     step = fsize if stride is None else stride
-    w = np.array([max(1, (len(s) - fsize) // step + 1) if len(s) >= fsize else 1 for s in seqs])
-    groups = lpt_partition(w, world)
-    mine = groups[rank]
-    return [names[i] for i in mine], [seqs[i] for i in mine], groups
+    w = np.where(lengths >= fsize, np.maximum(1, (lengths - fsize) // step + 1), 1)
+    return lpt_partition(w, world)
 
 
 # ---- run_core ---------------------------------------------------------------------------------
@@ -217,7 +220,10 @@ def run_core(**kwargs) -> int:
     user_min_len = kwargs.get("min_len")
     min_len = user_min_len or fsize
     try:
-        num = validate_fasta_entries(str(input_path), min_len=min_len)
+        t_ingest = time.time()
+        fa = frag.load_fasta(str(input_path))
+        t_ingest = time.time() - t_ingest
+        num = validate_fasta_entries(fa, min_len=min_len)
     except Exception as e:
         lg.error(e)
         sys.exit(1)
@@ -258,35 +264,37 @@ def run_core(**kwargs) -> int:
     if msg:
         lg.warning(msg)
 
-    records = list(frag.read_fasta(str(input_path)))
-    names, seqs = [r[0] for r in records], [r[1] for r in records]
-    groups = None
+    groups, subset = None, None
     if world > 1:
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl")
-        all_names = names
-        names, seqs, groups = _shard_records(names, seqs, fsize, stride, world, rank)
+        groups = _shard_records(fa.lengths, fsize, stride, world)
+        subset = np.sort(np.asarray(groups[rank], np.int64))
+    all_names = fa.names
     common = dict(dynamic_stride=kwargs.get("dynamic_stride", False),
                   dynamic_stride_threshold=kwargs.get("dynamic_stride_threshold", 10.0),
-                  batch=kwargs.get("batch", 96))
+                  batch=kwargs.get("batch", 96), subset=subset)
+    t_predict = time.time()
     try:
         if user_min_len is not None and user_min_len < fsize:
             lg.info(f"Two-pass prediction: long contigs (>= {fsize} bp) then short contigs "
                     f"({user_min_len}-{fsize - 1} bp)")
-            y_long = predict_records(engine, names, seqs, fsize, stride, min_len=fsize, max_len=None, **common)
-            y_short = predict_records(engine, names, seqs, fsize, stride, min_len=user_min_len,
-                                      max_len=fsize - 1, padded=True, **common)
+            y_long = predict_batch(engine, fa, fsize, stride, min_len=fsize, max_len=None, **common)
+            y_short = predict_batch(engine, fa, fsize, stride, min_len=user_min_len, max_len=fsize - 1,
+                                    padded=True, **common)
             y_pred = _concat_predictions(y_long, y_short)
         else:
-            y_pred = predict_records(engine, names, seqs, fsize, stride, min_len=min_len, max_len=None, **common)
+            y_pred = predict_batch(engine, fa, fsize, stride, min_len=min_len, max_len=None, **common)
     except Exception as e:
         lg.debug(traceback.format_exc())
         lg.error(f"an error {e} occured during inference on MI355X #{local_rank}!")
         sys.exit(1)
 
+    t_predict = time.time() - t_predict
+    t_post = time.time()
     if world > 1:
         import torch.distributed as dist
         objs = [None] * world if rank == 0 else None
@@ -325,6 +333,10 @@ def run_core(**kwargs) -> int:
         np.savez(out_dir / f"{file_base}_embedding.npz", embedding=y_pred["embedding"], headers=headers)
     if kwargs.get("save_nmd") and "nmd" in y_pred:
         np.savez(out_dir / f"{file_base}_nmd.npz", embedding=y_pred["nmd"], headers=headers)   # legacy key name
-    lg.info(f"wall time(s) : {time.time() - t_start:.2f}  ({len(y_pred['meta_2'])} windows)")
+    n_bp = float(np.minimum(np.asarray(y_pred["meta_4"], np.int64), fsize).sum()) if "meta_4" in y_pred else 0.0
+    t_all = time.time() - t_start
+    lg.info(f"wall time(s) : {t_all:.2f}  ({len(y_pred['meta_2'])} windows; FASTA ingest {t_ingest:.2f} s, "
+            f"encode+forward {t_predict:.2f} s = {n_bp / 1e6 / max(t_predict, 1e-9):.1f} Mbp/s, aggregation+TSV "
+            f"{time.time() - t_post:.2f} s; end to end {n_bp / 1e6 / max(t_all, 1e-9):.1f} Mbp/s)")
     engine.close()
     return n_written

@@ -49,15 +49,13 @@ def load_ood_params(model_path: Path, config: dict):
     raise ValueError(f"unsupported reliability model file {p.name}")
 
 
-def predict_records_legacy(engine, names, seqs, fsize, stride, min_len, dynamic_stride=False,
-                           dynamic_stride_threshold=10.0) -> dict:
-    lengths = np.fromiter((len(s) for s in seqs), np.int64, len(seqs))
-    table = frag.build_window_table(lengths, fsize, stride, dynamic_stride, dynamic_stride_threshold, min_len, None)
+def predict_batch_legacy(engine, fa, fsize, stride, min_len, dynamic_stride=False,
+                         dynamic_stride_threshold=10.0) -> dict:
+    table = frag.build_window_table(fa.lengths, fsize, stride, dynamic_stride, dynamic_stride_threshold, min_len, None)
     if len(table) == 0:
         return {}
-    bases, offsets = frag.concat_records(seqs)
-    out = engine.predict_windows(bases, offsets[table.contig] + table.start, table.length, fsize)
-    meta = frag.window_metadata(table, names, out.pop("counts"))
+    out = engine.predict_windows(fa.bases, fa.offsets[table.contig] + table.start, table.length, fsize)
+    meta = frag.window_metadata(table, fa.names, out.pop("counts"))
     return {"y_hat": {"output": out["output"], "embedding": out["embedding"]},
             "meta": [meta[f"meta_{i}"] for i in range(10)]}
 
@@ -82,7 +80,8 @@ def run_core(**kwargs) -> int:
         if min_len < fsize:
             lg.warning(f"--min-len < --fsize is not supported in legacy prediction mode; using --min-len={fsize}.")
             min_len = fsize
-        num = validate_fasta_entries(str(input_path), min_len=min_len)
+        fa = frag.load_fasta(str(input_path))
+        num = validate_fasta_entries(fa, min_len=min_len)
     except Exception as e:
         lg.error(e)
         sys.exit(1)
@@ -111,11 +110,10 @@ def run_core(**kwargs) -> int:
         sys.exit(1)
     lg.info(f"input file: {input_path.name}  fragment size: {fsize}  stride: {kwargs.get('stride')}  "
             f"model: {model} (exact-f32 MFMA path)")
-    records = list(frag.read_fasta(str(input_path)))
     try:
-        y_pred = predict_records_legacy(engine, [r[0] for r in records], [r[1] for r in records], fsize,
-                                        kwargs.get("stride", 1500), min_len, kwargs.get("dynamic_stride", False),
-                                        kwargs.get("dynamic_stride_threshold", 10.0))
+        y_pred = predict_batch_legacy(engine, fa, fsize, kwargs.get("stride", 1500), min_len,
+                                      kwargs.get("dynamic_stride", False),
+                                      kwargs.get("dynamic_stride_threshold", 10.0))
     except Exception as e:
         lg.debug(traceback.format_exc())
         lg.error(f"an error {e} occured during inference!")
