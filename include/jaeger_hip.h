@@ -203,6 +203,13 @@ int jg_fasta_count(const uint8_t *text, int64_t n, int64_t *n_records, int64_t *
 int jg_fasta_parse(const uint8_t *text, int64_t n, int64_t max_records, uint8_t *bases, int64_t *offsets,
                    uint8_t *names, int64_t *name_off, int64_t *n_records, int64_t *n_bases);
 
+/* ---- DUST soft-masking (host only; replaces pydustmasker.DustMasker(seq, window_size=64,
+ * score_threshold=20).mask() of seqops/io.py:104-108) -------------------------------------------
+ * Upper-cases every record of the base buffer, then lower-cases the symmetric-DUST intervals, in
+ * place; n_threads <= 0 = all cores.  The buffer is then "pre-cased" for jg_encode (soft_mask bit 0). */
+int jg_dust_mask(uint8_t *bases, const int64_t *offsets, int64_t n_records, int32_t window,
+                 int32_t threshold, int32_t n_threads, int64_t *n_masked);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ def main():
 @click.option("--crf-switch-cost", type=float, default=1.0)
 @click.option("--crf-smooth-sigma", type=float, default=0.0)
 @click.option("--crf-min-prob", type=float, default=0.5)
-@click.option("--dustmask/--no-dustmask", default=True, help="[DUST is not implemented: runs as --no-dustmask]")
+@click.option("--dustmask/--no-dustmask", default=True, help="soft-mask low-complexity regions (symmetric DUST)")
 @click.option("--min-len", "min_len", type=int, default=None, help="Minimum contig length to process")
 @click.option("-m", "--model", type=str, default="default")
 @click.option("--model_path", type=click.Path(exists=True), default=None,

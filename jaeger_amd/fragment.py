@@ -86,6 +86,24 @@ def load_fasta(path) -> FastaBatch:
     return FastaBatch(names, text[:nb.value], offsets[:got.value + 1])
 
 
+def dust_mask(fa: FastaBatch, window: int = 64, threshold: int = 20, threads: int = 0) -> int:
+    """Soft-mask low-complexity intervals of every record in place (``jg_dust_mask``): all bases
+    upper-cased, DUST intervals lower-cased - what ``fragment_generator`` does per contig with
+    ``pydustmasker`` (io.py:104-108).  Returns the number of masked bases.  Afterwards pass
+    ``pre_cased=True`` to the encoder."""
+    import ctypes as C
+
+    from . import _lib as L
+    lib = L.load()
+    n = C.c_int64()
+    if not fa.bases.flags.writeable or not fa.bases.flags.c_contiguous:
+        fa.bases = np.ascontiguousarray(fa.bases).copy()
+    offsets = np.ascontiguousarray(fa.offsets, np.int64)
+    L.check(lib.jg_dust_mask(fa.bases.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), len(fa),
+                             int(window), int(threshold), int(threads), C.byref(n)), "jg_dust_mask")
+    return int(n.value)
+
+
 def window_indices(seqlen: int, fragsize: int, stride: int | None, dynamic_stride: bool = False,
                    dynamic_stride_threshold: float = 10.0) -> list[int]:
     """Window starts of one contig (io.py:38-71)."""

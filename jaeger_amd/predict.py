@@ -127,7 +127,7 @@ def _concat_predictions(a: dict, b: dict) -> dict:
 def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None, min_len: int | None = None,
                   max_len: int | None = None, dynamic_stride: bool = False,
                   dynamic_stride_threshold: float = 10.0, batch: int = 96, padded: bool = False,
-                  subset=None) -> dict[str, np.ndarray]:
+                  subset=None, pre_cased: bool = False) -> dict[str, np.ndarray]:
     """Window table + GPU encode/forward for the records of ``fa`` (optionally only those listed in
     ``subset``, kept in that order); returns the dict ``InferModel.predict`` would (model outputs +
     ``meta_0..9``).  ``padded`` reproduces ``padded_batch`` of the short-contig pass: windows run in
@@ -141,14 +141,15 @@ def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None,
         return {}
     starts = fa.offsets[idx][table.contig] + table.start
     if not padded:
-        out = engine.predict_windows(fa.bases, starts, table.length, fsize)
+        out = engine.predict_windows(fa.bases, starts, table.length, fsize, pre_cased=pre_cased)
     else:
         off3 = (-2, -1, 0)[fsize % 3]
         parts = []
         for i in range(0, len(table), batch):
             sl = slice(i, i + batch)
             lmax = int(max(0, -(-(int(table.length[sl].max()) - 5 + off3) // 3)))
-            parts.append(engine.predict_windows(fa.bases, starts[sl], table.length[sl], fsize, l_pad=max(lmax, 1)))
+            parts.append(engine.predict_windows(fa.bases, starts[sl], table.length[sl], fsize, l_pad=max(lmax, 1),
+                                                pre_cased=pre_cased))
         out = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
     counts = out.pop("counts")
     out.update(frag.window_metadata(table, names, counts))
@@ -236,9 +237,13 @@ def run_core(**kwargs) -> int:
             lg.error(f"--{flag} is not available on the MI355X predict path (jaeger_amd has no CPU / "
                      "alternative-backend fallback; prophage / refinement / CRF post-processing is out of scope)")
             sys.exit(1)
+    dusted = False
     if kwargs.get("dustmask", True):
-        lg.warning("DUST low-complexity masking (pydustmasker) is not implemented on this path: running as "
-                   "--no-dustmask; G+C / N% columns can differ from a masked reference run")
+        t_dust = time.time()
+        n_masked = frag.dust_mask(fa)
+        dusted = True
+        lg.info(f"DUST (window 64, threshold 20): {n_masked} of {fa.bases.size} bases soft-masked in "
+                f"{time.time() - t_dust:.2f} s")
     lg.warning("terminal-repeat scan (parasail) is not implemented: terminal_repeats / repeat_length stay empty")
 
     weights = None
@@ -276,7 +281,7 @@ def run_core(**kwargs) -> int:
     all_names = fa.names
     common = dict(dynamic_stride=kwargs.get("dynamic_stride", False),
                   dynamic_stride_threshold=kwargs.get("dynamic_stride_threshold", 10.0),
-                  batch=kwargs.get("batch", 96), subset=subset)
+                  batch=kwargs.get("batch", 96), subset=subset, pre_cased=dusted)
     t_predict = time.time()
     try:
         if user_min_len is not None and user_min_len < fsize:

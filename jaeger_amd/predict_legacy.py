@@ -50,11 +50,12 @@ def load_ood_params(model_path: Path, config: dict):
 
 
 def predict_batch_legacy(engine, fa, fsize, stride, min_len, dynamic_stride=False,
-                         dynamic_stride_threshold=10.0) -> dict:
+                         dynamic_stride_threshold=10.0, pre_cased=False) -> dict:
     table = frag.build_window_table(fa.lengths, fsize, stride, dynamic_stride, dynamic_stride_threshold, min_len, None)
     if len(table) == 0:
         return {}
-    out = engine.predict_windows(fa.bases, fa.offsets[table.contig] + table.start, table.length, fsize)
+    out = engine.predict_windows(fa.bases, fa.offsets[table.contig] + table.start, table.length, fsize,
+                                 pre_cased=pre_cased)
     meta = frag.window_metadata(table, fa.names, out.pop("counts"))
     return {"y_hat": {"output": out["output"], "embedding": out["embedding"]},
             "meta": [meta[f"meta_{i}"] for i in range(10)]}
@@ -98,8 +99,11 @@ def run_core(**kwargs) -> int:
         if kwargs.get(flag):
             lg.error(f"--{flag} is not available on the MI355X predict path")
             sys.exit(1)
+    dusted = False
     if kwargs.get("dustmask", True):
-        lg.warning("DUST low-complexity masking is not implemented on this path: running as --no-dustmask")
+        n_masked = frag.dust_mask(fa)
+        dusted = True
+        lg.info(f"DUST (window 64, threshold 20): {n_masked} of {fa.bases.size} bases soft-masked")
     lg.warning("terminal-repeat scan is not implemented: terminal_repeats / repeat_length stay empty")
     ood_params = load_ood_params(model_path, config)
     try:
@@ -113,7 +117,7 @@ def run_core(**kwargs) -> int:
     try:
         y_pred = predict_batch_legacy(engine, fa, fsize, kwargs.get("stride", 1500), min_len,
                                       kwargs.get("dynamic_stride", False),
-                                      kwargs.get("dynamic_stride_threshold", 10.0))
+                                      kwargs.get("dynamic_stride_threshold", 10.0), pre_cased=dusted)
     except Exception as e:
         lg.debug(traceback.format_exc())
         lg.error(f"an error {e} occured during inference!")

@@ -126,3 +126,52 @@ def test_cli_two_pass_short_contigs(tmp_path):
     assert "ctg_6" not in set(got["contig_id"])            # 400 bp < --min-len
     # long pass first; contigs under 0.7 * fsize fall to the N% < 0.3 filter (collect.py:575)
     assert list(got["contig_id"]) == ["ctg_0", "ctg_3", "ctg_7", "ctg_9", "ctg_2", "ctg_5"]
+
+
+def test_cli_default_dustmask(tmp_path):
+    """--dustmask (the default): contigs are soft-masked before windowing, so the G/C/A/T counts skip
+    low-complexity bases (io.py:104-138) while the ids do not change (masking: false)."""
+    from jaeger_amd.cli import main
+    from oracle import dust as odust
+    from oracle import forward as ofwd
+    rng = np.random.Generator(np.random.PCG64(5))
+    records = []
+    for i, n in enumerate([4700, 3300, 1800]):
+        s = bytearray("".join(rng.choice(list("ACGT"), n)).encode())
+        s[500:700] = b"A" * 200
+        s[1200:1290] = b"CA" * 45
+        if i == 1:
+            s[2000:2400] = b"GGC" * 133 + b"G"
+        records.append((f"lc_{i}", s.decode()))
+    fasta = tmp_path / "lowcomplexity.fasta"
+    fasta.write_text("".join(f">{n}\n{s}\n" for n, s in records))
+    root = make_model_dir(tmp_path / "m")
+    cfg = load_model_cfg("brain")
+    weights = ofwd.random_weights(cfg, seed=38341)
+    r = CliRunner().invoke(main, ["predict", "-i", str(fasta), "-o", str(tmp_path / "out"), "--model_path", str(root),
+                                  "--fsize", "1500", "--stride", "1500"])
+    assert r.exit_code == 0, r.output
+    masked = [(n, odust.soft_mask(s.encode()).decode()) for n, s in records]
+    assert sum(c.islower() for _, s in masked for c in s) > 1200
+
+    # oracle pipeline on the soft-masked strings (fragment_strings upper-cases, then applies the mask)
+    from oracle import fragmenter as ofr
+    lookup = {s.upper(): m for (_, s), (_, m) in zip(records, masked)}
+    rows = [x.split(",") for x in ofr.fragment_strings(records, 1500, 1500, soft_mask=lambda q: lookup[q])]
+    from oracle import encoder as oenc
+    wins = [x[0] for x in rows]
+    out = ofwd.forward(cfg, weights, oenc.encode_windows(wins, 1500, pad_to=oenc.frame_length(1500)))
+    out["meta_0"] = np.array([x[1] for x in rows])
+    for j, k in ((2, "meta_1"), (3, "meta_2"), (4, "meta_3"), (5, "meta_4"), (6, "meta_5"), (7, "meta_6"),
+                 (8, "meta_7"), (9, "meta_8")):
+        out[k] = np.array([int(x[j]) for x in rows])
+    out["meta_9"] = np.array([float(x[10]) for x in rows])
+    from jaeger_amd.postprocess import pred_to_dict, write_output
+    classes = [c["class"] for c in cfg["class_label_map"]]
+    data, _ = pred_to_dict(out, class_map={"num_classes": 6}, fsize=1500, term_repeats=None)
+    exp = tmp_path / "expected.tsv"
+    write_output(data, labels=classes, indices=[c["label"] for c in cfg["class_label_map"]], output_table_path=exp,
+                 output_phage_table_path=tmp_path / "e_ph.tsv", reliability_cutoff=0.1, phage_score=3)
+    _compare_tsv(tmp_path / "out" / "38341_1.4M" / "lowcomplexity.tsv", exp)
+    got = pd.read_csv(tmp_path / "out" / "38341_1.4M" / "lowcomplexity.tsv", sep="\t")
+    assert (got["N%"] > 0.05).all()                 # masked bases count as "not ACGT"
