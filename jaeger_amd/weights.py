@@ -4,8 +4,8 @@
 shipped (He-uniform kernels, BN gamma~U[0.5,1.5], beta/mu~N(0,0.1),
 var~U[0.5,1.5], seed 38341).  ``load_weights`` reads a model directory entry as produced by
 ``AvailableModels`` (utils/misc.py:346-392): a canonical ``.npz`` (written by
-``save_npz``) is read directly; Keras-3 ``.weights.h5`` files need the optional ``h5py``
-module (layout per scripts/convert_legacy_classifier_checkpoint.py:29-175 of the reference:
+``save_npz``) is read directly; Keras-3 ``.weights.h5`` files are read with the built-in
+:mod:`jaeger_amd.hdf5_lite` (layout per scripts/convert_legacy_classifier_checkpoint.py:29-175 of the reference:
 ``layers/<layer>/vars/<i>`` in variable-creation order).
 """
 
@@ -80,36 +80,63 @@ def _layer_order(plan: ModelPlan) -> list[tuple[str, list[str]]]:
     return out
 
 
+_BLOCK_SUBLAYERS = ("conv1", "conv2", "conv3", "bn1", "bn2", "bn3")
+
+
+def _natural_key(path: tuple[str, ...]):
+    """Keras de-duplicates auto names as ``name``, ``name_1``, ``name_2`` ...: sort by (base, index)."""
+    key = []
+    for comp in path:
+        base, _, idx = comp.rpartition("_")
+        key.append((base, int(idx)) if base and idx.isdigit() else (comp, -1))
+    return key
+
+
 def load_keras3_h5(path, plan: ModelPlan) -> dict[str, np.ndarray]:
-    """Keras-3 ``.weights.h5``: walk ``layers/**/vars/<i>`` groups in file order and assign them
-    to the plan's weighted layers by type and order (names in the file are Keras-generated and
-    differ between export generations - the reference's own converter maps by order too,
-    scripts/convert_legacy_classifier_checkpoint.py:76-175)."""
-    try:
-        import h5py
-    except ImportError as e:          # pragma: no cover - h5py is optional
-        raise RuntimeError(
-            "reading Keras .weights.h5 needs the optional 'h5py' module; alternatively convert the "
-            "weights once to the canonical .npz with jaeger_amd.weights.save_npz") from e
+    """Keras-3 ``.weights.h5`` -> canonical names.  The file holds ``layers/<name>/vars/<i>`` groups
+    (containers add another ``layers/`` level; variables in ``add_weight`` order), with Keras-generated
+    names that differ between export generations - the reference's own converter maps by position too
+    (scripts/convert_legacy_classifier_checkpoint.py:76-175).  Mapping rules: residual blocks are paired
+    in natural name order (``residual_block``, ``residual_block_1`` ...) and their sub-layers by their
+    attribute names (``conv1 conv2 conv3 bn1 bn2 bn3``, layers.py:1839-1876); every other weighted
+    layer takes the first unused group with its variable shapes in natural name order, which is
+    creation order for same-type layers."""
+    from .hdf5_lite import read_datasets
     shapes = weight_shapes(plan)
-    groups: list[list[np.ndarray]] = []
-    with h5py.File(path, "r") as f:
-        def visit(name, obj):
-            if isinstance(obj, h5py.Group) and name.endswith("/vars") and len(obj):
-                groups.append([np.asarray(obj[str(i)]) for i in range(len(obj))])
-        f.visititems(visit)
+    by_group: dict[tuple[str, ...], dict[int, np.ndarray]] = {}
+    for key, arr in read_datasets(path).items():
+        parts = [c for c in key.strip("/").split("/")]
+        if len(parts) >= 3 and parts[-2] == "vars" and parts[-1].isdigit():
+            comps = tuple(c for c in parts[:-2] if c != "layers")
+            by_group.setdefault(comps, {})[int(parts[-1])] = arr
+    groups = {k: [g[i] for i in range(len(g))] for k, g in by_group.items() if g}
+    block_paths = sorted({k[:-1] for k in groups if k[-1] in _BLOCK_SUBLAYERS and len(k) >= 2}, key=_natural_key)
+    loose = sorted((k for k in groups if not (k[-1] in _BLOCK_SUBLAYERS and k[:-1] in block_paths)), key=_natural_key)
     order = _layer_order(plan)
-    if len(groups) != len(order):
-        raise ValueError(f"{path}: {len(groups)} weighted layers in the file, the plan has {len(order)}")
+    plan_blocks: list[str] = []
+    for prefix, _ in order:
+        head, _, sub = prefix.rpartition("/")
+        if sub in _BLOCK_SUBLAYERS and head not in plan_blocks:
+            plan_blocks.append(head)
+    if len(plan_blocks) != len(block_paths):
+        raise ValueError(f"{path}: {len(block_paths)} residual blocks in the file, the plan has {len(plan_blocks)}")
+    n_file, n_plan = len(groups), len(order)
+    if n_file != n_plan:
+        raise ValueError(f"{path}: {n_file} weighted layers in the file, the plan has {n_plan}")
     out = {}
-    used = [False] * len(groups)
+    used: set = set()
     for prefix, leaves in order:
         want = [tuple(shapes[f"{prefix}/{v}"]) for v in leaves]
-        for gi, g in enumerate(groups):          # first unused group with matching shapes
-            if not used[gi] and [tuple(a.shape) for a in g] == want:
-                used[gi] = True
-                for v, a in zip(leaves, g):
-                    out[f"{prefix}/{v}"] = a.astype(np.float32)
+        head, _, sub = prefix.rpartition("/")
+        if sub in _BLOCK_SUBLAYERS and head in plan_blocks:
+            cands = [block_paths[plan_blocks.index(head)] + (sub,)]
+        else:
+            cands = [k for k in loose if k not in used]
+        for k in cands:
+            if k in groups and k not in used and [tuple(a.shape) for a in groups[k]] == want:
+                used.add(k)
+                for v, a in zip(leaves, groups[k]):
+                    out[f"{prefix}/{v}"] = np.asarray(a, np.float32)
                 break
         else:
             raise ValueError(f"{path}: no weight group matches {prefix} {want}")

@@ -231,6 +231,35 @@ def main():
                                 output_phage_table_path=HERE / "postprocess_legacy_phages.tsv",
                                 reliability_cutoff=0.1, phage_score=3)
     rep.to_csv(HERE / "postprocess_legacy_repeats.csv", index=False)
+    # ---- a Keras-3 style .weights.h5 (layers/<name>/vars/<i>) for the 500-bp baseline plan, written
+    # with HDF5's own h5import tool from seeded random weights: exercises the h5py-free reader on a
+    # file produced by the HDF5 library with default settings
+    import tempfile
+    import yaml
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import _layer_order, random_weights
+    plan = build_plan(yaml.safe_load((HERE / "baseline500_project.yaml").read_text())["model"])
+    w500 = random_weights(plan, seed=500)
+    keras_names = {"embedding": "embedding", "rep/0": "masked_conv1d", "rep/1": "masked_batch_norm",
+                   "rep/4": "masked_batch_norm_1", "classifier/1": "dense"}
+    out_h5 = HERE / "baseline500_keras3.weights.h5"
+    out_h5.unlink(missing_ok=True)
+    with tempfile.TemporaryDirectory() as td:
+        for prefix, leaves in _layer_order(plan):
+            if prefix in keras_names:
+                group = f"layers/{keras_names[prefix]}"
+            else:                                              # rep/3/block0/conv1 -> residual_block/conv1
+                _, _, blk, sub = prefix.split("/")
+                n = int(blk.removeprefix("block"))
+                group = f"layers/residual_block_stack/layers/residual_block{'' if n == 0 else '_' + str(n)}/{sub}"
+            for i, leaf in enumerate(leaves):
+                arr = w500[f"{prefix}/{leaf}"]
+                txt, cfg = Path(td) / "t.txt", Path(td) / "t.cfg"
+                np.savetxt(txt, arr.reshape(-1, 1), fmt="%.9g")
+                cfg.write_text(f"PATH {group}/vars/{i}\nINPUT-CLASS TEXTFP\nRANK {arr.ndim}\n"
+                               f"DIMENSION-SIZES {' '.join(map(str, arr.shape))}\nOUTPUT-CLASS FP\nOUTPUT-SIZE 32\n")
+                subprocess.run(["/opt/conda/bin/h5import", str(txt), "-c", str(cfg), "-o", str(out_h5)], check=True,
+                               capture_output=True)         # one call per dataset: appends to the file
     print("golden vectors written to", HERE)
 
 

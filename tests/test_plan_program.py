@@ -4,7 +4,7 @@ import copy
 import numpy as np
 import pytest
 
-from conftest import load_model_cfg
+from conftest import GOLDEN, load_model_cfg
 
 
 def test_plan_defaults_follow_reference_constructors():
@@ -114,3 +114,18 @@ def test_missing_or_misshaped_weights_rejected():
     bad["rep/0/kernel"] = bad["rep/0/kernel"][:, :, :16]
     with pytest.raises(ValueError):
         G.compile_plan(P.build_plan(cfg), bad)
+
+
+def test_keras3_weights_h5_reader():
+    """A Keras-3 style weights file (layers/<auto name>/vars/<i>, residual blocks as containers) written
+    by HDF5's h5import from seeded weights maps back onto the plan's canonical names."""
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import load_keras3_h5, load_weights, random_weights
+    plan = build_plan(load_model_cfg("baseline500"))
+    want = random_weights(plan, seed=500)
+    got = load_keras3_h5(GOLDEN / "baseline500_keras3.weights.h5", plan)
+    assert set(got) == set(want)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    again = load_weights({"weights": GOLDEN / "baseline500_keras3.weights.h5"}, plan)
+    assert all(np.array_equal(again[k], want[k]) for k in want)
