@@ -210,6 +210,15 @@ int jg_fasta_parse(const uint8_t *text, int64_t n, int64_t max_records, uint8_t 
 int jg_dust_mask(uint8_t *bases, const int64_t *offsets, int64_t n_records, int32_t window,
                  int32_t threshold, int32_t n_threads, int64_t *n_masked);
 
+/* ---- terminal-repeat scan (replaces utils/termini.py:88-189 scan_for_terminal_repeats: parasail
+ * sw_trace_scan_16 of the first vs the last min(max(int(0.04 len), 400), 4000) bases, direct and
+ * reverse-complemented; match 2 / mismatch -100 / gap 100 + 5(k-1)) -------------------------------
+ * results: (n_records, 10) int32 on the host, per record DTR then ITR: score, alignment length,
+ * gaps in the query row, end in the query, end in the reference; -1 for records shorter than min_len.
+ * bases: host or device per bases_loc; offsets (n_records + 1) on the host.  Synchronous. */
+int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n_bases, int bases_loc,
+                        const int64_t *offsets, int64_t n_records, int32_t min_len, int32_t *results);
+
 #ifdef __cplusplus
 }
 #endif

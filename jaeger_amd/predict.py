@@ -244,7 +244,6 @@ def run_core(**kwargs) -> int:
         dusted = True
         lg.info(f"DUST (window 64, threshold 20): {n_masked} of {fa.bases.size} bases soft-masked in "
                 f"{time.time() - t_dust:.2f} s")
-    lg.warning("terminal-repeat scan (parasail) is not implemented: terminal_repeats / repeat_length stay empty")
 
     weights = None
     wnpz = model_info.get("weights_npz")
@@ -259,6 +258,13 @@ def run_core(**kwargs) -> int:
         lg.debug(traceback.format_exc())
         lg.error(f"could not set up the model on GPU {local_rank}: {e}")
         sys.exit(1)
+    term_repeats = None
+    if rank == 0:
+        from .termini import scan_for_terminal_repeats
+        t_term = time.time()
+        term_repeats = scan_for_terminal_repeats(engine.device, fa, fsize)
+        lg.info(f"terminal repeats: {int(term_repeats['terminal_repeats'].notna().sum())} of {len(term_repeats)} "
+                f"contigs in {time.time() - t_term:.2f} s")
     sp = engine.string_processor_config
     lg.info(f"input file: {input_path.name}")
     lg.info(f"outpath: {out_dir.resolve()}")
@@ -323,7 +329,7 @@ def run_core(**kwargs) -> int:
         y_pred = {k: np.concatenate([yr[k][b:e] for yr, b, e in ordered], axis=0) for k in keys}
         dist.barrier()
 
-    data, data_full = pred_to_dict(y_pred, class_map=engine.class_map, fsize=fsize, term_repeats=None)
+    data, data_full = pred_to_dict(y_pred, class_map=engine.class_map, fsize=fsize, term_repeats=term_repeats)
     n_written = write_output(data, labels=engine.class_map.get("class"), indices=engine.class_map.get("index"),
                              output_table_path=table_path, output_phage_table_path=phage_path,
                              reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))

@@ -104,7 +104,6 @@ def run_core(**kwargs) -> int:
         n_masked = frag.dust_mask(fa)
         dusted = True
         lg.info(f"DUST (window 64, threshold 20): {n_masked} of {fa.bases.size} bases soft-masked")
-    lg.warning("terminal-repeat scan is not implemented: terminal_repeats / repeat_length stay empty")
     ood_params = load_ood_params(model_path, config)
     try:
         engine = LegacyHipEngine(weights_path, device_id=kwargs.get("physicalid", 0), chunk=kwargs.get("chunk", 0))
@@ -112,6 +111,8 @@ def run_core(**kwargs) -> int:
         lg.debug(traceback.format_exc())
         lg.error(f"could not set up the legacy model on GPU {kwargs.get('physicalid', 0)}: {e}")
         sys.exit(1)
+    from .termini import scan_for_terminal_repeats
+    term_repeats = scan_for_terminal_repeats(engine.device, fa, fsize)
     lg.info(f"input file: {input_path.name}  fragment size: {fsize}  stride: {kwargs.get('stride')}  "
             f"model: {model} (exact-f32 MFMA path)")
     try:
@@ -126,7 +127,7 @@ def run_core(**kwargs) -> int:
     key = "all_labels" if kwargs.get("getalllabels") else "default_labels"
     config["labels"] = [v for _, v in config[key].items()]
     data, data_full = pred_to_dict_legacy(config, y_pred, model=model, fsize=fsize, ood_params=ood_params,
-                                          term_repeats=None)
+                                          term_repeats=term_repeats)
     n = write_output_legacy(config, data, output_table_path=table_path, output_phage_table_path=phage_path,
                             reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 3))
     lg.info(f"processed {data.get('headers').shape[0]}/{num} sequences")

@@ -1,0 +1,49 @@
+"""Terminal-repeat scan on the GPU (``utils/termini.py:88-189`` ``scan_for_terminal_repeats``).
+
+``jg_terminal_repeats`` aligns the two ends of every contig (direct and reverse-complemented) with the
+reference's scoring and returns score / alignment length / query gaps per alignment; the decision rule
+(``termini.py:137-154``, ``:58-63``) and the DataFrame the summary merges (``postprocess/collect.py:527-532``:
+``contig_id``, ``terminal_repeats``, ``repeat_length``) are assembled here.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pandas as pd
+
+from . import _lib as L
+
+
+def scan_for_terminal_repeats(device, fa, fsize: int) -> pd.DataFrame:
+    """``device``: :class:`~jaeger_amd.engine.HipDevice`; ``fa``: FastaBatch.  One row per record with
+    ``len >= fsize`` (the reference's filter, termini.py:164-168)."""
+    n = len(fa)
+    res = np.full((max(n, 1), 10), -1, np.int32)
+    bases = np.ascontiguousarray(fa.bases, np.uint8)
+    offsets = np.ascontiguousarray(fa.offsets, np.int64)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    L.check(device.lib.jg_terminal_repeats(device.handle, ptr(bases), bases.size, L.JG_PTR_HOST, ptr(offsets), n,
+                                           int(fsize), ptr(res)), "jg_terminal_repeats")
+    res = res[:n]
+    keep = np.nonzero(res[:, 0] >= 0)[0]
+    d_score, d_len, d_fg = res[keep, 0], res[keep, 1], res[keep, 2]
+    i_score, i_len = res[keep, 5], res[keep, 6]
+    found = (i_len > 12) | (d_len > 12)
+    is_itr = found & (i_score > d_score)
+    is_dtr = found & ~is_itr
+    kind = np.full(keep.size, None, dtype=object)
+    kind[is_itr] = "ITR"
+    kind[is_dtr] = "DTR"
+    kind[is_dtr & ((d_len - d_fg) >= 250)] = "LTR_DTR"
+    length = np.where(is_itr, i_len, d_len).astype(np.float64)
+    length[~found] = np.nan
+    score = np.where(is_itr, i_score, d_score).astype(np.float64)
+    score[~found] = np.nan
+    lengths = fa.lengths
+    return pd.DataFrame({
+        "contig_id": [fa.names[i].strip().replace(",", "___") for i in keep.tolist()],
+        "repeat_length": length, "score": score, "terminal_repeats": kind,
+        "seq_len": lengths[keep] if keep.size else np.array([], np.int64),
+    })

@@ -1,0 +1,91 @@
+"""Terminal-repeat scan kernel (jg_terminal_repeats) vs the CPU Smith-Waterman restatement."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(rng, n):
+    return "".join(rng.choice(list("ACGT"), n))
+
+
+def _cases():
+    rng = np.random.Generator(np.random.PCG64(42))
+    from oracle.termini import reverse_complement
+    out = {}
+    body = _rand(rng, 3000)
+    rep = _rand(rng, 60)
+    out["dtr_exact"] = rep + body + rep
+    out["itr_exact"] = rep + body + reverse_complement(rep)
+    out["none"] = _rand(rng, 2500)
+    long_rep = _rand(rng, 300)
+    out["ltr_dtr"] = long_rep + body + long_rep
+    mm = list(_rand(rng, 140))
+    mm2 = mm.copy()
+    mm2[70] = "A" if mm[70] != "A" else "C"                    # one mismatch with > 50 matches on both sides
+    out["dtr_mismatch"] = "".join(mm) + body + "".join(mm2)
+    g = _rand(rng, 160)
+    out["dtr_gap_in_rear"] = g + body + g[:80] + g[83:]          # 3 bases missing at the rear end: gap in the ref row
+    out["dtr_gap_in_front"] = g[:80] + g[83:] + body + g          # gap in the query row
+    out["inner_offset"] = _rand(rng, 37) + rep + body + _rand(rng, 11) + rep + _rand(rng, 90)
+    out["with_n"] = rep[:30] + "N" + rep[31:] + body + rep
+    out["lower_case"] = rep.lower() + body + rep
+    out["short_1200"] = rep + _rand(rng, 1080) + rep              # scan 400 overlapping regions
+    out["big_60kb"] = long_rep + _rand(rng, 60000) + long_rep      # scan = 2412
+    return out
+
+
+def test_kernel_matches_smith_waterman():
+    from jaeger_amd import fragment as frag
+    from jaeger_amd import _lib as L
+    from jaeger_amd.engine import HipDevice
+    from jaeger_amd.termini import scan_for_terminal_repeats
+    from oracle import termini as ot
+    import ctypes as C
+    cases = _cases()
+    names = list(cases)
+    bases, offsets = frag.concat_records([cases[k].encode() for k in names])
+    fa = frag.FastaBatch(names, bases, offsets)
+    dev = HipDevice(0)
+    res = np.full((len(names), 10), -1, np.int32)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    L.check(dev.lib.jg_terminal_repeats(dev.handle, ptr(bases), bases.size, L.JG_PTR_HOST, ptr(offsets), len(names),
+                                        1000, ptr(res)))
+    df = scan_for_terminal_repeats(dev, fa, 1000)
+    dev.close()
+    for k, name in enumerate(names):
+        seq = cases[name]
+        scan = ot.scan_length(len(seq))
+        if scan > 1300:                      # keep the pure-Python oracle fast: check the big case by its plant
+            assert res[k, 0] == 600 and res[k, 1] == 300 and res[k, 2] == 0, res[k]
+            continue
+        front, rear = seq[:scan], seq[-scan:]
+        for col, ref in ((0, rear), (5, ot.reverse_complement(rear))):
+            want = ot.smith_waterman(front, ref)
+            got = dict(score=int(res[k, col]), length=int(res[k, col + 1]), fgaps=int(res[k, col + 2]),
+                       end_query=int(res[k, col + 3]), end_ref=int(res[k, col + 4]))
+            assert got["score"] == want["score"], (name, col, got, want)
+            assert (got["length"], got["fgaps"]) == (want["length"], want["fgaps"]), (name, col, got, want)
+            if want["score"] > 0:
+                assert (got["end_query"], got["end_ref"]) == (want["end_query"], want["end_ref"]), (name, col)
+        kind, length = ot.scan_record(seq)
+        row = df[df.contig_id == name].iloc[0]
+        assert (row.terminal_repeats if isinstance(row.terminal_repeats, str) else None) == kind, (name, row)
+        assert (np.isnan(row.repeat_length) and length is None) or row.repeat_length == length, (name, row)
+    d = dict(zip(df.contig_id, df.terminal_repeats))
+    assert d["dtr_exact"] == "DTR" and d["itr_exact"] == "ITR" and d["ltr_dtr"] == "LTR_DTR" and d["big_60kb"] == "LTR_DTR"
+    assert d["dtr_mismatch"] == "DTR" and df[df.contig_id == "dtr_mismatch"].repeat_length.iloc[0] == 140
+    assert df[df.contig_id == "dtr_gap_in_rear"].repeat_length.iloc[0] == 160
+
+
+def test_short_records_are_skipped():
+    from jaeger_amd import fragment as frag
+    from jaeger_amd.engine import HipDevice
+    from jaeger_amd.termini import scan_for_terminal_repeats
+    rng = np.random.Generator(np.random.PCG64(1))
+    seqs = [_rand(rng, 900).encode(), _rand(rng, 2100).encode()]
+    bases, offsets = frag.concat_records(seqs)
+    dev = HipDevice(0)
+    df = scan_for_terminal_repeats(dev, frag.FastaBatch(["a,b", "c"], bases, offsets), 2000)
+    dev.close()
+    assert list(df.contig_id) == ["c"]
