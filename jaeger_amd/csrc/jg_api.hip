@@ -382,6 +382,7 @@ static bool slot_needs_f32(const jg_model *m, size_t i, int buf) {
 
 static int prepare_f16(jg_model *m, const float *weights) {
   m->hprep.assign(m->ops.size(), ConvHPrep());
+  m->pool_fused_by.assign(m->ops.size(), -1);
   m->f16_eligible = true;
   m->f16_reason.clear();
   auto fail = [&](const char *why) { m->f16_eligible = false; m->f16_reason = why; };
@@ -403,6 +404,29 @@ static int prepare_f16(jg_model *m, const float *weights) {
     ConvHPrep &hp = m->hprep[i];
     hp.out_f16s = !slot_needs_f32(m, i, op.out_buf);
     f32_fmt[op.out_buf] = !hp.out_f16s;
+    if (!hp.out_f16s && getenv("JG_NO_POOL_FUSE") == nullptr) {
+      // the only reader of the f32 output is a masked global max pool over the conv's own output mask:
+      // reduce in the epilogue instead of storing 4 B per element and reading it back
+      int readers = 0, pool_idx = -1;
+      for (size_t j = i + 1; j < m->ops.size(); ++j) {
+        const jg_op &o = m->ops[j];
+        const bool reads = ((o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D ||
+                             o.kind == JG_OP_FRAMESUM || o.kind == JG_OP_POOL) && o.in_buf == op.out_buf);
+        bool adds = false;
+        if (o.kind == JG_OP_CONV)
+          for (int q = 0; q < o.n_stages; ++q) adds |= o.stages[q].kind == JG_ST_ADD && o.stages[q].arg == op.out_buf;
+        if (reads || adds) {
+          ++readers;
+          if (o.kind == JG_OP_POOL && o.arg == JG_POOL_MAX && o.in_mask == op.out_mask) pool_idx = (int)j;
+          else pool_idx = -2;
+        }
+        if ((o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE) && o.out_buf == op.out_buf) break;   // overwritten
+      }
+      if (readers == 1 && pool_idx >= 0) {
+        hp.pool_op = pool_idx;
+        m->pool_fused_by[(size_t)pool_idx] = (int)i;
+      }
+    }
     const int cin16 = (op.cin + 15) / 16 * 16, cin_pad = (op.cin + 1) & ~1, cout_pad = 128;
     hp.cc_in = cin16 / 16;
     const float *w = weights + op.w_off;   // (k, cin_pad, cout_pad32) f32
@@ -637,6 +661,7 @@ extern "C" int jg_model_destroy(jg_model *m) {
   if (m->d_win) (void)hipFree(m->d_win);
   if (m->d_lut) (void)hipFree(m->d_lut);
   if (m->d_overflow) (void)hipFree(m->d_overflow);
+  if (m->pool_part) (void)hipFree(m->pool_part);
   for (auto &hp : m->hprep) {
     if (hp.d_wh) (void)hipFree(hp.d_wh);
     if (hp.d_embh) (void)hipFree(hp.d_embh);
@@ -739,6 +764,17 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           for (int q = 0; q < hp.n_hst; ++q) a.hst[q] = hp.hst[q];
           if (hp.add_slot >= 0) a.addh = reinterpret_cast<const uint4 *>(m->act[hp.add_slot]);
           if (hp.nmd_slot >= 0) a.nmd_out = m->nmd_part[hp.nmd_slot];
+          if (hp.pool_op >= 0) {
+            const int64_t need = (int64_t)a.rows * a.tiles_m * 2 * op.cout;
+            if (need > m->pool_part_cap) {
+              JG_HIP(hipStreamSynchronize(s));
+              if (m->pool_part) (void)hipFree(m->pool_part);
+              m->pool_part = nullptr;
+              JG_HIP(hipMalloc(reinterpret_cast<void **>(&m->pool_part), (size_t)need * sizeof(float)));
+              m->pool_part_cap = need;
+            }
+            a.pool_out = m->pool_part;
+          }
           if (hp.d_lut != nullptr) {
             a.lut = hp.d_lut;
             a.lut_vocab = m->vocab;
@@ -809,6 +845,12 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
       case JG_OP_POOL: {
         const Shape in = sh[op.in_buf];
         const uint8_t *mk = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
+        if (m->precision == 1 && m->pool_fused_by[i] >= 0) {
+          const int tiles = (in.L + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m();
+          rc = jg_launch_pool_final(m->pool_part, in.frames * tiles * 2, nw, in.C,
+                                    m->vec[op.out_vec] + op.vec_off, m->vec_w[op.out_vec], s);
+          break;
+        }
         rc = jg_launch_pool(m->act[op.in_buf], mk, nw, in.frames * in.L, in.C, op.arg,
                             m->vec[op.out_vec] + op.vec_off, m->vec_w[op.out_vec], s);
       } break;

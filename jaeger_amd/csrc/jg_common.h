@@ -84,7 +84,8 @@ struct ConvHArgs {
   const uint4 *wh;         // [2 planes][k][cc_in*2][cout_pad]
   void *y;                 // F16S [rows][cout_pad/16][4][L_out] items, or f32 (rows, L_out, cout)
   const uint4 *addh;       // residual shortcut in F16S (same geometry as y) or null
-  float *nmd_out;          // NMD partial sums [rows][tiles_m][4][cout] or null
+  float *nmd_out;          // NMD partial sums [rows][tiles_m * 2][cout] (one row per wave strip) or null
+  float *pool_out;         // fused masked max-pool partials, same geometry; when set the output is not stored
   int *overflow;           // set to 1 when an output leaves the f16 range
   int rows, L_in, L_out;
   int cc_in, cout, cout_pad;
@@ -142,6 +143,7 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   int n_hst = 0, n_epi_rows = 0;
   HStageArg hst[JG_MAX_STAGES] = {};
   int add_slot = -1, nmd_slot = -1;
+  int pool_op = -1;         // index of the OP_POOL (masked max) fused into this conv's epilogue, or -1
   unsigned ep = JG_EP_GENERIC;
   float alpha1 = 0.f, alpha2 = 0.f;
   int dytmask1 = 0, dytmask2 = 0;
@@ -176,6 +178,9 @@ struct jg_model {
   void *d_win = nullptr;
   int64_t d_win_cap = 0;
   uint8_t *d_lut = nullptr;
+  float *pool_part = nullptr;       // fused max-pool partial rows (split-f16 path)
+  int64_t pool_part_cap = 0;
+  std::vector<int> pool_fused_by;   // per op: conv op index that produces this OP_POOL's partials, or -1
 };
 
 // ---- kernel launchers (defined in jg_kernels.hip) ---------------------------
@@ -198,6 +203,8 @@ int jg_launch_oodsig(const float *logits, int n_cls, const float *nmd, int nmd_w
                      hipStream_t s);
 int jg_launch_maxpool1d(const float *x, const uint8_t *mask_in, int rows, int L_in, int L_out, int c,
                         float *y, uint8_t *mask_out, hipStream_t s);
+int jg_launch_pool_final(const float *part, int rows_per_win, int n_win, int c, float *out, int out_ld,
+                         hipStream_t s);
 int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,
                        hipStream_t s);
 int jg_conv_tile_m(int cout);

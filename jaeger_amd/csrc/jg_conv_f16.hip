@@ -366,16 +366,20 @@ void conv_f16x3_kernel(ConvHArgs a) {
         if (t == 0) zero_fill(abuf);
         __syncthreads();
         JG_ST(1);
-        // -- keep the DMA queue full --------------------------------------------------------------
-        if (t + WA < K) {
-          issue_w(cc, t + WA);
-        } else if (!tail) {
-          issue_w(last_chunk ? 0 : cc + 1, t + WA - K);
-        }
-        if (t == 0 && !tail) {
-          if (last_chunk) build_pieces(np);        // the next pass's pieces take over from here
-          issue_x(last_chunk ? 0 : cc + 1, abuf ^ 1);
-        }
+        // -- keep the DMA queue full: issued from inside the matrix-core stream (after the first half
+        // of the step's MFMAs are queued) so that the DMA issue cost runs under matrix-core time ------
+        auto issue_step = [&]() {
+          if (t + WA < K) {
+            issue_w(cc, t + WA);
+          } else if (!tail) {
+            issue_w(last_chunk ? 0 : cc + 1, t + WA - K);
+          }
+          if (t == 0 && !tail) {
+            if (last_chunk) build_pieces(np);        // the next pass's pieces take over from here
+            issue_x(last_chunk ? 0 : cc + 1, abuf ^ 1);
+          }
+        };
+        if (a.dbg & 2) issue_step();
         JG_ST(2);
         // -- matrix-core work: one tap of one 16-channel chunk ----------------------------------
         if (!(a.dbg & 2)) {
@@ -408,6 +412,11 @@ void conv_f16x3_kernel(ConvHArgs a) {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[tn], xh[tq], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xh[tq], c, 0, 0, 0);
               }
+            if (tp == 0) {
+              __builtin_amdgcn_sched_barrier(0);
+              issue_step();
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         }
       }
@@ -613,38 +622,44 @@ void conv_f16x3_kernel(ConvHArgs a) {
           }
         }
       };
-      // Cross-lane reduction of the NMD sums over a half's 32 lanes by register halving: at each
-      // step a lane keeps half of its registers and receives the partner's copy of that half (DPP
-      // within rows of 16, one bpermute across rows), so 16 registers cost 16 exchanges instead
-      // of 80.  Afterwards lane i holds channel register r = 8*b2 + 4*b1 + 2*b0 + b3 (bits of i).
-      auto nmd_flush = [&](const Tile &tile, int tn) {
+      // Cross-lane reduction over a half's 32 lanes by register halving: at each step a lane keeps half of
+      // its registers and receives the partner's copy of that half (DPP within rows of 16, one bpermute
+      // across rows), so 16 registers cost 16 exchanges instead of 80.  Afterwards lane i holds the
+      // reduction of channel register r = 8*b2 + 4*b1 + 2*b0 + b3 (bits of i).
 #define JG_DPP(v, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), (ctrl), 0xf, 0xf, false))
+      auto lane_reduce = [&](const float (&in)[16], auto op) -> float {
         const bool b2 = (i & 4) != 0, b1 = (i & 2) != 0, b0 = (i & 1) != 0, b3 = (i & 8) != 0;
         float s8[8], s4[4], s2[2];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {        // partner i ^ 7 (row_half_mirror)
-          const float keep = b2 ? nmd_acc[8 + q] : nmd_acc[q], send = b2 ? nmd_acc[q] : nmd_acc[8 + q];
-          s8[q] = keep + JG_DPP(send, 0x141);
+          const float keep = b2 ? in[8 + q] : in[q], send = b2 ? in[q] : in[8 + q];
+          s8[q] = op(keep, JG_DPP(send, 0x141));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {        // partner i ^ 2 (quad_perm [2,3,0,1])
           const float keep = b1 ? s8[4 + q] : s8[q], send = b1 ? s8[q] : s8[4 + q];
-          s4[q] = keep + JG_DPP(send, 0x4e);
+          s4[q] = op(keep, JG_DPP(send, 0x4e));
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {        // partner i ^ 1 (quad_perm [1,0,3,2])
           const float keep = b0 ? s4[2 + q] : s4[q], send = b0 ? s4[q] : s4[2 + q];
-          s2[q] = keep + JG_DPP(send, 0xb1);
+          s2[q] = op(keep, JG_DPP(send, 0xb1));
         }
         const float keep1 = b3 ? s2[1] : s2[0], send1 = b3 ? s2[0] : s2[1];
-        float v = keep1 + JG_DPP(send1, 0x128);   // partner i ^ 8 (row_ror:8)
-        v += __shfl_xor(v, 16, 32);                                           // partner i ^ 16
-        if (i < 16 && tile.valid) {
-          const int r = 8 * (int)b2 + 4 * (int)b1 + 2 * (int)b0 + (int)b3;
-          const int ch = (wn * 2 + tn) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-          const int tileno = tile.m0 / HM;
-          if (ch < a.cout) a.nmd_out[(((size_t)tile.rowblk * a.tiles_m + tileno) * 2 + wm) * a.cout + ch] = v;
-        }
+        const float v = op(keep1, JG_DPP(send1, 0x128));      // partner i ^ 8 (row_ror:8)
+        return op(v, __shfl_xor(v, 16, 32));                  // partner i ^ 16
+      };
+      // where lane i's reduced channel lives, and the partial row of this wave's 128 positions
+      auto reduced_slot = [&](const Tile &tile, int tn, int &ch) -> size_t {
+        const int r = 8 * (int)((i & 4) != 0) + 4 * (int)((i & 2) != 0) + 2 * (int)((i & 1) != 0) + (int)((i & 8) != 0);
+        ch = (wn * 2 + tn) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        return (((size_t)tile.rowblk * a.tiles_m + tile.m0 / HM) * 2 + wm) * a.cout + ch;
+      };
+      auto nmd_flush = [&](const Tile &tile, int tn) {
+        const float v = lane_reduce(nmd_acc, [](float x, float y) { return x + y; });
+        int ch;
+        const size_t slot = reduced_slot(tile, tn, ch);
+        if (i < 16 && tile.valid && ch < a.cout) a.nmd_out[slot] = v;
       };
       const bool has_nmd = EP == JG_EP_GENERIC ? a.nmd_out != nullptr : (EP & (JG_EP_NMD1 | JG_EP_NMD2)) != 0;
 #pragma unroll
@@ -655,10 +670,38 @@ void conv_f16x3_kernel(ConvHArgs a) {
         for (int tm = 0; tm < TM; ++tm) epi_block(acc[tm][tn], cur[0], tm, tn);
         if (has_nmd) nmd_flush(cur[0], tn);
       }
+      if (a.pool_out != nullptr) {
+        // fused masked global max pool (layers.py:496-538): the block outputs are not stored at all; each
+        // wave reduces its 128 positions to one partial row, pool_final takes the max over a window's rows
+        float mkv[TM];
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        store_block(acc[tm][0], cur[0], tm, 0);
-        store_block(acc[tm][1], cur[0], tm, 1);
+        for (int tm = 0; tm < TM; ++tm) {
+          const int m = cur[0].m0 + (wm * TM + tm) * 32 + i;
+          const bool live = m < a.L_out && cur[0].valid;
+          const int mc = m < a.L_out ? m : 0;
+          const unsigned char mb = a.mask_out != nullptr ? a.mask_out[(size_t)cur[0].rowblk * a.L_out + mc] : (unsigned char)1;
+          mkv[tm] = (live && mb != 0) ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          float pa[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pa[r] = -INFINITY;
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pa[r] = mkv[tm] != 0.f ? fmaxf(pa[r], acc[tm][tn][r]) : pa[r];
+          const float v = lane_reduce(pa, [](float x, float y) { return fmaxf(x, y); });
+          int ch;
+          const size_t slot = reduced_slot(cur[0], tn, ch);
+          if (i < 16 && cur[0].valid && ch < a.cout) a.pool_out[slot] = v;
+        }
+      } else {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          store_block(acc[tm][0], cur[0], tm, 0);
+          store_block(acc[tm][1], cur[0], tm, 1);
+        }
       }
       if (!(vmax <= 65000.0f) && a.overflow != nullptr && a.dbg == 0) atomicOr(a.overflow, 1);
     }

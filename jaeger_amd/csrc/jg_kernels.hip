@@ -516,6 +516,27 @@ int jg_launch_pool(const float *x, const uint8_t *mask, int n_win, int positions
   return JG_OK;
 }
 
+// finish of the max pool fused into the last conv's epilogue: max over a window's partial rows
+// (-inf = no valid position in that strip); a window without any valid position pools to zeros
+__global__ __launch_bounds__(128) void pool_final_kernel(const float *__restrict__ part, int rows_per_win, int c,
+                                                         float *__restrict__ out, int out_ld) {
+  const int w = blockIdx.x;
+  for (int ch = threadIdx.x; ch < c; ch += 128) {
+    const float *p = part + (size_t)w * rows_per_win * c + ch;
+    float m = -INFINITY;
+    for (int r = 0; r < rows_per_win; ++r) m = fmaxf(m, p[(size_t)r * c]);
+    out[(size_t)w * out_ld + ch] = m == -INFINITY ? 0.f : m;
+  }
+}
+
+int jg_launch_pool_final(const float *part, int rows_per_win, int n_win, int c, float *out, int out_ld,
+                         hipStream_t s) {
+  if (n_win == 0) return JG_OK;
+  hipLaunchKernelGGL(pool_final_kernel, dim3((unsigned)n_win), dim3(128), 0, s, part, rows_per_win, c, out, out_ld);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Dense head layer: out[w, o] = act(sum_i in[w, i] * W[i, o] + b[o])
 // ---------------------------------------------------------------------------
