@@ -92,7 +92,6 @@ struct ConvHArgs {
   int k, dil, pad_left, tiles_m;
   int mask_from_ids, out_f16s;
   int dbg;                 // ablation switches (JG_DBG env, timing experiments only)
-  int stagger;             // shader cycles the second half of the grid waits before starting
   unsigned ep;             // JG_EP_* pattern of the stage list (JG_EP_GENERIC: interpret hst[])
   float alpha1, alpha2;    // DyT alphas of norm1 / norm2
   int dytmask1, dytmask2;

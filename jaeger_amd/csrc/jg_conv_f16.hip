@@ -277,14 +277,6 @@ void conv_f16x3_kernel(ConvHArgs a) {
   const int w_frag = h * HN + wn * 64 + i;                  // + plane*2*HN + tn*32 (+ slot*W_ITEMS)
   const int x_frag = h * rows_a + wm * (TM * 32) + i;       // + plane*2*rows_a + tm*32 + t*dil
 
-  // The two workgroups sharing a CU would otherwise run in lockstep (same program, same work)
-  // and reach their VALU-only epilogues together; delaying the second-dispatched half of the
-  // grid by about half a pass lets one workgroup's epilogue run under the other's MFMA steps.
-  if (a.stagger > 0 && blockIdx.x >= gridDim.x / 2) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(32);
-  }
-
   // ---- software pipeline -----------------------------------------------------------------
   // step (cc, t): weights of step +WA are issued into slot (t+WA)%K, whose last reader was step
   // -2; the next chunk's activations are issued at tap 0 into the other buffer.  A step may
@@ -480,7 +472,6 @@ void conv_f16x3_kernel(ConvHArgs a) {
         const int nb = (wn * 2 + tn) * 32;
         const int m = tile.m0 + (wm * TM + tm) * 32 + i;
         const bool live = m < a.L_out && tile.valid;
-        const int mc = m < a.L_out ? m : 0;
         const float mk = p.mkb != 0 ? 1.f : 0.f;
         // ---- stage primitives on this lane's 16 channels of one position -----------------
         auto st_affine = [&](int row) {
@@ -726,16 +717,12 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   }
   const int n_tiles = a.rows * a.tiles_m;
   const int n_pairs = (n_tiles + NT - 1) / NT;
-  // two 4-wave workgroups per CU when their LDS fits (<= 80 KB each): the two run out of phase,
-  // so one's epilogue and stores overlap the other's matrix-core steps
+  // two 4-wave workgroups per CU when their LDS fits (<= 80 KB each): one's epilogue and stores overlap
+  // the other's matrix-core steps.  (Forcing the two out of phase - by dispatch order or by a per-CU
+  // arrival ticket - was measured and changes nothing; neither does storing each block early.)
   int grid = (smem <= 80 * 1024 ? 2 : 1) * e->n_cu;
   if (grid > n_pairs) grid = n_pairs;
   ConvHArgs b = a;
-  static int stag = -1;
-  // JG_STAGGER: experiment switch (measured: no gain on MI355X), off by default
-  if (stag < 0) { const char *ev = getenv("JG_STAGGER"); stag = ev ? atoi(ev) : 0; }
-  // half a pass of matrix-core time (cycles): cc_in*K steps of 24 MFMAs x 32 cycles, two waves per SIMD
-  b.stagger = (stag && grid > e->n_cu && n_pairs >= 2 * grid) ? a.cc_in * K * 24 * 32 * stag : 0;
   hipLaunchKernelGGL((conv_f16x3_kernel<K, EP>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, b);
   JG_HIP(hipGetLastError());
 #ifdef JG_STAMP
