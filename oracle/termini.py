@@ -23,6 +23,62 @@ def reverse_complement(seq: str) -> str:
 
 
 def smith_waterman(query: str, ref: str) -> dict:
+    """Row-vectorised (numpy) evaluation of the same recurrences as :func:`smith_waterman_loops`, same
+    traceback; used for end-sized inputs.  E needs no in-row recursion: a gap opened from a cell that was
+    itself reached through a gap never beats extending that gap (open >= extend), so
+    E[i][j] = max_{k<j}(H'[i][k] - open - ext (j-1-k)) with H' = max(0, diagonal, F), a prefix maximum."""
+    import numpy as np
+    q = np.frombuffer(query.upper().encode(), np.uint8)
+    r = np.frombuffer(ref.upper().encode(), np.uint8)
+    n, m = len(q), len(r)
+    acgt = np.isin(r, np.frombuffer(b"ACGT", np.uint8))
+    H = np.zeros((n + 1, m + 1), np.int64)
+    E = np.full((n + 1, m + 1), NEG, np.int64)
+    F = np.full((n + 1, m + 1), NEG, np.int64)
+    jj = np.arange(m + 1)
+    for i in range(1, n + 1):
+        sub = np.where((r == q[i - 1]) & acgt, MATCH, MISMATCH)
+        F[i, 1:] = np.maximum(F[i - 1, 1:] - EXT, H[i - 1, 1:] - OPEN)
+        hp = np.zeros(m + 1, np.int64)
+        hp[1:] = np.maximum(0, np.maximum(H[i - 1, :-1] + sub, F[i, 1:]))
+        a = hp + EXT * jj                                   # H'[k] + ext k   (column 0: H = 0)
+        best_prev = np.maximum.accumulate(a)[:-1]           # max over k <= j-1
+        E[i, 1:] = best_prev - OPEN - EXT * (jj[1:] - 1)
+        H[i, 1:] = np.maximum(hp[1:], E[i, 1:])
+    best = int(H.max())
+    if best == 0:
+        return {"score": 0, "length": 0, "fgaps": 0, "rgaps": 0, "end_query": -1, "end_ref": -1}
+    cols = np.nonzero((H == best).any(axis=0))[0]
+    bj = int(cols[0])                                       # first maximum in (reference, query) order
+    bi = int(np.nonzero(H[:, bj] == best)[0][0])
+    i, j, state = bi, bj, "H"
+    length = fgaps = rgaps = 0
+    qs, rs = query.upper(), ref.upper()
+    while True:
+        if state == "H":
+            if H[i, j] == 0:
+                break
+            sub = MATCH if (qs[i - 1] == rs[j - 1] and qs[i - 1] in "ACGT") else MISMATCH
+            if H[i, j] == H[i - 1, j - 1] + sub:
+                i, j, length = i - 1, j - 1, length + 1
+            elif H[i, j] == E[i, j]:
+                state = "E"
+            else:
+                state = "F"
+        elif state == "E":
+            length, fgaps = length + 1, fgaps + 1
+            if E[i, j] != E[i, j - 1] - EXT:
+                state = "H"
+            j -= 1
+        else:
+            length, rgaps = length + 1, rgaps + 1
+            if F[i, j] != F[i - 1, j] - EXT:
+                state = "H"
+            i -= 1
+    return {"score": best, "length": length, "fgaps": fgaps, "rgaps": rgaps, "end_query": bi - 1, "end_ref": bj - 1}
+
+
+def smith_waterman_loops(query: str, ref: str) -> dict:
     """-> score, alignment length (traceback columns), gaps in the query row, end positions."""
     q, r = query.upper(), ref.upper()
     n, m = len(q), len(r)

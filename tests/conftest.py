@@ -41,3 +41,20 @@ def make_model_dir(root: Path, name: str = "brain", model_name: str = "jaeger_38
     (d / f"{model_name}_classes.yaml").write_text(yaml.safe_dump({"classes": cfg["class_label_map"]}))
     save_npz(d / f"{model_name}.weights.npz", random_weights(build_plan(cfg), seed))
     return Path(root)
+
+
+def oracle_term_repeats(records, fsize: int):
+    """Terminal-repeat table (contig_id, terminal_repeats, repeat_length) from the CPU oracle for (name, seq)
+    records; what ``scan_for_terminal_repeats`` feeds into the summaries (utils/termini.py:88-189)."""
+    import numpy as np
+    import pandas as pd
+
+    from oracle import termini as ot
+    rows = []
+    for name, seq in records:
+        if len(seq) < fsize:
+            continue
+        kind, length = ot.scan_record(seq)
+        rows.append({"contig_id": name.strip().replace(",", "___"), "terminal_repeats": kind,
+                     "repeat_length": np.nan if length is None else float(length)})
+    return pd.DataFrame(rows, columns=["contig_id", "terminal_repeats", "repeat_length"])

@@ -6,7 +6,7 @@ import numpy as np
 import pandas as pd
 import pytest
 from click.testing import CliRunner
-from conftest import GOLDEN, load_model_cfg, make_model_dir
+from conftest import GOLDEN, load_model_cfg, make_model_dir, oracle_term_repeats
 
 pytestmark = pytest.mark.gpu
 
@@ -56,7 +56,8 @@ def _expected(tmp_path, records, cfg, weights, fsize, stride, min_len, batch):
     else:
         y = _oracle_pass(records, cfg, weights, fsize, stride, min_len or fsize, None)
     classes = [c["class"] for c in cfg["class_label_map"]]
-    data, _ = pred_to_dict(y, class_map={"num_classes": len(classes)}, fsize=fsize, term_repeats=None)
+    data, _ = pred_to_dict(y, class_map={"num_classes": len(classes)}, fsize=fsize,
+                           term_repeats=oracle_term_repeats(records, fsize))
     exp, exp_ph = tmp_path / "expected.tsv", tmp_path / "expected_phages.tsv"
     write_output(data, labels=classes, indices=[c["label"] for c in cfg["class_label_map"]], output_table_path=exp,
                  output_phage_table_path=exp_ph, reliability_cutoff=0.1, phage_score=3)
@@ -168,7 +169,7 @@ def test_cli_default_dustmask(tmp_path):
     out["meta_9"] = np.array([float(x[10]) for x in rows])
     from jaeger_amd.postprocess import pred_to_dict, write_output
     classes = [c["class"] for c in cfg["class_label_map"]]
-    data, _ = pred_to_dict(out, class_map={"num_classes": 6}, fsize=1500, term_repeats=None)
+    data, _ = pred_to_dict(out, class_map={"num_classes": 6}, fsize=1500, term_repeats=oracle_term_repeats(records, 1500))
     exp = tmp_path / "expected.tsv"
     write_output(data, labels=classes, indices=[c["label"] for c in cfg["class_label_map"]], output_table_path=exp,
                  output_phage_table_path=tmp_path / "e_ph.tsv", reliability_cutoff=0.1, phage_score=3)

@@ -6,7 +6,7 @@ import numpy as np
 import pandas as pd
 import pytest
 from click.testing import CliRunner
-from conftest import GOLDEN
+from conftest import GOLDEN, oracle_term_repeats
 
 pytestmark = pytest.mark.gpu
 LEGACY = GOLDEN / "legacy_data"
@@ -83,7 +83,7 @@ def test_cli_config1_default_model(tmp_path):
     assert r.exit_code == 0, r.output
     out = tmp_path / "out" / "default"
     w = legacy.load_legacy_h5(H5)
-    _, rows = _windows()
+    records, rows = _windows()
     res = ol.forward(w, _oracle_ids([r_[0] for r_ in rows], 2000))
     meta = [np.array([r_[1] for r_ in rows])] + [np.array([int(r_[j]) for r_ in rows]) for j in range(2, 10)] + \
            [np.array([float(r_[10]) for r_ in rows])]
@@ -94,7 +94,7 @@ def test_cli_config1_default_model(tmp_path):
            "batch_mean": np.load(LEGACY / "models/default/batch_means.npy"),
            "batch_std": np.load(LEGACY / "models/default/batch_std.npy")}
     data, _ = pred_to_dict_legacy(conf, {"y_hat": res, "meta": meta}, model="default", fsize=2000, ood_params=ood,
-                                  term_repeats=None)
+                                  term_repeats=oracle_term_repeats(records, 2000))
     write_output_legacy(conf, data, output_table_path=tmp_path / "exp.tsv",
                         output_phage_table_path=tmp_path / "exp_ph.tsv", reliability_cutoff=0.1, phage_score=3)
     got, exp = pd.read_csv(out / "test_contigs_jaeger.tsv", sep="\t"), pd.read_csv(tmp_path / "exp.tsv", sep="\t")
