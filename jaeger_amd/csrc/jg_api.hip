@@ -370,9 +370,8 @@ static inline float f16_value(float x) { return (float)(_Float16)x; }
 static bool slot_needs_f32(const jg_model *m, size_t i, int buf) {
   for (size_t j = i + 1; j < m->ops.size(); ++j) {
     const jg_op &o = m->ops[j];
-    if ((o.kind == JG_OP_POOL || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D ||
-         o.kind == JG_OP_FRAMESUM) && o.in_buf == buf)
-      return true;
+    if ((o.kind == JG_OP_POOL || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_FRAMESUM) && o.in_buf == buf)
+      return true;       // (MAXPOOL1D has an F16S form)
     if ((o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D ||
          o.kind == JG_OP_FRAMESUM) && o.out_buf == buf)
       return false;   // overwritten
@@ -389,9 +388,20 @@ static int prepare_f16(jg_model *m, const float *weights) {
   bool f32_fmt[JG_MAX_BUFS] = {};   // current format of each slot while walking the program
   for (size_t i = 0; i < m->ops.size() && m->f16_eligible; ++i) {
     const jg_op &op = m->ops[i];
-    if (op.kind == JG_OP_ELTWISE || op.kind == JG_OP_MAXPOOL1D || op.kind == JG_OP_FRAMESUM) {
-      fail("program has standalone elementwise / pooling ops");
+    if (op.kind == JG_OP_ELTWISE) {
+      fail("program has standalone elementwise ops");
       break;
+    }
+    if (op.kind == JG_OP_MAXPOOL1D) {                 // legacy tower: pooled in the F16S form
+      if (op.in_buf < 0 || f32_fmt[op.in_buf]) { fail("maxpool input produced in f32"); break; }
+      m->hprep[i].pool_f16s = true;
+      f32_fmt[op.out_buf] = false;
+      continue;
+    }
+    if (op.kind == JG_OP_FRAMESUM) {
+      if (op.in_buf < 0 || !f32_fmt[op.in_buf]) { fail("frame sum needs an f32 input"); break; }
+      f32_fmt[op.out_buf] = true;
+      continue;
     }
     if (op.kind != JG_OP_CONV) continue;
     if (op.stride != 1) { fail("strided conv"); break; }
@@ -519,7 +529,6 @@ static int prepare_f16(jg_model *m, const float *weights) {
           case JG_ST_ADD: h.kind = JG_HST_ADD; hp.add_slot = st.arg; break;
           case JG_ST_ACT:
             h.kind = JG_HST_ACT;
-            if (st.arg == JG_ACT_GELU_ERF) fail("exact-erf GELU is only implemented on the f32 path");
             break;
           case JG_ST_NMD: h.kind = JG_HST_NMD; hp.nmd_slot = st.arg; break;
           case JG_ST_MASKMUL: h.kind = JG_HST_MASKMUL; break;
@@ -546,12 +555,22 @@ static int prepare_f16(jg_model *m, const float *weights) {
           if (is(JG_HST_AFFINE)) { ep |= JG_EP_NORM1_AFF; ++q; }
           else if (is(JG_HST_DYT)) { ep |= JG_EP_NORM1_DYT; hp.alpha1 = hp.hst[q].f0; hp.dytmask1 = hp.hst[q].arg; ++q; }
           if (is(JG_HST_ADD)) { ep |= JG_EP_ADD; ++q; }
-          if (is(JG_HST_ACT) && hp.hst[q].arg == JG_ACT_GELU_TANH) { ep |= JG_EP_ACT1; ++q; }
+          int gelu_kind = 0;   // all GELU stages of a compiled pattern share one form
+          auto is_gelu = [&]() {
+            if (!is(JG_HST_ACT)) return false;
+            const int k = hp.hst[q].arg;
+            if (k != JG_ACT_GELU_TANH && k != JG_ACT_GELU_ERF) return false;
+            if (gelu_kind != 0 && gelu_kind != k) return false;
+            gelu_kind = k;
+            return true;
+          };
+          if (is_gelu()) { ep |= JG_EP_ACT1; ++q; }
           if (is(JG_HST_NMD)) { ep |= JG_EP_NMD2; ++q; }
           if (is(JG_HST_AFFINE)) { ep |= JG_EP_NORM2_AFF; ++q; }
           else if (is(JG_HST_DYT)) { ep |= JG_EP_NORM2_DYT; hp.alpha2 = hp.hst[q].f0; hp.dytmask2 = hp.hst[q].arg; ++q; }
-          if (is(JG_HST_ACT) && hp.hst[q].arg == JG_ACT_GELU_TANH) { ep |= JG_EP_ACT2; ++q; }
+          if (is_gelu()) { ep |= JG_EP_ACT2; ++q; }
           ok = q == n;
+          hp.act_erf = gelu_kind == JG_ACT_GELU_ERF;
         }
         hp.ep = ok ? ep : JG_EP_GENERIC;
       }
@@ -755,6 +774,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           a.k = op.k; a.dil = op.dilation; a.pad_left = pl;
           a.tiles_m = (lo + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m();
           a.out_f16s = hp.out_f16s ? 1 : 0;
+          a.act_erf = hp.act_erf ? 1 : 0;
           a.n_hst = hp.n_hst;
           a.ep = hp.ep;
           a.alpha1 = hp.alpha1; a.alpha2 = hp.alpha2;
@@ -832,8 +852,12 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
       case JG_OP_MAXPOOL1D: {
         const Shape in = sh[op.in_buf];
         const int lo = in.L / 2;
-        rc = jg_launch_maxpool1d(m->act[op.in_buf], nullptr, nw * in.frames, in.L, lo, in.C,
-                                 m->act[op.out_buf], nullptr, s);
+        if (m->precision == 1 && m->hprep[i].pool_f16s)
+          rc = jg_launch_maxpool1d_f16s(reinterpret_cast<const uint4 *>(m->act[op.in_buf]), nw * in.frames, in.L, lo,
+                                        in.C, reinterpret_cast<uint4 *>(m->act[op.out_buf]), s);
+        else
+          rc = jg_launch_maxpool1d(m->act[op.in_buf], nullptr, nw * in.frames, in.L, lo, in.C,
+                                   m->act[op.out_buf], nullptr, s);
         sh[op.out_buf] = Shape{in.frames, lo, in.C};
       } break;
       case JG_OP_FRAMESUM: {

@@ -91,6 +91,7 @@ struct ConvHArgs {
   int cc_in, cout, cout_pad;
   int k, dil, pad_left, tiles_m;
   int mask_from_ids, out_f16s;
+  int act_erf;             // the compiled patterns' GELU is the exact-erf form (legacy tower) instead of tanh
   int dbg;                 // ablation switches (JG_DBG env, timing experiments only)
   unsigned ep;             // JG_EP_* pattern of the stage list (JG_EP_GENERIC: interpret hst[])
   float alpha1, alpha2;    // DyT alphas of norm1 / norm2
@@ -143,6 +144,8 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   HStageArg hst[JG_MAX_STAGES] = {};
   int add_slot = -1, nmd_slot = -1;
   int pool_op = -1;         // index of the OP_POOL (masked max) fused into this conv's epilogue, or -1
+  bool act_erf = false;     // the op's GELU stages are the exact-erf form
+  bool pool_f16s = false;   // (MAXPOOL1D ops) input and output are F16S tensors
   unsigned ep = JG_EP_GENERIC;
   float alpha1 = 0.f, alpha2 = 0.f;
   int dytmask1 = 0, dytmask2 = 0;
@@ -204,6 +207,7 @@ int jg_launch_maxpool1d(const float *x, const uint8_t *mask_in, int rows, int L_
                         float *y, uint8_t *mask_out, hipStream_t s);
 int jg_launch_pool_final(const float *part, int rows_per_win, int n_win, int c, float *out, int out_ld,
                          hipStream_t s);
+int jg_launch_maxpool1d_f16s(const uint4 *x, int rows, int L_in, int L_out, int c, uint4 *y, hipStream_t s);
 int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,
                        hipStream_t s);
 int jg_conv_tile_m(int cout);

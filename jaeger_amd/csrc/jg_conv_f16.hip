@@ -59,12 +59,15 @@ __device__ __forceinline__ float fast_gelu(float v) {
   const float t = v * (-2.3022082f - 0.10294324f * v * v);   // -2u * log2(e)
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
+// exact GELU 0.5 x (1 + erf(x / sqrt 2)): tf.nn.gelu's default, used by the legacy tower (nnlib/v1/layers.py:72-79)
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678f)); }
 __device__ __forceinline__ float fast_tanh(float v) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853901f * v));
 }
 __device__ __forceinline__ float jg_act(float v, int act) {
   switch (act) {
     case JG_ACT_GELU_TANH: return fast_gelu(v);
+    case JG_ACT_GELU_ERF: return gelu_erf(v);
     case JG_ACT_RELU: return fmaxf(v, 0.0f);
     case JG_ACT_TANH: return fast_tanh(v);
     case JG_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950f * v));
@@ -510,7 +513,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
         };
         auto st_gelu = [&]() {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) x[r] = fast_gelu(x[r]);
+          for (int r = 0; r < 16; ++r) x[r] = a.act_erf ? gelu_erf(x[r]) : fast_gelu(x[r]);
         };
         auto st_nmd = [&]() {
           // masked channel sums: accumulated per lane over the wave's four position blocks of this

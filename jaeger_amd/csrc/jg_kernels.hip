@@ -698,6 +698,45 @@ int jg_launch_maxpool1d(const float *x, const uint8_t *mask_in, int rows, int L_
   return JG_OK;
 }
 
+// MaxPooling1D(2) on an F16S tensor [row][c/16][plane][h][L][8 x f16]: x = hi + lo is rebuilt in f32,
+// pooled, and split again (the split is exact for f32 values, so this equals pooling the f32 tensor)
+typedef _Float16 jg_half8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void maxpool1d_f16s_kernel(const uint4 *__restrict__ x, int64_t total, int L_in,
+                                                             int L_out, uint4 *__restrict__ y) {
+  for (int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t run = idx / L_out;                 // (row, chunk, h): two planes per run pair
+    const int m = (int)(idx - run * L_out);
+    const int64_t rc = run >> 1;                     // row * chunks + chunk
+    const int h = (int)(run & 1);
+    const uint4 *hi = x + ((rc * 4 + h) * (int64_t)L_in + 2 * m);
+    const uint4 *lo = x + ((rc * 4 + 2 + h) * (int64_t)L_in + 2 * m);
+    const uint4 h0 = hi[0], h1 = hi[1], l0 = lo[0], l1 = lo[1];
+    const jg_half8 a0 = *reinterpret_cast<const jg_half8 *>(&h0), a1 = *reinterpret_cast<const jg_half8 *>(&h1);
+    const jg_half8 b0 = *reinterpret_cast<const jg_half8 *>(&l0), b1 = *reinterpret_cast<const jg_half8 *>(&l1);
+    jg_half8 oh, ol;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float v = fmaxf((float)a0[q] + (float)b0[q], (float)a1[q] + (float)b1[q]);
+      const _Float16 hv = (_Float16)v;
+      oh[q] = hv;
+      ol[q] = (_Float16)(v - (float)hv);
+    }
+    y[(rc * 4 + h) * (int64_t)L_out + m] = *reinterpret_cast<const uint4 *>(&oh);
+    y[(rc * 4 + 2 + h) * (int64_t)L_out + m] = *reinterpret_cast<const uint4 *>(&ol);
+  }
+}
+
+int jg_launch_maxpool1d_f16s(const uint4 *x, int rows, int L_in, int L_out, int c, uint4 *y, hipStream_t s) {
+  JG_REQUIRE(c % 16 == 0, JG_ERR_UNSUPPORTED, "maxpool1d_f16s: c=%d must be a multiple of 16", c);
+  const int64_t total = (int64_t)rows * (c / 16) * 2 * L_out;
+  if (total == 0) return JG_OK;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(maxpool1d_f16s_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, total, L_in, L_out, y);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
 __global__ __launch_bounds__(256) void framesum_kernel(const float *__restrict__ x, int64_t total4,
                                                        int frames, int64_t per_frame4,
                                                        float *__restrict__ y) {

@@ -106,7 +106,8 @@ def run_core(**kwargs) -> int:
         lg.info(f"DUST (window 64, threshold 20): {n_masked} of {fa.bases.size} bases soft-masked")
     ood_params = load_ood_params(model_path, config)
     try:
-        engine = LegacyHipEngine(weights_path, device_id=kwargs.get("physicalid", 0), chunk=kwargs.get("chunk", 0))
+        engine = LegacyHipEngine(weights_path, device_id=kwargs.get("physicalid", 0), chunk=kwargs.get("chunk", 0),
+                                 precision="f32")
     except Exception as e:
         lg.debug(traceback.format_exc())
         lg.error(f"could not set up the legacy model on GPU {kwargs.get('physicalid', 0)}: {e}")
@@ -114,7 +115,7 @@ def run_core(**kwargs) -> int:
     from .termini import scan_for_terminal_repeats
     term_repeats = scan_for_terminal_repeats(engine.device, fa, fsize)
     lg.info(f"input file: {input_path.name}  fragment size: {fsize}  stride: {kwargs.get('stride')}  "
-            f"model: {model} (exact-f32 MFMA path)")
+            f"model: {model}  arithmetic: {engine.model.precision}")
     try:
         y_pred = predict_batch_legacy(engine, fa, fsize, kwargs.get("stride", 1500), min_len,
                                       kwargs.get("dynamic_stride", False),

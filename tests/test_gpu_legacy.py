@@ -26,7 +26,8 @@ def _oracle_ids(wins, fsize):
     return oenc.encode_windows(wins, fsize, codon_id=[v - 1 for v in V1_TRIMER_INT], masking=True)
 
 
-def test_legacy_forward_parity_real_weights():
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_legacy_forward_parity_real_weights(precision):
     from jaeger_amd import legacy
     from jaeger_amd.fragment import concat_records
     from oracle import legacy as ol
@@ -37,7 +38,8 @@ def test_legacy_forward_parity_real_weights():
     ids = _oracle_ids(wins, 2000)
     assert ids.shape == (135, 6, 665) and ids.max() == 21
     ref = ol.forward(w, ids)
-    eng = legacy.LegacyHipEngine(w)
+    eng = legacy.LegacyHipEngine(w, precision=precision)
+    assert eng.model.precision == precision
     got_ids = eng.forward_ids(ids)
     # fused path: window table on the raw contigs
     bases, offsets = concat_records([s.encode() for _, s in records])
