@@ -296,14 +296,16 @@ class JaegerHipEngine:
 
     # -- fused path ---------------------------------------------------------------
     def predict_windows(self, bases: np.ndarray, win_start: np.ndarray, win_len: np.ndarray, fsize: int,
-                        l_pad: int | None = None, pre_cased: bool = False) -> dict[str, np.ndarray]:
-        """Encode + forward for windows given as (start, length) into ``bases``."""
+                        l_pad: int | None = None, pre_cased: bool = False,
+                        want=("prediction", "reliability", "embedding", "nmd")) -> dict[str, np.ndarray]:
+        """Encode + forward for windows given as (start, length) into ``bases``.  ``want`` limits the
+        outputs copied back (the embedding and NMD vectors are 2.6 KB per window)."""
         bases = np.ascontiguousarray(bases, np.uint8)
         ws = np.ascontiguousarray(win_start, np.int64)
         wl = np.ascontiguousarray(win_len, np.int32)
         flags = self.encode_flags | (1 if pre_cased else 0)
         return self.model.predict_windows(bases, bases.size, ws, wl, ws.size, fsize, self.lut, flags,
-                                          l_pad, self.chunk)
+                                          l_pad, self.chunk, want=want)
 
     def close(self):
         self.model.close()

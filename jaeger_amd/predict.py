@@ -127,7 +127,8 @@ def _concat_predictions(a: dict, b: dict) -> dict:
 def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None, min_len: int | None = None,
                   max_len: int | None = None, dynamic_stride: bool = False,
                   dynamic_stride_threshold: float = 10.0, batch: int = 96, padded: bool = False,
-                  subset=None, pre_cased: bool = False) -> dict[str, np.ndarray]:
+                  subset=None, pre_cased: bool = False,
+                  want=("prediction", "reliability", "embedding", "nmd")) -> dict[str, np.ndarray]:
     """Window table + GPU encode/forward for the records of ``fa`` (optionally only those listed in
     ``subset``, kept in that order); returns the dict ``InferModel.predict`` would (model outputs +
     ``meta_0..9``).  ``padded`` reproduces ``padded_batch`` of the short-contig pass: windows run in
@@ -141,7 +142,7 @@ def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None,
         return {}
     starts = fa.offsets[idx][table.contig] + table.start
     if not padded:
-        out = engine.predict_windows(fa.bases, starts, table.length, fsize, pre_cased=pre_cased)
+        out = engine.predict_windows(fa.bases, starts, table.length, fsize, pre_cased=pre_cased, want=want)
     else:
         off3 = (-2, -1, 0)[fsize % 3]
         parts = []
@@ -149,7 +150,7 @@ def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None,
             sl = slice(i, i + batch)
             lmax = int(max(0, -(-(int(table.length[sl].max()) - 5 + off3) // 3)))
             parts.append(engine.predict_windows(fa.bases, starts[sl], table.length[sl], fsize, l_pad=max(lmax, 1),
-                                                pre_cased=pre_cased))
+                                                pre_cased=pre_cased, want=want))
         out = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
     counts = out.pop("counts")
     out.update(frag.window_metadata(table, names, counts))
@@ -287,7 +288,9 @@ def run_core(**kwargs) -> int:
     all_names = fa.names
     common = dict(dynamic_stride=kwargs.get("dynamic_stride", False),
                   dynamic_stride_threshold=kwargs.get("dynamic_stride_threshold", 10.0),
-                  batch=kwargs.get("batch", 96), subset=subset, pre_cased=dusted)
+                  batch=kwargs.get("batch", 96), subset=subset, pre_cased=dusted,
+                  want=("prediction", "reliability") + (("embedding",) if kwargs.get("save_embedding") else ())
+                  + (("nmd",) if kwargs.get("save_nmd") else ()))
     t_predict = time.time()
     try:
         if user_min_len is not None and user_min_len < fsize:

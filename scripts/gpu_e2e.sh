@@ -20,6 +20,6 @@ from conftest import make_model_dir
 make_model_dir(Path('/tmp/model_brain'))
 PY
 time python -m jaeger_amd predict -i /tmp/synth10k.fasta -o /tmp/out_e2e --model_path /tmp/model_brain --fsize 1500 --stride 1500 --no-dustmask -f 2>&1 | grep -E "wall time|processed|error" 
-time python -m jaeger_amd predict -i /tmp/synth10k.fasta -o /tmp/out_e2e --model_path /tmp/model_brain --fsize 1500 --stride 1500 --no-dustmask -f 2>&1 | grep -E "wall time|processed|error" 
+time python -m jaeger_amd predict -i /tmp/synth10k.fasta -o /tmp/out_e2e --model_path /tmp/model_brain --fsize 1500 --stride 1500 -f 2>&1 | grep -E "wall time|processed|error|DUST" 
 wc -l /tmp/out_e2e/*/synth10k.tsv
 grep -h "terminal repeats\|DUST" /tmp/out_e2e/*/*_jaeger.log | tail -3
