@@ -379,6 +379,25 @@ static bool slot_needs_f32(const jg_model *m, size_t i, int buf) {
   return false;
 }
 
+// exact-f32 conv operands: weights grouped by 8 input channels so that a lane fetches the four
+// k-steps of a group with one 16-byte load (see conv_f32_kernel)
+static int prepare_f32(jg_model *m, const float *weights) {
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    const jg_op &op = m->ops[i];
+    if (op.kind != JG_OP_CONV) continue;
+    const int cin_pad2 = (op.cin + 1) & ~1, cout_pad = (op.cout + 31) / 32 * 32, cin8 = (op.cin + 7) / 8 * 8;
+    const float *w = weights + op.w_off;
+    std::vector<float> w8((size_t)op.k * (cin8 / 8) * cout_pad * 8, 0.f);
+    for (int t = 0; t < op.k; ++t)
+      for (int c = 0; c < op.cin; ++c)
+        for (int n = 0; n < op.cout; ++n)
+          w8[(((size_t)t * (cin8 / 8) + c / 8) * cout_pad + n) * 8 + c % 8] = w[((size_t)t * cin_pad2 + c) * cout_pad + n];
+    JG_HIP(hipMalloc(reinterpret_cast<void **>(&m->hprep[i].d_w8), w8.size() * sizeof(float)));
+    JG_HIP(hipMemcpy(m->hprep[i].d_w8, w8.data(), w8.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return JG_OK;
+}
+
 static int prepare_f16(jg_model *m, const float *weights) {
   m->hprep.assign(m->ops.size(), ConvHPrep());
   m->pool_fused_by.assign(m->ops.size(), -1);
@@ -649,6 +668,8 @@ extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const 
   JG_HIP(hipMemset(m->d_overflow, 0, sizeof(int)));
   rc = prepare_f16(m, weights);
   if (rc != JG_OK) { jg_model_destroy(m); return rc; }
+  rc = prepare_f32(m, weights);
+  if (rc != JG_OK) { jg_model_destroy(m); return rc; }
   m->precision = m->f16_eligible ? 1 : 0;
   *out = m;
   return JG_OK;
@@ -685,6 +706,7 @@ extern "C" int jg_model_destroy(jg_model *m) {
     if (hp.d_wh) (void)hipFree(hp.d_wh);
     if (hp.d_embh) (void)hipFree(hp.d_embh);
     if (hp.d_epi) (void)hipFree(hp.d_epi);
+    if (hp.d_w8) (void)hipFree(hp.d_w8);
     if (hp.d_lut) (void)hipFree(hp.d_lut);
     if (hp.d_epi_lut) (void)hipFree(hp.d_epi_lut);
   }
@@ -811,10 +833,11 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           a.mask_in = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
           a.mask_out = op.out_mask >= 0 ? m->msk[op.out_mask] : nullptr;
           a.w = m->d_w + op.w_off;
+          a.w8 = m->hprep[i].d_w8;
           a.y = m->act[op.out_buf];
           a.rows = nw * in.frames;
           a.L_in = in.L; a.L_out = lo;
-          a.cin = op.cin; a.cin_pad = (op.cin + 1) & ~1;
+          a.cin = op.cin; a.cin_pad = (op.cin + 7) / 8 * 8;
           a.cout = op.cout; a.cout_pad = (op.cout + 31) / 32 * 32;
           a.k = op.k; a.stride = op.stride; a.dil = op.dilation; a.pad_left = pl;
           a.tiles_m = (lo + 127) / 128;

@@ -41,7 +41,8 @@ struct ConvArgs {
   const float *emb;        // (vocab, cin)
   const uint8_t *mask_in;  // (rows, L_in) or null
   const uint8_t *mask_out; // (rows, L_out) or null
-  const float *w;          // (k, cin_pad, cout_pad)
+  const float *w;          // (k, cin_pad2, cout_pad) as handed over in the weight blob
+  const float *w8;         // re-packed for the kernel: [k][cin_pad/8][cout_pad][8], cin_pad = cin rounded up to 8
   float *y;                // (rows, L_out, cout)
   int rows, L_in, L_out;
   int cin, cin_pad, cout, cout_pad;
@@ -138,6 +139,7 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   int cc_in = 0;
   bool out_f16s = false;
   float *d_epi = nullptr;   // compact epilogue parameter table
+  float *d_w8 = nullptr;    // exact-f32 path: weights re-packed [k][cin8/8][cout_pad32][8]
   float *d_lut = nullptr;   // first-layer table E.W_t (conv on ids) and its epilogue table (no acc un-scale)
   float *d_epi_lut = nullptr;
   int n_hst = 0, n_epi_rows = 0;

@@ -231,9 +231,11 @@ int jg_launch_mask(const uint8_t *in, int rows, int L_in, int L_out, int k, int 
 //   out[m, n] = sum_{t, c} x[m*stride - pad_left + t*dil, c] * w[t, c, n]
 // The (BM-1)*stride + (k-1)*dil + 1 input positions it touches are staged once
 // in LDS (mask multiply / embedding gather fused into the staging), row pitch
-// cin_pad+1 floats so the 32 rows an MFMA A-fragment reads fall in 32 banks.
-// B fragments (2 x 32 consecutive output channels per k-step) stream from
-// the weight blob, which is L2-resident (<= 460 KB per layer).
+// cin8+4 floats: 16-byte aligned rows whose 32 A-fragment rows spread over all banks.
+// The contraction runs in groups of 8 input channels = four 32x32x2 MFMA steps: lane half h
+// takes channels 8q+4h..8q+4h+3 of its row with ONE ds_read_b128 and the matching weights
+// with ONE 16-byte load from the re-packed blob [tap][cin/8][cout_pad][8] (L2-resident),
+// fetched one group ahead of its use.
 // Accumulators go through LDS once so the epilogue runs on float4 channel
 // quads with fully coalesced stores.
 template <int WM, int WN, int TM, int TN>
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
   const int tile = blockIdx.x - row * a.tiles_m;
   const int n_blk = blockIdx.y * BN;
   const int m0 = tile * BM;
-  const int ldr = a.cin_pad + 1;
+  const int ldr = a.cin_pad + 4;           // cin_pad is a multiple of 8 here
   const int rows_in = (BM - 1) * a.stride + (a.k - 1) * a.dil + 1;
   const int p0 = m0 * a.stride - a.pad_left;
 
@@ -269,10 +271,9 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
           v = *reinterpret_cast<const float4 *>(a.x + pos * a.cin + cq * 4);
         }
       }
-      float *d = smem + r * ldr + cq * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      *reinterpret_cast<float4 *>(smem + r * ldr + cq * 4) = v;
     }
-    if (a.cin_pad != a.cin) {  // zero K padding (cin not a multiple of the k-step)
+    if (a.cin_pad != a.cin) {  // zero K padding (cin not a multiple of the 8-channel group)
       for (int r = tid; r < rows_in; r += NT)
         for (int c = a.cin; c < a.cin_pad; ++c) smem[r * ldr + c] = 0.f;
     }
@@ -289,23 +290,36 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
   const int i = lane & 31, h = lane >> 5;
-  const float *wcol = a.w + n_blk + wn * (TN * 32) + i;
-  for (int t = 0; t < a.k; ++t) {
-    const float *arow = smem + ((wm * (TM * 32) + i) * a.stride + t * a.dil) * ldr + h;
-    const float *wt = wcol + ((size_t)t * a.cin_pad + h) * a.cout_pad;
-#pragma unroll 4
-    for (int c = 0; c < a.cin_pad; c += 2) {
-      float av[TM], bv[TN];
+  const int groups = a.cin_pad >> 3;
+  // this lane's weight quads: [tap][group][cout_pad][8], channels 4h..4h+3 of output column n
+  const float4 *wq = reinterpret_cast<const float4 *>(a.w8) + ((size_t)n_blk + wn * (TN * 32) + i) * 2 + h;
+  const size_t w_group = (size_t)a.cout_pad * 2;                 // float4 units per (tap, group)
+  const int steps = a.k * groups;
+  float4 bnext[TN];
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) av[tm] = arow[(tm * 32 * a.stride) * ldr + c];
+  for (int tn = 0; tn < TN; ++tn) bnext[tn] = wq[(size_t)tn * 64];
+  int t = 0, g = 0;
+  for (int sidx = 0; sidx < steps; ++sidx) {
+    float4 bv[TN], av[TM];
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) bv[tn] = wt[(size_t)c * a.cout_pad + tn * 32];
+    for (int tn = 0; tn < TN; ++tn) bv[tn] = bnext[tn];
+    if (sidx + 1 < steps) {
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+      for (int tn = 0; tn < TN; ++tn) bnext[tn] = wq[(size_t)(sidx + 1) * w_group + (size_t)tn * 64];
     }
+    const float *arow = smem + ((wm * (TM * 32) + i) * a.stride + t * a.dil) * ldr + g * 8 + 4 * h;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) av[tm] = *reinterpret_cast<const float4 *>(arow + (tm * 32 * a.stride) * ldr);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].x, bv[tn].x, acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].y, bv[tn].y, acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].z, bv[tn].z, acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].w, bv[tn].w, acc[tm][tn], 0, 0, 0);
+      }
+    if (++g == groups) { g = 0; ++t; }
   }
   __syncthreads();  // every wave is done reading the input rows
 
@@ -375,7 +389,7 @@ template <int WM, int WN, int TM, int TN>
 static int launch_conv_t(const ConvArgs &a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int rows_in = (BM - 1) * a.stride + (a.k - 1) * a.dil + 1;
-  size_t lds_a = (size_t)rows_in * (a.cin_pad + 1) * sizeof(float);
+  size_t lds_a = (size_t)rows_in * (a.cin_pad + 4) * sizeof(float);
   size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
   size_t smem = lds_a > lds_c ? lds_a : lds_c;
   smem = (smem + 15) & ~(size_t)15;
