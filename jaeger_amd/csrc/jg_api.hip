@@ -293,7 +293,7 @@ static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
         sh[op.out_buf] = Shape{in.frames, lo, op.cout};
         act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)in.frames * lo * op.cout);
         fl += 2.0 * op.k * op.cin * op.cout * (double)in.frames * lo;
-        const int tiles = std::max((lo + 127) / 128, 8 * ((lo + 255) / 256));
+        const int tiles = std::max((lo + 63) / 64, 8 * ((lo + 255) / 256));
         for (int s = 0; s < op.n_stages; ++s)
           if (op.stages[s].kind == JG_ST_NMD)
             nmd_elems[op.stages[s].arg] = std::max<int64_t>(nmd_elems[op.stages[s].arg],
@@ -840,7 +840,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           a.cin = op.cin; a.cin_pad = (op.cin + 7) / 8 * 8;
           a.cout = op.cout; a.cout_pad = (op.cout + 31) / 32 * 32;
           a.k = op.k; a.stride = op.stride; a.dil = op.dilation; a.pad_left = pl;
-          a.tiles_m = (lo + 127) / 128;
+          a.tiles_m = (lo + jg_conv_tile_m(lo) - 1) / jg_conv_tile_m(lo);
           resolve_stages(m, op, a.st, &a.n_stages);
           rc = jg_launch_conv(e, a, s);
         }
@@ -912,7 +912,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         const Shape in = sh[op.in_buf];
         const int parts = m->precision == 1
                               ? 2 * ((in.L + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m())
-                              : (in.L + 127) / 128;
+                              : (in.L + jg_conv_tile_m(in.L) - 1) / jg_conv_tile_m(in.L);
         const uint8_t *mk = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
         rc = jg_launch_nmd_final(m->nmd_part[op.arg], in.frames * parts, mk, in.frames * in.L,
                                  m->d_w + op.b_off, op.f0, nw, op.cout, m->vec[op.out_vec],

@@ -212,7 +212,7 @@ int jg_launch_pool_final(const float *part, int rows_per_win, int n_win, int c, 
 int jg_launch_maxpool1d_f16s(const uint4 *x, int rows, int L_in, int L_out, int c, uint4 *y, hipStream_t s);
 int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,
                        hipStream_t s);
-int jg_conv_tile_m(int cout);
+int jg_conv_tile_m(int l_out);
 int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_lds_bytes(int k, int dil);
 bool jg_conv_f16_supports(int k, int dil);

@@ -380,9 +380,11 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
   }
 }
 
-int jg_conv_tile_m(int cout) {
-  (void)cout;
-  return 128;
+// positions per workgroup tile of the exact-f32 conv: 128, or 64 when that wastes clearly less of the
+// last tile (e.g. the legacy tower's 166-codon frames: 3 x 64 = 192 instead of 2 x 128 = 256)
+int jg_conv_tile_m(int l_out) {
+  const int t128 = (l_out + 127) / 128 * 128, t64 = (l_out + 63) / 64 * 64;
+  return (t64 * 10 <= t128 * 9) ? 64 : 128;
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -414,9 +416,12 @@ int jg_launch_conv(jg_engine *e, const ConvArgs &a, hipStream_t s) {
   JG_REQUIRE(a.cin % 4 == 0 && a.cout % 4 == 0, JG_ERR_UNSUPPORTED,
              "conv: cin=%d / cout=%d must be multiples of 4", a.cin, a.cout);
   if (a.rows == 0 || a.L_out <= 0) return JG_OK;
-  if (a.cout_pad % 128 == 0) return launch_conv_t<2, 2, 2, 2>(a, s);
-  if (a.cout_pad % 64 == 0) return launch_conv_t<2, 2, 2, 1>(a, s);
-  return launch_conv_t<4, 1, 1, 1>(a, s);
+  const bool bm64 = jg_conv_tile_m(a.L_out) == 64;
+  JG_REQUIRE(a.tiles_m == (a.L_out + (bm64 ? 63 : 127)) / (bm64 ? 64 : 128), JG_ERR_INVALID,
+             "conv: tiles_m=%d does not match the tile size chosen for L_out=%d", a.tiles_m, a.L_out);
+  if (a.cout_pad % 128 == 0) return bm64 ? launch_conv_t<2, 2, 1, 2>(a, s) : launch_conv_t<2, 2, 2, 2>(a, s);
+  if (a.cout_pad % 64 == 0) return bm64 ? launch_conv_t<2, 2, 1, 1>(a, s) : launch_conv_t<2, 2, 2, 1>(a, s);
+  return bm64 ? launch_conv_t<2, 1, 1, 1>(a, s) : launch_conv_t<4, 1, 1, 1>(a, s);
 }
 
 // ---------------------------------------------------------------------------
