@@ -795,6 +795,30 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           a.cc_in = hp.cc_in; a.cout = op.cout; a.cout_pad = 128;
           a.k = op.k; a.dil = op.dilation; a.pad_left = pl;
           a.tiles_m = (lo + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m();
+          int strips_per_win = in.frames * a.tiles_m * 2;        // partial rows (128-position strips) per window
+          {
+            // window-packed tiling when the frames fill their own 256-position tiles badly (e.g. 665 codons)
+            static const bool no_flat = getenv("JG_NO_FLAT") != nullptr;
+            const int halo = (op.k - 1) * op.dilation;
+            const int gap = std::max(pl, halo - pl);
+            const int fp = lo + gap;
+            const int wp = (in.frames * fp + 127) / 128 * 128;
+            const int64_t flat_tiles = ((int64_t)nw * wp + 255) / 256;
+            const int64_t row_tiles = (int64_t)a.rows * a.tiles_m;
+            if (!no_flat && op.in_buf != JG_BUF_IDS && hp.d_lut == nullptr && op.stride == 1 && in.L == lo &&
+                (int64_t)nw * wp < (1 << 24) && flat_tiles * 100 <= row_tiles * 95) {
+              a.flat = 1;
+              a.flat_p = fp;
+              a.flat_wp = wp;
+              a.flat_frames = in.frames;
+              a.flat_tiles = (int)flat_tiles;
+              a.flat_inv_p = 1.0f / (float)fp;
+              a.flat_inv_wp = 1.0f / (float)wp;
+              strips_per_win = wp / 128;
+            }
+          }
+          if (hp.nmd_slot >= 0) m->part_rows[hp.nmd_slot] = strips_per_win;
+          if (hp.pool_op >= 0) m->pool_rows = strips_per_win;
           a.out_f16s = hp.out_f16s ? 1 : 0;
           a.act_erf = hp.act_erf ? 1 : 0;
           a.n_hst = hp.n_hst;
@@ -893,8 +917,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         const Shape in = sh[op.in_buf];
         const uint8_t *mk = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
         if (m->precision == 1 && m->pool_fused_by[i] >= 0) {
-          const int tiles = (in.L + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m();
-          rc = jg_launch_pool_final(m->pool_part, in.frames * tiles * 2, nw, in.C,
+          rc = jg_launch_pool_final(m->pool_part, m->pool_rows, nw, in.C,
                                     m->vec[op.out_vec] + op.vec_off, m->vec_w[op.out_vec], s);
           break;
         }
@@ -910,11 +933,11 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         // op.arg = partial slot, in_mask = mask the tap used, cout = channels,
         // in_buf = activation slot whose shape gives the position count
         const Shape in = sh[op.in_buf];
-        const int parts = m->precision == 1
-                              ? 2 * ((in.L + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m())
-                              : (in.L + jg_conv_tile_m(in.L) - 1) / jg_conv_tile_m(in.L);
+        const int rows_per_win = m->precision == 1
+                                     ? m->part_rows[op.arg]
+                                     : in.frames * ((in.L + jg_conv_tile_m(in.L) - 1) / jg_conv_tile_m(in.L));
         const uint8_t *mk = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
-        rc = jg_launch_nmd_final(m->nmd_part[op.arg], in.frames * parts, mk, in.frames * in.L,
+        rc = jg_launch_nmd_final(m->nmd_part[op.arg], rows_per_win, mk, in.frames * in.L,
                                  m->d_w + op.b_off, op.f0, nw, op.cout, m->vec[op.out_vec],
                                  m->vec_w[op.out_vec], op.vec_off, s);
       } break;

@@ -91,6 +91,10 @@ struct ConvHArgs {
   int rows, L_in, L_out;
   int cc_in, cout, cout_pad;
   int k, dil, pad_left, tiles_m;
+  // window-packed tiling (see jg_conv_f16.hip): frames of a window on one axis, row pitch flat_p, window
+  // pitch flat_wp (multiple of 128), flat_tiles tiles of 256; 0 = every row tiled on its own
+  int flat, flat_p, flat_wp, flat_frames, flat_tiles;
+  float flat_inv_p, flat_inv_wp;
   int mask_from_ids, out_f16s;
   int act_erf;             // the compiled patterns' GELU is the exact-erf form (legacy tower) instead of tanh
   int dbg;                 // ablation switches (JG_DBG env, timing experiments only)
@@ -185,6 +189,8 @@ struct jg_model {
   float *pool_part = nullptr;       // fused max-pool partial rows (split-f16 path)
   int64_t pool_part_cap = 0;
   std::vector<int> pool_fused_by;   // per op: conv op index that produces this OP_POOL's partials, or -1
+  int part_rows[JG_MAX_BUFS] = {};  // split-f16 path: partial rows per window the last conv wrote to each NMD slot
+  int pool_rows = 0;                // same for the fused max pool
 };
 
 // ---- kernel launchers (defined in jg_kernels.hip) ---------------------------

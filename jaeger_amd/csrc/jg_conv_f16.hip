@@ -94,7 +94,16 @@ __device__ __forceinline__ void wait_vm() {
 
 struct Tile {
   int rowblk, m0, valid;
+  int T;          // tile index: strips (128 positions) 2T and 2T+1 of the launch
 };
+
+// v = q * d + r for v < 2^24 (float reciprocal, one correction step)
+__device__ __forceinline__ void udivmod24(int v, int d, float inv, int &q, int &r) {
+  q = (int)((float)v * inv);
+  r = v - q * d;
+  if (r < 0) { --q; r += d; }
+  else if (r >= d) { ++q; r -= d; }
+}
 
 // -DJG_STAMP: experiment build that accumulates per-phase shader cycles of every wave
 // (wait / barrier / DMA issue / LDS+MFMA / epilogue / whole kernel) and prints them per launch.
@@ -147,8 +156,27 @@ void conv_f16x3_kernel(ConvHArgs a) {
   const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);                       // + buf*a_items*16 + it*4096
   const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + wid * 1024);   // + slot*8192 + it*4096
 
-  const int n_tiles = a.rows * a.tiles_m;
+  const int n_tiles = a.flat ? a.flat_tiles : a.rows * a.tiles_m;
   const int n_pairs = (n_tiles + TPER - 1) / TPER;
+  // Position of a lane.  Row-tiled launches cut every (window, frame) row into 256-position tiles of its
+  // own.  Window-packed ("flat") launches lay a window's frames end to end on one axis, each followed by a
+  // gap >= the conv's halo (row pitch P), the window padded to a multiple of 128 (WP), and tile that axis:
+  // frames whose length is an awkward fraction of 256 (665 codons at 2000 bp) no longer waste a third of
+  // their last tile.  A tile may then span frames, so row and position are per lane.
+  auto resolve = [&](const Tile &tile, int local, int len, int &row, int &p) -> bool {
+    if (!a.flat) {
+      row = tile.rowblk;
+      p = tile.m0 + local;
+      return tile.valid && p >= 0 && p < len;
+    }
+    const int v = tile.T * HM + local;
+    if (v < 0 || !tile.valid) { row = 0; p = 0; return false; }
+    int g, u, f;
+    udivmod24(v, a.flat_wp, a.flat_inv_wp, g, u);
+    udivmod24(u, a.flat_p, a.flat_inv_p, f, p);
+    row = g * a.flat_frames + f;
+    return f < a.flat_frames && p < len && row < a.rows;
+  };
   int my_pairs = 0;
   if (vb < n_pairs) my_pairs = (n_pairs - 1 - vb) / vgrid + 1;
   if (my_pairs == 0) return;
@@ -178,6 +206,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
       t[u].rowblk = Tc / a.tiles_m;
       t[u].m0 = (Tc - t[u].rowblk * a.tiles_m) * HM;
       t[u].valid = T < n_tiles;
+      t[u].T = Tc;
     }
   };
 
@@ -192,11 +221,10 @@ void conv_f16x3_kernel(ConvHArgs a) {
   unsigned x_ok = 0;
   auto piece_pos = [&](const Tile *tl2, int it, int &pc, bool &inr) -> int {
     const int a_u = (int)(a_pk[it] >> 20), a_r = (int)(a_pk[it] & 0xffff);
-    const int m0 = tl2[0].m0, rb = tl2[0].rowblk, vd = tl2[0].valid;
-    const int p = m0 - a.pad_left + a_r;
+    int rb, p;
+    inr = resolve(tl2[0], a_r - a.pad_left, a.L_in, rb, p) && a_u < NT;
     pc = min(max(p, 0), a.L_in - 1);
-    inr = a_u < NT && vd && p >= 0 && p < a.L_in;
-    return rb;
+    return min(rb, a.rows - 1);
   };
   auto load_bytes = [&](const Tile *tl2) {
     if (bsrc != nullptr) {
@@ -439,20 +467,28 @@ void conv_f16x3_kernel(ConvHArgs a) {
         lo_half_keeps = r[0];
         hi_half_keeps = r[1];
       };
-      auto item4 = [&](const Tile &tile, int mc, int nb, int j) -> unsigned {
+      auto item4 = [&](int row, int mc, int nb, int j) -> unsigned {
         // hi-plane item of group 2j + h (uint4 units); lo plane = + 2*L_out
         const int G = (nb >> 3) + 2 * j + h;
-        return (unsigned)(((tile.rowblk * (a.cout_pad >> 4) + (G >> 1)) * 4 + (G & 1)) * a.L_out + mc);
+        return (unsigned)(((row * (a.cout_pad >> 4) + (G >> 1)) * 4 + (G & 1)) * a.L_out + mc);
+      };
+      // this lane's output position in block tm: row, clamped position, alive
+      auto out_pos = [&](const Tile &tile, int tm, int &row, int &mc) -> bool {
+        int p;
+        const bool live = resolve(tile, (wm * TM + tm) * 32 + i, a.L_out, row, p);
+        mc = live ? p : 0;
+        if (!live) row = min(max(row, 0), a.rows - 1);
+        return live;
       };
       auto prefetch = [&](Pre &p, const Tile &tile, int tm, int tn) {
         const int nb = (wn * 2 + tn) * 32;
-        const int m = tile.m0 + (wm * TM + tm) * 32 + i;
-        const int mc = m < a.L_out ? m : 0;
-        p.mkb = a.mask_out != nullptr ? a.mask_out[(size_t)tile.rowblk * a.L_out + mc] : (unsigned char)1;
+        int orow, mc;
+        out_pos(tile, tm, orow, mc);
+        p.mkb = a.mask_out != nullptr ? a.mask_out[(size_t)orow * a.L_out + mc] : (unsigned char)1;
         if (a.addh != nullptr && !(a.dbg & 128)) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const unsigned it4 = item4(tile, mc, nb, j);
+            const unsigned it4 = item4(orow, mc, nb, j);
             uint4 vh = a.addh[it4];                        // whole item of group 2j+h
             uint4 vl = a.addh[it4 + 2u * (unsigned)a.L_out];
             // give each lane back its own 4 channels of groups 2j and 2j+1
@@ -473,8 +509,8 @@ void conv_f16x3_kernel(ConvHArgs a) {
         Pre p;
         prefetch(p, tile, tm, tn);
         const int nb = (wn * 2 + tn) * 32;
-        const int m = tile.m0 + (wm * TM + tm) * 32 + i;
-        const bool live = m < a.L_out && tile.valid;
+        int orow_, mc_;
+        const bool live = out_pos(tile, tm, orow_, mc_);
         const float mk = p.mkb != 0 ? 1.f : 0.f;
         // ---- stage primitives on this lane's 16 channels of one position -----------------
         auto st_affine = [&](int row) {
@@ -591,15 +627,14 @@ void conv_f16x3_kernel(ConvHArgs a) {
       };
       auto store_block = [&](const f32x16 &x, const Tile &tile, int tm, int tn) {
         const int nb = (wn * 2 + tn) * 32;
-        const int m = tile.m0 + (wm * TM + tm) * 32 + i;
-        const bool live = m < a.L_out && tile.valid;
-        const int mc = m < a.L_out ? m : 0;
+        int orow, mc;
+        const bool live = out_pos(tile, tm, orow, mc);
         if (live && !(a.dbg & 64)) {
           if (a.out_f16s) {
             uint4 *yh = reinterpret_cast<uint4 *>(a.y);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-              const unsigned it4 = item4(tile, mc, nb, j);
+              const unsigned it4 = item4(orow, mc, nb, j);
               typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
               const u32x4 vhi = {__float_as_uint(x[4 * j]), __float_as_uint(x[4 * j + 1]),
                                  __float_as_uint(x[4 * j + 2]), __float_as_uint(x[4 * j + 3])};
@@ -611,7 +646,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
               __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)a.L_out));
             }
           } else {
-            float *yf = reinterpret_cast<float *>(a.y) + ((size_t)tile.rowblk * a.L_out + mc) * a.cout + nb + 4 * h;
+            float *yf = reinterpret_cast<float *>(a.y) + ((size_t)orow * a.L_out + mc) * a.cout + nb + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
               if (nb + 8 * g + 4 * h < a.cout)
@@ -651,7 +686,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
       auto reduced_slot = [&](const Tile &tile, int tn, int &ch) -> size_t {
         const int r = 8 * (int)((i & 4) != 0) + 4 * (int)((i & 2) != 0) + 2 * (int)((i & 1) != 0) + (int)((i & 8) != 0);
         ch = (wn * 2 + tn) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-        return (((size_t)tile.rowblk * a.tiles_m + tile.m0 / HM) * 2 + wm) * a.cout + ch;
+        return ((size_t)tile.T * 2 + wm) * a.cout + ch;     // one partial row per 128-position strip
       };
       auto nmd_flush = [&](const Tile &tile, int tn) {
         const float v = lane_reduce(nmd_acc, [](float x, float y) { return x + y; });
@@ -674,10 +709,9 @@ void conv_f16x3_kernel(ConvHArgs a) {
         float mkv[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-          const int m = cur[0].m0 + (wm * TM + tm) * 32 + i;
-          const bool live = m < a.L_out && cur[0].valid;
-          const int mc = m < a.L_out ? m : 0;
-          const unsigned char mb = a.mask_out != nullptr ? a.mask_out[(size_t)cur[0].rowblk * a.L_out + mc] : (unsigned char)1;
+          int orow, mc;
+          const bool live = out_pos(cur[0], tm, orow, mc);
+          const unsigned char mb = a.mask_out != nullptr ? a.mask_out[(size_t)orow * a.L_out + mc] : (unsigned char)1;
           mkv[tm] = (live && mb != 0) ? 1.f : 0.f;
         }
 #pragma unroll
@@ -722,7 +756,7 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  const int n_tiles = a.rows * a.tiles_m;
+  const int n_tiles = a.flat ? a.flat_tiles : a.rows * a.tiles_m;
   const int n_pairs = (n_tiles + NT - 1) / NT;
   // two 4-wave workgroups per CU when their LDS fits (<= 80 KB each): one's epilogue and stores overlap
   // the other's matrix-core steps.  (Forcing the two out of phase - by dispatch order or by a per-CU
