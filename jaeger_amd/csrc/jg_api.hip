@@ -805,7 +805,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
             const int wp = (in.frames * fp + 127) / 128 * 128;
             const int64_t flat_tiles = ((int64_t)nw * wp + 255) / 256;
             const int64_t row_tiles = (int64_t)a.rows * a.tiles_m;
-            if (!no_flat && op.in_buf != JG_BUF_IDS && hp.d_lut == nullptr && op.stride == 1 && in.L == lo &&
+            if (!no_flat && op.k == 5 && op.in_buf != JG_BUF_IDS && hp.d_lut == nullptr && op.stride == 1 && in.L == lo &&
                 (int64_t)nw * wp < (1 << 24) && flat_tiles * 100 <= row_tiles * 95) {
               a.flat = 1;
               a.flat_p = fp;

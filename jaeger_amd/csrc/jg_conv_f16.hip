@@ -124,7 +124,7 @@ __device__ unsigned long long jg_stamp_acc[8];
 // output position); the epilogue is the same code.  A workgroup owns one 64-channel half of the
 // table (k * (vocab + 1) rows, row `vocab` = zeros for padding) and its four waves cover two
 // 256-position tiles: waves {0,1} the first, {2,3} the second.  K is unused (taps come from a.k).
-template <int K, unsigned EP, bool LUT = false>
+template <int K, unsigned EP, bool LUT = false, bool FLAT = false>
 // K = 5 fits two workgroups per CU in LDS (<= 80 KB each): hold the register file to 256 per
 // lane so that both are really resident (without the bound hipcc takes ~340 and the second
 // workgroup of a CU only starts when the first has finished).
@@ -156,7 +156,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
   const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);                       // + buf*a_items*16 + it*4096
   const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + wid * 1024);   // + slot*8192 + it*4096
 
-  const int n_tiles = a.flat ? a.flat_tiles : a.rows * a.tiles_m;
+  const int n_tiles = FLAT ? a.flat_tiles : a.rows * a.tiles_m;
   const int n_pairs = (n_tiles + TPER - 1) / TPER;
   // Position of a lane.  Row-tiled launches cut every (window, frame) row into 256-position tiles of its
   // own.  Window-packed ("flat") launches lay a window's frames end to end on one axis, each followed by a
@@ -164,7 +164,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
   // frames whose length is an awkward fraction of 256 (665 codons at 2000 bp) no longer waste a third of
   // their last tile.  A tile may then span frames, so row and position are per lane.
   auto resolve = [&](const Tile &tile, int local, int len, int &row, int &p) -> bool {
-    if (!a.flat) {
+    if constexpr (!FLAT) {
       row = tile.rowblk;
       p = tile.m0 + local;
       return tile.valid && p >= 0 && p < len;
@@ -224,7 +224,8 @@ void conv_f16x3_kernel(ConvHArgs a) {
     int rb, p;
     inr = resolve(tl2[0], a_r - a.pad_left, a.L_in, rb, p) && a_u < NT;
     pc = min(max(p, 0), a.L_in - 1);
-    return min(rb, a.rows - 1);
+    if constexpr (FLAT) rb = min(rb, a.rows - 1);
+    return rb;
   };
   auto load_bytes = [&](const Tile *tl2) {
     if (bsrc != nullptr) {
@@ -477,7 +478,9 @@ void conv_f16x3_kernel(ConvHArgs a) {
         int p;
         const bool live = resolve(tile, (wm * TM + tm) * 32 + i, a.L_out, row, p);
         mc = live ? p : 0;
-        if (!live) row = min(max(row, 0), a.rows - 1);
+        if constexpr (FLAT) {
+          if (!live) row = min(max(row, 0), a.rows - 1);
+        }
         return live;
       };
       auto prefetch = [&](Pre &p, const Tile &tile, int tm, int tn) {
@@ -747,16 +750,16 @@ void conv_f16x3_kernel(ConvHArgs a) {
   JG_ST_END;
 }
 
-template <int K, unsigned EP>
+template <int K, unsigned EP, bool FLAT = false>
 int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   const int smem = jg_conv_f16_lds_bytes(K, a.dil);
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<K, EP>),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<K, EP, false, FLAT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  const int n_tiles = a.flat ? a.flat_tiles : a.rows * a.tiles_m;
+  const int n_tiles = FLAT ? a.flat_tiles : a.rows * a.tiles_m;
   const int n_pairs = (n_tiles + NT - 1) / NT;
   // two 4-wave workgroups per CU when their LDS fits (<= 80 KB each): one's epilogue and stores overlap
   // the other's matrix-core steps.  (Forcing the two out of phase - by dispatch order or by a per-CU
@@ -765,7 +768,7 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   int grid = ((smem <= 80 * 1024 && !one_wg) ? 2 : 1) * e->n_cu;
   if (grid > n_pairs) grid = n_pairs;
   ConvHArgs b = a;
-  hipLaunchKernelGGL((conv_f16x3_kernel<K, EP>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, b);
+  hipLaunchKernelGGL((conv_f16x3_kernel<K, EP, false, FLAT>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, b);
   JG_HIP(hipGetLastError());
 #ifdef JG_STAMP
   {
@@ -814,6 +817,24 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
 // compiled epilogue patterns (see jg_common.h JG_EP_*); everything else runs the interpreter
 template <int K>
 int launch_k(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  if (a.flat) {       // window-packed tiling: the stage patterns of the residual stacks (k = 5 in every model family in-tree)
+    if constexpr (K == 5) {
+      switch (a.ep) {
+#define JG_CASE(ep) case (ep): return launch_ke<K, (ep), true>(e, a, s);
+        JG_CASE(JG_EP_NORM1_AFF | JG_EP_ACT1)
+        JG_CASE(JG_EP_NORM1_DYT | JG_EP_ACT1)
+        JG_CASE(JG_EP_ADD | JG_EP_ACT1)
+        JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1)
+        JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)
+        JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2)
+        JG_CASE(JG_EP_ACT1)
+#undef JG_CASE
+        default: return launch_ke<K, JG_EP_GENERIC, true>(e, a, s);
+      }
+    }
+    jg_set_error("conv_f16x3: window-packed tiling is only built for k = 5");
+    return JG_ERR_UNSUPPORTED;
+  }
   switch (a.ep) {
 #define JG_CASE(ep) case (ep): return launch_ke<K, (ep)>(e, a, s);
     JG_CASE(JG_EP_ACT1)
