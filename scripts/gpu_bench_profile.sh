@@ -15,7 +15,8 @@ for d in sorted(glob.glob("$R/gpurun_out/pmc_*")):
     for f in glob.glob(d+"/*/*counter_collection.csv"):
         agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(collections.Counter)
         for row in csv.DictReader(open(f)):
-            k=row["Kernel_Name"].split("(")[0][:60]
+            name=row["Kernel_Name"]
+            k="conv_f16x3_kernel" if "conv_f16x3_kernel" in name else name.split("(")[0][:60]
             agg[k][row["Counter_Name"]]+=float(row["Counter_Value"]); n[k][row["Counter_Name"]]+=1
         for k in agg:
             for c in agg[k]:
