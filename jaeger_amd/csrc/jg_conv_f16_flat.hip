@@ -1,0 +1,3 @@
+// instantiation set 3 of the split-f16 convolution kernel (see jg_conv_f16_impl.h)
+#define JG_CONV_PART 3
+#include "jg_conv_f16_impl.h"

@@ -1,0 +1,867 @@
+// Split-f16 ("f16x3") MaskedConv1D for gfx950: f32-accurate convolution on the
+// f16 matrix cores.
+//
+// Every f32 operand is carried as an f16 pair  x = hi + lo  (hi = f16(x),
+// lo = f16(x - hi), 22 significant bits together) and each logical product is
+// three MFMAs accumulating in f32:  x.w ~= hi_x*hi_w + lo_x*hi_w + hi_x*lo_w
+// (the dropped lo*lo term is 2^-22 relative).  v_mfma_f32_32x32x16_f16 runs at
+// 16x the rate of the exact-f32 MFMA, so the scheme nets ~5.3x the f32 roof
+// while keeping the logits inside the 1e-4 gate (tests/test_gpu_parity.py).
+//
+// Layouts
+//   F16S activations, per (window, frame) row block of L positions and C = 16*CC
+//     channels:  [cc][plane hi|lo][h][L][8 halfs]   (16-byte items; channel
+//     c = 16*cc + 8*h + j).  Same 4 B/element as f32, but a tile's operand slice
+//     for one 16-channel chunk is 4 contiguous runs - coalesced 16-B DMA in,
+//     conflict-free ds_read_b128 MFMA fragments out.
+//   weights  [plane][tap][kc = cin/8][cout_pad][8 halfs], pre-scaled by 2^s so
+//     the lo parts stay out of the f16 subnormal range (undone in the epilogue).
+//
+// Work decomposition.  One persistent workgroup (8 waves, 4 x 2, each wave 64
+// positions x 64 channels of a tile) walks PAIRS of 256-position x 128-channel
+// output tiles that share every weight slice.  The K loop runs in steps = (16-
+// channel chunk, tap): a step needs one 8 KB weight slice and the chunk's two
+// activation slices.  Everything moves global->LDS by DMA (global_load_lds with
+// an SGPR base + per-lane 32-bit offset, no register staging): weight slices
+// K-2 steps ahead into a ring with one slot per tap, activation slices one chunk
+// ahead into a double buffer.  Steps wait with COUNTED s_waitcnt vmcnt, so the
+// DMA queue never drains; zero padding / mask multiply are applied by zero-
+// filling the affected 16-byte pieces after the DMA has landed (rare), the
+// embedding gather of the first conv is a DMA from the pre-split table.
+// The MFMAs take the WEIGHTS as their A operand, so an accumulator register
+// holds one channel and a lane holds one position: the fused epilogue (folded
+// bias/batch-norm affine, residual add, GELU, NMD tap, f16 re-split) needs no
+// cross-lane transpose and reads its per-channel parameters from LDS.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "jg_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int HM = 256;       // tile rows (positions)
+constexpr int HN = 128;       // tile cols (output channels)
+constexpr int HT = 256;       // threads: 4 waves, 2 (positions) x 2 (channels), 128 x 64 outputs each
+constexpr int NT = 1;         // tiles per workgroup pass
+constexpr int A_ITERS = 5;    // 16-B activation pieces per thread per chunk (4*rows_a <= 1280)
+constexpr int W_ITERS = 2;    // 16-B weight items per thread per slice
+constexpr int TM = 4;         // 32-position blocks per wave
+constexpr int W_ITEMS = 2 * 2 * HN;           // 16-B items of one weight slice (chunk, tap): 8 KB
+constexpr int LUT_RS = 68;    // floats per LDS row of the first-layer table (64 + 4: rows 16 apart share banks)
+
+// GELU (tanh form) as x * sigmoid(2u), u = sqrt(2/pi)(x + 0.044715 x^3): one v_exp_f32 and
+// one v_rcp_f32 (~1 ulp each) instead of a libm tanhf; abs error < 1e-6 * |x|.
+__device__ __forceinline__ float fast_gelu(float v) {
+  const float t = v * (-2.3022082f - 0.10294324f * v * v);   // -2u * log2(e)
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+}
+// exact GELU 0.5 x (1 + erf(x / sqrt 2)): tf.nn.gelu's default, used by the legacy tower (nnlib/v1/layers.py:72-79)
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678f)); }
+__device__ __forceinline__ float fast_tanh(float v) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853901f * v));
+}
+__device__ __forceinline__ float jg_act(float v, int act) {
+  switch (act) {
+    case JG_ACT_GELU_TANH: return fast_gelu(v);
+    case JG_ACT_GELU_ERF: return gelu_erf(v);
+    case JG_ACT_RELU: return fmaxf(v, 0.0f);
+    case JG_ACT_TANH: return fast_tanh(v);
+    case JG_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950f * v));
+    default: return v;
+  }
+}
+
+// 16-byte-per-lane global -> LDS DMA: global address = SGPR base + per-lane 32-bit byte offset,
+// LDS address = wave-uniform base (M0) + lane*16.  Issued from inline asm on purpose: hipcc
+// serialises the builtin form behind vmcnt(0) waits (one per DMA, and again before the first
+// ds_read), which forbids any overlap with the matrix cores.  The kernel tracks the DMA queue
+// itself with counted s_waitcnt vmcnt(N).
+__device__ __forceinline__ void glds16(const void *sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct Tile {
+  int rowblk, m0, valid;
+  int T;          // tile index: strips (128 positions) 2T and 2T+1 of the launch
+};
+
+// v = q * d + r for v < 2^24 (float reciprocal, one correction step)
+__device__ __forceinline__ void udivmod24(int v, int d, float inv, int &q, int &r) {
+  q = (int)((float)v * inv);
+  r = v - q * d;
+  if (r < 0) { --q; r += d; }
+  else if (r >= d) { ++q; r -= d; }
+}
+
+// -DJG_STAMP: experiment build that accumulates per-phase shader cycles of every wave
+// (wait / barrier / DMA issue / LDS+MFMA / epilogue / whole kernel) and prints them per launch.
+#ifdef JG_STAMP
+static __device__ unsigned long long jg_stamp_acc[8];
+#define JG_ST_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime(); const unsigned long long st_t0 = st_t
+#define JG_ST(idx) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[idx] += n_ - st_t; st_t = n_; } while (0)
+#define JG_ST_END do { st_[5] = __builtin_amdgcn_s_memtime() - st_t0; if (lane == 0) { for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&jg_stamp_acc[q_], st_[q_]); } } while (0)
+#else
+#define JG_ST_DECL
+#define JG_ST(idx)
+#define JG_ST_END
+#endif
+
+// LUT = true is the first-layer variant: a convolution whose input is an embedding gather is linear
+// in one-hot ids, so y[p] = sum_t T_t[id[p + t]] with T_t = E . W_t (vocab x Cout, exact f32, built
+// on the host in f64).  The matrix-core loop is replaced by LDS row lookups (k rows of 64 channels per
+// output position); the epilogue is the same code.  A workgroup owns one 64-channel half of the
+// table (k * (vocab + 1) rows, row `vocab` = zeros for padding) and its four waves cover two
+// 256-position tiles: waves {0,1} the first, {2,3} the second.  K is unused (taps come from a.k).
+template <int K, unsigned EP, bool LUT = false, bool FLAT = false>
+// K = 5 fits two workgroups per CU in LDS (<= 80 KB each): hold the register file to 256 per
+// lane so that both are really resident (without the bound hipcc takes ~340 and the second
+// workgroup of a CU only starts when the first has finished).
+__global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(K == 5 ? 2 : 1, 2)))
+void conv_f16x3_kernel(ConvHArgs a) {
+  constexpr int WA = K - 2;                  // weight slices in flight ahead of the matrix cores
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = LUT ? (wid & 1) : (wid >> 1);
+  const int wn = LUT ? (int)(blockIdx.x & 1u) : (wid & 1);
+  const int i = lane & 31, h = lane >> 5;
+  // virtual block index / grid / tiles per pass (LUT: two blocks = the two channel halves share one index)
+  const int vb = LUT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+  const int vgrid = LUT ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+  constexpr int TPER = LUT ? 2 : NT;
+  const int tsub = LUT ? (wid >> 1) : 0;
+  // LDS carve (16-byte units)
+  const int rows_a = HM + (K - 1) * a.dil;                 // rows of one activation slice
+  const int a_items = NT * 4 * rows_a;                      // [NT][4 ph][rows_a]
+  uint4 *Abuf = lds;                                        // [2 bufs][a_items]
+  uint4 *Wbuf = lds + 2 * a_items;                          // [K slots][2 planes][2 h][HN]
+  const int lut_rows = a.k * (a.lut_vocab + 1);
+  float *epiL = LUT ? reinterpret_cast<float *>(lds) + lut_rows * LUT_RS
+                    : reinterpret_cast<float *>(Wbuf + K * W_ITEMS);
+  for (int q = tid; q < a.n_epi_rows * 2 * HN; q += HT) epiL[q] = a.epi[q];   // visible after the first barrier
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+  // wave-uniform LDS byte addresses of this wave's DMA destinations
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);                       // + buf*a_items*16 + it*4096
+  const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + wid * 1024);   // + slot*8192 + it*4096
+
+  const int n_tiles = FLAT ? a.flat_tiles : a.rows * a.tiles_m;
+  const int n_pairs = (n_tiles + TPER - 1) / TPER;
+  // Position of a lane.  Row-tiled launches cut every (window, frame) row into 256-position tiles of its
+  // own.  Window-packed ("flat") launches lay a window's frames end to end on one axis, each followed by a
+  // gap >= the conv's halo (row pitch P), the window padded to a multiple of 128 (WP), and tile that axis:
+  // frames whose length is an awkward fraction of 256 (665 codons at 2000 bp) no longer waste a third of
+  // their last tile.  A tile may then span frames, so row and position are per lane.
+  auto resolve = [&](const Tile &tile, int local, int len, int &row, int &p) -> bool {
+    if constexpr (!FLAT) {
+      row = tile.rowblk;
+      p = tile.m0 + local;
+      return tile.valid && p >= 0 && p < len;
+    }
+    const int v = tile.T * HM + local;
+    if (v < 0 || !tile.valid) { row = 0; p = 0; return false; }
+    int g, u, f;
+    udivmod24(v, a.flat_wp, a.flat_inv_wp, g, u);
+    udivmod24(u, a.flat_p, a.flat_inv_p, f, p);
+    row = g * a.flat_frames + f;
+    return f < a.flat_frames && p < len && row < a.rows;
+  };
+  int my_pairs = 0;
+  if (vb < n_pairs) my_pairs = (n_pairs - 1 - vb) / vgrid + 1;
+  if (my_pairs == 0) return;
+
+  // per-thread activation piece coordinates: q -> (tile u, plane/half ph, row r)
+  // packed as (u << 20) | (ph << 16) | r to keep the register footprint small
+  unsigned a_pk[A_ITERS];
+#pragma unroll
+  for (int it = 0; it < A_ITERS; ++it) {
+    const int q = tid + it * HT;
+    const int ph = q / rows_a;          // >= 4: no piece
+    a_pk[it] = ((unsigned)(ph >> 2) << 20) | ((unsigned)(ph & 3) << 16) | (unsigned)(q - ph * rows_a);
+  }
+  // weight slice: one item per thread, [plane][h][n] -> byte offset inside the tap-major blob
+  unsigned w_voff[W_ITERS];
+#pragma unroll
+  for (int it = 0; it < W_ITERS; ++it) {
+    const int q = tid + it * HT;          // [plane][h][n]
+    w_voff[it] = (unsigned)((((q >> 8) * K * a.cc_in * 2 + ((q >> 7) & 1)) * HN + (q & (HN - 1))) * 16);
+  }
+
+  auto tiles_of = [&](int pass, Tile *t) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int T = (vb + pass * vgrid) * TPER + tsub + u;
+      const int Tc = min(T, n_tiles - 1);
+      t[u].rowblk = Tc / a.tiles_m;
+      t[u].m0 = (Tc - t[u].rowblk * a.tiles_m) * HM;
+      t[u].valid = T < n_tiles;
+      t[u].T = Tc;
+    }
+  };
+
+  // ---- per-pass piece table --------------------------------------------------------------
+  // A piece's source offset and validity depend on its input position only (in range, mask
+  // byte / codon id non-zero), not on the channel chunk: per pass each thread keeps 5 byte
+  // offsets (relative to the chunk's SGPR base) and 5 validity bits.  The position bytes are
+  // read one pass ahead (raw[]), so no step ever waits on a dependent load.
+  const uint8_t *bsrc = a.ids != nullptr ? a.ids : a.mask_in;
+  unsigned char raw[A_ITERS];
+  unsigned x_voff[A_ITERS];
+  unsigned x_ok = 0;
+  auto piece_pos = [&](const Tile *tl2, int it, int &pc, bool &inr) -> int {
+    const int a_u = (int)(a_pk[it] >> 20), a_r = (int)(a_pk[it] & 0xffff);
+    int rb, p;
+    inr = resolve(tl2[0], a_r - a.pad_left, a.L_in, rb, p) && a_u < NT;
+    pc = min(max(p, 0), a.L_in - 1);
+    if constexpr (FLAT) rb = min(rb, a.rows - 1);
+    return rb;
+  };
+  auto load_bytes = [&](const Tile *tl2) {
+    if (bsrc != nullptr) {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        int pc; bool inr;
+        const int rb = piece_pos(tl2, it, pc, inr);
+        raw[it] = bsrc[(size_t)rb * a.L_in + pc];
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) raw[it] = 1;
+    }
+  };
+  auto build_pieces = [&](const Tile *tl2) {     // consumes raw[] (loaded a pass ago)
+    x_ok = 0;
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      int pc; bool inr;
+      const int rb = piece_pos(tl2, it, pc, inr);
+      const unsigned ph = (a_pk[it] >> 16) & 3;
+      const unsigned byte = raw[it];
+      bool keep;
+      if (a.ids != nullptr) {       // embedding gather (first conv): byte = codon id
+        x_voff[it] = (byte * a.cc_in * 4 + ph) * 16;
+        keep = byte != 0 || !a.mask_from_ids;
+      } else {
+        x_voff[it] = (unsigned)(((rb * a.cc_in * 4 + (int)ph) * a.L_in + pc) * 16);
+        keep = byte != 0;
+      }
+      if (inr && keep) x_ok |= 1u << it;
+    }
+  };
+  const char *x_base = a.ids != nullptr ? reinterpret_cast<const char *>(a.embh)
+                                        : reinterpret_cast<const char *>(a.xh);
+  const unsigned x_cc_stride = a.ids != nullptr ? 4u * 16u : 4u * (unsigned)a.L_in * 16u;   // bytes per chunk
+
+  // ---- DMA issue ---------------------------------------------------------------------------
+  // does this wave own pieces in the last (partial) activation iteration?
+  const bool x_last_wave = __builtin_amdgcn_readfirstlane((int)((A_ITERS - 1) * HT + wid * 64 < 4 * rows_a)) != 0;
+  auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
+    if (a.dbg & 16) return;
+    const char *sb = reinterpret_cast<const char *>(a.wh) + ((size_t)(t * a.cc_in * 2 + cc * 2) * HN) * 16;
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) glds16(sb, w_voff[it], ldsW + t * (W_ITEMS * 16) + it * (HT * 16));
+  };
+  auto issue_x = [&](int cc, int buf) {      // both tiles' activation slices of chunk cc
+    if (a.dbg & 8) return;
+    const char *sb = x_base + (size_t)cc * x_cc_stride;
+    const unsigned dst = ldsA + buf * (a_items * 16);
+    // Iterations 0..A_ITERS-2 are full (4*rows_a > 4*HT); the last one covers the halo remainder
+    // and exists only in the leading wave(s).  The branch around it is wave-uniform on purpose:
+    // the counted waits below must know exactly how many DMAs each wave has in flight.
+#pragma unroll
+    for (int it = 0; it < A_ITERS - 1; ++it) glds16(sb, x_voff[it], dst + it * (HT * 16));
+    if (x_last_wave) {
+      if ((a_pk[A_ITERS - 1] >> 20) < NT) glds16(sb, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
+    }
+  };
+  // after a slice's DMA has landed: overwrite padding / masked-out pieces with zeros (by the
+  // lanes that fetched them); the step barrier then publishes the slice
+  auto zero_fill = [&](int buf) {
+    uint4 *A = Abuf + buf * a_items;
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it)
+      if ((a_pk[it] >> 20) < NT && !((x_ok >> it) & 1u)) A[tid + it * HT] = make_uint4(0u, 0u, 0u, 0u);
+  };
+
+  f32x16 acc[TM][2];        // [tm: position block][tn: channel block]
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+  };
+  zero_acc();
+
+  // LDS fragment addresses (16-byte items): weights [plane][h][n], activations [u][plane][h][row]
+  const int w_frag = h * HN + wn * 64 + i;                  // + plane*2*HN + tn*32 (+ slot*W_ITEMS)
+  const int x_frag = h * rows_a + wm * (TM * 32) + i;       // + plane*2*rows_a + tm*32 + t*dil
+
+  // ---- software pipeline -----------------------------------------------------------------
+  // step (cc, t): weights of step +WA are issued into slot (t+WA)%K, whose last reader was step
+  // -2; the next chunk's activations are issued at tap 0 into the other buffer.  A step may
+  // leave outstanding only what was issued after its own weight slice: WA-1 weight DMAs, plus
+  // the A_ITERS activation DMAs when those went out in between (taps 1..WA).
+  Tile cur[NT], np[NT];            // tiles of this pass / of the next pass
+  JG_ST_DECL;
+  tiles_of(0, cur);
+  tiles_of(1, np);
+  // ---- LUT variant: table half -> LDS once; per pass the wave stages the table-row index of
+  // each of its 128 + (k-1)*dil input positions in LDS (fetched one pass ahead) ----------------
+  unsigned char *stage = reinterpret_cast<unsigned char *>(epiL + JG_EPI_ROWS * 2 * HN) + wid * 256;
+  unsigned char nxt[4] = {0, 0, 0, 0};
+  auto lut_fetch = [&](const Tile &tl) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int p = tl.m0 + wm * (TM * 32) - a.pad_left + lane + 64 * q4;
+      const int pc = min(max(p, 0), a.L_in - 1);
+      const unsigned char b = a.ids[(size_t)tl.rowblk * a.L_in + pc];
+      nxt[q4] = (tl.valid && p >= 0 && p < a.L_in) ? b : (unsigned char)a.lut_vocab;   // row `vocab` = zeros
+    }
+  };
+  if constexpr (LUT) {
+    float4 *T4 = reinterpret_cast<float4 *>(lds);
+    const float4 *src = reinterpret_cast<const float4 *>(a.lut) + (size_t)wn * lut_rows * 16;
+    for (int q = tid; q < lut_rows * 16; q += HT) T4[(q >> 4) * (LUT_RS / 4) + (q & 15)] = src[q];
+    lut_fetch(cur[0]);
+    __syncthreads();
+  } else {
+    load_bytes(cur);
+    build_pieces(cur);               // the only exposed byte-load latency of the launch
+    load_bytes(np);
+    issue_x(0, 0);
+#pragma unroll
+    for (int t = 0; t < WA; ++t) issue_w(0, t);
+  }
+  int xc = 0;                      // running chunk count: activation buffer parity
+  for (int pass = 0; pass < my_pairs; ++pass) {
+    if constexpr (LUT) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) stage[lane + 64 * q4] = nxt[q4];
+      lut_fetch(np[0]);                                   // next pass's indices fly under this pass
+      __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the wave's own staging writes
+      __builtin_amdgcn_wave_barrier();
+      const float *Tl = reinterpret_cast<const float *>(lds) + 4 * h;
+      for (int t = 0; t < a.k; ++t) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int rowi = stage[tm * 32 + i + t * a.dil];
+          const float *r = Tl + (t * (a.lut_vocab + 1) + rowi) * LUT_RS;
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float4 v = *reinterpret_cast<const float4 *>(r + tn * 32 + 8 * g);
+              acc[tm][tn][4 * g + 0] += v.x; acc[tm][tn][4 * g + 1] += v.y;
+              acc[tm][tn][4 * g + 2] += v.z; acc[tm][tn][4 * g + 3] += v.w;
+            }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (!LUT) for (int cc = 0; cc < a.cc_in; ++cc) {
+      const int abuf = xc & 1;
+      const bool last_chunk = cc == a.cc_in - 1;
+      const bool tail = last_chunk && pass == my_pairs - 1;     // nothing is issued behind this chunk
+      const uint4 *A = Abuf + abuf * a_items + x_frag;
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        // -- wait for this step's operands, publish them ---------------------------------------
+        JG_ST(6);
+        if (tail) wait_vm<0>();
+        else if (t >= 1 && t <= WA) {
+          if (x_last_wave) wait_vm<(WA - 1) * W_ITERS + A_ITERS>();
+          else wait_vm<(WA - 1) * W_ITERS + A_ITERS - 1>();
+        }
+        else wait_vm<(WA - 1) * W_ITERS>();
+        JG_ST(0);
+        if (t == 0) zero_fill(abuf);
+        __syncthreads();
+        JG_ST(1);
+        // -- keep the DMA queue full: issued from inside the matrix-core stream (after the first half
+        // of the step's MFMAs are queued) so that the DMA issue cost runs under matrix-core time ------
+        auto issue_step = [&]() {
+          if (t + WA < K) {
+            issue_w(cc, t + WA);
+          } else if (!tail) {
+            issue_w(last_chunk ? 0 : cc + 1, t + WA - K);
+          }
+          if (t == 0 && !tail) {
+            if (last_chunk) build_pieces(np);        // the next pass's pieces take over from here
+            issue_x(last_chunk ? 0 : cc + 1, abuf ^ 1);
+          }
+        };
+        if (a.dbg & 2) issue_step();
+        JG_ST(2);
+        // -- matrix-core work: one tap of one 16-channel chunk ----------------------------------
+        if (!(a.dbg & 2)) {
+          const uint4 *B = Wbuf + t * W_ITEMS + w_frag;
+          half8 wh[2], wl[2];
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            const uint4 vh = B[tn * 32];
+            const uint4 vl = B[2 * HN + tn * 32];
+            wh[tn] = *reinterpret_cast<const half8 *>(&vh);
+            wl[tn] = *reinterpret_cast<const half8 *>(&vl);
+          }
+#pragma unroll
+          for (int tp = 0; tp < TM / 2; ++tp) {           // two position blocks at a time
+            half8 xh[2], xl[2];
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq) {
+              const uint4 vh = A[(tp * 2 + tq) * 32 + t * a.dil];
+              const uint4 vl = A[2 * rows_a + (tp * 2 + tq) * 32 + t * a.dil];
+              xh[tq] = *reinterpret_cast<const half8 *>(&vh);
+              xl[tq] = *reinterpret_cast<const half8 *>(&vl);
+            }
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+              for (int tn = 0; tn < 2; ++tn) {
+                // weights are the MFMA A operand: acc rows = channels, cols = positions
+                f32x16 &c = acc[tp * 2 + tq][tn];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xl[tq], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[tn], xh[tq], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xh[tq], c, 0, 0, 0);
+              }
+            if (tp == 0) {
+              __builtin_amdgcn_sched_barrier(0);
+              issue_step();
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      }
+      ++xc;
+    }
+    JG_ST(3);
+
+    // ---- pass finished: fused epilogue straight from the accumulators ----------------------
+    if (a.dbg & 1) {
+      if (acc[0][0][0] + acc[1][1][3] + acc[2][1][7] + acc[3][0][9] == 12345.678f) a.overflow[0] = 2;
+    } else {
+      float vmax = 0.f;             // running max |output|: f16-range guard
+      float nmd_acc[16];            // per-lane NMD sums of the current channel block
+      // what a block needs from memory, fetched one block ahead so the loads of block b+1
+      // fly under the arithmetic of block b
+      struct Pre {
+        uint2 sh[4], sl[4];
+        unsigned char mkb;
+      };
+      // lanes i and i+32 hold channels 0-3 / 4-7 of the same 8-channel F16S item: a
+      // v_permlane32_swap per dword turns two 8-byte accesses per lane into one 16-byte access
+      // (lane half h then owns the whole item of group 2j+h)
+      auto swap32 = [](unsigned &lo_half_keeps, unsigned &hi_half_keeps) {
+        const auto r = __builtin_amdgcn_permlane32_swap(lo_half_keeps, hi_half_keeps, false, false);
+        lo_half_keeps = r[0];
+        hi_half_keeps = r[1];
+      };
+      auto item4 = [&](int row, int mc, int nb, int j) -> unsigned {
+        // hi-plane item of group 2j + h (uint4 units); lo plane = + 2*L_out
+        const int G = (nb >> 3) + 2 * j + h;
+        return (unsigned)(((row * (a.cout_pad >> 4) + (G >> 1)) * 4 + (G & 1)) * a.L_out + mc);
+      };
+      // this lane's output position in block tm: row, clamped position, alive
+      auto out_pos = [&](const Tile &tile, int tm, int &row, int &mc) -> bool {
+        int p;
+        const bool live = resolve(tile, (wm * TM + tm) * 32 + i, a.L_out, row, p);
+        mc = live ? p : 0;
+        if constexpr (FLAT) {
+          if (!live) row = min(max(row, 0), a.rows - 1);
+        }
+        return live;
+      };
+      auto prefetch = [&](Pre &p, const Tile &tile, int tm, int tn) {
+        const int nb = (wn * 2 + tn) * 32;
+        int orow, mc;
+        out_pos(tile, tm, orow, mc);
+        p.mkb = a.mask_out != nullptr ? a.mask_out[(size_t)orow * a.L_out + mc] : (unsigned char)1;
+        if (a.addh != nullptr && !(a.dbg & 128)) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const unsigned it4 = item4(orow, mc, nb, j);
+            uint4 vh = a.addh[it4];                        // whole item of group 2j+h
+            uint4 vl = a.addh[it4 + 2u * (unsigned)a.L_out];
+            // give each lane back its own 4 channels of groups 2j and 2j+1
+            swap32(vh.x, vh.z); swap32(vh.y, vh.w);
+            swap32(vl.x, vl.z); swap32(vl.y, vl.w);
+            p.sh[2 * j] = make_uint2(vh.x, vh.y);  p.sh[2 * j + 1] = make_uint2(vh.z, vh.w);
+            p.sl[2 * j] = make_uint2(vl.x, vl.y);  p.sl[2 * j + 1] = make_uint2(vl.z, vl.w);
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) p.sh[g] = p.sl[g] = make_uint2(0u, 0u);
+        }
+      };
+      // one 32-channel x 32-position accumulator block, processed in place (static register
+      // indices only).  C/D layout: col = lane&31 -> position, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+      // -> channel
+      auto epi_block = [&](f32x16 &x, const Tile &tile, int tm, int tn) {
+        Pre p;
+        prefetch(p, tile, tm, tn);
+        const int nb = (wn * 2 + tn) * 32;
+        int orow_, mc_;
+        const bool live = out_pos(tile, tm, orow_, mc_);
+        const float mk = p.mkb != 0 ? 1.f : 0.f;
+        // ---- stage primitives on this lane's 16 channels of one position -----------------
+        auto st_affine = [&](int row) {
+          const float *pr = epiL + (row * 2) * HN + nb + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 sc = *reinterpret_cast<const float4 *>(pr + 8 * g);
+            const float4 of = *reinterpret_cast<const float4 *>(pr + HN + 8 * g);
+            x[4 * g + 0] = fmaf(x[4 * g + 0], sc.x, of.x);
+            x[4 * g + 1] = fmaf(x[4 * g + 1], sc.y, of.y);
+            x[4 * g + 2] = fmaf(x[4 * g + 2], sc.z, of.z);
+            x[4 * g + 3] = fmaf(x[4 * g + 3], sc.w, of.w);
+          }
+        };
+        auto st_dyt = [&](int row, float alpha, int use_mask) {
+          const float *pr = epiL + (row * 2) * HN + nb + 4 * h;
+          const float mm = use_mask ? mk : 1.0f;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 ga = *reinterpret_cast<const float4 *>(pr + 8 * g);
+            const float4 be = *reinterpret_cast<const float4 *>(pr + HN + 8 * g);
+            x[4 * g + 0] = (fast_tanh(alpha * x[4 * g + 0]) * ga.x + be.x) * mm;
+            x[4 * g + 1] = (fast_tanh(alpha * x[4 * g + 1]) * ga.y + be.y) * mm;
+            x[4 * g + 2] = (fast_tanh(alpha * x[4 * g + 2]) * ga.z + be.z) * mm;
+            x[4 * g + 3] = (fast_tanh(alpha * x[4 * g + 3]) * ga.w + be.w) * mm;
+          }
+        };
+        auto st_add = [&]() {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const half4 hh4 = *reinterpret_cast<const half4 *>(&p.sh[g]);
+            const half4 ll4 = *reinterpret_cast<const half4 *>(&p.sl[g]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[4 * g + j] += (float)hh4[j] + (float)ll4[j];
+          }
+        };
+        auto st_gelu = [&]() {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] = a.act_erf ? gelu_erf(x[r]) : fast_gelu(x[r]);
+        };
+        auto st_nmd = [&]() {
+          // masked channel sums: accumulated per lane over the wave's four position blocks of this
+          // channel block, reduced across lanes once (nmd_flush) - one partial row per 128 positions
+          const float mkl = live ? mk : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) nmd_acc[r] = fmaf(x[r], mkl, nmd_acc[r]);
+        };
+        if constexpr (EP == JG_EP_GENERIC) {
+          // any stage list: interpreted at run time (slow path: the accumulators bounce through
+          // the interpreter's switch); the model families in-tree all hit a compiled pattern
+          for (int q = 0; q < ((a.dbg & 32) ? 0 : a.n_hst); ++q) {
+            const HStageArg st = a.hst[q];
+            switch (st.kind) {
+              case JG_HST_AFFINE: st_affine(st.pad_); break;
+              case JG_HST_DYT: st_dyt(st.pad_, st.f0, st.arg); break;
+              case JG_HST_ADD: st_add(); break;
+              case JG_HST_ACT:
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = jg_act(x[r], st.arg);
+                break;
+              case JG_HST_NMD: st_nmd(); break;
+              case JG_HST_MASKMUL:
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] *= mk;
+                break;
+              default: break;
+            }
+          }
+        } else if (!(a.dbg & 32)) {
+          // compiled pattern: affine [nmd] [norm1] [add] [gelu] [nmd] [norm2] [gelu], straight line
+          constexpr int N1 = (EP >> 1) & 3, N2 = (EP >> 6) & 3;
+          st_affine(0);
+          if constexpr (EP & JG_EP_NMD1) st_nmd();
+          if constexpr (N1 == 1) st_affine(1);
+          if constexpr (N1 == 2) st_dyt(1, a.alpha1, a.dytmask1);
+          if constexpr (EP & JG_EP_ADD) st_add();
+          if constexpr (EP & JG_EP_ACT1) st_gelu();
+          if constexpr (EP & JG_EP_NMD2) st_nmd();
+          if constexpr (N2 == 1) st_affine(N1 ? 2 : 1);
+          if constexpr (N2 == 2) st_dyt(N1 ? 2 : 1, a.alpha2, a.dytmask2);
+          if constexpr (EP & JG_EP_ACT2) st_gelu();
+        }
+        // results stay in the block's registers (F16S: re-split, lane-pair swapped and bit-cast,
+        // dword 4j..4j+3 = hi item, 8+4j.. = lo item of group 2j+h); stored by store_block() once
+        // every block's loads are done - no load ever queues behind a store
+        if (a.out_f16s) {
+          uint2 ph[4], pl[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            half4 hh4, ll4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float v = x[4 * g + j];
+              const _Float16 hv = (_Float16)v;
+              hh4[j] = hv;
+              ll4[j] = (_Float16)(v - (float)hv);
+              vmax = fmaxf(vmax, live ? fabsf(v) : 0.f);
+            }
+            ph[g] = *reinterpret_cast<uint2 *>(&hh4);
+            pl[g] = *reinterpret_cast<uint2 *>(&ll4);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            unsigned h0 = ph[2 * j].x, h1 = ph[2 * j].y, h2 = ph[2 * j + 1].x, h3 = ph[2 * j + 1].y;
+            unsigned l0 = pl[2 * j].x, l1 = pl[2 * j].y, l2 = pl[2 * j + 1].x, l3 = pl[2 * j + 1].y;
+            swap32(h0, h2); swap32(h1, h3);      // -> whole item of group 2j+h
+            swap32(l0, l2); swap32(l1, l3);
+            x[4 * j + 0] = __uint_as_float(h0); x[4 * j + 1] = __uint_as_float(h1);
+            x[4 * j + 2] = __uint_as_float(h2); x[4 * j + 3] = __uint_as_float(h3);
+            x[8 + 4 * j + 0] = __uint_as_float(l0); x[8 + 4 * j + 1] = __uint_as_float(l1);
+            x[8 + 4 * j + 2] = __uint_as_float(l2); x[8 + 4 * j + 3] = __uint_as_float(l3);
+          }
+        }
+      };
+      auto store_block = [&](const f32x16 &x, const Tile &tile, int tm, int tn) {
+        const int nb = (wn * 2 + tn) * 32;
+        int orow, mc;
+        const bool live = out_pos(tile, tm, orow, mc);
+        if (live && !(a.dbg & 64)) {
+          if (a.out_f16s) {
+            uint4 *yh = reinterpret_cast<uint4 *>(a.y);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const unsigned it4 = item4(orow, mc, nb, j);
+              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+              const u32x4 vhi = {__float_as_uint(x[4 * j]), __float_as_uint(x[4 * j + 1]),
+                                 __float_as_uint(x[4 * j + 2]), __float_as_uint(x[4 * j + 3])};
+              const u32x4 vlo = {__float_as_uint(x[8 + 4 * j]), __float_as_uint(x[8 + 4 * j + 1]),
+                                 __float_as_uint(x[8 + 4 * j + 2]), __float_as_uint(x[8 + 4 * j + 3])};
+              // the output (1.5 GB per launch) is read next by another launch, far beyond any cache:
+              // streamed (nt) rather than write-allocated in L2 (+1.3 % measured)
+              __builtin_nontemporal_store(vhi, reinterpret_cast<u32x4 *>(yh + it4));
+              __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)a.L_out));
+            }
+          } else {
+            float *yf = reinterpret_cast<float *>(a.y) + ((size_t)orow * a.L_out + mc) * a.cout + nb + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              if (nb + 8 * g + 4 * h < a.cout)
+                *reinterpret_cast<float4 *>(yf + 8 * g) =
+                    make_float4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+          }
+        }
+      };
+      // Cross-lane reduction over a half's 32 lanes by register halving: at each step a lane keeps half of
+      // its registers and receives the partner's copy of that half (DPP within rows of 16, one bpermute
+      // across rows), so 16 registers cost 16 exchanges instead of 80.  Afterwards lane i holds the
+      // reduction of channel register r = 8*b2 + 4*b1 + 2*b0 + b3 (bits of i).
+#define JG_DPP(v, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), (ctrl), 0xf, 0xf, false))
+      auto lane_reduce = [&](const float (&in)[16], auto op) -> float {
+        const bool b2 = (i & 4) != 0, b1 = (i & 2) != 0, b0 = (i & 1) != 0, b3 = (i & 8) != 0;
+        float s8[8], s4[4], s2[2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {        // partner i ^ 7 (row_half_mirror)
+          const float keep = b2 ? in[8 + q] : in[q], send = b2 ? in[q] : in[8 + q];
+          s8[q] = op(keep, JG_DPP(send, 0x141));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {        // partner i ^ 2 (quad_perm [2,3,0,1])
+          const float keep = b1 ? s8[4 + q] : s8[q], send = b1 ? s8[q] : s8[4 + q];
+          s4[q] = op(keep, JG_DPP(send, 0x4e));
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {        // partner i ^ 1 (quad_perm [1,0,3,2])
+          const float keep = b0 ? s4[2 + q] : s4[q], send = b0 ? s4[q] : s4[2 + q];
+          s2[q] = op(keep, JG_DPP(send, 0xb1));
+        }
+        const float keep1 = b3 ? s2[1] : s2[0], send1 = b3 ? s2[0] : s2[1];
+        const float v = op(keep1, JG_DPP(send1, 0x128));      // partner i ^ 8 (row_ror:8)
+        return op(v, __shfl_xor(v, 16, 32));                  // partner i ^ 16
+      };
+      // where lane i's reduced channel lives, and the partial row of this wave's 128 positions
+      auto reduced_slot = [&](const Tile &tile, int tn, int &ch) -> size_t {
+        const int r = 8 * (int)((i & 4) != 0) + 4 * (int)((i & 2) != 0) + 2 * (int)((i & 1) != 0) + (int)((i & 8) != 0);
+        ch = (wn * 2 + tn) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        return ((size_t)tile.T * 2 + wm) * a.cout + ch;     // one partial row per 128-position strip
+      };
+      auto nmd_flush = [&](const Tile &tile, int tn) {
+        const float v = lane_reduce(nmd_acc, [](float x, float y) { return x + y; });
+        int ch;
+        const size_t slot = reduced_slot(tile, tn, ch);
+        if (i < 16 && tile.valid && ch < a.cout) a.nmd_out[slot] = v;
+      };
+      const bool has_nmd = EP == JG_EP_GENERIC ? a.nmd_out != nullptr : (EP & (JG_EP_NMD1 | JG_EP_NMD2)) != 0;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nmd_acc[r] = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) epi_block(acc[tm][tn], cur[0], tm, tn);
+        if (has_nmd) nmd_flush(cur[0], tn);
+      }
+      if (a.pool_out != nullptr) {
+        // fused masked global max pool (layers.py:496-538): the block outputs are not stored at all; each
+        // wave reduces its 128 positions to one partial row, pool_final takes the max over a window's rows
+        float mkv[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          int orow, mc;
+          const bool live = out_pos(cur[0], tm, orow, mc);
+          const unsigned char mb = a.mask_out != nullptr ? a.mask_out[(size_t)orow * a.L_out + mc] : (unsigned char)1;
+          mkv[tm] = (live && mb != 0) ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          float pa[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pa[r] = -INFINITY;
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pa[r] = mkv[tm] != 0.f ? fmaxf(pa[r], acc[tm][tn][r]) : pa[r];
+          const float v = lane_reduce(pa, [](float x, float y) { return fmaxf(x, y); });
+          int ch;
+          const size_t slot = reduced_slot(cur[0], tn, ch);
+          if (i < 16 && cur[0].valid && ch < a.cout) a.pool_out[slot] = v;
+        }
+      } else {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          store_block(acc[tm][0], cur[0], tm, 0);
+          store_block(acc[tm][1], cur[0], tm, 1);
+        }
+      }
+      if (!(vmax <= 65000.0f) && a.overflow != nullptr && a.dbg == 0) atomicOr(a.overflow, 1);
+    }
+    zero_acc();
+#pragma unroll
+    for (int u = 0; u < NT; ++u) cur[u] = np[u];
+    tiles_of(pass + 2, np);
+    if constexpr (!LUT) load_bytes(np);   // position bytes of the pass after next
+    JG_ST(4);
+  }
+  JG_ST_END;
+}
+
+template <int K, unsigned EP, bool FLAT = false>
+int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  const int smem = jg_conv_f16_lds_bytes(K, a.dil);
+  static bool attr_set = false;
+  if (!attr_set) {
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<K, EP, false, FLAT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int n_tiles = FLAT ? a.flat_tiles : a.rows * a.tiles_m;
+  const int n_pairs = (n_tiles + NT - 1) / NT;
+  // two 4-wave workgroups per CU when their LDS fits (<= 80 KB each): one's epilogue and stores overlap
+  // the other's matrix-core steps.  (Forcing the two out of phase - by dispatch order or by a per-CU
+  // arrival ticket - was measured and changes nothing; neither does storing each block early.)
+  static const bool one_wg = getenv("JG_ONE_WG") != nullptr;      // experiment switch: one workgroup per CU
+  int grid = ((smem <= 80 * 1024 && !one_wg) ? 2 : 1) * e->n_cu;
+  if (grid > n_pairs) grid = n_pairs;
+  ConvHArgs b = a;
+  hipLaunchKernelGGL((conv_f16x3_kernel<K, EP, false, FLAT>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, b);
+  JG_HIP(hipGetLastError());
+#ifdef JG_STAMP
+  {
+    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    JG_HIP(hipStreamSynchronize(s));
+    JG_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(jg_stamp_acc), sizeof(h)));
+    JG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(jg_stamp_acc), z, sizeof(z)));
+    const double tot = (double)h[5];
+    fprintf(stderr, "STAMP k=%d ep=%u rows=%d grid=%d total_cyc/wave=%.0f wait=%.3f barrier=%.3f issue=%.3f lds_mfma=%.3f epilogue=%.3f\n",
+            K, EP, a.rows, grid, tot / (grid * 4.0), h[0] / tot, h[1] / tot, h[2] / tot, (h[3] + h[6]) / tot, h[4] / tot);
+  }
+#endif
+  return JG_OK;
+}
+
+#if JG_CONV_PART == 4
+template <unsigned EP>
+int launch_lut_e(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  const int smem = jg_conv_lut_lds_bytes(a.k, a.lut_vocab);
+  static bool attr_set = false;
+  if (!attr_set) {
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<0, EP, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int n_tiles = a.rows * a.tiles_m;
+  const int n_pairs = (n_tiles + 1) / 2;
+  const int grid = 2 * (n_pairs < e->n_cu / 2 ? n_pairs : e->n_cu / 2);   // (tile pair, channel half); one per CU
+  hipLaunchKernelGGL((conv_f16x3_kernel<0, EP, true>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, a);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  switch (a.ep) {
+#define JG_CASE(ep) case (ep): return launch_lut_e<(ep)>(e, a, s);
+    JG_CASE(JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_AFF | JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ACT1)
+    JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1)
+    JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1)
+#undef JG_CASE
+    default: return launch_lut_e<JG_EP_GENERIC>(e, a, s);
+  }
+}
+
+#endif
+
+// ---- per-translation-unit instantiation sets (JG_CONV_PART selects one; the kernel template is
+// instantiated ~45 times, split over four objects so that they compile in parallel) ---------------
+#define JG_ROW_CASES(K)                                                                              \
+  switch (a.ep) {                                                                                    \
+    case (JG_EP_ACT1): return launch_ke<K, (JG_EP_ACT1)>(e, a, s);                                   \
+    case (JG_EP_NORM1_AFF | JG_EP_ACT1): return launch_ke<K, (JG_EP_NORM1_AFF | JG_EP_ACT1)>(e, a, s); \
+    case (JG_EP_NORM1_DYT | JG_EP_ACT1): return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ACT1)>(e, a, s); \
+    case (JG_EP_ADD | JG_EP_ACT1): return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1)>(e, a, s);           \
+    case (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1):                                                 \
+      return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1)>(e, a, s);                      \
+    case (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2):                       \
+      return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)>(e, a, s); \
+    case (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2):     \
+      return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2)>(e, a, s); \
+    case (JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1):                                                \
+      return launch_ke<K, (JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1)>(e, a, s);                     \
+    case (JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1):                                                \
+      return launch_ke<K, (JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1)>(e, a, s);                     \
+    default: return launch_ke<K, JG_EP_GENERIC>(e, a, s);                                            \
+  }
+
+}  // namespace
+
+#if JG_CONV_PART == 1      // row-tiled, k = 5 (the residual stacks)
+int jg_conv_f16_part_k5(jg_engine *e, const ConvHArgs &a, hipStream_t s) { JG_ROW_CASES(5) }
+#elif JG_CONV_PART == 2    // row-tiled, k = 7 and 9
+int jg_conv_f16_part_k79(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  if (a.k == 7) { JG_ROW_CASES(7) }
+  JG_ROW_CASES(9)
+}
+#elif JG_CONV_PART == 3    // window-packed tiling, k = 5: the stage patterns of the residual stacks
+int jg_conv_f16_part_flat(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  switch (a.ep) {
+#define JG_CASE(ep) case (ep): return launch_ke<5, (ep), true>(e, a, s);
+    JG_CASE(JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_AFF | JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ACT1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2)
+#undef JG_CASE
+    default: return launch_ke<5, JG_EP_GENERIC, true>(e, a, s);
+  }
+}
+#elif JG_CONV_PART == 4    // first-layer table variant
+int jg_conv_f16_part_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) { return launch_lut(e, a, s); }
+#endif
