@@ -75,7 +75,7 @@ struct HStageArg {
   int pad_;
 };
 
-// split-f16 conv (jg_conv_f16.hip); uint4 = one 16-byte item of 8 halfs
+// split-f16 conv (jg_conv_f16_impl.h); uint4 = one 16-byte item of 8 halfs
 struct ConvHArgs {
   const uint4 *xh;         // F16S input [rows][cc_in][4][L_in] or null when ids != null
   const uint8_t *ids;      // (rows, L_in) embedding-gather source
@@ -91,7 +91,7 @@ struct ConvHArgs {
   int rows, L_in, L_out;
   int cc_in, cout, cout_pad;
   int k, dil, pad_left, tiles_m;
-  // window-packed tiling (see jg_conv_f16.hip): frames of a window on one axis, row pitch flat_p, window
+  // window-packed tiling (see jg_conv_f16_impl.h): frames of a window on one axis, row pitch flat_p, window
   // pitch flat_wp (multiple of 128), flat_tiles tiles of 256; 0 = every row tiled on its own
   int flat, flat_p, flat_wp, flat_frames, flat_tiles;
   float flat_inv_p, flat_inv_wp;
