@@ -592,6 +592,12 @@ static int prepare_f16(jg_model *m, const float *weights) {
           hp.act_erf = gelu_kind == JG_ACT_GELU_ERF;
         }
         hp.ep = ok ? ep : JG_EP_GENERIC;
+        // Only compiled stage patterns run on the split-f16 path: the interpreted epilogue was measured
+        // 12x slower than the compiled ones (and 3x slower than the exact-f32 kernels), so anything else
+        // stays on the exact-f32 path.
+        if (m->f16_eligible && !jg_conv_f16_has_pattern(hp.ep, op.in_buf == JG_BUF_IDS)) {
+          fail("a conv's stage list is not one of the compiled split-f16 epilogue patterns");
+        }
       }
       if (m->f16_eligible) {
         JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_epi), tab.size() * sizeof(float)));

@@ -36,6 +36,26 @@ bool jg_conv_f16_supports(int k, int dil) {
 
 int jg_conv_f16_tile_m(void) { return HM; }
 
+// stage patterns with a compiled epilogue (keep in step with the instantiation sets in jg_conv_f16_impl.h);
+// a first-layer conv may end up on the table variant, which carries a subset
+bool jg_conv_f16_has_pattern(unsigned ep, bool first_layer) {
+  const unsigned lut[] = {JG_EP_ACT1, JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ACT1,
+                          JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1,
+                          JG_EP_ACT1 | JG_EP_NORM2_AFF};
+  const unsigned all[] = {JG_EP_ACT1, JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ACT1,
+                          JG_EP_ADD | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1,
+                          JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2,
+                          JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2,
+                          JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1,
+                          JG_EP_ACT1 | JG_EP_NORM2_AFF, JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2};
+  if (first_layer) {
+    for (unsigned p : lut) if (p == ep) return true;
+    return false;      // (a first layer the table variant cannot take also needs one of `all`: same subset)
+  }
+  for (unsigned p : all) if (p == ep) return true;
+  return false;
+}
+
 int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   JG_REQUIRE(a.cout_pad == HN && a.cout % 16 == 0, JG_ERR_UNSUPPORTED,
              "conv_f16x3: cout=%d (needs 128 padded, multiple of 16)", a.cout);

@@ -810,9 +810,12 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ACT1)
     JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1)
     JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1)
+    JG_CASE(JG_EP_ACT1 | JG_EP_NORM2_AFF)
 #undef JG_CASE
-    default: return launch_lut_e<JG_EP_GENERIC>(e, a, s);
+    default: break;
   }
+  jg_set_error("conv lut: stage pattern 0x%x has no compiled epilogue", a.ep);
+  return JG_ERR_UNSUPPORTED;
 }
 
 #endif
@@ -835,8 +838,13 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
       return launch_ke<K, (JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1)>(e, a, s);                     \
     case (JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1):                                                \
       return launch_ke<K, (JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1)>(e, a, s);                     \
-    default: return launch_ke<K, JG_EP_GENERIC>(e, a, s);                                            \
-  }
+    case (JG_EP_ACT1 | JG_EP_NORM2_AFF): return launch_ke<K, (JG_EP_ACT1 | JG_EP_NORM2_AFF)>(e, a, s); \
+    case (JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2):                                                \
+      return launch_ke<K, (JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)>(e, a, s);                     \
+    default: break;                                                                                  \
+  }                                                                                                  \
+  jg_set_error("conv_f16x3: stage pattern 0x%x has no compiled epilogue", a.ep);                     \
+  return JG_ERR_UNSUPPORTED;
 
 }  // namespace
 
@@ -845,7 +853,7 @@ int jg_conv_f16_part_k5(jg_engine *e, const ConvHArgs &a, hipStream_t s) { JG_RO
 #elif JG_CONV_PART == 2    // row-tiled, k = 7 and 9
 int jg_conv_f16_part_k79(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   if (a.k == 7) { JG_ROW_CASES(7) }
-  JG_ROW_CASES(9)
+  { JG_ROW_CASES(9) }
 }
 #elif JG_CONV_PART == 3    // window-packed tiling, k = 5: the stage patterns of the residual stacks
 int jg_conv_f16_part_flat(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
@@ -858,9 +866,13 @@ int jg_conv_f16_part_flat(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1)
     JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2)
+    JG_CASE(JG_EP_ACT1 | JG_EP_NORM2_AFF)
+    JG_CASE(JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)
 #undef JG_CASE
-    default: return launch_ke<5, JG_EP_GENERIC, true>(e, a, s);
+    default: break;
   }
+  jg_set_error("conv_f16x3: stage pattern 0x%x has no compiled window-packed epilogue", a.ep);
+  return JG_ERR_UNSUPPORTED;
 }
 #elif JG_CONV_PART == 4    // first-layer table variant
 int jg_conv_f16_part_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) { return launch_lut(e, a, s); }

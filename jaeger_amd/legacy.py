@@ -8,8 +8,9 @@ the MI355X engine.
 * network: ``nnlib/v1/layers.py:154-207,399-423`` (see ``oracle/legacy.py`` for the statement) compiled
   to the same op program the modern models use: conv ops with fused bias / exact-erf GELU /
   batch-norm stages, ``MAXPOOL1D``, ``FRAMESUM``, an unmasked global max pool and three dense ops; it
-  runs on the exact-f32 MFMA kernels by default, and on the split-f16 conv kernels on request (first conv
-  by table lookup, ``MaxPool`` on the F16S tensors, erf-GELU in the epilogue; ``precision="f16x3"``);
+  runs on the split-f16 conv kernels (first conv by table lookup, ``MaxPool`` on the F16S tensors, erf-GELU
+  in the compiled epilogue, window-packed tiles for its short frames) or, with ``precision="f32"``, on the
+  exact-f32 MFMA kernels;
 * weights: Keras-2.5 ``WRes_1024.h5`` read with :mod:`jaeger_amd.hdf5_lite`;
 * outputs keyed like ``JaegerModel.predict`` (``nnlib/inference.py:69-75``): ``y_hat.output``,
   ``y_hat.embedding``, ``meta``.
@@ -153,15 +154,14 @@ class LegacyHipEngine:
     """``JaegerModel`` (``nnlib/inference.py:20-75``) stand-in for the ``default`` model."""
 
     def __init__(self, weights: dict[str, np.ndarray] | str | Path, device_id: int = 0, chunk: int = 0,
-                 precision: str | None = "f32"):
+                 precision: str | None = None):
         from .engine import HipDevice, HipModel, codon_lut
         if not isinstance(weights, dict):
             weights = load_legacy_h5(weights)
         self.program = compile_legacy(weights)
         self.device = HipDevice(device_id)
-        # Default exact-f32: measured 75 Mbp/s vs 17 Mbp/s for the split-f16 kernels on this tower (its
-        # frames shrink to 166 positions - two thirds of a 256-position tile - and its stage order runs the
-        # interpreted epilogue); both paths agree with the oracle to 2e-5.
+        # split-f16 by default like the modern models (f32-accurate; measured 186 Mbp/s of 2000-bp windows
+        # vs 75 on the exact-f32 kernels, both within 2e-5 of the oracle); precision="f32" forces the latter
         self.model = HipModel(self.device, self.program)
         if precision is not None:
             self.model.set_precision(precision)

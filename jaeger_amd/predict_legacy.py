@@ -107,7 +107,7 @@ def run_core(**kwargs) -> int:
     ood_params = load_ood_params(model_path, config)
     try:
         engine = LegacyHipEngine(weights_path, device_id=kwargs.get("physicalid", 0), chunk=kwargs.get("chunk", 0),
-                                 precision="f32")
+                                 precision="f32" if kwargs.get("exact_f32") else None)
     except Exception as e:
         lg.debug(traceback.format_exc())
         lg.error(f"could not set up the legacy model on GPU {kwargs.get('physicalid', 0)}: {e}")

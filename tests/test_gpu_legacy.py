@@ -49,8 +49,10 @@ def test_legacy_forward_parity_real_weights(precision):
             starts.append(offsets[ci] + st)
             lens.append(2000)
     got = eng.predict_windows(bases, np.array(starts), np.array(lens), 2000)
+    again = eng.forward_ids(ids)
     eng.close()
     for k in ("output", "embedding"):
+        np.testing.assert_array_equal(again[k], got_ids[k])          # repeatable bit for bit
         err = float(np.abs(got[k] - ref[k]).max())
         print(k, f"{err:.2e}", float(np.abs(ref[k]).max()))
         assert err <= 1e-4 * max(1.0, float(np.abs(ref[k]).max()) / 8), (k, err)
