@@ -574,11 +574,11 @@ static int prepare_f16(jg_model *m, const float *weights) {
           if (is(JG_HST_AFFINE)) { ep |= JG_EP_NORM1_AFF; ++q; }
           else if (is(JG_HST_DYT)) { ep |= JG_EP_NORM1_DYT; hp.alpha1 = hp.hst[q].f0; hp.dytmask1 = hp.hst[q].arg; ++q; }
           if (is(JG_HST_ADD)) { ep |= JG_EP_ADD; ++q; }
-          int gelu_kind = 0;   // all GELU stages of a compiled pattern share one form
+          int gelu_kind = 0;   // all activation stages of a compiled pattern share one kind
           auto is_gelu = [&]() {
             if (!is(JG_HST_ACT)) return false;
             const int k = hp.hst[q].arg;
-            if (k != JG_ACT_GELU_TANH && k != JG_ACT_GELU_ERF) return false;
+            if (k != JG_ACT_GELU_TANH && k != JG_ACT_GELU_ERF && k != JG_ACT_RELU) return false;
             if (gelu_kind != 0 && gelu_kind != k) return false;
             gelu_kind = k;
             return true;
@@ -589,7 +589,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
           else if (is(JG_HST_DYT)) { ep |= JG_EP_NORM2_DYT; hp.alpha2 = hp.hst[q].f0; hp.dytmask2 = hp.hst[q].arg; ++q; }
           if (is_gelu()) { ep |= JG_EP_ACT2; ++q; }
           ok = q == n;
-          hp.act_erf = gelu_kind == JG_ACT_GELU_ERF;
+          hp.act_kind = gelu_kind != 0 ? gelu_kind : JG_ACT_GELU_TANH;
         }
         hp.ep = ok ? ep : JG_EP_GENERIC;
         // Only compiled stage patterns run on the split-f16 path: the interpreted epilogue was measured
@@ -826,7 +826,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           if (hp.nmd_slot >= 0) m->part_rows[hp.nmd_slot] = strips_per_win;
           if (hp.pool_op >= 0) m->pool_rows = strips_per_win;
           a.out_f16s = hp.out_f16s ? 1 : 0;
-          a.act_erf = hp.act_erf ? 1 : 0;
+          a.act_kind = hp.act_kind;
           a.n_hst = hp.n_hst;
           a.ep = hp.ep;
           a.alpha1 = hp.alpha1; a.alpha2 = hp.alpha2;

@@ -96,7 +96,7 @@ struct ConvHArgs {
   int flat, flat_p, flat_wp, flat_frames, flat_tiles;
   float flat_inv_p, flat_inv_wp;
   int mask_from_ids, out_f16s;
-  int act_erf;             // the compiled patterns' GELU is the exact-erf form (legacy tower) instead of tanh
+  int act_kind;            // jg_act of the compiled patterns' activation stages (one kind per op)
   int dbg;                 // ablation switches (JG_DBG env, timing experiments only)
   unsigned ep;             // JG_EP_* pattern of the stage list (JG_EP_GENERIC: interpret hst[])
   float alpha1, alpha2;    // DyT alphas of norm1 / norm2
@@ -150,7 +150,7 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   HStageArg hst[JG_MAX_STAGES] = {};
   int add_slot = -1, nmd_slot = -1;
   int pool_op = -1;         // index of the OP_POOL (masked max) fused into this conv's epilogue, or -1
-  bool act_erf = false;     // the op's GELU stages are the exact-erf form
+  int act_kind = JG_ACT_GELU_TANH;   // activation of the op's ACT stages (the compiled patterns allow one kind per op)
   bool pool_f16s = false;   // (MAXPOOL1D ops) input and output are F16S tensors
   unsigned ep = JG_EP_GENERIC;
   float alpha1 = 0.f, alpha2 = 0.f;

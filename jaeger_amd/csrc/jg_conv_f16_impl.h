@@ -551,8 +551,16 @@ void conv_f16x3_kernel(ConvHArgs a) {
           }
         };
         auto st_gelu = [&]() {
+          if (a.act_kind == JG_ACT_GELU_TANH) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) x[r] = a.act_erf ? gelu_erf(x[r]) : fast_gelu(x[r]);
+            for (int r = 0; r < 16; ++r) x[r] = fast_gelu(x[r]);
+          } else if (a.act_kind == JG_ACT_GELU_ERF) {    // one activation kind per op: uniform branches
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = gelu_erf(x[r]);
+          } else {                                        // ReLU
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = fmaxf(x[r], 0.0f);
+          }
         };
         auto st_nmd = [&]() {
           // masked channel sums: accumulated per lane over the wave's four position blocks of this
@@ -838,6 +846,10 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
       return launch_ke<K, (JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1)>(e, a, s);                     \
     case (JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1):                                                \
       return launch_ke<K, (JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1)>(e, a, s);                     \
+    case (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2):                                    \
+      return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)>(e, a, s);         \
+    case (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_DYT | JG_EP_ACT2):                  \
+      return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_DYT | JG_EP_ACT2)>(e, a, s); \
     case (JG_EP_ACT1 | JG_EP_NORM2_AFF): return launch_ke<K, (JG_EP_ACT1 | JG_EP_NORM2_AFF)>(e, a, s); \
     case (JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2):                                                \
       return launch_ke<K, (JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)>(e, a, s);                     \
@@ -868,6 +880,8 @@ int jg_conv_f16_part_flat(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2)
     JG_CASE(JG_EP_ACT1 | JG_EP_NORM2_AFF)
     JG_CASE(JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_DYT | JG_EP_ACT2)
 #undef JG_CASE
     default: break;
   }

@@ -201,3 +201,35 @@ def test_f16x3_repeatable(name, fsize, n_win):
         bad += any(not np.array_equal(first[k], again[k]) for k in first)
     eng.close()
     assert bad == 0, f"{bad}/40 repeats differ"
+
+
+def test_forward_variant_without_inner_nmd_taps():
+    """A 128-channel model whose residual stacks are followed by BN + GELU without an NMD tap
+    (stage list conv2: BIAS+BN+ADD+ACT+BN+ACT) must stay on the split-f16 path (compiled pattern) and
+    match the oracle."""
+    import copy
+
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("brain"))
+    layers = cfg["representation_learner"]["hidden_layers"]
+    taps = [i for i, layer in enumerate(layers) if layer["name"] == "nmd"]
+    for i in (taps[2], taps[1]):
+        del layers[i]
+    cfg["reliability_model"]["input_shape"] = 256
+    weights = ofwd.random_weights(cfg, seed=11)
+    rng = np.random.Generator(np.random.PCG64(12))
+    fsize, n_win = 1500, 8
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.01)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0)
+    assert eng.model.precision == "f16x3"
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    eng.close()
+    ids = oenc.encode_windows([seq[s:s + fsize].tobytes() for s in starts], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    assert ref["nmd"].shape == (n_win, 256)
+    for k in ("prediction", "reliability"):
+        assert float(np.abs(got[k] - ref[k]).max()) <= TOL, k
