@@ -233,3 +233,34 @@ def test_forward_variant_without_inner_nmd_taps():
     assert ref["nmd"].shape == (n_win, 256)
     for k in ("prediction", "reliability"):
         assert float(np.abs(got[k] - ref[k]).max()) <= TOL, k
+
+
+@pytest.mark.parametrize("fsize", [1500, 2000])
+def test_full_chunks_f16x3_vs_exact_f32(fsize):
+    """At bench-sized chunks (several full 1024-window chunks + a ragged tail, N runs, ragged last
+    windows) the split-f16 path must agree with the exact-f32 path window by window and be repeatable -
+    covers the persistent-grid scheduling, the table first layer, the fused pool and (at 2000 bp) the
+    window-packed tiling at sizes the CPU oracle cannot reach."""
+    from jaeger_amd.engine import JaegerHipEngine
+    cfg = load_model_cfg("brain")
+    from oracle import forward as ofwd
+    weights = ofwd.random_weights(cfg, seed=38341)
+    rng = np.random.Generator(np.random.PCG64(99))
+    n_win = 2 * 1024 + 333
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.004)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    lens[::97] = rng.integers(fsize // 2, fsize, lens[::97].size)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, precision="f16x3")
+    a = eng.predict_windows(seq, starts, lens, fsize)
+    b = eng.predict_windows(seq, starts, lens, fsize)
+    eng.model.set_precision("f32")
+    c = eng.predict_windows(seq, starts, lens, fsize)
+    eng.close()
+    for k in ("prediction", "reliability", "embedding", "nmd"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    np.testing.assert_array_equal(a["counts"], c["counts"])
+    for k in ("prediction", "reliability"):
+        err = float(np.abs(a[k] - c[k]).max())
+        print(fsize, k, f"{err:.2e}")
+        assert err <= TOL, (k, err)
