@@ -112,11 +112,17 @@ def load():
             "jaeger_amd has no CPU fallback.")
     # PyTorch-ROCm bundles its own libamdhip64.so.7; importing it first makes the loader
     # resolve our DT_NEEDED to that same copy, so torch tensors, RCCL and this library
-    # share ONE HIP runtime in the process (torch is plumbing here, never compute).
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # share ONE HIP runtime in the process (torch is plumbing here, never compute).  A
+    # single-GPU command-line run needs no torch at all: JAEGER_HIP_TORCH=0 (set by
+    # `python -m jaeger_amd` outside torchrun) skips the ~2 s import and binds the ROCm copy.
+    import sys
+    want_torch = os.environ.get("JAEGER_HIP_TORCH", "1") != "0" or "torch" in sys.modules \
+        or int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if want_torch:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(str(path))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)            # AttributeError if the .so misses a declared symbol
