@@ -17,21 +17,21 @@
 //   weights  [plane][tap][kc = cin/8][cout_pad][8 halfs], pre-scaled by 2^s so
 //     the lo parts stay out of the f16 subnormal range (undone in the epilogue).
 //
-// Work decomposition.  One persistent workgroup (8 waves, 4 x 2, each wave 64
-// positions x 64 channels of a tile) walks PAIRS of 256-position x 128-channel
-// output tiles that share every weight slice.  The K loop runs in steps = (16-
-// channel chunk, tap): a step needs one 8 KB weight slice and the chunk's two
-// activation slices.  Everything moves global->LDS by DMA (global_load_lds with
-// an SGPR base + per-lane 32-bit offset, no register staging): weight slices
-// K-2 steps ahead into a ring with one slot per tap, activation slices one chunk
-// ahead into a double buffer.  Steps wait with COUNTED s_waitcnt vmcnt, so the
-// DMA queue never drains; zero padding / mask multiply are applied by zero-
-// filling the affected 16-byte pieces after the DMA has landed (rare), the
-// embedding gather of the first conv is a DMA from the pre-split table.
-// The MFMAs take the WEIGHTS as their A operand, so an accumulator register
-// holds one channel and a lane holds one position: the fused epilogue (folded
-// bias/batch-norm affine, residual add, GELU, NMD tap, f16 re-split) needs no
+// Work decomposition.  Persistent workgroups of 4 waves (2 x 2, each wave 128 positions x 64
+// channels = 8 accumulator blocks of 32 x 32) walk 256-position x 128-channel output tiles; two
+// workgroups are resident per CU for k = 5.  The K loop runs in steps = (16-channel chunk, tap): a
+// step needs one 8 KB weight slice and the chunk's activation slice.  Everything moves
+// global->LDS by DMA (global_load_lds with an SGPR base + per-lane 32-bit offset, no register
+// staging): weight slices K-2 steps ahead into a ring with one slot per tap, activation slices one
+// chunk ahead into a double buffer.  Steps wait with COUNTED s_waitcnt vmcnt, so the DMA queue
+// never drains; zero padding / mask multiply are applied by zero-filling the affected 16-byte
+// pieces after the DMA has landed (rare).  The MFMAs take the WEIGHTS as their A operand, so an
+// accumulator register holds one channel and a lane holds one position: the fused epilogue (folded
+// bias / batch-norm affine, DyT, residual add, GELU, NMD tap, max pool, f16 re-split) needs no
 // cross-lane transpose and reads its per-channel parameters from LDS.
+// Variants of the same kernel (template parameters): LUT - the first layer as table lookups
+// instead of matrix-core work; FLAT - window-packed position tiling.  The instantiations are
+// compiled in four translation units (JG_CONV_PART, see the bottom of this file).
 #include <stdio.h>
 #include <stdlib.h>
 
