@@ -346,6 +346,11 @@ void conv_f16x3_kernel(ConvHArgs a) {
     for (int t = 0; t < WA; ++t) issue_w(0, t);
   }
   int xc = 0;                      // running chunk count: activation buffer parity
+#ifdef JG_VALU_PROBE
+  float probe[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) probe[q] = (float)(lane + q);
+#endif
   for (int pass = 0; pass < my_pairs; ++pass) {
     if constexpr (LUT) {
 #pragma unroll
@@ -436,6 +441,19 @@ void conv_f16x3_kernel(ConvHArgs a) {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[tn], xh[tq], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xh[tq], c, 0, 0, 0);
               }
+#ifdef JG_VALU_PROBE
+            // experiment: independent VALU work next to the MFMAs of a step (does the scheduler hide it
+            // in the matrix cores' shadow?)  JG_VALU_PROBE = number of dummy FMAs per 12-MFMA group
+#pragma unroll
+            for (int q = 0; q < JG_VALU_PROBE; ++q) probe[q & 7] = fmaf(probe[q & 7], 1.0001f, 0.5f);
+#if JG_VALU_PROBE_SCHED
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // one MFMA
+              __builtin_amdgcn_sched_group_barrier(0x002, JG_VALU_PROBE / 12, 0);         // then its share of VALU
+            }
+#endif
+#endif
             if (tp == 0) {
               __builtin_amdgcn_sched_barrier(0);
               issue_step();
@@ -755,6 +773,9 @@ void conv_f16x3_kernel(ConvHArgs a) {
     if constexpr (!LUT) load_bytes(np);   // position bytes of the pass after next
     JG_ST(4);
   }
+#ifdef JG_VALU_PROBE
+  if (probe[0] + probe[1] + probe[2] + probe[3] + probe[4] + probe[5] + probe[6] + probe[7] == 12345.678f) a.overflow[0] = 4;
+#endif
   JG_ST_END;
 }
 
