@@ -636,7 +636,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
               const _Float16 hv = (_Float16)v;
               hh4[j] = hv;
               ll4[j] = (_Float16)(v - (float)hv);
-              vmax = fmaxf(vmax, live ? fabsf(v) : 0.f);
+              vmax = fmaxf(vmax, fabsf(v));      // dead lanes hold finite values too (zero-filled inputs)
             }
             ph[g] = *reinterpret_cast<uint2 *>(&hh4);
             pl[g] = *reinterpret_cast<uint2 *>(&ll4);
