@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-dbg", type=int, default=None,
+                    help="experiments only: set the conv kernel's JG_DBG ablation mask after the warm-up steps "
+                         "(the timed steps then read real activations; their results are wrong)")
     args = ap.parse_args()
 
     import torch
@@ -164,6 +167,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if args.timed_dbg is not None:
+        os.environ["JG_DBG"] = str(args.timed_dbg)
     eng.device.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -58,6 +58,13 @@ bool jg_conv_f16_has_pattern(unsigned ep, bool first_layer) {
   return false;
 }
 
+// JG_DBG ablation mask: read at every launch, so that an experiment can warm up on real data and then
+// switch (bench.py --timed-dbg)
+static int jg_dbg_env(void) {
+  const char *ev = getenv("JG_DBG");
+  return ev ? atoi(ev) : 0;
+}
+
 int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   JG_REQUIRE(a.cout_pad == HN && a.cout % 16 == 0, JG_ERR_UNSUPPORTED,
              "conv_f16x3: cout=%d (needs 128 padded, multiple of 16)", a.cout);
@@ -65,9 +72,7 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_REQUIRE(a.ids != nullptr && jg_conv_lut_supports(a.k, a.dil, a.lut_vocab), JG_ERR_UNSUPPORTED,
                "conv lut: k=%d dilation=%d vocab=%d outside the table variant's limits", a.k, a.dil, a.lut_vocab);
     if (a.rows == 0 || a.L_out <= 0) return JG_OK;
-    static int dbg_l = -1;
-    if (dbg_l < 0) { const char *ev = getenv("JG_DBG"); dbg_l = ev ? atoi(ev) : 0; }
-    const_cast<ConvHArgs &>(a).dbg = dbg_l;
+    const_cast<ConvHArgs &>(a).dbg = jg_dbg_env();
     return jg_conv_f16_part_lut(e, a, s);
   }
   JG_REQUIRE(jg_conv_f16_supports(a.k, a.dil), JG_ERR_UNSUPPORTED,
@@ -76,9 +81,7 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   JG_REQUIRE((double)a.rows * a.cc_in * 4.0 * a.L_in * 16.0 < 4.0e9, JG_ERR_UNSUPPORTED,
              "conv_f16x3: activation tensor of %d rows exceeds the 32-bit DMA offset range", a.rows);
   if (a.rows == 0 || a.L_out <= 0) return JG_OK;
-  static int dbg = -1;
-  if (dbg < 0) { const char *ev = getenv("JG_DBG"); dbg = ev ? atoi(ev) : 0; }
-  const_cast<ConvHArgs &>(a).dbg = dbg;
+  const_cast<ConvHArgs &>(a).dbg = jg_dbg_env();
   if (a.flat) {
     JG_REQUIRE(a.k == 5, JG_ERR_UNSUPPORTED, "conv_f16x3: window-packed tiling is only built for k = 5");
     return jg_conv_f16_part_flat(e, a, s);

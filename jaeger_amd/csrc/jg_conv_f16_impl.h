@@ -118,6 +118,15 @@ static __device__ unsigned long long jg_stamp_acc[8];
 #define JG_ST_END
 #endif
 
+// Wave priority: a wave in its main loop runs at priority 2, in its epilogue at 0, so that the matrix-core
+// stream of one resident workgroup is not held up by the other's epilogue arithmetic (+1.4 % measured A/B;
+// the reverse, or raising the priority only around each step's MFMA cluster, gains less).  -DJG_PRIO=0: off.
+#ifndef JG_PRIO
+#define JG_PRIO 1
+#endif
+#define JG_PRIO_MAIN() do { if (JG_PRIO) __builtin_amdgcn_s_setprio(2); } while (0)
+#define JG_PRIO_EPI() do { if (JG_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+
 // LUT = true is the first-layer variant: a convolution whose input is an embedding gather is linear
 // in one-hot ids, so y[p] = sum_t T_t[id[p + t]] with T_t = E . W_t (vocab x Cout, exact f32, built
 // on the host in f64).  The matrix-core loop is replaced by LDS row lookups (k rows of 64 channels per
@@ -351,6 +360,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) probe[q] = (float)(lane + q);
 #endif
+  JG_PRIO_MAIN();
   for (int pass = 0; pass < my_pairs; ++pass) {
     if constexpr (LUT) {
 #pragma unroll
@@ -437,6 +447,25 @@ void conv_f16x3_kernel(ConvHArgs a) {
               for (int tn = 0; tn < 2; ++tn) {
                 // weights are the MFMA A operand: acc rows = channels, cols = positions
                 f32x16 &c = acc[tp * 2 + tq][tn];
+#ifdef JG_MFMA16_PROBE
+                // experiment build (timing only, results are garbage): the same operand registers and LDS
+                // reads, but every 32x32x16 MFMA replaced by two 16x16x32 ones (same MACs) on quarter slices
+                // of the accumulator block - does the chip hold a higher clock on that shape in THIS loop?
+                {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const half8 *ops[3][2] = {{&wh[tn], &xl[tq]}, {&wl[tn], &xh[tq]}, {&wh[tn], &xh[tq]}};
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                  for (int s2 = 0; s2 < 2; ++s2) {
+                    const int q0 = 4 * (2 * (t & 1) + s2);
+                    f32x4 d = {c[q0], c[q0 + 1], c[q0 + 2], c[q0 + 3]};
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(*ops[m][0], *ops[m][1], d, 0, 0, 0);
+                    c[q0] = d[0]; c[q0 + 1] = d[1]; c[q0 + 2] = d[2]; c[q0 + 3] = d[3];
+                  }
+                continue;
+                }
+#endif
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xl[tq], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[tn], xh[tq], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xh[tq], c, 0, 0, 0);
@@ -470,6 +499,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
     if (a.dbg & 1) {
       if (acc[0][0][0] + acc[1][1][3] + acc[2][1][7] + acc[3][0][9] == 12345.678f) a.overflow[0] = 2;
     } else {
+      JG_PRIO_EPI();
       float vmax = 0.f;             // running max |output|: f16-range guard
       float nmd_acc[16];            // per-lane NMD sums of the current channel block
       // what a block needs from memory, fetched one block ahead so the loads of block b+1
@@ -765,6 +795,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
         }
       }
       if (!(vmax <= 65000.0f) && a.overflow != nullptr && a.dbg == 0) atomicOr(a.overflow, 1);
+      JG_PRIO_MAIN();
     }
     zero_acc();
 #pragma unroll
