@@ -210,6 +210,15 @@ int jg_fasta_parse(const uint8_t *text, int64_t n, int64_t max_records, uint8_t 
 int jg_dust_mask(uint8_t *bases, const int64_t *offsets, int64_t n_records, int32_t window,
                  int32_t threshold, int32_t n_threads, int64_t *n_masked);
 
+/* ---- CRF window decoding (host only; replaces the per-contig loop over postprocess/helpers.py:398-449
+ * viterbi_decode that postprocess/collect.py:343-346 runs for `jaeger predict --crf`) ---------------
+ * logits (n_windows, n_classes) f32 row-major; chain c covers windows [first[c], first[c+1]) (first has
+ * n_chains + 1 entries); costs (n_classes, n_classes) f64, costs[a][b] = price of a -> b between adjacent
+ * windows (build_transition_costs, helpers.py:347-395); path (n_windows) receives the MAP class of every
+ * window.  f64 log-softmax emissions, ties to the lowest class index, chains of one window = argmax. */
+int jg_viterbi_decode(const float *logits, int64_t n_windows, int32_t n_classes, const int64_t *first,
+                      int64_t n_chains, const double *costs, int32_t *path);
+
 /* ---- terminal-repeat scan (replaces utils/termini.py:88-189 scan_for_terminal_repeats: parasail
  * sw_trace_scan_16 of the first vs the last min(max(int(0.04 len), 400), 4000) bases, direct and
  * reverse-complemented; match 2 / mismatch -100 / gap 100 + 5(k-1)) -------------------------------

@@ -2,7 +2,7 @@
 (cli.py:122-370) in front of :func:`jaeger_amd.predict.run_core`.
 
 Flags that select machinery outside the MI355X hot path (``--cpu``, ``--onnx``, ``--quantized``,
-``--int8``, ``--prophage``, ``--crf``, ``--refine``, ``--getsequences``) are accepted so existing
+``--int8``, ``--prophage``, ``--refine``, ``--getsequences``) are accepted so existing
 command lines parse, and rejected at run time with an explicit message - there is no silent
 fallback.  Extra flags: ``--exact-f32`` (disable the split-f16 conv path), ``--chunk``.
 """
@@ -24,10 +24,12 @@ def main():
 @click.option("--stride", type=int, default=1500, help="Stride of the sliding window.")
 @click.option("--dynamic-stride", is_flag=True, help="adaptive overlap per contig")
 @click.option("--dynamic-stride-threshold", type=float, default=10.0)
-@click.option("--crf", is_flag=True, help="[unsupported here]")
-@click.option("--crf-switch-cost", type=float, default=1.0)
-@click.option("--crf-smooth-sigma", type=float, default=0.0)
-@click.option("--crf-min-prob", type=float, default=0.5)
+@click.option("--crf", is_flag=True, help="(experimental) decode per-window calls jointly with a linear-chain CRF "
+                                          "(Viterbi) instead of independent argmax")
+@click.option("--crf-switch-cost", type=float, default=2.0, help="global CRF transition cost lambda (log-prob units)")
+@click.option("--crf-prior", type=click.Choice(["biological", "uniform"]), default="biological")
+@click.option("--crf-transition-matrix", type=click.Path(exists=True), default=None,
+              help='JSON class-name-keyed cost matrix, e.g. {"bacteria": {"phage": 0.5}}; overrides --crf-prior')
 @click.option("--dustmask/--no-dustmask", default=True, help="soft-mask low-complexity regions (symmetric DUST)")
 @click.option("--min-len", "min_len", type=int, default=None, help="Minimum contig length to process")
 @click.option("-m", "--model", type=str, default="default")

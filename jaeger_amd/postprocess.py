@@ -6,8 +6,8 @@ it: ``pred_to_dict`` / ``generate_summary`` / ``write_output`` follow
 ``postprocess/helpers.py:8-219`` - including the quirks a TSV diff would notice
 (entropy on clipped raw logits, fp16 storage of the per-contig statistics, the
 element-wise ``energy`` of multi-class logits, G+C and N% divided by ``fsize``).
-Not implemented (optional flags, out of the hot path's scope): CRF/Viterbi window
-decoding, ``--refine``, prophage extraction.
+``--crf`` window decoding (``helpers.py:273-449``) runs natively for all contigs at once
+(``jg_viterbi_decode``).  Not implemented: ``--refine``, prophage extraction.
 """
 
 from __future__ import annotations
@@ -86,6 +86,97 @@ def frac_above_threshold(pairs, threshold: float = 0.5, fmt: str = "{:.2f}", non
     return fmt.format((arr > threshold).mean())
 
 
+# ---- CRF window decoding (postprocess/helpers.py:273-449) --------------------------------
+#: co-occurrence tiers of the biological transition prior, lower-cased class names
+#: (helpers.py:283-313): 0.5 = plausible on one contig, 3.0 = implausible, others 1.0
+_CRF_PRIOR_TIERS = (
+    (0.5, (("bacteria", "phage"), ("bacteria", "plasmid"), ("archaea", "phage"), ("archaea", "plasmid"),
+           ("phage", "plasmid"), ("eukarya", "virus"))),
+    (3.0, (("bacteria", "eukarya"), ("archaea", "eukarya"), ("bacteria", "archaea"), ("eukarya", "phage"),
+           ("eukarya", "plasmid"))),
+)
+
+
+def default_transition_prior(class_names: list[str]) -> np.ndarray:
+    """Symmetric prior matrix P, zero diagonal, neutral cost 1.0 for unlisted pairs; class names
+    that are absent are skipped (helpers.py:316-344)."""
+    names = [str(n).lower() for n in class_names]
+    prior = np.ones((len(names), len(names)), dtype=np.float64)
+    np.fill_diagonal(prior, 0.0)
+    for value, pairs in _CRF_PRIOR_TIERS:
+        for a, b in pairs:
+            if a in names and b in names:
+                i, j = names.index(a), names.index(b)
+                prior[i, j] = prior[j, i] = value
+    return prior
+
+
+def build_transition_costs(class_names: list[str], switch_cost: float, prior: str = "biological",
+                           user_matrix: dict | None = None) -> np.ndarray:
+    """``lambda * P`` (helpers.py:347-395): ``user_matrix`` ({"bacteria": {"phage": 0.5}}, applied
+    symmetrically, unknown names ignored) overrides ``prior`` ("biological" | "uniform")."""
+    names = [str(n).lower() for n in class_names]
+    n = len(names)
+    if user_matrix:
+        p = np.ones((n, n), dtype=np.float64)
+        np.fill_diagonal(p, 0.0)
+        for a, row in user_matrix.items():
+            a = str(a).lower()
+            if a not in names or not isinstance(row, dict):
+                continue
+            for b, value in row.items():
+                b = str(b).lower()
+                if b not in names:
+                    continue
+                i, j = names.index(a), names.index(b)
+                p[i, j] = p[j, i] = float(value)
+        np.fill_diagonal(p, 0.0)
+    elif prior == "uniform":
+        p = np.ones((n, n), dtype=np.float64)
+        np.fill_diagonal(p, 0.0)
+    else:
+        p = default_transition_prior(names)
+    return float(switch_cost) * p
+
+
+def viterbi_decode_chains(logits: np.ndarray, first: np.ndarray, switch_cost: float = 2.0,
+                          transition_costs: np.ndarray | None = None) -> np.ndarray:
+    """MAP class path of every chain (contig) of a window-logit matrix in one native call
+    (``jg_viterbi_decode``): chain c = rows ``first[c]:first[c+1]``.  Semantics of
+    helpers.py:398-449 per chain (f64 log-softmax emissions, uniform ``switch_cost`` off the
+    diagonal when no matrix is given, ties to the lowest class index)."""
+    import ctypes as C
+
+    from . import _lib as L
+    z = np.ascontiguousarray(np.asarray(logits, dtype=np.float32))
+    if z.ndim == 1:
+        z = z.reshape(1, -1)
+    n, c = z.shape
+    if transition_costs is None:
+        costs = np.full((c, c), float(switch_cost), dtype=np.float64)
+        np.fill_diagonal(costs, 0.0)
+    else:
+        costs = np.ascontiguousarray(np.asarray(transition_costs, dtype=np.float64))
+        if costs.shape != (c, c):
+            raise ValueError(f"transition costs {costs.shape} do not match {c} classes")
+    first = np.ascontiguousarray(np.asarray(first, dtype=np.int64))
+    path = np.zeros(n, dtype=np.int32)
+    L.check(L.load().jg_viterbi_decode(z.ctypes.data_as(C.c_void_p), n, c, first.ctypes.data_as(C.c_void_p),
+                                       len(first) - 1, costs.ctypes.data_as(C.c_void_p),
+                                       path.ctypes.data_as(C.c_void_p)), "jg_viterbi_decode")
+    return path.astype(np.int64)
+
+
+def viterbi_decode(logits: np.ndarray, switch_cost: float = 2.0,
+                   transition_costs: np.ndarray | None = None) -> np.ndarray:
+    """One contig's window sequence (T, C) -> (T,) class indices (helpers.py:398-449).  The reference
+    takes f64 logits; the engine's are f32, and that is what the native decoder reads."""
+    z = np.asarray(logits)
+    if z.ndim == 1:
+        z = z.reshape(1, -1)
+    return viterbi_decode_chains(z, np.array([0, z.shape[0]], np.int64), switch_cost, transition_costs)
+
+
 # ---- aggregation (postprocess/collect.py:247-435) --------------------------------------
 def pred_to_dict(y_pred: dict, **kwargs) -> tuple[dict, dict]:
     """Window outputs + metadata -> per-contig statistics.
@@ -95,8 +186,7 @@ def pred_to_dict(y_pred: dict, **kwargs) -> tuple[dict, dict]:
     length, ``meta_5..8`` base counts, ``meta_9`` gc skew.  kwargs: ``fsize``,
     ``class_map`` ({"num_classes": ...}), ``term_repeats`` (DataFrame).
     """
-    if kwargs.get("crf_switch_cost") is not None:
-        raise NotImplementedError("--crf window decoding is not part of the MI355X predict path")
+    crf_switch_cost = kwargs.get("crf_switch_cost")
     split_flags = np.array(y_pred["meta_2"], dtype=np.int32)
     split_indices = np.where(split_flags == 1)[0] + 1
     classifier_type = "binary" if y_pred["prediction"].shape[-1] == 1 else "softmax"
@@ -104,6 +194,7 @@ def pred_to_dict(y_pred: dict, **kwargs) -> tuple[dict, dict]:
         split_indices = split_indices[:-1]
 
     predictions = np.split(y_pred["prediction"], split_indices, axis=0)
+    chain_first = np.concatenate(([0], split_indices, [y_pred["prediction"].shape[0]])).astype(np.int64)
     has_reliability = "reliability" in y_pred
     ood = np.split(y_pred["reliability"], split_indices, axis=0) if has_reliability else None
 
@@ -125,7 +216,16 @@ def pred_to_dict(y_pred: dict, **kwargs) -> tuple[dict, dict]:
     if classifier_type == "softmax":
         entropy_pred = [softmax_entropy(p) for p in predictions]
         consensus = np.argmax(pred_sum, axis=1)
-        frag_pred = [np.argmax(p, axis=-1) for p in predictions]
+        if crf_switch_cost is not None:
+            # joint MAP decoding of each contig's windows instead of independent argmax (collect.py:269-289,343-346)
+            cm = kwargs.get("class_map")
+            names = [name for _, name in sorted(zip(cm.get("index"), cm.get("class")), key=lambda t: int(t[0]))]
+            costs = build_transition_costs(names, switch_cost=crf_switch_cost, prior=kwargs.get("crf_prior", "biological"),
+                                           user_matrix=kwargs.get("crf_transition_matrix"))
+            frag_pred = np.split(viterbi_decode_chains(y_pred["prediction"], chain_first, crf_switch_cost, costs),
+                                 split_indices)
+        else:
+            frag_pred = [np.argmax(p, axis=-1) for p in predictions]
         per_class_counts = [update_dict(np.unique(fp, return_counts=True), num_classes) for fp in frag_pred]
         prophage_contam = (pred_sum[:, 1] < pred_var[:, 1]) & (consensus == 0)
         host_contam = (pred_sum[:, 1] < pred_var[:, 1]) & (consensus == 1)
@@ -134,7 +234,13 @@ def pred_to_dict(y_pred: dict, **kwargs) -> tuple[dict, dict]:
         consensus = np.array([sigmoid(p) for p in pred_sum])
         consensus[consensus > 0.5] = 1.0
         consensus[consensus <= 0.5] = 0.0
-        frag_pred = [(sigmoid(p) > 0.5).astype(int) for p in predictions]
+        if crf_switch_cost is not None:
+            # two-class CRF on stacked [0, z] logits, uniform switch cost (collect.py:365-372)
+            z = np.asarray(y_pred["prediction"], np.float32).reshape(-1, 1)
+            frag_pred = np.split(viterbi_decode_chains(np.concatenate([np.zeros_like(z), z], axis=-1), chain_first,
+                                                       crf_switch_cost), split_indices)
+        else:
+            frag_pred = [(sigmoid(p) > 0.5).astype(int) for p in predictions]
         per_class_counts = [update_dict(np.unique(fp, return_counts=True), num_classes) for fp in frag_pred]
         prophage_contam = (pred_sum < pred_var) & (consensus == 0)
         host_contam = (pred_sum < pred_var) & (consensus == 1)

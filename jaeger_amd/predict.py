@@ -233,11 +233,19 @@ def run_core(**kwargs) -> int:
     if table_path.exists() and not kwargs.get("overwrite"):
         lg.error("output file exists. enable --overwrite option to overwrite the output file.")
         sys.exit(1)
-    for flag in ("prophage", "refine", "crf", "quantized", "onnx", "int8", "cpu", "getsequences"):
+    for flag in ("prophage", "refine", "quantized", "onnx", "int8", "cpu", "getsequences"):
         if kwargs.get(flag):
             lg.error(f"--{flag} is not available on the MI355X predict path (jaeger_amd has no CPU / "
-                     "alternative-backend fallback; prophage / refinement / CRF post-processing is out of scope)")
+                     "alternative-backend fallback; prophage / refinement post-processing is out of scope)")
             sys.exit(1)
+    # experimental CRF (Viterbi) window decoding (commands/predict.py:288-307)
+    crf_kw = {}
+    if kwargs.get("crf"):
+        lg.warning("CRF window decoding is experimental; results may change between releases")
+        crf_kw = {"crf_switch_cost": kwargs.get("crf_switch_cost", 2.0), "crf_prior": kwargs.get("crf_prior", "biological")}
+        matrix_path = kwargs.get("crf_transition_matrix")
+        if matrix_path:
+            crf_kw["crf_transition_matrix"] = json.loads(Path(matrix_path).read_text())
     dusted = False
     if kwargs.get("dustmask", True):
         t_dust = time.time()
@@ -332,7 +340,7 @@ def run_core(**kwargs) -> int:
         y_pred = {k: np.concatenate([yr[k][b:e] for yr, b, e in ordered], axis=0) for k in keys}
         dist.barrier()
 
-    data, data_full = pred_to_dict(y_pred, class_map=engine.class_map, fsize=fsize, term_repeats=term_repeats)
+    data, data_full = pred_to_dict(y_pred, class_map=engine.class_map, fsize=fsize, term_repeats=term_repeats, **crf_kw)
     n_written = write_output(data, labels=engine.class_map.get("class"), indices=engine.class_map.get("index"),
                              output_table_path=table_path, output_phage_table_path=phage_path,
                              reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))

@@ -45,11 +45,12 @@ def test_cli_defaults_and_required():
     assert r.exit_code != 0 and "--input" in r.output
     r = CliRunner().invoke(main, ["predict", "--help"])
     for flag in ("--fsize", "--stride", "--dynamic-stride", "--min-len", "--model_path", "--rc", "--pc",
-                 "--window-scores", "--save-embedding", "--save-nmd", "--overwrite", "--no-dustmask"):
+                 "--window-scores", "--save-embedding", "--save-nmd", "--overwrite", "--no-dustmask", "--crf",
+                 "--crf-switch-cost", "--crf-prior", "--crf-transition-matrix"):
         assert flag in r.output
 
 
-@pytest.mark.parametrize("flag", ["--cpu", "--onnx", "--prophage", "--refine", "--crf", "--quantized"])
+@pytest.mark.parametrize("flag", ["--cpu", "--onnx", "--prophage", "--refine", "--quantized"])
 def test_cli_rejects_out_of_scope_flags(tmp_path, flag):
     root = make_model_dir(tmp_path / "m")
     r = CliRunner().invoke(main, ["predict", "-i", str(GOLDEN / "test_contigs.fasta"), "-o", str(tmp_path / "out"),

@@ -47,7 +47,7 @@ def _compare_tsv(got_path, exp_path):
             assert got[col].astype(str).tolist() == exp[col].astype(str).tolist(), col
 
 
-def _expected(tmp_path, records, cfg, weights, fsize, stride, min_len, batch):
+def _expected(tmp_path, records, cfg, weights, fsize, stride, min_len, batch, **crf_kw):
     from jaeger_amd.postprocess import pred_to_dict, write_output
     from jaeger_amd.predict import _concat_predictions
     if min_len is not None and min_len < fsize:
@@ -56,8 +56,8 @@ def _expected(tmp_path, records, cfg, weights, fsize, stride, min_len, batch):
     else:
         y = _oracle_pass(records, cfg, weights, fsize, stride, min_len or fsize, None)
     classes = [c["class"] for c in cfg["class_label_map"]]
-    data, _ = pred_to_dict(y, class_map={"num_classes": len(classes)}, fsize=fsize,
-                           term_repeats=oracle_term_repeats(records, fsize))
+    cm = {"num_classes": len(classes), "class": classes, "index": [c["label"] for c in cfg["class_label_map"]]}
+    data, _ = pred_to_dict(y, class_map=cm, fsize=fsize, term_repeats=oracle_term_repeats(records, fsize), **crf_kw)
     exp, exp_ph = tmp_path / "expected.tsv", tmp_path / "expected_phages.tsv"
     write_output(data, labels=classes, indices=[c["label"] for c in cfg["class_label_map"]], output_table_path=exp,
                  output_phage_table_path=exp_ph, reliability_cutoff=0.1, phage_score=3)
@@ -93,6 +93,33 @@ def test_cli_predict_bundled_contigs(tmp_path):
     r = CliRunner().invoke(main, ["predict", "-i", str(fasta), "-o", str(tmp_path / "out"), "--model_path", str(root),
                                   "--fsize", "1500"])
     assert r.exit_code == 1
+
+
+def test_cli_crf_window_decoding(tmp_path):
+    """--crf: per-window calls decoded jointly per contig (commands/predict.py:288-307, collect.py:269-346);
+    the window_summary / per-class counts change, the scores do not."""
+    import json
+
+    from jaeger_amd.cli import main
+    from jaeger_amd.fragment import read_fasta
+    from oracle import forward as ofwd
+    root = make_model_dir(tmp_path / "m")
+    cfg = load_model_cfg("brain")
+    weights = ofwd.random_weights(cfg, seed=38341)
+    fasta = GOLDEN / "test_contigs.fasta"
+    matrix = {"bacteria": {"phage": 0.25}, "eukarya": {"virus": 0.1}}
+    (tmp_path / "costs.json").write_text(json.dumps(matrix))
+    records = [(n, s.decode()) for n, s in read_fasta(str(fasta))]
+    for tag, extra, kw in (
+            ("a", ["--crf"], dict(crf_switch_cost=2.0, crf_prior="biological")),
+            ("b", ["--crf", "--crf-switch-cost", "0.7", "--crf-prior", "uniform"], dict(crf_switch_cost=0.7, crf_prior="uniform")),
+            ("c", ["--crf", "--crf-transition-matrix", str(tmp_path / "costs.json")],
+             dict(crf_switch_cost=2.0, crf_transition_matrix=matrix))):
+        r = CliRunner().invoke(main, ["predict", "-i", str(fasta), "-o", str(tmp_path / f"out_{tag}"), "--model_path",
+                                      str(root), "--fsize", "1500", "--stride", "1500", "--no-dustmask"] + extra)
+        assert r.exit_code == 0, r.output
+        exp, _, _ = _expected(tmp_path, records, cfg, weights, 1500, 1500, None, 96, **kw)
+        _compare_tsv(tmp_path / f"out_{tag}" / "38341_1.4M" / "test_contigs.tsv", exp)
 
 
 def test_cli_two_pass_short_contigs(tmp_path):
