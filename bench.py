@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="experiments only: no HIP events around the conv launches (roofline fields read 0)")
     ap.add_argument("--timed-dbg", type=int, default=None,
                     help="experiments only: set the conv kernel's JG_DBG ablation mask after the warm-up steps "
                          "(the timed steps then read real activations; their results are wrong)")
@@ -169,7 +171,7 @@ def main():
     fence()
     if args.timed_dbg is not None:
         os.environ["JG_DBG"] = str(args.timed_dbg)
-    eng.device.profile_enable(True)
+    eng.device.profile_enable(not args.no_profile)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         gathered = step()

@@ -124,6 +124,9 @@ static __device__ unsigned long long jg_stamp_acc[8];
 #ifndef JG_PRIO
 #define JG_PRIO 1
 #endif
+#ifndef JG_PAIRED
+#define JG_PAIRED 1     // k = 5: one barrier per two taps (+1.3 % measured A/B); 0 = one per tap
+#endif
 #define JG_PRIO_MAIN() do { if (JG_PRIO) __builtin_amdgcn_s_setprio(2); } while (0)
 #define JG_PRIO_EPI() do { if (JG_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 
@@ -352,7 +355,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
     load_bytes(np);
     issue_x(0, 0);
 #pragma unroll
-    for (int t = 0; t < WA; ++t) issue_w(0, t);
+    for (int t = 0; t < ((K == 5 && JG_PAIRED) ? 4 : WA); ++t) issue_w(0, t);
   }
   int xc = 0;                      // running chunk count: activation buffer parity
 #ifdef JG_VALU_PROBE
@@ -391,6 +394,90 @@ void conv_f16x3_kernel(ConvHArgs a) {
       const bool last_chunk = cc == a.cc_in - 1;
       const bool tail = last_chunk && pass == my_pairs - 1;     // nothing is issued behind this chunk
       const uint4 *A = Abuf + abuf * a_items + x_frag;
+      if constexpr (K == 5 && JG_PAIRED) {
+        // Paired steps: one barrier per TWO taps - (t0 t1) (t2 t3) (t4) - so a chunk costs three barriers and
+        // three counted waits instead of five.  Ring slots stay one per tap; the slices of a step are issued two
+        // steps ahead: (cc, t4) and the next chunk's activations at step A, the next chunk's (t0 t1) at B,
+        // (t2 t3) at C.
+        const int ncc = last_chunk ? 0 : cc + 1;
+        auto taps = [&](int t, auto &&mid) {
+          const uint4 *B = Wbuf + t * W_ITEMS + w_frag;
+          half8 wh[2], wl[2];
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            const uint4 vh = B[tn * 32];
+            const uint4 vl = B[2 * HN + tn * 32];
+            wh[tn] = *reinterpret_cast<const half8 *>(&vh);
+            wl[tn] = *reinterpret_cast<const half8 *>(&vl);
+          }
+#pragma unroll
+          for (int tp = 0; tp < TM / 2; ++tp) {
+            half8 xh[2], xl[2];
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq) {
+              const uint4 vh = A[(tp * 2 + tq) * 32 + t * a.dil];
+              const uint4 vl = A[2 * rows_a + (tp * 2 + tq) * 32 + t * a.dil];
+              xh[tq] = *reinterpret_cast<const half8 *>(&vh);
+              xl[tq] = *reinterpret_cast<const half8 *>(&vl);
+            }
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+              for (int tn = 0; tn < 2; ++tn) {
+                f32x16 &c = acc[tp * 2 + tq][tn];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xl[tq], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[tn], xh[tq], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xh[tq], c, 0, 0, 0);
+              }
+            if (tp == 0) {
+              __builtin_amdgcn_sched_barrier(0);
+              mid();
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        };
+        auto nop = []() {};
+        // ---- step A: taps 0, 1 ----
+        JG_ST(6);
+        wait_vm<2 * W_ITERS>();
+        JG_ST(0);
+        zero_fill(abuf);
+        __syncthreads();
+        JG_ST(1);
+        taps(0, [&]() {
+          issue_w(cc, 4);
+          if (!tail) {
+            if (last_chunk) build_pieces(np);
+            issue_x(ncc, abuf ^ 1);
+          }
+        });
+        taps(1, nop);
+        // ---- step B: taps 2, 3 ----
+        JG_ST(6);
+        if (tail) wait_vm<W_ITERS>();
+        else if (x_last_wave) wait_vm<W_ITERS + A_ITERS>();
+        else wait_vm<W_ITERS + A_ITERS - 1>();
+        JG_ST(0);
+        __syncthreads();
+        JG_ST(1);
+        taps(2, [&]() {
+          if (!tail) { issue_w(ncc, 0); issue_w(ncc, 1); }
+        });
+        taps(3, nop);
+        // ---- step C: tap 4 ----
+        JG_ST(6);
+        if (tail) wait_vm<0>();
+        else if (x_last_wave) wait_vm<2 * W_ITERS + A_ITERS>();
+        else wait_vm<2 * W_ITERS + A_ITERS - 1>();
+        JG_ST(0);
+        __syncthreads();
+        JG_ST(1);
+        taps(4, [&]() {
+          if (!tail) { issue_w(ncc, 2); issue_w(ncc, 3); }
+        });
+        ++xc;
+        continue;
+      }
 #pragma unroll
       for (int t = 0; t < K; ++t) {
         // -- wait for this step's operands, publish them ---------------------------------------
