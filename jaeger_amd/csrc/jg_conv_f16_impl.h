@@ -400,7 +400,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
         // steps ahead: (cc, t4) and the next chunk's activations at step A, the next chunk's (t0 t1) at B,
         // (t2 t3) at C.
         const int ncc = last_chunk ? 0 : cc + 1;
-        auto taps = [&](int t, auto &&mid) {
+        auto taps = [&](int t, auto &&mid, bool has_mid = true) {
           const uint4 *B = Wbuf + t * W_ITEMS + w_frag;
           half8 wh[2], wl[2];
 #pragma unroll
@@ -429,7 +429,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[tn], xh[tq], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xh[tq], c, 0, 0, 0);
               }
-            if (tp == 0) {
+            if (tp == 0 && has_mid) {
               __builtin_amdgcn_sched_barrier(0);
               mid();
               __builtin_amdgcn_sched_barrier(0);
@@ -451,7 +451,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
             issue_x(ncc, abuf ^ 1);
           }
         });
-        taps(1, nop);
+        taps(1, nop, false);
         // ---- step B: taps 2, 3 ----
         JG_ST(6);
         if (tail) wait_vm<W_ITERS>();
@@ -463,7 +463,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
         taps(2, [&]() {
           if (!tail) { issue_w(ncc, 0); issue_w(ncc, 1); }
         });
-        taps(3, nop);
+        taps(3, nop, false);
         // ---- step C: tap 4 ----
         JG_ST(6);
         if (tail) wait_vm<0>();
