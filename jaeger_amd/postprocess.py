@@ -69,7 +69,9 @@ def energy(x: np.ndarray, axis: int = -1) -> np.ndarray:
     if x.shape[-1] == 2:
         return -logsumexp(x, axis=axis)
     squeezed = x.squeeze(axis=-1) if x.shape[-1] == 1 else x
-    return -logsumexp(np.stack([squeezed, np.zeros_like(squeezed)], axis=-1), axis=-1)
+    # -logsumexp([z, 0]): of the two exponentials one is exp(0) = 1 exactly and the other exp(-|z|), so the
+    # pair sum is 1 + exp(-|z|) bit for bit (IEEE addition commutes) - one exp and no stacked temporary
+    return -(np.maximum(squeezed, 0.0) + np.log(1.0 + np.exp(-np.abs(squeezed))))
 
 
 def sigmoid(x):
@@ -178,43 +180,112 @@ def viterbi_decode(logits: np.ndarray, switch_cost: float = 2.0,
 
 
 # ---- aggregation (postprocess/collect.py:247-435) --------------------------------------
+# The reference loops over contigs in Python (np.split + one numpy call per contig and statistic): 78 s for a
+# million single-window fragments.  Here every statistic is computed for all contigs at once.  Results must
+# not move by a bit (they are rounded to fp16 and printed with three decimals), so reductions keep numpy's own
+# summation order: contigs are grouped by window count T, a group is gathered into an (n, T, ...) block and
+# reduced along T with the same ufunc loop the per-contig call would run (sequential over rows for the (T, C)
+# statistics, numpy's pairwise scheme for the 1-D means).  tests/test_postprocess.py compares byte for byte with
+# the per-contig restatement (oracle/postprocess.py) and with TSVs written by the reference itself.
+class _Segments:
+    """Contigs as runs of consecutive windows: ``first[i] .. first[i] + count[i]``; ``groups`` yields
+    (T, contig indices with T windows, (n, T) window-index block)."""
+
+    def __init__(self, split_indices: np.ndarray, n_windows: int):
+        self.first = np.concatenate(([0], split_indices)).astype(np.int64)
+        self.count = np.diff(np.concatenate((self.first, [n_windows]))).astype(np.int64)
+        self.n = len(self.first)
+        order = np.argsort(self.count, kind="stable")
+        ts, starts = np.unique(self.count[order], return_index=True)
+        bounds = np.append(starts, len(order))
+        self._groups = [(int(t), order[a:b]) for t, a, b in zip(ts, bounds[:-1], bounds[1:])]
+
+    def groups(self):
+        for t, idx in self._groups:
+            yield t, idx, self.first[idx][:, None] + np.arange(t, dtype=np.int64)[None, :]
+
+    def mean_1d(self, v: np.ndarray) -> np.ndarray:
+        """[np.mean(v[a:b]) for every contig] for a 1-D per-window array."""
+        out = np.empty(self.n, dtype=np.result_type(v.dtype, np.float32) if v.dtype.kind != "f" else v.dtype)
+        for t, idx, rows in self.groups():
+            out[idx] = np.mean(v[rows], axis=1)
+        return out
+
+    def mean_flat(self, m: np.ndarray) -> np.ndarray:
+        """[np.mean(m[a:b]) for every contig] for an (N, C) array (mean over windows AND columns)."""
+        out = np.empty(self.n, dtype=m.dtype)
+        for t, idx, rows in self.groups():
+            out[idx] = np.mean(m[rows].reshape(len(idx), -1), axis=1)
+        return out
+
+    def mean_var_rows(self, m: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """[np.mean(m[a:b], axis=0)], [np.var(m[a:b], axis=0)] for an (N, C) array."""
+        mean = np.empty((self.n, m.shape[1]), dtype=m.dtype)
+        var = np.empty_like(mean)
+        for t, idx, rows in self.groups():
+            block = m[rows]                                   # (n, T, C)
+            mean[idx] = np.mean(block, axis=1)
+            var[idx] = np.var(block, axis=1)
+        return mean, var
+
+
+def _frac_strings(flags: np.ndarray, seg: _Segments) -> np.ndarray:
+    """frac_above_threshold per contig -> the fp16 array the reference builds from the formatted strings
+    (collect.py:233-244, :402-405): "{:.2f}".format(mean(flags)) parsed back.  ``flags`` is the (N, W) boolean
+    block of all windows; one format per distinct (count above, elements) pair."""
+    width = flags.shape[1]
+    k = np.add.reduceat(flags.sum(axis=1).astype(np.int64), seg.first)
+    total = seg.count * width
+    base = int(total.max()) + 1
+    uniq, inv = np.unique(k * base + total, return_inverse=True)
+    table = np.empty(len(uniq), dtype=np.float16)
+    for j, u in enumerate(uniq.tolist()):
+        kk, tt = divmod(u, base)
+        f = np.zeros(tt, dtype=bool)
+        f[:kk] = True
+        table[j] = np.float16("{:.2f}".format(f.mean()))
+    return table[inv]
+
+
 def pred_to_dict(y_pred: dict, **kwargs) -> tuple[dict, dict]:
     """Window outputs + metadata -> per-contig statistics.
 
     ``y_pred`` keys as returned by the engine: ``prediction`` (N, C), optional
     ``reliability`` (N, 1), ``meta_0`` header, ``meta_2`` is-last flag, ``meta_4`` contig
     length, ``meta_5..8`` base counts, ``meta_9`` gc skew.  kwargs: ``fsize``,
-    ``class_map`` ({"num_classes": ...}), ``term_repeats`` (DataFrame).
+    ``class_map`` ({"num_classes": ...}), ``term_repeats`` (DataFrame), ``crf_*``;
+    ``want_full=False`` skips the per-contig lists of ``data_full`` (only the ``--window-scores`` writer
+    reads them).
     """
     crf_switch_cost = kwargs.get("crf_switch_cost")
+    pred = np.asarray(y_pred["prediction"])
+    n_win = pred.shape[0]
     split_flags = np.array(y_pred["meta_2"], dtype=np.int32)
     split_indices = np.where(split_flags == 1)[0] + 1
-    classifier_type = "binary" if y_pred["prediction"].shape[-1] == 1 else "softmax"
-    if y_pred["prediction"].shape[0] == split_indices[-1]:
+    classifier_type = "binary" if pred.shape[-1] == 1 else "softmax"
+    if n_win == split_indices[-1]:
         split_indices = split_indices[:-1]
-
-    predictions = np.split(y_pred["prediction"], split_indices, axis=0)
-    chain_first = np.concatenate(([0], split_indices, [y_pred["prediction"].shape[0]])).astype(np.int64)
+    seg = _Segments(split_indices, n_win)
+    chain_first = np.append(seg.first, n_win)
     has_reliability = "reliability" in y_pred
-    ood = np.split(y_pred["reliability"], split_indices, axis=0) if has_reliability else None
 
-    headers = np.array([h[0] for h in np.split(np.array(y_pred["meta_0"], dtype=str), split_indices)])
-    lengths = np.array([b[0] for b in np.split(np.array(y_pred["meta_4"], dtype=np.int32), split_indices)])
-    gc_skews = np.split(np.asarray(y_pred["meta_9"]).astype(float), split_indices)
-
+    headers = np.array(y_pred["meta_0"], dtype=str)[seg.first]
+    lengths = np.array(y_pred["meta_4"], dtype=np.int32)[seg.first]
     # nucleotide content; the reference labels the columns a,t,g,c = meta_7,8,6,5 and only
     # uses their sums (collect.py:319-324)
     a, t, g, c = (np.asarray(y_pred[k]).astype(float) for k in ("meta_7", "meta_8", "meta_6", "meta_5"))
     fsize = kwargs["fsize"]
-    ns = np.split((fsize - (a + t + g + c)) / fsize, split_indices)
-    gcs = np.split((g + c) / fsize, split_indices)
+    ns_w = (fsize - (a + t + g + c)) / fsize
+    gcs_w = (g + c) / fsize
 
-    pred_sum = np.array([np.squeeze(np.mean(p, axis=0)) for p in predictions], dtype=np.float16)
-    pred_var = np.array([np.squeeze(np.var(p, axis=0)) for p in predictions], dtype=np.float16)
+    mean, var = seg.mean_var_rows(pred)
+    pred_sum = np.array(mean[:, 0] if pred.shape[1] == 1 else mean, dtype=np.float16)
+    pred_var = np.array(var[:, 0] if pred.shape[1] == 1 else var, dtype=np.float16)
     num_classes = kwargs.get("class_map").get("num_classes")
-    energy_pred = [energy(p) for p in predictions]
+    energy_w = energy(pred)                                   # element-wise for every head width but 2
+    energy_mean_ = seg.mean_1d(energy_w) if energy_w.ndim == 1 else seg.mean_flat(energy_w)
     if classifier_type == "softmax":
-        entropy_pred = [softmax_entropy(p) for p in predictions]
+        entropy_mean_ = seg.mean_1d(softmax_entropy(pred))
         consensus = np.argmax(pred_sum, axis=1)
         if crf_switch_cost is not None:
             # joint MAP decoding of each contig's windows instead of independent argmax (collect.py:269-289,343-346)
@@ -222,45 +293,83 @@ def pred_to_dict(y_pred: dict, **kwargs) -> tuple[dict, dict]:
             names = [name for _, name in sorted(zip(cm.get("index"), cm.get("class")), key=lambda t: int(t[0]))]
             costs = build_transition_costs(names, switch_cost=crf_switch_cost, prior=kwargs.get("crf_prior", "biological"),
                                            user_matrix=kwargs.get("crf_transition_matrix"))
-            frag_pred = np.split(viterbi_decode_chains(y_pred["prediction"], chain_first, crf_switch_cost, costs),
-                                 split_indices)
+            calls = viterbi_decode_chains(pred, chain_first, crf_switch_cost, costs)
         else:
-            frag_pred = [np.argmax(p, axis=-1) for p in predictions]
-        per_class_counts = [update_dict(np.unique(fp, return_counts=True), num_classes) for fp in frag_pred]
+            calls = np.argmax(pred, axis=-1)
         prophage_contam = (pred_sum[:, 1] < pred_var[:, 1]) & (consensus == 0)
         host_contam = (pred_sum[:, 1] < pred_var[:, 1]) & (consensus == 1)
     else:
-        entropy_pred = [binary_entropy(p) for p in predictions]
-        consensus = np.array([sigmoid(p) for p in pred_sum])
+        entropy_mean_ = seg.mean_flat(binary_entropy(pred))
+        consensus = np.array(sigmoid(pred_sum))
         consensus[consensus > 0.5] = 1.0
         consensus[consensus <= 0.5] = 0.0
         if crf_switch_cost is not None:
             # two-class CRF on stacked [0, z] logits, uniform switch cost (collect.py:365-372)
-            z = np.asarray(y_pred["prediction"], np.float32).reshape(-1, 1)
-            frag_pred = np.split(viterbi_decode_chains(np.concatenate([np.zeros_like(z), z], axis=-1), chain_first,
-                                                       crf_switch_cost), split_indices)
+            z = np.asarray(pred, np.float32).reshape(-1, 1)
+            calls = viterbi_decode_chains(np.concatenate([np.zeros_like(z), z], axis=-1), chain_first, crf_switch_cost)
         else:
-            frag_pred = [(sigmoid(p) > 0.5).astype(int) for p in predictions]
-        per_class_counts = [update_dict(np.unique(fp, return_counts=True), num_classes) for fp in frag_pred]
+            calls = (sigmoid(pred) > 0.5).astype(int)[:, 0]
         prophage_contam = (pred_sum < pred_var) & (consensus == 0)
         host_contam = (pred_sum < pred_var) & (consensus == 1)
+    # windows per class and contig (update_dict(np.unique(...)), helpers.py:111-127): row i = counts of contig i
+    width = max(int(num_classes), int(calls.max()) + 1 if calls.size else 0)
+    cid = np.repeat(np.arange(seg.n), seg.count)
+    per_class_counts = np.bincount(cid * width + calls, minlength=seg.n * width).reshape(seg.n, width)
 
-    if ood is not None:
-        ood = np.array([frac_above_threshold(sigmoid(p)) for p in ood], dtype=np.float16)
-    entropy_mean = np.array([np.squeeze(np.mean(e)) for e in entropy_pred], dtype=np.float16)
-    energy_mean = np.array([np.squeeze(np.mean(e)) for e in energy_pred], dtype=np.float16)
-
+    ood = None
+    if has_reliability:
+        ood = _frac_strings((sigmoid(np.asarray(y_pred["reliability"])) > 0.5).reshape(n_win, -1), seg)
     data = {
         "headers": headers, "length": lengths, "consensus": consensus,
         "per_class_counts": per_class_counts, "pred_sum": pred_sum, "pred_var": pred_var,
-        "frag_pred": frag_pred, "ood": ood, "has_reliability": has_reliability,
-        "entropy": entropy_mean, "energy": energy_mean, "host_contam": host_contam,
-        "prophage_contam": prophage_contam, "repeats": kwargs.get("term_repeats"),
-        "gc": gcs, "ns": ns,
+        "frag_pred": _Runs(calls, seg), "ood": ood, "has_reliability": has_reliability,
+        "entropy": np.array(entropy_mean_, dtype=np.float16), "energy": np.array(energy_mean_, dtype=np.float16),
+        "host_contam": host_contam, "prophage_contam": prophage_contam, "repeats": kwargs.get("term_repeats"),
+        "gc": _Means(seg.mean_1d(gcs_w)), "ns": _Means(seg.mean_1d(ns_w)),
     }
-    data_full = {"predictions": predictions, "headers": headers, "lengths": lengths,
-                 "gc_skews": gc_skews, "gcs": gcs}
+    data_full = {"headers": headers, "lengths": lengths}
+    if kwargs.get("want_full", True):
+        data_full.update(predictions=np.split(pred, split_indices, axis=0),
+                         gc_skews=np.split(np.asarray(y_pred["meta_9"]).astype(float), split_indices),
+                         gcs=np.split(gcs_w, split_indices))
     return data, data_full
+
+
+class _Means:
+    """Per-contig means of a per-window quantity, already reduced (generate_summary takes the mean of
+    ``data["gc"]`` / ``data["ns"]`` entries, collect.py:470-471)."""
+
+    def __init__(self, means: np.ndarray):
+        self.means = means
+
+
+class _Runs:
+    """Per-window calls of all contigs + the contig segmentation; ``summaries`` builds every contig's
+    run-length string (helpers.py:8-40,73-108) from one pass over the runs."""
+
+    def __init__(self, calls: np.ndarray, seg: _Segments):
+        self.calls, self.seg = np.asarray(calls), seg
+
+    def __len__(self):
+        return self.seg.n
+
+    def __getitem__(self, i):
+        a = int(self.seg.first[i])
+        return self.calls[a:a + int(self.seg.count[i])]
+
+    def summaries(self, letter: dict) -> list[str]:
+        calls, seg = self.calls, self.seg
+        if calls.size == 0:
+            return []
+        start = np.ones(calls.size, dtype=bool)
+        start[1:] = calls[1:] != calls[:-1]
+        start[seg.first] = True
+        run_start = np.nonzero(start)[0]
+        run_len = np.diff(np.append(run_start, calls.size))
+        run_val = calls[run_start]
+        pieces = np.array([f"{n}{letter.get(int(v), '')}" for v, n in zip(run_val.tolist(), run_len.tolist())], dtype=object)
+        first_run = np.searchsorted(run_start, seg.first)
+        return np.add.reduceat(pieces, first_run).tolist()
 
 
 def generate_summary(data, **kwargs) -> pd.DataFrame:
@@ -268,29 +377,35 @@ def generate_summary(data, **kwargs) -> pd.DataFrame:
     classes_, indices_ = kwargs.get("labels"), kwargs.get("indices")
     class_map = {int(k): v for k, v in zip(indices_, classes_)}
     reliability = data["ood"] if data.get("has_reliability", True) else ["unavailable"] * len(data["headers"])
+    mean_of = lambda x: x.means if isinstance(x, _Means) else [np.mean(v) for v in x]          # noqa: E731
+    counts = data["per_class_counts"]
     columns = {
         "contig_id": data["headers"],
         "length": data["length"],
-        "prediction": [class_map[x] for x in data["consensus"]],
+        "prediction": [class_map[x] for x in np.asarray(data["consensus"]).tolist()],
         "entropy": data["entropy"],
         "energy": data["energy"],
         "reliability_score": reliability,
         "host_contam": data["host_contam"],
         "prophage_contam": data["prophage_contam"],
-        "G+C": [np.mean(x) for x in data["gc"]],
-        "N%": [np.mean(x) for x in data["ns"]],
+        "G+C": mean_of(data["gc"]),
+        "N%": mean_of(data["ns"]),
     }
     for i, label in class_map.items():
-        columns[f"#_{label}_windows"] = [x[i] for x in data["per_class_counts"]]
+        columns[f"#_{label}_windows"] = counts[:, i] if isinstance(counts, np.ndarray) else [x[i] for x in counts]
     if len(class_map) > 2:
         for i, label in class_map.items():
-            columns[f"{label}_score"] = [x[i] for x in data["pred_sum"]]
-            columns[f"{label}_var"] = [x[i] for x in data["pred_var"]]
+            columns[f"{label}_score"] = data["pred_sum"][:, i]
+            columns[f"{label}_var"] = data["pred_var"][:, i]
     else:
         columns["score"] = data["pred_sum"]
         columns["var"] = data["pred_var"]
-    columns["window_summary"] = [get_window_summary(x, class_map=class_map, classes=["virus", "phage"])
-                                 for x in data["frag_pred"]]
+    frag = data["frag_pred"]
+    if isinstance(frag, _Runs):
+        letter = {k: (v[0].upper() if v.lower() in ("virus", "phage") else v[0].lower()) for k, v in class_map.items()}
+        columns["window_summary"] = frag.summaries(letter)
+    else:
+        columns["window_summary"] = [get_window_summary(x, class_map=class_map, classes=["virus", "phage"]) for x in frag]
     df = pd.DataFrame(columns)
     repeats = data.get("repeats")
     if repeats is None:
@@ -305,10 +420,27 @@ def generate_summary(data, **kwargs) -> pd.DataFrame:
     return df
 
 
+def _to_tsv(df: pd.DataFrame, path) -> None:
+    """``df.to_csv(path, sep="\t", index=False, float_format="%.3f")`` with the float columns formatted by one
+    vectorised ``%`` per column instead of pandas' per-value Python formatter (same text: ``"%.3f" % float(v)``,
+    empty for NaN)."""
+    out = {}
+    for col in df.columns:
+        v = df[col]
+        if v.dtype.kind == "f":
+            arr = v.to_numpy().astype(np.float64)
+            txt = np.char.mod("%.3f", arr).astype(object)
+            txt[np.isnan(arr)] = ""
+            out[col] = txt
+        else:
+            out[col] = v
+    pd.DataFrame(out, columns=df.columns).to_csv(path, sep="\t", index=False)
+
+
 def write_output(data: dict, reliability_cutoff: float = 0.5, phage_score=1, **kwargs) -> int:
     """Write ``<base>.tsv`` and (if non-empty) ``<base>_phages.tsv`` (collect.py:561-608)."""
     df = generate_summary(data, **kwargs).query("`N%` < 0.3")
-    df.to_csv(kwargs.get("output_table_path"), sep="\t", index=False, float_format="%.3f")
+    _to_tsv(df, kwargs.get("output_table_path"))
     classes = kwargs.get("labels", [])
     lower = [label.lower() for label in classes]
     viral_label = "phage"
@@ -319,5 +451,5 @@ def write_output(data: dict, reliability_cutoff: float = 0.5, phage_score=1, **k
     clause = f" and (reliability_score > {reliability_cutoff})" if data.get("has_reliability", True) else ""
     phage_df = df.query(f'(prediction == "{viral_label}") and ({viral_label}_score > {phage_score}){clause}')
     if not phage_df.empty:
-        phage_df.to_csv(kwargs.get("output_phage_table_path"), sep="\t", index=False, float_format="%.3f")
+        _to_tsv(phage_df, kwargs.get("output_phage_table_path"))
     return len(df)

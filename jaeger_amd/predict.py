@@ -340,7 +340,8 @@ def run_core(**kwargs) -> int:
         y_pred = {k: np.concatenate([yr[k][b:e] for yr, b, e in ordered], axis=0) for k in keys}
         dist.barrier()
 
-    data, data_full = pred_to_dict(y_pred, class_map=engine.class_map, fsize=fsize, term_repeats=term_repeats, **crf_kw)
+    data, data_full = pred_to_dict(y_pred, class_map=engine.class_map, fsize=fsize, term_repeats=term_repeats,
+                                   want_full=bool(kwargs.get("window_scores")), **crf_kw)
     n_written = write_output(data, labels=engine.class_map.get("class"), indices=engine.class_map.get("index"),
                              output_table_path=table_path, output_phage_table_path=phage_path,
                              reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))

@@ -57,3 +57,70 @@ def test_window_summary_and_unavailable_reliability():
     df = P.generate_summary(data, labels=CLASSES, indices=list(range(6)))
     assert (df["reliability_score"] == "unavailable").all()
     assert df["contig_id"].iloc[0] == "contig_0,x"           # '___' -> ',' restored
+
+
+def _random_case(rng, n_contigs, n_cls, with_rel, big=False):
+    t = rng.integers(1, 40, n_contigs)
+    t[rng.integers(0, n_contigs, max(1, n_contigs // 10))] = rng.integers(100, 700 if big else 300, max(1, n_contigs // 10))
+    t[: min(3, n_contigs)] = [1, 8, 129][: min(3, n_contigs)]            # pairwise-summation block edges
+    n = int(t.sum())
+    y = {"prediction": rng.normal(0, 3, (n, n_cls)).astype(np.float32),
+         "meta_0": np.array(sum([[f"ctg_{i}___z"] * int(k) for i, k in enumerate(t)], [])),
+         "meta_2": np.array(sum([[0] * (int(k) - 1) + [1] for k in t], [])),
+         "meta_4": np.array(sum([[1500 * int(k) + 11] * int(k) for k in t], [])),
+         "meta_9": np.round(rng.normal(0, 0.1, n), 2)}
+    for k in ("meta_5", "meta_6", "meta_7", "meta_8"):
+        y[k] = rng.integers(250, 380, n)
+    y["meta_5"][: int(t[0])] = 5                                           # first contig mostly N
+    if with_rel:
+        y["reliability"] = rng.normal(0, 2, (n, 1)).astype(np.float32)
+    rep = pd.DataFrame({"contig_id": [f"ctg_{i}___z" for i in range(n_contigs)],
+                        "terminal_repeats": [("DTR" if i % 7 == 0 else None) for i in range(n_contigs)],
+                        "repeat_length": [(40.0 + i if i % 7 == 0 else np.nan) for i in range(n_contigs)]})
+    return y, rep
+
+
+@pytest.mark.parametrize("n_cls,with_rel,crf", [(6, True, None), (6, False, 2.0), (3, True, None),
+                                               (1, True, None), (1, False, 1.5), (4, True, 0.7)])
+def test_vectorised_aggregation_equals_per_contig_restatement(n_cls, with_rel, crf, tmp_path):
+    """The product computes every statistic for all contigs at once; the oracle loops over contigs like the
+    reference.  Same TSV bytes, same per-contig arrays - including fp16 rounding and numpy's summation order."""
+    from jaeger_amd import postprocess as P
+    from oracle import postprocess as O
+    rng = np.random.default_rng(100 * n_cls + (7 if with_rel else 0))
+    names = (CLASSES + ["x", "y"])[:max(n_cls, 2)]
+    idx = list(range(len(names)))
+    for n_contigs in (1, 2, 57, 400):
+        y, rep = _random_case(rng, n_contigs, n_cls, with_rel, big=n_contigs == 57)
+        kw = dict(class_map={"num_classes": len(names), "class": names, "index": idx}, fsize=1500, term_repeats=rep)
+        if crf is not None:
+            kw.update(crf_switch_cost=crf, crf_prior="biological")
+        outs = {}
+        for tag, mod in (("p", P), ("o", O)):
+            data, full = mod.pred_to_dict(y, **kw)
+            out, out_ph = tmp_path / f"{tag}.tsv", tmp_path / f"{tag}_ph.tsv"
+            out_ph.unlink(missing_ok=True)
+            if n_cls == 1:
+                # the reference's write_output needs a "<viral>_score" column and raises for one-logit heads:
+                # compare the summary table through each side's own TSV formatter instead
+                df = mod.generate_summary(data, labels=names, indices=idx)
+                n = len(df)
+                if mod is P:
+                    P._to_tsv(df, out)
+                else:
+                    df.to_csv(out, sep="\t", index=False, float_format="%.3f")
+            else:
+                n = mod.write_output(data, labels=names, indices=idx, output_table_path=out,
+                                     output_phage_table_path=out_ph, reliability_cutoff=0.1, phage_score=1)
+            outs[tag] = (data, full, n, out.read_bytes(), out_ph.read_bytes() if out_ph.exists() else None)
+        dp, fp, n_p, tsv_p, ph_p = outs["p"]
+        do, fo, n_o, tsv_o, ph_o = outs["o"]
+        assert n_p == n_o and tsv_p == tsv_o and ph_p == ph_o
+        for key in ("pred_sum", "pred_var", "entropy", "energy", "consensus", "host_contam", "prophage_contam", "length"):
+            a, b = np.asarray(dp[key]), np.asarray(do[key])
+            assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b, equal_nan=True), key
+        if with_rel:
+            assert np.array_equal(np.asarray(dp["ood"]), np.asarray(do["ood"]))
+        assert [np.asarray(x).ravel().tolist() for x in dp["frag_pred"]] == [np.asarray(x).ravel().tolist() for x in do["frag_pred"]]
+        assert len(fp["predictions"]) == len(fo["predictions"]) == n_contigs
+        assert all(np.array_equal(a, b) for a, b in zip(fp["gcs"], fo["gcs"]))
