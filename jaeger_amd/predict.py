@@ -171,6 +171,68 @@ def _shard_records(lengths: np.ndarray, fsize: int, stride: int | None, world: i
     return lpt_partition(w, world)
 
 
+def _record_groups(fa: "frag.FastaBatch", target_bases: int = 48_000_000, max_groups: int = 24) -> list[tuple[int, int]]:
+    """Contiguous record ranges [r0, r1) of about equal base counts: the units the host pipeline works in."""
+    n, total = len(fa), int(fa.offsets[-1] - fa.offsets[0]) if len(fa) else 0
+    k = int(min(max_groups, max(1, total // max(target_bases, 1)), max(n, 1)))
+    cuts = np.searchsorted(fa.offsets[:-1], fa.offsets[0] + np.arange(1, k) * (total / k)) if k > 1 else []
+    bounds = sorted(set([0, n] + [int(c) for c in cuts]))
+    return [(a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+
+
+def _sub_batch(fa: "frag.FastaBatch", r0: int, r1: int) -> "frag.FastaBatch":
+    """Records [r0, r1) as a FastaBatch of its own (views, nothing is copied)."""
+    o0, o1 = int(fa.offsets[r0]), int(fa.offsets[r1])
+    return frag.FastaBatch(fa.names[r0:r1], fa.bases[o0:o1], fa.offsets[r0:r1 + 1] - o0)
+
+
+class _HostPipeline:
+    """Single-GPU host pipeline: a worker thread owns the engine (creates it, then classifies record groups as they
+    arrive) while the calling thread soft-masks the next group (DUST) and scans for terminal repeats on a second
+    stream - the library calls release the GIL, so ingest-side host work runs under the GPU's forward time instead
+    of in front of it.  Results come back in group (= FASTA) order."""
+
+    def __init__(self, make_engine, predict_kw: dict):
+        import queue
+        import threading
+        self.q = queue.Queue()
+        self.ready = threading.Event()
+        self.engine, self.error, self.outs = None, None, []
+        self.busy_s = 0.0
+        self._kw = predict_kw
+        self._make = make_engine
+        self.thread = threading.Thread(target=self._run, name="jaeger-gpu", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        try:
+            self.engine = self._make()
+        except BaseException as e:          # reported by the caller
+            self.error = ("engine", e, traceback.format_exc())
+            self.ready.set()
+            return
+        self.ready.set()
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if self.error is not None:
+                continue
+            try:
+                t0 = time.time()
+                self.outs.append(predict_batch(self.engine, item, **self._kw))
+                self.busy_s += time.time() - t0
+            except BaseException as e:
+                self.error = ("predict", e, traceback.format_exc())
+
+    def submit(self, sub_fa):
+        self.q.put(sub_fa)
+
+    def finish(self):
+        self.q.put(None)
+        self.thread.join()
+
+
 # ---- run_core ---------------------------------------------------------------------------------
 def run_core(**kwargs) -> int:
     """Equivalent of ``commands/predict.py:run_core``; returns the number of table rows written."""
@@ -246,74 +308,134 @@ def run_core(**kwargs) -> int:
         matrix_path = kwargs.get("crf_transition_matrix")
         if matrix_path:
             crf_kw["crf_transition_matrix"] = json.loads(Path(matrix_path).read_text())
-    dusted = False
-    if kwargs.get("dustmask", True):
-        t_dust = time.time()
-        n_masked = frag.dust_mask(fa)
-        dusted = True
-        lg.info(f"DUST (window 64, threshold 20): {n_masked} of {fa.bases.size} bases soft-masked in "
-                f"{time.time() - t_dust:.2f} s")
-
     weights = None
     wnpz = model_info.get("weights_npz")
     if wnpz is not None:
         from .weights import load_npz
         weights = load_npz(wnpz)
     precision = "f32" if kwargs.get("exact_f32") else None
-    try:
-        engine = JaegerHipEngine(model_info, weights=weights, device_id=local_rank, chunk=kwargs.get("chunk", 0),
-                                 precision=precision)
-    except Exception as e:
-        lg.debug(traceback.format_exc())
+
+    def make_engine():
+        return JaegerHipEngine(model_info, weights=weights, device_id=local_rank, chunk=kwargs.get("chunk", 0),
+                               precision=precision)
+
+    def engine_failed(e, tb):
+        lg.debug(tb)
         lg.error(f"could not set up the model on GPU {local_rank}: {e}")
         sys.exit(1)
-    term_repeats = None
-    if rank == 0:
+
+    def log_setup(engine):
+        sp = engine.string_processor_config
+        lg.info(f"input file: {input_path.name}")
+        lg.info(f"outpath: {out_dir.resolve()}")
+        lg.info(f"fragment size: {fsize}  stride: {stride}  batch: {kwargs.get('batch', 96)}")
+        lg.info(f"model: {model_id}  arithmetic: {engine.model.precision}  device: MI355X #{local_rank} "
+                f"(rank {rank}/{world})")
+        msg = _crop_length_warning(sp.get("crop_size_codons"), sp.get("crop_size_nt"), fsize)
+        if msg:
+            lg.warning(msg)
+
+    def scan_repeats(device):
         from .termini import scan_for_terminal_repeats
         t_term = time.time()
-        term_repeats = scan_for_terminal_repeats(engine.device, fa, fsize)
-        lg.info(f"terminal repeats: {int(term_repeats['terminal_repeats'].notna().sum())} of {len(term_repeats)} "
+        rep = scan_for_terminal_repeats(device, fa, fsize)
+        lg.info(f"terminal repeats: {int(rep['terminal_repeats'].notna().sum())} of {len(rep)} "
                 f"contigs in {time.time() - t_term:.2f} s")
-    sp = engine.string_processor_config
-    lg.info(f"input file: {input_path.name}")
-    lg.info(f"outpath: {out_dir.resolve()}")
-    lg.info(f"fragment size: {fsize}  stride: {stride}  batch: {kwargs.get('batch', 96)}")
-    lg.info(f"model: {model_id}  arithmetic: {engine.model.precision}  device: MI355X #{local_rank} "
-            f"(rank {rank}/{world})")
-    msg = _crop_length_warning(sp.get("crop_size_codons"), sp.get("crop_size_nt"), fsize)
-    if msg:
-        lg.warning(msg)
+        return rep
 
-    groups, subset = None, None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl")
-        groups = _shard_records(fa.lengths, fsize, stride, world)
-        subset = np.sort(np.asarray(groups[rank], np.int64))
-    all_names = fa.names
+    dust = bool(kwargs.get("dustmask", True))
+    two_pass = user_min_len is not None and user_min_len < fsize
+    want = ("prediction", "reliability") + (("embedding",) if kwargs.get("save_embedding") else ()) \
+        + (("nmd",) if kwargs.get("save_nmd") else ())
     common = dict(dynamic_stride=kwargs.get("dynamic_stride", False),
                   dynamic_stride_threshold=kwargs.get("dynamic_stride_threshold", 10.0),
-                  batch=kwargs.get("batch", 96), subset=subset, pre_cased=dusted,
-                  want=("prediction", "reliability") + (("embedding",) if kwargs.get("save_embedding") else ())
-                  + (("nmd",) if kwargs.get("save_nmd") else ()))
+                  batch=kwargs.get("batch", 96), pre_cased=dust, want=want)
+    all_names = fa.names
+    groups, subset = None, None
+    term_repeats = None
     t_predict = time.time()
-    try:
-        if user_min_len is not None and user_min_len < fsize:
+    if world == 1 and not kwargs.get("no_pipeline"):
+        # ---- one GPU: DUST, engine set-up and the terminal-repeat scan run beside the forward ---------------
+        if two_pass:
             lg.info(f"Two-pass prediction: long contigs (>= {fsize} bp) then short contigs "
                     f"({user_min_len}-{fsize - 1} bp)")
-            y_long = predict_batch(engine, fa, fsize, stride, min_len=fsize, max_len=None, **common)
-            y_short = predict_batch(engine, fa, fsize, stride, min_len=user_min_len, max_len=fsize - 1,
-                                    padded=True, **common)
-            y_pred = _concat_predictions(y_long, y_short)
-        else:
-            y_pred = predict_batch(engine, fa, fsize, stride, min_len=min_len, max_len=None, **common)
-    except Exception as e:
-        lg.debug(traceback.format_exc())
-        lg.error(f"an error {e} occured during inference on MI355X #{local_rank}!")
-        sys.exit(1)
+        pipe = _HostPipeline(make_engine, dict(fsize=fsize, stride=stride, min_len=fsize if two_pass else min_len,
+                                               max_len=None, **common))
+        t_dust, n_masked = 0.0, 0
+        for r0, r1 in _record_groups(fa):
+            sub = _sub_batch(fa, r0, r1)
+            if dust:
+                t0 = time.time()
+                n_masked += frag.dust_mask(sub)
+                t_dust += time.time() - t0
+            pipe.submit(sub)
+        if dust:
+            lg.info(f"DUST (window 64, threshold 20): {n_masked} of {fa.bases.size} bases soft-masked in "
+                    f"{t_dust:.2f} s (beside the forward)")
+        pipe.ready.wait()
+        if pipe.error is not None and pipe.error[0] == "engine":
+            engine_failed(pipe.error[1], pipe.error[2])
+        engine = pipe.engine
+        log_setup(engine)
+        try:
+            from .engine import HipDevice
+            side = HipDevice(local_rank)                       # its own stream: the scan interleaves with the forward
+            term_repeats = scan_repeats(side)
+            side.close()
+        finally:
+            pipe.finish()
+        if pipe.error is not None:
+            lg.debug(pipe.error[2])
+            lg.error(f"an error {pipe.error[1]} occured during inference on MI355X #{local_rank}!")
+            sys.exit(1)
+        y_pred = {}
+        for part in pipe.outs:
+            y_pred = _concat_predictions(y_pred, part)
+        if two_pass:
+            try:
+                y_short = predict_batch(engine, fa, fsize, stride, min_len=user_min_len, max_len=fsize - 1,
+                                        padded=True, **common)
+            except Exception as e:
+                lg.debug(traceback.format_exc())
+                lg.error(f"an error {e} occured during inference on MI355X #{local_rank}!")
+                sys.exit(1)
+            y_pred = _concat_predictions(y_pred, y_short)
+    else:
+        # ---- torchrun: every rank masks the whole input (host threads), owns a contig shard -----------------
+        if dust:
+            t_dust = time.time()
+            n_masked = frag.dust_mask(fa)
+            lg.info(f"DUST (window 64, threshold 20): {n_masked} of {fa.bases.size} bases soft-masked in "
+                    f"{time.time() - t_dust:.2f} s")
+        try:
+            engine = make_engine()
+        except Exception as e:
+            engine_failed(e, traceback.format_exc())
+        if rank == 0:
+            term_repeats = scan_repeats(engine.device)
+        log_setup(engine)
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl")
+            groups = _shard_records(fa.lengths, fsize, stride, world)
+            subset = np.sort(np.asarray(groups[rank], np.int64))
+        try:
+            if two_pass:
+                lg.info(f"Two-pass prediction: long contigs (>= {fsize} bp) then short contigs "
+                        f"({user_min_len}-{fsize - 1} bp)")
+                y_long = predict_batch(engine, fa, fsize, stride, min_len=fsize, max_len=None, subset=subset, **common)
+                y_short = predict_batch(engine, fa, fsize, stride, min_len=user_min_len, max_len=fsize - 1,
+                                        padded=True, subset=subset, **common)
+                y_pred = _concat_predictions(y_long, y_short)
+            else:
+                y_pred = predict_batch(engine, fa, fsize, stride, min_len=min_len, max_len=None, subset=subset, **common)
+        except Exception as e:
+            lg.debug(traceback.format_exc())
+            lg.error(f"an error {e} occured during inference on MI355X #{local_rank}!")
+            sys.exit(1)
 
     t_predict = time.time() - t_predict
     t_post = time.time()
