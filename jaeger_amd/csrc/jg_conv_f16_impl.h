@@ -19,11 +19,12 @@
 //
 // Work decomposition.  Persistent workgroups of 4 waves (2 x 2, each wave 128 positions x 64
 // channels = 8 accumulator blocks of 32 x 32) walk 256-position x 128-channel output tiles; two
-// workgroups are resident per CU for k = 5.  The K loop runs in steps = (16-channel chunk, tap): a
-// step needs one 8 KB weight slice and the chunk's activation slice.  Everything moves
-// global->LDS by DMA (global_load_lds with an SGPR base + per-lane 32-bit offset, no register
-// staging): weight slices K-2 steps ahead into a ring with one slot per tap, activation slices one
-// chunk ahead into a double buffer.  Steps wait with COUNTED s_waitcnt vmcnt, so the DMA queue
+// workgroups are resident per CU for k = 5.  The K loop runs over (16-channel chunk, tap): a tap
+// needs one 8 KB weight slice and the chunk's activation slice; k = 5 synchronises once per TWO
+// taps - steps (t0 t1)(t2 t3)(t4) - k = 7 / 9 once per tap.  Everything moves global->LDS by DMA
+// (global_load_lds with an SGPR base + per-lane 32-bit offset, no register staging): weight slices
+// two steps (k = 5) / K-2 taps ahead into a ring with one slot per tap, activation slices one chunk
+// ahead into a double buffer.  Waves run at priority 2 in this loop and 0 in the epilogue.  Steps wait with COUNTED s_waitcnt vmcnt, so the DMA queue
 // never drains; zero padding / mask multiply are applied by zero-filling the affected 16-byte
 // pieces after the DMA has landed (rare).  The MFMAs take the WEIGHTS as their A operand, so an
 // accumulator register holds one channel and a lane holds one position: the fused epilogue (folded
