@@ -264,3 +264,29 @@ def test_full_chunks_f16x3_vs_exact_f32(fsize):
         err = float(np.abs(a[k] - c[k]).max())
         print(fsize, k, f"{err:.2e}")
         assert err <= TOL, (k, err)
+
+
+def test_f16_range_guard_falls_back_to_exact_f32():
+    """Activations beyond the f16 range (|y| > 65 000) poison the split-f16 path: the epilogue's range guard must
+    notice, and the library must rerun on the exact-f32 kernels - same logits as the oracle, relative to their size."""
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = load_model_cfg("brain")
+    weights = ofwd.random_weights(cfg, seed=38341)
+    weights["rep/0/kernel"] = weights["rep/0/kernel"] * np.float32(3.0e5)       # first conv's outputs ~1e5..1e6
+    rng = np.random.Generator(np.random.PCG64(9))
+    fsize, n_win = 1500, 6
+    seq = _random_dna(rng, fsize * n_win)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0)
+    assert eng.model.precision == "f16x3"
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    assert eng.model.precision == "f32"                     # the guard tripped; the model stays on the exact path
+    eng.close()
+    ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    assert np.isfinite(got["prediction"]).all()
+    scale = max(1.0, float(np.abs(ref["prediction"]).max()))
+    assert float(np.abs(got["prediction"] - ref["prediction"]).max()) <= 1e-4 * scale
