@@ -1,0 +1,126 @@
+"""The torchrun path of ``run_core`` on CPU: world_size 2 over gloo with a stand-in engine (deterministic logits
+computed from the window bases on the host - the GPU engine itself is covered by the -m gpu tests).  Contig
+sharding (LPT), the object gather, the restoration of the reference's emission order (FASTA order, long pass before
+short pass) and the TSV must equal a single-process run byte for byte."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, make_model_dir
+
+
+class _StandInModel:
+    precision = "stand-in"
+
+
+class _StandInEngine:
+    """Same surface as JaegerHipEngine for run_core: class_map, string_processor_config, predict_windows, device."""
+
+    def __init__(self, path_dict=None, **kw):
+        import yaml
+        classes = yaml.safe_load(Path(path_dict["classes"]).read_text())["classes"]
+        self.class_map = {"num_classes": len(classes), "class": [c["class"] for c in classes],
+                          "index": [c["label"] for c in classes]}
+        self.string_processor_config = {"crop_size_codons": None, "crop_size_nt": None}
+        self.model = _StandInModel()
+        self.device = None
+
+    def predict_windows(self, bases, win_start, win_len, fsize, l_pad=None, pre_cased=False,
+                        want=("prediction", "reliability")):
+        n = len(win_start)
+        pred = np.zeros((n, self.class_map["num_classes"]), np.float32)
+        rel = np.zeros((n, 1), np.float32)
+        counts = np.zeros((n, 4), np.int32)
+        for i, (s, ln) in enumerate(zip(np.asarray(win_start).tolist(), np.asarray(win_len).tolist())):
+            w = np.asarray(bases[s:s + ln])
+            up = w & 0xDF if not pre_cased else w
+            c = np.array([(up == ord(ch)).sum() for ch in "GCAT"], np.int32)          # meta_5..8 order: G C A T
+            counts[i] = c
+            h = np.cumsum(w.astype(np.int64) * (np.arange(ln) % 7 + 1))[-1] if ln else 0
+            pred[i] = [((h >> (3 * k)) % 97) / 9.0 - 5.0 for k in range(pred.shape[1])]
+            rel[i, 0] = ((h >> 5) % 31) / 5.0 - 3.0
+        return {"prediction": pred, "reliability": rel, "counts": counts}
+
+    def close(self):
+        pass
+
+
+def _write_fasta(path, seed=5):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lens = [5200, 700, 1499, 3100, 650, 1203, 400, 1500, 999, 2999, 12000, 1800, 4700, 800, 6100]
+    with open(path, "w") as fh:
+        for i, n in enumerate(lens):
+            seq = "".join(rng.choice(list("ACGT"), n))
+            if i == 3:
+                seq = seq[:500] + "AT" * 60 + seq[620:]          # a low-complexity stretch for DUST
+            fh.write(f">ctg_{i} len={n}\n")
+            for j in range(0, n, 60):
+                fh.write(seq[j:j + 60] + "\n")
+    return lens
+
+
+def _run(out_dir, fasta, model_root, min_len, no_pipeline=True):
+    import pandas as pd
+
+    import jaeger_amd.engine as E
+    import jaeger_amd.termini as T
+    from jaeger_amd.predict import run_core
+    E.JaegerHipEngine = _StandInEngine
+    E.HipDevice = lambda *a, **k: type("SideStream", (), {"close": lambda self: None})()
+    T.scan_for_terminal_repeats = lambda device, fa, fsize: pd.DataFrame(
+        {"contig_id": [n.strip().replace(",", "___") for n, ln in zip(fa.names, fa.lengths.tolist()) if ln >= fsize],
+         "terminal_repeats": None, "repeat_length": np.nan})
+    return run_core(input=str(fasta), output=str(out_dir), model_path=str(model_root), fsize=1500, stride=1500,
+                    min_len=min_len, batch=2, dustmask=True, rc=0.1, pc=1, overwrite=True, verbose=1,
+                    no_pipeline=no_pipeline)
+
+
+def _worker(rank, world, port, tmp, min_len):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _run(Path(tmp) / "sharded", Path(tmp) / "in.fasta", Path(tmp) / "m", min_len)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("min_len", [None, 600])
+def test_sharded_run_core_equals_single_process(tmp_path, min_len, monkeypatch):
+    import torch.multiprocessing as mp
+    _write_fasta(tmp_path / "in.fasta")
+    make_model_dir(tmp_path / "m")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    import jaeger_amd.engine as E
+    import jaeger_amd.termini as T
+    keep = (E.JaegerHipEngine, E.HipDevice, T.scan_for_terminal_repeats)
+    try:
+        n_single = _run(tmp_path / "single", tmp_path / "in.fasta", tmp_path / "m", min_len)
+        # the single-GPU host pipeline (worker thread owns the engine, record groups masked beside the forward)
+        import jaeger_amd.predict as P
+        monkeypatch.setattr(P, "_record_groups", lambda fa, **k: [(0, 4), (4, 5), (5, 11), (11, len(fa))])
+        n_piped = _run(tmp_path / "piped", tmp_path / "in.fasta", tmp_path / "m", min_len, no_pipeline=False)
+    finally:
+        E.JaegerHipEngine, E.HipDevice, T.scan_for_terminal_repeats = keep
+    assert n_piped == n_single
+    assert (tmp_path / "piped" / "38341_1.4M" / "in.tsv").read_text() == \
+        (tmp_path / "single" / "38341_1.4M" / "in.tsv").read_text()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), min_len), nprocs=2, join=True)
+    single = (tmp_path / "single" / "38341_1.4M" / "in.tsv").read_text()
+    sharded = (tmp_path / "sharded" / "38341_1.4M" / "in.tsv").read_text()
+    assert n_single > 0 and single == sharded
+    ids = [ln.split("\t")[0] for ln in single.splitlines()[1:]]
+    long_first = [f"ctg_{i}" for i in (0, 3, 7, 9, 10, 11, 12, 14)]
+    assert ids[:len(long_first)] == long_first                      # FASTA order, long pass first
+    if min_len is not None:
+        assert set(ids[len(long_first):]) <= {"ctg_1", "ctg_2", "ctg_4", "ctg_5", "ctg_8", "ctg_13"}
