@@ -1,3 +1,6 @@
+# Build the probe library first (not part of `make`):
+#   make -C jaeger_amd/csrc -j6 BUILD=build_m16 OUT=$PWD/jaeger_amd/libjaeger_hip_m16.so \
+#     "FLAGS=-O3 -std=c++17 --offload-arch=gfx950 -fPIC -I$PWD/include -I. -Wall -Wno-pass-failed -DJG_MFMA16_PROBE"
 # MFMA-shape probe (timing only): libjaeger_hip_m16.so (-DJG_MFMA16_PROBE) replaces every 32x32x16 MFMA of the main
 # loop by two 16x16x32 (same operand registers, same LDS reads, same MACs; results are garbage of the same
 # statistics).  Warm-up with the full kernel so that the activation buffers hold random-looking data (the chip's clock
