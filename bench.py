@@ -50,7 +50,22 @@ def cpu_baseline(cfg, weights, bases, offsets, table, fsize, target_s: float = 1
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 64))       # beyond ~64 threads the batch-96 GEMMs stop scaling
+    # a container may see every host core but own a CPU-time quota of a few: threads beyond the quota only
+    # preempt each other (cgroup v2 cpu.max "quota period", v1 cpu.cfs_quota_us / cpu.cfs_period_us)
+    quota = avail
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(per) + 0.5))
+    except (OSError, ValueError):
+        try:
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                quota = max(1, int(q / per + 0.5))
+        except (OSError, ValueError):
+            pass
+    cores = max(1, min(avail, quota, 64))       # beyond ~64 threads the batch-96 GEMMs stop scaling
     torch.set_num_threads(cores)
     n_contigs_all = len(offsets) - 1
     win_per_contig = np.array([(offsets[i + 1] - offsets[i]) // fsize for i in range(min(n_contigs_all, 4000))])
@@ -78,7 +93,7 @@ def cpu_baseline(cfg, weights, bases, offsets, table, fsize, target_s: float = 1
     return {"value": round(n_w * fsize / dt / 1e6, 5), "unit": "Mbp/s", "cores": cores, "kind": "port",
             "sample": f"first {n_w} windows x {fsize} bp of the workload; oracle = python fragmenter + "
                       f"numpy encoder + torch-CPU f32 forward, batch 96, {cores} threads "
-                      f"({avail} cores visible), {dt:.1f} s"}
+                      f"({avail} cores visible, CPU quota {quota}), {dt:.1f} s"}
 
 
 def main():
