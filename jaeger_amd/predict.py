@@ -21,10 +21,8 @@ from pathlib import Path
 from typing import Any
 
 import numpy as np
-import pandas as pd
 
 from . import fragment as frag
-from .postprocess import pred_to_dict, write_output
 
 logger = logging.getLogger("Jaeger")
 
@@ -462,6 +460,7 @@ def run_core(**kwargs) -> int:
         y_pred = {k: np.concatenate([yr[k][b:e] for yr, b, e in ordered], axis=0) for k in keys}
         dist.barrier()
 
+    from .postprocess import pred_to_dict, write_output       # pandas: imported beside the forward (termini, above)
     data, data_full = pred_to_dict(y_pred, class_map=engine.class_map, fsize=fsize, term_repeats=term_repeats,
                                    want_full=bool(kwargs.get("window_scores")), **crf_kw)
     n_written = write_output(data, labels=engine.class_map.get("class"), indices=engine.class_map.get("index"),
