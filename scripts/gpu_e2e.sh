@@ -19,10 +19,10 @@ sys.path.insert(0, 'tests')
 from conftest import make_model_dir
 make_model_dir(Path('/tmp/model_brain'))
 PY
-time python -m jaeger_amd predict -i /tmp/synth10k.fasta -o /tmp/out_e2e --model_path /tmp/model_brain --fsize 1500 --stride 1500 --no-dustmask -f 2>&1 | grep -E "wall time|processed|error" 
-time python -m jaeger_amd predict -i /tmp/synth10k.fasta -o /tmp/out_e2e --model_path /tmp/model_brain --fsize 1500 --stride 1500 -f 2>&1 | grep -E "wall time|processed|error|DUST" 
+time python -m jaeger_amd predict -i /tmp/synth10k.fasta -o /tmp/out_e2e --model_path /tmp/model_brain --fsize 1500 --stride 1500 --no-dustmask -f 2>&1 | grep -E "wall time|processed|error|GPU worker"
+time python -m jaeger_amd predict -i /tmp/synth10k.fasta -o /tmp/out_e2e --model_path /tmp/model_brain --fsize 1500 --stride 1500 -f 2>&1 | grep -E "wall time|processed|error|DUST|GPU worker" 
 cp /tmp/out_e2e/*/synth10k.tsv /tmp/piped.tsv
-time python -m jaeger_amd predict -i /tmp/synth10k.fasta -o /tmp/out_e2e --model_path /tmp/model_brain --fsize 1500 --stride 1500 -f --no-pipeline 2>&1 | grep -E "wall time|processed|error|DUST"
+time python -m jaeger_amd predict -i /tmp/synth10k.fasta -o /tmp/out_e2e --model_path /tmp/model_brain --fsize 1500 --stride 1500 -f --no-pipeline 2>&1 | grep -E "wall time|processed|error|DUST|GPU worker"
 cmp /tmp/piped.tsv /tmp/out_e2e/*/synth10k.tsv && echo "pipelined and sequential TSVs identical"
 wc -l /tmp/out_e2e/*/synth10k.tsv
 grep -h "terminal repeats\|DUST" /tmp/out_e2e/*/*_jaeger.log | tail -3
