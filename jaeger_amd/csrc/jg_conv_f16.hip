@@ -14,7 +14,7 @@ constexpr int HM = 256, HN = 128, HT = 256, NT = 1, A_ITERS = 5, W_ITEMS = 2 * 2
 }
 
 int jg_conv_lut_lds_bytes(int k, int vocab) {
-  return k * (vocab + 1) * LUT_RS * 4 + JG_EPI_ROWS * 2 * HN * 4 + 4 * 256;
+  return k * (vocab + 1) * LUT_RS * 4 + JG_EPI_ROWS * 2 * HN * 4 + 8 * 256;     // table half, epilogue rows, 256 B of row indices per wave
 }
 
 // first-layer table variant: LDS holds k*(vocab+1) rows, a wave stages <= 256 positions

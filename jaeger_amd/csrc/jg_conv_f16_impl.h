@@ -125,6 +125,9 @@ static __device__ unsigned long long jg_stamp_acc[8];
 #ifndef JG_PRIO
 #define JG_PRIO 1
 #endif
+#ifndef JG_LUT_WAVES
+#define JG_LUT_WAVES 8  // waves of a first-layer table workgroup: 8 = two per SIMD share one table half (4 tiles per pass)
+#endif
 #ifndef JG_PAIRED
 #define JG_PAIRED 1     // k = 5: one barrier per two taps (+1.3 % measured A/B); 0 = one per tap
 #endif
@@ -135,14 +138,16 @@ static __device__ unsigned long long jg_stamp_acc[8];
 // in one-hot ids, so y[p] = sum_t T_t[id[p + t]] with T_t = E . W_t (vocab x Cout, exact f32, built
 // on the host in f64).  The matrix-core loop is replaced by LDS row lookups (k rows of 64 channels per
 // output position); the epilogue is the same code.  A workgroup owns one 64-channel half of the
-// table (k * (vocab + 1) rows, row `vocab` = zeros for padding) and its four waves cover two
-// 256-position tiles: waves {0,1} the first, {2,3} the second.  K is unused (taps come from a.k).
+// table (k * (vocab + 1) rows, row `vocab` = zeros for padding) and its JG_LUT_WAVES (8) waves cover
+// four 256-position tiles per pass: waves {0,1} the first, {2,3} the second, ... - two waves per SIMD
+// share the table, so one's row lookups run under the other's epilogue.  K is unused (taps come from a.k).
 template <int K, unsigned EP, bool LUT = false, bool FLAT = false>
 // K = 5 fits two workgroups per CU in LDS (<= 80 KB each): hold the register file to 256 per
 // lane so that both are really resident (without the bound hipcc takes ~340 and the second
 // workgroup of a CU only starts when the first has finished).
-__global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(K == 5 ? 2 : 1, 2)))
+__global__ __launch_bounds__(LUT ? JG_LUT_WAVES * 64 : HT) __attribute__((amdgpu_waves_per_eu(K == 5 ? 2 : 1, 2)))
 void conv_f16x3_kernel(ConvHArgs a) {
+  constexpr int NTHR = LUT ? JG_LUT_WAVES * 64 : HT;      // threads of this variant's workgroup
   constexpr int WA = K - 2;                  // weight slices in flight ahead of the matrix cores
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -153,7 +158,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
   // virtual block index / grid / tiles per pass (LUT: two blocks = the two channel halves share one index)
   const int vb = LUT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
   const int vgrid = LUT ? (int)(gridDim.x >> 1) : (int)gridDim.x;
-  constexpr int TPER = LUT ? 2 : NT;
+  constexpr int TPER = LUT ? JG_LUT_WAVES / 2 : NT;       // tiles per pass (LUT: two waves per 256-position tile)
   const int tsub = LUT ? (wid >> 1) : 0;
   // LDS carve (16-byte units)
   const int rows_a = HM + (K - 1) * a.dil;                 // rows of one activation slice
@@ -163,7 +168,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
   const int lut_rows = a.k * (a.lut_vocab + 1);
   float *epiL = LUT ? reinterpret_cast<float *>(lds) + lut_rows * LUT_RS
                     : reinterpret_cast<float *>(Wbuf + K * W_ITEMS);
-  for (int q = tid; q < a.n_epi_rows * 2 * HN; q += HT) epiL[q] = a.epi[q];   // visible after the first barrier
+  for (int q = tid; q < a.n_epi_rows * 2 * HN; q += NTHR) epiL[q] = a.epi[q];   // visible after the first barrier
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
   // wave-uniform LDS byte addresses of this wave's DMA destinations
   const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);                       // + buf*a_items*16 + it*4096
@@ -347,7 +352,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
   if constexpr (LUT) {
     float4 *T4 = reinterpret_cast<float4 *>(lds);
     const float4 *src = reinterpret_cast<const float4 *>(a.lut) + (size_t)wn * lut_rows * 16;
-    for (int q = tid; q < lut_rows * 16; q += HT) T4[(q >> 4) * (LUT_RS / 4) + (q & 15)] = src[q];
+    for (int q = tid; q < lut_rows * 16; q += NTHR) T4[(q >> 4) * (LUT_RS / 4) + (q & 15)] = src[q];
     lut_fetch(cur[0]);
     __syncthreads();
   } else {
@@ -943,9 +948,10 @@ int launch_lut_e(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     attr_set = true;
   }
   const int n_tiles = a.rows * a.tiles_m;
-  const int n_pairs = (n_tiles + 1) / 2;
-  const int grid = 2 * (n_pairs < e->n_cu / 2 ? n_pairs : e->n_cu / 2);   // (tile pair, channel half); one per CU
-  hipLaunchKernelGGL((conv_f16x3_kernel<0, EP, true>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, a);
+  constexpr int tper = JG_LUT_WAVES / 2;
+  const int n_pairs = (n_tiles + tper - 1) / tper;
+  const int grid = 2 * (n_pairs < e->n_cu / 2 ? n_pairs : e->n_cu / 2);   // (tile group, channel half); one per CU
+  hipLaunchKernelGGL((conv_f16x3_kernel<0, EP, true>), dim3((unsigned)grid), dim3(JG_LUT_WAVES * 64), (size_t)smem, s, a);
   JG_HIP(hipGetLastError());
   return JG_OK;
 }
