@@ -193,33 +193,60 @@ int jg_launch_encode(const uint8_t *bases, const int64_t *win_start, const int32
 // ---------------------------------------------------------------------------
 // conv output mask
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mask_kernel(const uint8_t *__restrict__ in, int64_t total,
-                                                   int L_in, int L_out, int k, int stride, int dil,
-                                                   int pad_left, int mode,
+// One thread = 4 consecutive output positions of one row.  The launch is bound by memory INSTRUCTIONS, not bytes
+// (a byte per lane and tap): for stride 1 a tap of four neighbouring outputs is one (unaligned) 32-bit load and the
+// result one 32-bit store - a quarter of the instructions, 14.7 -> ~5 us per launch, 13 launches per chunk.
+__global__ __launch_bounds__(256) void mask_kernel(const uint8_t *__restrict__ in, int64_t n_groups,
+                                                   int groups_per_row, int L_in, int L_out, int k, int stride,
+                                                   int dil, int pad_left, int mode,
                                                    uint8_t *__restrict__ out) {
-  const int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x;
-  if (idx >= total) return;
-  const int64_t row = idx / L_out;
-  const int m = (int)(idx - row * L_out);
+  const int64_t gidx = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (gidx >= n_groups) return;
+  const int64_t row = gidx / groups_per_row;
+  const int m0 = (int)(gidx - row * groups_per_row) * 4;
   const uint8_t *r = in + row * L_in;
-  int cnt = 0;
+  unsigned cnt = 0;                         // four byte-wide counters (k <= 255)
   for (int t = 0; t < k; ++t) {
-    const int p = m * stride - pad_left + t * dil;
-    if (p >= 0 && p < L_in) cnt += r[p] != 0;
+    const int p = m0 * stride - pad_left + t * dil;
+    if (stride == 1 && p >= 0 && p + 3 < L_in) {
+      unsigned v;
+      __builtin_memcpy(&v, r + p, 4);
+      // per byte: != 0 -> 1  (set bit 7 of every non-zero byte, move it to bit 0)
+      cnt += (((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) >> 7 & 0x01010101u;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = (m0 + j) * stride - pad_left + t * dil;
+        if (q >= 0 && q < L_in && r[q] != 0) cnt += 1u << (8 * j);
+      }
+    }
   }
-  uint8_t v;
-  if (mode == JG_MASK_ANY) v = cnt > 0;
-  else if (mode == JG_MASK_MAJORITY) v = cnt >= (k + 1) / 2;
-  else v = cnt == k;
-  out[idx] = v;
+  unsigned res = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned c = (cnt >> (8 * j)) & 0xffu;
+    unsigned v;
+    if (mode == JG_MASK_ANY) v = c > 0;
+    else if (mode == JG_MASK_MAJORITY) v = c >= (unsigned)((k + 1) / 2);
+    else v = c == (unsigned)k;
+    res |= v << (8 * j);
+  }
+  uint8_t *o = out + row * L_out + m0;
+  if (m0 + 3 < L_out) {
+    __builtin_memcpy(o, &res, 4);
+  } else {
+    for (int j = 0; m0 + j < L_out; ++j) o[j] = (uint8_t)(res >> (8 * j));
+  }
 }
 
 int jg_launch_mask(const uint8_t *in, int rows, int L_in, int L_out, int k, int stride, int dil,
                    int pad_left, int mode, uint8_t *out, hipStream_t s) {
-  const int64_t total = (int64_t)rows * L_out;
-  if (total == 0) return JG_OK;
-  hipLaunchKernelGGL(mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, total,
-                     L_in, L_out, k, stride, dil, pad_left, mode, out);
+  if (rows == 0 || L_out <= 0) return JG_OK;
+  JG_REQUIRE(k >= 1 && k <= 255, JG_ERR_UNSUPPORTED, "mask: k=%d outside the byte-wide tap counters", k);
+  const int groups_per_row = (L_out + 3) / 4;
+  const int64_t n_groups = (int64_t)rows * groups_per_row;
+  hipLaunchKernelGGL(mask_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, in, n_groups,
+                     groups_per_row, L_in, L_out, k, stride, dil, pad_left, mode, out);
   JG_HIP(hipGetLastError());
   return JG_OK;
 }
@@ -575,10 +602,53 @@ __global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ in
   out[win * out_ld + o] = jg_apply_act(acc, act);
 }
 
+// Narrow heads (cout <= 8, e.g. 128 -> 6 logits, 512 -> 8): one WAVE per window, lanes stride over the inputs and
+// reduce with DPP-free shuffles - a thread per output would walk all cin inputs alone (70 us for 512 -> 8)
+template <int CO>
+__global__ __launch_bounds__(256) void dense_narrow_kernel(const float *__restrict__ in, int in_ld,
+                                                           const float *__restrict__ w,
+                                                           const float *__restrict__ b, int n_win, int cin,
+                                                           int cout, int act, float *__restrict__ out, int out_ld) {
+  const int win = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (win >= n_win) return;
+  const float *xi = in + (size_t)win * in_ld;
+  float acc[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+  for (int i = lane; i < cin; i += 64) {
+    const float x = xi[i];
+    const float *wr = w + (size_t)i * cout;
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+      if (o < cout) acc[o] = fmaf(x, wr[o], acc[o]);
+  }
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    float v = acc[o];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    acc[o] = v;
+  }
+  if (lane < cout) {
+    float v = 0.f;
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+      if (o == lane) v = acc[o];
+    if (b != nullptr) v += b[lane];
+    out[(size_t)win * out_ld + lane] = jg_apply_act(v, act);
+  }
+}
+
 int jg_launch_dense(const float *in, int in_ld, const float *w, const float *b, int n_win, int cin,
                     int cout, int act, float *out, int out_ld, hipStream_t s) {
   const int64_t total = (int64_t)n_win * cout;
   if (total == 0) return JG_OK;
+  if (cout <= 8 && cin >= 64) {
+    hipLaunchKernelGGL(dense_narrow_kernel<8>, dim3((unsigned)((n_win + 3) / 4)), dim3(256), 0, s, in, in_ld, w, b,
+                       n_win, cin, cout, act, out, out_ld);
+    JG_HIP(hipGetLastError());
+    return JG_OK;
+  }
   hipLaunchKernelGGL(dense_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, in_ld,
                      w, b, total, cin, cout, act, out, out_ld);
   JG_HIP(hipGetLastError());
