@@ -8,8 +8,6 @@ int jg_conv_f16_part_k5(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_k79(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_flat(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s);
-bool jg_conv_v3_supports(const ConvHArgs &a);
-int jg_launch_conv_v3(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 
 namespace {
 constexpr int HM = 256, HN = 128, HT = 256, NT = 1, A_ITERS = 5, W_ITEMS = 2 * 2 * HN, LUT_RS = 68;   // as in jg_conv_f16_impl.h
@@ -84,7 +82,6 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
              "conv_f16x3: activation tensor of %d rows exceeds the 32-bit DMA offset range", a.rows);
   if (a.rows == 0 || a.L_out <= 0) return JG_OK;
   const_cast<ConvHArgs &>(a).dbg = jg_dbg_env();
-  if ((a.dbg & 256) && jg_conv_v3_supports(a)) return jg_launch_conv_v3(e, a, s);     // prototype: timing only
   if (a.flat) {
     JG_REQUIRE(a.k == 5, JG_ERR_UNSUPPORTED, "conv_f16x3: window-packed tiling is only built for k = 5");
     return jg_conv_f16_part_flat(e, a, s);
