@@ -93,6 +93,25 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Mixed-precision FMAs (v_fma_mix_f32 reads f16 operands out of packed registers, f32 result): the compiler only
+// forms them from fma(fpext, fpext, .) and folds a multiplication by one away, so they are written out.
+//   mix_sum<H>(hi2, lo2) = f32(hi2.half[H]) + f32(lo2.half[H])      (exact: hi + lo of one split value)
+//   mix_rem<H>(v, hi2)   = v - f32(hi2.half[H])                      (the remainder that becomes the lo half)
+template <int H>
+__device__ __forceinline__ float mix_sum(unsigned hi2, unsigned lo2) {
+  float r;
+  if constexpr (H == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hi2), "v"(lo2));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hi2), "v"(lo2));
+  return r;
+}
+template <int H>
+__device__ __forceinline__ float mix_rem(float v, unsigned hi2) {
+  float r;
+  if constexpr (H == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi2), "v"(v));
+  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi2), "v"(v));
+  return r;
+}
+
 struct Tile {
   int rowblk, m0, valid;
   int T;          // tile index: strips (128 positions) 2T and 2T+1 of the launch
@@ -684,11 +703,11 @@ void conv_f16x3_kernel(ConvHArgs a) {
         };
         auto st_add = [&]() {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const half4 hh4 = *reinterpret_cast<const half4 *>(&p.sh[g]);
-            const half4 ll4 = *reinterpret_cast<const half4 *>(&p.sl[g]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[4 * g + j] += (float)hh4[j] + (float)ll4[j];
+          for (int g = 0; g < 4; ++g) {          // hi + lo is exact in f32: one mixed-precision instruction each
+            x[4 * g + 0] += mix_sum<0>(p.sh[g].x, p.sl[g].x);
+            x[4 * g + 1] += mix_sum<1>(p.sh[g].x, p.sl[g].x);
+            x[4 * g + 2] += mix_sum<0>(p.sh[g].y, p.sl[g].y);
+            x[4 * g + 3] += mix_sum<1>(p.sh[g].y, p.sl[g].y);
           }
         };
         auto st_gelu = [&]() {
@@ -755,13 +774,15 @@ void conv_f16x3_kernel(ConvHArgs a) {
             half4 hh4, ll4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float v = x[4 * g + j];
-              const _Float16 hv = (_Float16)v;
-              hh4[j] = hv;
-              ll4[j] = (_Float16)(v - (float)hv);
-              vmax = fmaxf(vmax, fabsf(v));      // dead lanes hold finite values too (zero-filled inputs)
+              hh4[j] = (_Float16)x[4 * g + j];
+              vmax = fmaxf(vmax, fabsf(x[4 * g + j]));      // dead lanes hold finite values too (zero-filled inputs)
             }
             ph[g] = *reinterpret_cast<uint2 *>(&hh4);
+            // lo = f16(v - hi): the remainder straight from the packed hi halves (no conversion back)
+            ll4[0] = (_Float16)mix_rem<0>(x[4 * g + 0], ph[g].x);
+            ll4[1] = (_Float16)mix_rem<1>(x[4 * g + 1], ph[g].x);
+            ll4[2] = (_Float16)mix_rem<0>(x[4 * g + 2], ph[g].y);
+            ll4[3] = (_Float16)mix_rem<1>(x[4 * g + 3], ph[g].y);
             pl[g] = *reinterpret_cast<uint2 *>(&ll4);
           }
 #pragma unroll
