@@ -290,3 +290,36 @@ def test_f16_range_guard_falls_back_to_exact_f32():
     assert np.isfinite(got["prediction"]).all()
     scale = max(1.0, float(np.abs(ref["prediction"]).max()))
     assert float(np.abs(got["prediction"] - ref["prediction"]).max()) <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("mode", ["majority", "strict"])
+def test_forward_variant_mask_modes_and_strided_block(mode):
+    """Mask rules other than "any" on the first conv (layers.py:1226-1255), a residual block with strides 2 (1x1
+    bypass conv + norm, layers.py:1827-1915: sequence length 498 -> 249) and one with use_1x1conv: the strided
+    convs and their masks run on the exact-f32 kernels, the rest of the network stays where it was."""
+    import copy
+
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("brain"))
+    layers = cfg["representation_learner"]["hidden_layers"]
+    layers[0]["config"]["mask_mode"] = mode
+    blocks = [layer for layer in layers if layer["name"] == "residual_block"]
+    blocks[1]["config"]["strides"] = 2
+    blocks[2]["config"]["use_1x1conv"] = True
+    weights = ofwd.random_weights(cfg, seed=21)
+    rng = np.random.Generator(np.random.PCG64(22))
+    fsize, n_win = 1500, 9
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.02)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    lens[2::4] = rng.integers(fsize // 3, fsize, lens[2::4].size)            # ragged windows: padded frames
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0)
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    eng.close()
+    ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    for k in ("prediction", "reliability"):
+        assert got[k].shape == ref[k].shape
+        assert float(np.abs(got[k] - ref[k]).max()) <= TOL, (mode, k, float(np.abs(got[k] - ref[k]).max()))
