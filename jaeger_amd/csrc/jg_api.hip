@@ -254,6 +254,11 @@ static int validate_program(const jg_model *m) {
           JG_REQUIRE(st.arg >= 0 && st.arg < JG_MAX_BUFS, JG_ERR_INVALID,
                      "op %zu stage %d: nmd partial slot", i, s);
           break;
+        case JG_ST_LN:
+          JG_REQUIRE(op.kind == JG_OP_ELTWISE && s == 0, JG_ERR_UNSUPPORTED,
+                     "op %zu stage %d: a layer norm must lead an element-wise op", i, s);
+          JG_REQUIRE(off_ok(st.p2, c) && off_ok(st.p3, c), JG_ERR_INVALID, "op %zu stage %d: layernorm offsets", i, s);
+          break;
         case JG_ST_ACT:
         case JG_ST_MASKMUL:
           break;
@@ -312,6 +317,11 @@ static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
         JG_REQUIRE(in.C == op.cout, JG_ERR_INVALID, "op %zu: eltwise channel mismatch", i);
         sh[op.out_buf] = in;
         act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)in.frames * in.L * in.C);
+        for (int s = 0; s < op.n_stages; ++s)           // an NMD tap behind a LayerNorm: partial rows like a conv's
+          if (op.stages[s].kind == JG_ST_NMD) {
+            const int tiles = std::max((in.L + 63) / 64, 8 * ((in.L + 255) / 256));
+            nmd_elems[op.stages[s].arg] = std::max<int64_t>(nmd_elems[op.stages[s].arg], (int64_t)in.frames * tiles * in.C);
+          }
       } break;
       case JG_OP_MAXPOOL1D: {
         const Shape in = sh[op.in_buf];
@@ -899,7 +909,10 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         a.n_pos = (int64_t)nw * in.frames * in.L;
         a.c = in.C;
         resolve_stages(m, op, a.st, &a.n_stages);
-        rc = jg_launch_eltwise(a, s);
+        if (a.n_stages > 0 && a.st[0].kind == JG_ST_LN)
+          rc = jg_launch_layernorm(a, nw * in.frames, in.L, (in.L + jg_conv_tile_m(in.L) - 1) / jg_conv_tile_m(in.L), s);
+        else
+          rc = jg_launch_eltwise(a, s);
         sh[op.out_buf] = in;
       } break;
       case JG_OP_MAXPOOL1D: {

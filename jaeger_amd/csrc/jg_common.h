@@ -205,6 +205,7 @@ int jg_launch_nmd_final(const float *part, int parts_per_win, const uint8_t *mas
                         const float *moving_mean, float eps, int n_win, int c, float *out,
                         int out_ld, int out_off, hipStream_t s);
 int jg_launch_eltwise(const EltArgs &a, hipStream_t s);
+int jg_launch_layernorm(const EltArgs &a, int rows, int L, int tiles_m, hipStream_t s);
 int jg_launch_encode(const uint8_t *bases, const int64_t *win_start, const int32_t *win_len,
                      int64_t n_win, int fsize, const uint8_t *lut, int flags, int l_pad,
                      uint8_t *ids, int32_t *counts, hipStream_t s);

@@ -482,6 +482,99 @@ int jg_launch_eltwise(const EltArgs &a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
+// MaskedLayerNormalization (nnlib/v2/layers.py:293-382) + the stages that follow it: one workgroup per
+// (window, frame) row, a wave per position at a time, lanes over channel quads.  Input zeroed at masked positions,
+// moments over the channel axis, (x - mean) / sqrt(var + eps) * gamma + beta, times the mask; then the rest of the
+// stage list (shortcut add, activation, NMD tap ...).  An NMD tap leaves one partial row per (row, tile) like
+// the conv epilogue does: tile 0 carries the row's sums, the other tiles zeros.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(EltArgs a, int L, int tiles_m) {
+  __shared__ float4 red[4 * 64 * 2];                     // NMD partials: 4 waves x up to 128 quads (c <= 512)
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int nq = a.c >> 2;                               // channel quads
+  const StageArg ln = a.st[0];
+  const float inv_c = 1.0f / (float)a.c;
+  float4 nmd_acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  for (int p = wid; p < L; p += 4) {
+    const int64_t pos = (int64_t)row * L + p;
+    const float mk = a.mask != nullptr ? (a.mask[pos] != 0 ? 1.f : 0.f) : 1.f;
+    const float lmk = ln.arg ? mk : 1.f;                 // the layer's own mask multiply (use_masking)
+    float4 v[2];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = lane + 64 * j;
+      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < nq) {
+        v[j] = *reinterpret_cast<const float4 *>(a.x + (size_t)pos * a.c + q * 4);
+        v[j].x *= lmk; v[j].y *= lmk; v[j].z *= lmk; v[j].w *= lmk;
+        sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    const float mean = sum * inv_c;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (lane + 64 * j < nq) {
+        const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+        sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sq += __shfl_xor(sq, d, 64);
+    const float denom = sqrtf(sq * inv_c + ln.f0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = lane + 64 * j;
+      if (q >= nq) continue;
+      const int n = q * 4;
+      const size_t o = (size_t)pos * a.c + n;
+      const float4 ga = *reinterpret_cast<const float4 *>(ln.p2 + n);
+      const float4 be = *reinterpret_cast<const float4 *>(ln.p3 + n);
+      float4 y;
+      y.x = ((v[j].x - mean) / denom * ga.x + be.x) * lmk;
+      y.y = ((v[j].y - mean) / denom * ga.y + be.y) * lmk;
+      y.z = ((v[j].z - mean) / denom * ga.z + be.z) * lmk;
+      y.w = ((v[j].w - mean) / denom * ga.w + be.w) * lmk;
+      y = jg_apply_stages(y, a.st + 1, a.n_stages - 1, n, o, mk, &nmd_acc[j]);
+      *reinterpret_cast<float4 *>(a.y + o) = y;
+    }
+  }
+  float *nmd_out = nullptr;
+  for (int s = 1; s < a.n_stages; ++s)
+    if (a.st[s].kind == JG_ST_NMD) nmd_out = const_cast<float *>(a.st[s].p0);
+  if (nmd_out != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) red[(wid * 2 + j) * 64 + lane] = nmd_acc[j];
+    __syncthreads();
+    for (int q = tid; q < nq; q += 256) {
+      const int j = q >> 6, ln_ = q & 63;
+      float4 t = red[(0 * 2 + j) * 64 + ln_];
+      for (int w = 1; w < 4; ++w) {
+        const float4 u = red[(w * 2 + j) * 64 + ln_];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      float *dst = nmd_out + ((size_t)row * tiles_m) * a.c + q * 4;
+      *reinterpret_cast<float4 *>(dst) = t;
+      for (int tl = 1; tl < tiles_m; ++tl)
+        *reinterpret_cast<float4 *>(dst + (size_t)tl * a.c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+int jg_launch_layernorm(const EltArgs &a, int rows, int L, int tiles_m, hipStream_t s) {
+  JG_REQUIRE(a.c % 4 == 0 && a.c <= 512, JG_ERR_UNSUPPORTED, "layernorm: c=%d must be a multiple of 4 up to 512", a.c);
+  JG_REQUIRE(a.n_stages >= 1 && a.st[0].kind == JG_ST_LN, JG_ERR_INVALID, "layernorm: the op's first stage must be LN");
+  for (int q = 1; q < a.n_stages; ++q)
+    JG_REQUIRE(a.st[q].kind != JG_ST_LN, JG_ERR_UNSUPPORTED, "layernorm: a second LN in one op");
+  if (rows == 0 || L == 0) return JG_OK;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)rows), dim3(256), 0, s, a, L, tiles_m);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+// ---------------------------------------------------------------------------
 // masked global pooling over (frames, length): one workgroup per window
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ x,

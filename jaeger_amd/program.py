@@ -152,9 +152,33 @@ class _Compiler:
         if n.kind == "masked_dyt":
             return self._stage(L.ST_DYT, arg=1 if has_mask else 0, f0=float(w[f"{n.name}/alpha"].ravel()[0]),
                                p2=self.blob.add(w[f"{n.name}/gamma"]), p3=self.blob.add(w[f"{n.name}/beta"]))
+        if n.kind == "masked_layernorm":
+            # a reduction over the channel axis: cannot live in a conv epilogue; _emit_conv cuts the stage list here
+            return self._stage(L.ST_LN, arg=1 if has_mask else 0, f0=float(n.epsilon),
+                               p2=self.blob.add(w[f"{n.name}/gamma"]), p3=self.blob.add(w[f"{n.name}/beta"]))
         raise UnsupportedLayer(f"{n.name}: {n.kind} is not supported by the MI355X engine yet")
 
     def _emit_conv(self, c: Conv, in_buf: int, in_mask: int, stages: list, out_mask: int, out_buf: int):
+        # MaskedLayerNormalization needs a whole channel row: the conv keeps the stages in front of it and an
+        # element-wise op (LayerNorm kernel) runs the norm and everything behind it, in place on the conv's output
+        tail = []
+        for j, st in enumerate(stages):
+            if st.kind == L.ST_LN:
+                stages, tail = stages[:j], stages[j:]
+                break
+        self._emit_conv_op(c, in_buf, in_mask, stages, out_mask, out_buf)
+        while tail:                                   # one op per LayerNorm (each leads its own op)
+            nxt = next((j for j, st in enumerate(tail) if st.kind == L.ST_LN and j > 0), len(tail))
+            if nxt > L.JG_MAX_STAGES:
+                raise UnsupportedLayer(f"{c.name}: more than {L.JG_MAX_STAGES} stages behind a layer norm")
+            op = self._op(L.OP_ELTWISE, in_buf=out_buf, out_buf=out_buf, out_mask=out_mask, cout=c.filters)
+            op.n_stages = nxt
+            for j, st in enumerate(tail[:nxt]):
+                op.stages[j] = st
+            self.ops.append(op)
+            tail = tail[nxt:]
+
+    def _emit_conv_op(self, c: Conv, in_buf: int, in_mask: int, stages: list, out_mask: int, out_buf: int):
         if len(stages) > L.JG_MAX_STAGES:
             raise UnsupportedLayer(f"{c.name}: more than {L.JG_MAX_STAGES} fused epilogue stages")
         op = self._op(L.OP_CONV, in_buf=in_buf, out_buf=out_buf,
@@ -198,7 +222,7 @@ class _Compiler:
                 slot = self.parts.take()
                 stages.append(self._stage(L.ST_NMD, arg=slot))
                 pending_nmd.append((nxt, slot, mask))
-            elif isinstance(nxt, Norm) and nxt.kind in ("masked_batchnorm", "masked_dyt"):
+            elif isinstance(nxt, Norm) and nxt.kind in ("masked_batchnorm", "masked_dyt", "masked_layernorm"):
                 stages.append(self._norm_stage(nxt, mask != L.JG_BUF_NONE))
                 if nxt.kind == "masked_batchnorm" and not nxt.use_masking:
                     mask = L.JG_BUF_NONE          # supports_masking False drops the mask (layers.py:816)
@@ -282,11 +306,14 @@ class _Compiler:
                 if not stages:
                     raise UnsupportedLayer(f"{getattr(layer, 'name', layer)}: unsupported standalone layer")
                 channels = self._channels_before(layers, i)
-                op = self._op(L.OP_ELTWISE, in_buf=buf, out_buf=buf, out_mask=mask, cout=channels)
-                op.n_stages = len(stages)
-                for j, st in enumerate(stages):
-                    op.stages[j] = st
-                self.ops.append(op)
+                # a LayerNorm must lead its op (the LayerNorm kernel): cut the list in front of every LN stage
+                cuts = [0] + [j for j, st in enumerate(stages) if st.kind == L.ST_LN and j > 0] + [len(stages)]
+                for a_, b_ in zip(cuts[:-1], cuts[1:]):
+                    op = self._op(L.OP_ELTWISE, in_buf=buf, out_buf=buf, out_mask=mask, cout=channels)
+                    op.n_stages = b_ - a_
+                    for j, st in enumerate(stages[a_:b_]):
+                        op.stages[j] = st
+                    self.ops.append(op)
                 mask = mask2
             elif isinstance(layer, Nmd):
                 raise UnsupportedLayer("an nmd layer must directly follow a conv or residual block")

@@ -323,3 +323,40 @@ def test_forward_variant_mask_modes_and_strided_block(mode):
     for k in ("prediction", "reliability"):
         assert got[k].shape == ref[k].shape
         assert float(np.abs(got[k] - ref[k]).max()) <= TOL, (mode, k, float(np.abs(got[k] - ref[k]).max()))
+
+
+def test_forward_variant_layernorm():
+    """MaskedLayerNormalization (layers.py:293-382) as the residual blocks' norm_type and as standalone layers: a
+    per-position reduction over the channels, run by the LayerNorm kernel behind the exact-f32 convs (a program with
+    element-wise ops is not eligible for the split-f16 path), NMD taps behind it included."""
+    import copy
+
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("brain"))
+    layers = cfg["representation_learner"]["hidden_layers"]
+    n_std = 0
+    for layer in layers:
+        if layer["name"] == "residual_block":
+            layer["config"]["norm_type"] = "masked_layernorm"
+        elif layer["name"] == "masked_batchnorm" and n_std < 2:
+            layer["name"] = "masked_layernorm"
+            layer["config"] = {}
+            n_std += 1
+    weights = ofwd.random_weights(cfg, seed=31)
+    rng = np.random.Generator(np.random.PCG64(32))
+    fsize, n_win = 1500, 7
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.02)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    lens[1::3] = rng.integers(fsize // 2, fsize, lens[1::3].size)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0)
+    assert eng.model.precision == "f32"
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    eng.close()
+    ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    for k, r in ref.items():
+        tol = TOL if k in ("prediction", "reliability") else TOL * max(1.0, float(np.abs(r).max()) / 8)
+        assert got[k].shape == r.shape and float(np.abs(got[k] - r).max()) <= tol, (k, float(np.abs(got[k] - r).max()))

@@ -129,3 +129,25 @@ def test_keras3_weights_h5_reader():
         np.testing.assert_array_equal(got[k], want[k], err_msg=k)
     again = load_weights({"weights": GOLDEN / "baseline500_keras3.weights.h5"}, plan)
     assert all(np.array_equal(again[k], want[k]) for k in want)
+
+
+def test_layernorm_cuts_the_epilogue_into_an_elementwise_op():
+    """MaskedLayerNormalization reduces over the channels: the conv keeps the stages in front of it, an element-wise
+    op led by the LN stage runs the norm and everything behind it (shortcut add, activation, NMD tap, next norm)."""
+    from jaeger_amd import _lib as L
+    from jaeger_amd import plan as P
+    from jaeger_amd import program as G
+    from oracle import forward as F
+    cfg = copy.deepcopy(load_model_cfg("brain"))
+    for layer in cfg["representation_learner"]["hidden_layers"]:
+        if layer["name"] == "residual_block":
+            layer["config"]["norm_type"] = "masked_layernorm"
+    prog = G.compile_plan(P.build_plan(cfg), F.random_weights(cfg))
+    st = lambda op: [op.stages[i].kind for i in range(op.n_stages)]
+    convs = [op for op in prog.ops if op.kind == L.OP_CONV]
+    elts = [op for op in prog.ops if op.kind == L.OP_ELTWISE]
+    assert len(convs) == 13 and len(elts) == 12
+    assert st(convs[1]) == [L.ST_BIAS] and st(elts[0]) == [L.ST_LN, L.ST_ACT]                       # block conv1
+    assert st(convs[2]) == [L.ST_BIAS] and st(elts[1]) == [L.ST_LN, L.ST_ADD, L.ST_ACT]             # block conv2
+    assert st(elts[3]) == [L.ST_LN, L.ST_ADD, L.ST_ACT, L.ST_NMD, L.ST_BN, L.ST_ACT]                # end of a stack
+    assert all(e.in_buf == e.out_buf and st(e)[0] == L.ST_LN and L.ST_LN not in st(e)[1:] for e in elts)
