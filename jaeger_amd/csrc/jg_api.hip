@@ -962,8 +962,8 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
       } break;
       case JG_OP_OODSIG:
         // in_vec = logits (cin classes), op.k = nmd vector slot (width op.stride), arg = order
-        rc = jg_launch_oodsig(m->vec[op.in_vec], op.cin, m->vec[op.k], m->vec_w[op.k], nw,
-                              (unsigned)op.arg, op.f0, m->vec[op.out_vec], m->vec_w[op.out_vec],
+        rc = jg_launch_oodsig(m->vec[op.in_vec], m->vec_w[op.in_vec], op.cin, m->vec[op.k], m->vec_w[op.k], op.stride,
+                              nw, (unsigned)op.arg, op.f0, m->vec[op.out_vec], m->vec_w[op.out_vec],
                               op.vec_off, s);
         break;
       default:

@@ -209,8 +209,8 @@ int jg_launch_layernorm(const EltArgs &a, int rows, int L, int tiles_m, hipStrea
 int jg_launch_encode(const uint8_t *bases, const int64_t *win_start, const int32_t *win_len,
                      int64_t n_win, int fsize, const uint8_t *lut, int flags, int l_pad,
                      uint8_t *ids, int32_t *counts, hipStream_t s);
-int jg_launch_oodsig(const float *logits, int n_cls, const float *nmd, int nmd_w, int n_win,
-                     unsigned signal_bits, float eps, float *out, int out_ld, int out_off,
+int jg_launch_oodsig(const float *logits, int logits_ld, int n_cls, const float *nmd, int nmd_ld, int nmd_w,
+                     int n_win, unsigned signal_bits, float eps, float *out, int out_ld, int out_off,
                      hipStream_t s);
 int jg_launch_maxpool1d(const float *x, const uint8_t *mask_in, int rows, int L_in, int L_out, int c,
                         float *y, uint8_t *mask_out, hipStream_t s);

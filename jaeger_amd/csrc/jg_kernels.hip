@@ -796,14 +796,14 @@ int jg_launch_nmd_final(const float *part, int parts_per_win, const uint8_t *mas
 // bits: 1 max_prob, 2 entropy, 4 energy, 8 margin, 16 nmd_norm (emitted in the
 // order of the model's `signals` list, which the host encodes in `order`).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void oodsig_kernel(const float *__restrict__ logits, int n_cls,
-                                                     const float *__restrict__ nmd, int nmd_w,
+__global__ __launch_bounds__(256) void oodsig_kernel(const float *__restrict__ logits, int logits_ld, int n_cls,
+                                                     const float *__restrict__ nmd, int nmd_ld, int nmd_w,
                                                      int n_win, unsigned order, float eps,
                                                      float *__restrict__ out, int out_ld,
                                                      int out_off) {
   const int w = blockIdx.x * 256 + threadIdx.x;
   if (w >= n_win) return;
-  const float *lg = logits + (size_t)w * n_cls;
+  const float *lg = logits + (size_t)w * logits_ld;      // vector slots are padded to float4 rows: pitch != width
   float mx = -INFINITY;
   for (int i = 0; i < n_cls; ++i) mx = fmaxf(mx, lg[i]);
   float se = 0.f;
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void oodsig_kernel(const float *__restrict__ l
     else if (code == 4) v = p1 - p2;
     else if (code == 5) {
       float ss = 0.f;
-      for (int i = 0; i < nmd_w; ++i) { const float t = nmd[(size_t)w * nmd_w + i]; ss += t * t; }
+      for (int i = 0; i < nmd_w; ++i) { const float t = nmd[(size_t)w * nmd_ld + i]; ss += t * t; }
       v = sqrtf(ss);
     }
     out[(size_t)w * out_ld + out_off + col] = v;
@@ -834,12 +834,12 @@ __global__ __launch_bounds__(256) void oodsig_kernel(const float *__restrict__ l
   }
 }
 
-int jg_launch_oodsig(const float *logits, int n_cls, const float *nmd, int nmd_w, int n_win,
-                     unsigned signal_bits, float eps, float *out, int out_ld, int out_off,
+int jg_launch_oodsig(const float *logits, int logits_ld, int n_cls, const float *nmd, int nmd_ld, int nmd_w,
+                     int n_win, unsigned signal_bits, float eps, float *out, int out_ld, int out_off,
                      hipStream_t s) {
   if (n_win == 0) return JG_OK;
-  hipLaunchKernelGGL(oodsig_kernel, dim3((unsigned)((n_win + 255) / 256)), dim3(256), 0, s, logits,
-                     n_cls, nmd, nmd_w, n_win, signal_bits, eps, out, out_ld, out_off);
+  hipLaunchKernelGGL(oodsig_kernel, dim3((unsigned)((n_win + 255) / 256)), dim3(256), 0, s, logits, logits_ld,
+                     n_cls, nmd, nmd_ld, nmd_w, n_win, signal_bits, eps, out, out_ld, out_off);
   JG_HIP(hipGetLastError());
   return JG_OK;
 }

@@ -360,3 +360,35 @@ def test_forward_variant_layernorm():
     for k, r in ref.items():
         tol = TOL if k in ("prediction", "reliability") else TOL * max(1.0, float(np.abs(r).max()) / 8)
         assert got[k].shape == r.shape and float(np.abs(got[k] - r).max()) <= tol, (k, float(np.abs(got[k] - r).max()))
+
+
+@pytest.mark.parametrize("signals", [None, ["energy", "margin", "max_prob"]])
+def test_forward_variant_reliability_signals(signals):
+    """reliability_model.mode = nmd_plus_signals (OODSignalLayer, layers.py:1598-1667; builder.py:618-667): the
+    reliability head reads the NMD vector extended by per-window signals of the logits (max prob, entropy, energy,
+    margin, NMD norm; any subset, in the configured order)."""
+    import copy
+
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("brain"))
+    rel = cfg["reliability_model"]
+    rel["mode"] = "nmd_plus_signals"
+    if signals is not None:
+        rel["signals"] = signals
+    rel["input_shape"] = 512 + (5 if signals is None else len(signals))
+    weights = ofwd.random_weights(cfg, seed=41)
+    rng = np.random.Generator(np.random.PCG64(42))
+    fsize, n_win = 1500, 8
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.01)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0)
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    eng.close()
+    ids = oenc.encode_windows([seq[s:s + fsize].tobytes() for s in starts], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    for k in ("prediction", "reliability"):
+        assert got[k].shape == ref[k].shape
+        assert float(np.abs(got[k] - ref[k]).max()) <= TOL, (k, float(np.abs(got[k] - ref[k]).max()))
