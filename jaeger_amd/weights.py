@@ -144,7 +144,7 @@ def load_keras3_h5(path, plan: ModelPlan) -> dict[str, np.ndarray]:
 
 
 def load_weights(path_dict: dict, plan: ModelPlan) -> dict[str, np.ndarray]:
-    w = path_dict.get("weights")
+    w = path_dict.get("weights") or path_dict.get("weights_npz")     # AvailableModels keys (predict.py)
     if w is None:
         raise FileNotFoundError("model entry has no weights file (*.weights.h5 or canonical *.npz)")
     w = Path(w)

@@ -392,3 +392,42 @@ def test_forward_variant_reliability_signals(signals):
     for k in ("prediction", "reliability"):
         assert got[k].shape == ref[k].shape
         assert float(np.abs(got[k] - ref[k]).max()) <= TOL, (k, float(np.abs(got[k] - ref[k]).max()))
+
+
+def test_engine_predict_dataset_duck_type(tmp_path):
+    """The drop-in boundary (nnlib/inference.py:300-483): an engine built from the files AvailableModels
+    finds, fed the reference's dataset protocol - batches of (inputs_dict, meta0..meta9) with a float (B, 6, L)
+    "translated" tensor (id + 1, 0 = invalid) - returns the concatenated model outputs plus meta_0..9 in order."""
+    from conftest import make_model_dir
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from jaeger_amd.predict import AvailableModels
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    from oracle import fragmenter as ofr
+    root = make_model_dir(tmp_path / "m")
+    info = AvailableModels(path=root).info["jaeger_38341_1.4M_fragment"]
+    eng = JaegerHipEngine(info, device_id=0)
+    assert eng.class_map["num_classes"] == 6 and len(eng.class_map["class"]) == len(eng.class_map["index"]) == 6
+    sp = eng.string_processor_config
+    for key in ("input_type", "codon", "codon_id", "codon_depth", "vocab_size", "ngram_width", "seq_onehot", "masking"):
+        assert key in sp, key                      # crop_size_* only when the yaml has crop_size (inference.py:470-482)
+    assert sp["input_type"] == "translated" and sp["seq_onehot"] is False
+    rng = np.random.Generator(np.random.PCG64(5))
+    recs = [(f"c{i}", "".join(rng.choice(list("ACGT"), n))) for i, n in enumerate((4700, 1500, 9100, 3050))]
+    rows = [r.split(",") for r in ofr.fragment_strings(recs, 1500, 1500)]
+    ids = oenc.encode_windows([r[0] for r in rows], 1500, pad_to=frame_length(1500))
+
+    def dataset(batch=4):
+        for i in range(0, len(rows), batch):
+            meta = [np.array([r[j] for r in rows[i:i + batch]]) for j in range(1, 11)]
+            yield ({"translated": ids[i:i + batch].astype(np.float32)}, *meta)
+
+    got = eng.predict(dataset())
+    cfg = load_model_cfg("brain")
+    ref = ofwd.forward(cfg, ofwd.random_weights(cfg, seed=38341), ids)
+    eng.close()
+    assert got["prediction"].shape == (len(rows), 6)
+    assert float(np.abs(got["prediction"] - ref["prediction"]).max()) <= TOL
+    assert float(np.abs(got["reliability"] - ref["reliability"]).max()) <= TOL
+    for j in range(10):
+        assert got[f"meta_{j}"].tolist() == [r[j + 1] for r in rows]
