@@ -19,6 +19,9 @@ Produces
   postprocess_*.tsv/json  pred_to_dict + write_output on seeded synthetic logits
                           (postprocess/collect.py)
   *.fasta                 the reference's bundled test FASTA files (test data)
+  *_project.yaml          `model:` sections of the reference's train_config/*.yaml (configuration data): brain, zeus,
+                          baseline500 and nmdmerge500 = nn_config_500bp_nmd_merge.yaml, written by
+                          yaml.safe_dump({"model": cfg["model"]}, sort_keys=False)
 """
 import hashlib
 import json

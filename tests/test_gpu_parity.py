@@ -431,3 +431,9 @@ def test_engine_predict_dataset_duck_type(tmp_path):
     assert float(np.abs(got["reliability"] - ref["reliability"]).max()) <= TOL
     for j in range(10):
         assert got[f"meta_{j}"].tolist() == [r[j + 1] for r in rows]
+
+
+def test_forward_nmdmerge500():
+    """The fourth conv-family architecture of the reference's train_config (nn_config_500bp_nmd_merge.yaml):
+    500-bp windows, NMD merge + reliability head on a narrow network (exact-f32 path)."""
+    _forward_case("nmdmerge500", 500, 48, 6, n_frac=0.02)
