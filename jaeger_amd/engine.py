@@ -218,8 +218,9 @@ class JaegerHipEngine:
     """Drop-in for ``InferModel`` (nnlib/inference.py:300-483) on one MI355X.
 
     ``path_dict`` keys as produced by ``AvailableModels`` (utils/misc.py:346-392):
-    ``classes`` (yaml), ``project`` (yaml), ``weights`` (h5) and ``graph`` (dir;
-    only used for weight recovery when no ``weights`` file is present).
+    ``classes`` (yaml), ``project`` (yaml), ``weights`` (Keras-3 ``.weights.h5``) or ``weights_npz`` (canonical
+    names); ``graph`` (the SavedModel directory) is NOT read: the layer plan comes from ``project.yaml``, the
+    weights from the weights file, and a model entry without one is an error.
     Alternatively pass ``model_cfg`` + ``weights`` (canonical-name dict) directly.
     """
 
