@@ -203,3 +203,45 @@ def test_cli_default_dustmask(tmp_path):
     _compare_tsv(tmp_path / "out" / "38341_1.4M" / "lowcomplexity.tsv", exp)
     got = pd.read_csv(tmp_path / "out" / "38341_1.4M" / "lowcomplexity.tsv", sep="\t")
     assert (got["N%"] > 0.05).all()                 # masked bases count as "not ACGT"
+
+
+def test_cli_gz_dynamic_stride_exact_f32_small_chunks(tmp_path):
+    """A gzip-compressed FASTA, --dynamic-stride (io.py:38-71: adaptive overlap on short contigs), the CLI defaults
+    --fsize 2000 with stride 2000, --exact-f32 and a tiny --chunk: same TSV as the oracle pipeline."""
+    import gzip
+
+    from jaeger_amd.cli import main
+    from jaeger_amd.postprocess import pred_to_dict, write_output
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    from oracle import fragmenter as ofr
+    rng = np.random.Generator(np.random.PCG64(15))
+    records = [(f"gz_{i}", "".join(rng.choice(list("ACGT"), n))) for i, n in enumerate((2000, 5300, 7100, 21000, 1999, 3999))]
+    fasta = tmp_path / "dyn.fasta.gz"
+    with gzip.open(fasta, "wt") as fh:
+        for n, s in records:
+            fh.write(f">{n} some description\n{s}\n")
+    root = make_model_dir(tmp_path / "m")
+    cfg = load_model_cfg("brain")
+    weights = ofwd.random_weights(cfg, seed=38341)
+    r = CliRunner().invoke(main, ["predict", "-i", str(fasta), "-o", str(tmp_path / "out"), "--model_path", str(root),
+                                  "--fsize", "2000", "--stride", "2000", "--dynamic-stride", "--no-dustmask",
+                                  "--exact-f32", "--chunk", "3"])
+    assert r.exit_code == 0, r.output
+    rows = [x.split(",") for x in ofr.fragment_strings(records, 2000, 2000, dynamic_stride=True, min_len=2000)]
+    out = ofwd.forward(cfg, weights, oenc.encode_windows([x[0] for x in rows], 2000, pad_to=oenc.frame_length(2000)))
+    out["meta_0"] = np.array([x[1] for x in rows])
+    for j, k in ((2, "meta_1"), (3, "meta_2"), (4, "meta_3"), (5, "meta_4"), (6, "meta_5"), (7, "meta_6"), (8, "meta_7"),
+                 (9, "meta_8")):
+        out[k] = np.array([int(x[j]) for x in rows])
+    out["meta_9"] = np.array([float(x[10]) for x in rows])
+    classes = [c["class"] for c in cfg["class_label_map"]]
+    data, _ = pred_to_dict(out, class_map={"num_classes": 6}, fsize=2000, term_repeats=oracle_term_repeats(records, 2000))
+    exp = tmp_path / "expected.tsv"
+    write_output(data, labels=classes, indices=[c["label"] for c in cfg["class_label_map"]], output_table_path=exp,
+                 output_phage_table_path=tmp_path / "expected_phages.tsv", reliability_cutoff=0.1, phage_score=3)
+    got = tmp_path / "out" / "38341_1.4M" / "dyn.fasta.tsv"
+    if not got.exists():
+        got = next((tmp_path / "out" / "38341_1.4M").glob("*.tsv"))
+    _compare_tsv(got, exp)
+    assert "gz_4" not in set(pd.read_csv(got, sep="\t")["contig_id"])            # 1999 bp < --fsize
