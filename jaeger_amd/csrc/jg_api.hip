@@ -1021,9 +1021,10 @@ static int copy_out(jg_model *m, int slot, int width, float *dst, int64_t row0, 
 static int forward_device_ids(jg_model *m, const uint8_t *d_ids, int64_t n_win, int l,
                               float *prediction, float *reliability, float *embedding, float *nmd,
                               int out_loc, int chunk, hipStream_t s) {
-  // windows per launch group: amortises launch + pipeline fill.  1 024 windows of 498 codons per frame; shorter
-  // frames get proportionally more windows per pass (same positions, same workspace: +6 % at 500 bp)
-  if (chunk <= 0) chunk = (int)std::min<int64_t>(65536, std::max<int64_t>(1024, (int64_t)1024 * 498 / std::max(l, 1) / 256 * 256));
+  // windows per launch group: amortises launch + pipeline fill.  2 048 windows of 498 codons per frame (+0.7 % over
+  // 1 024; 3.1 GB per activation slot), proportionally more for shorter frames (same positions: +6 % at 500 bp),
+  // and the 32-bit DMA offset cap below for longer ones
+  if (chunk <= 0) chunk = (int)std::min<int64_t>(65536, std::max<int64_t>(1024, (int64_t)2048 * 498 / std::max(l, 1) / 256 * 256));
   // split-f16 DMA offsets are 32-bit: keep one activation tensor (6 frames x l x 512 B) < 3.5 GB
   if (m->precision == 1) {
     const int64_t cap = (int64_t)(3.5e9 / (6.0 * l * 512.0));
