@@ -121,6 +121,18 @@ const char *jg_last_error(void);
 int jg_engine_create(int device_id, jg_engine **out);
 int jg_engine_destroy(jg_engine *e);
 int jg_engine_sync(jg_engine *e);
+/* Engine options.  JG_OPT_STREAM_BYTES: host-resident base buffers larger than this (default 256 MiB) are
+ * streamed by jg_predict_windows - the start-sorted window list is cut into groups whose base span fits the
+ * budget, each span goes host -> pinned staging buffer -> device buffer on a copy stream (two of each) while the
+ * previous group is encoded and classified; the device never holds more than two spans of bases.  This is the
+ * "host-DRAM -> HBM streamed" ingest of BASELINE.json configs[4]; the reference streams Python strings through
+ * tf.data instead (commands/predict.py:186-245). */
+enum { JG_OPT_STREAM_BYTES = 1 };
+int jg_engine_set_option(jg_engine *e, int key, int64_t value);
+/* statistics of the engine's last jg_predict_windows call: number of streamed groups (0 = not streamed), bytes sent
+ * through the staging buffers, peak bytes of bases resident on the device */
+enum { JG_STAT_STREAM_GROUPS = 1, JG_STAT_STREAM_BYTES = 2, JG_STAT_PEAK_DEVICE_BASES = 3 };
+int64_t jg_engine_get_stat(const jg_engine *e, int key);
 
 /* Replaces tf.saved_model.load + serving_default (nnlib/inference.py:307-325):
  * `ops` is the layer plan compiled by jaeger_amd/program.py, `weights` one f32
@@ -190,6 +202,11 @@ int jg_timer_stop_ms(jg_engine *e, void *stream, float *ms);
  * enabled by jg_profile_enable(e, 1), which inserts events around every conv launch */
 int jg_profile_enable(jg_engine *e, int on);
 int jg_profile_read(jg_engine *e, double *conv_ms, int64_t *conv_launches, double *conv_flops);
+/* the same accumulators split by kernel family: split-f16 matrix-core convs, exact-f32 matrix-core convs, the
+ * first layer's table-lookup kernel (no matrix cores: its "FLOPs" are the algorithmic ones of the conv it replaces),
+ * and the fused small-window network kernel */
+enum { JG_PROF_MFMA_F16X3 = 0, JG_PROF_MFMA_F32 = 1, JG_PROF_TABLE = 2, JG_PROF_FUSED_SMALL = 3 };
+int jg_profile_read_class(jg_engine *e, int cls, double *ms, int64_t *launches, double *flops);
 
 /* ---- FASTA ingest (host only; replaces the pyfastx iteration of seqops/io.py:98-103 and the
  * per-record Python strings of utils/fs.py:99-115) ------------------------------------------

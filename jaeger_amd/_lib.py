@@ -16,6 +16,8 @@ JG_MAX_BUFS = 6
 JG_MAX_VECS = 12
 JG_PTR_HOST, JG_PTR_DEVICE = 0, 1
 JG_BUF_NONE, JG_BUF_IDS = -1, -2
+JG_OPT_STREAM_BYTES = 1
+JG_STAT_STREAM_GROUPS, JG_STAT_STREAM_BYTES, JG_STAT_PEAK_DEVICE_BASES = 1, 2, 3
 
 # jg_op_kind
 OP_CONV, OP_MASK, OP_POOL, OP_DENSE, OP_ELTWISE, OP_NMD_FINAL, OP_OODSIG, OP_MAXPOOL1D, OP_FRAMESUM = range(1, 10)
@@ -70,6 +72,8 @@ SYMBOLS = {
     "jg_engine_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "jg_engine_destroy": (C.c_int, [_vp]),
     "jg_engine_sync": (C.c_int, [_vp]),
+    "jg_engine_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
+    "jg_engine_get_stat": (C.c_int64, [_vp, C.c_int]),
     "jg_model_create": (C.c_int, [_vp, C.POINTER(JgOp), C.c_int, _vp, C.c_int64, C.c_int32, C.POINTER(_vp)]),
     "jg_model_destroy": (C.c_int, [_vp]),
     "jg_model_set_precision": (C.c_int, [_vp, C.c_int]),
@@ -91,6 +95,7 @@ SYMBOLS = {
     "jg_timer_stop_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "jg_profile_enable": (C.c_int, [_vp, C.c_int]),
     "jg_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "jg_profile_read_class": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "jg_terminal_repeats": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64, C.c_int32, _vp]),
     "jg_viterbi_decode": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int64, _vp, _vp]),
     "jg_dust_mask": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),

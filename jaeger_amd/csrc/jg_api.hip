@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <string>
+#include <thread>
 
 #include "jg_common.h"
 
@@ -57,6 +59,12 @@ extern "C" int jg_engine_destroy(jg_engine *e) {
   for (auto ev : e->pool) (void)hipEventDestroy(ev);
   (void)hipEventDestroy(e->t0);
   (void)hipEventDestroy(e->t1);
+  for (int i = 0; i < 2; ++i) {
+    if (e->pin[i]) (void)hipHostFree(e->pin[i]);
+    if (e->dbase[i]) (void)hipFree(e->dbase[i]);
+    if (e->h2d_done[i]) (void)hipEventDestroy(e->h2d_done[i]);
+  }
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   (void)hipStreamDestroy(e->stream);
   delete e;
   return JG_OK;
@@ -67,6 +75,29 @@ extern "C" int jg_engine_sync(jg_engine *e) {
   JG_HIP(hipSetDevice(e->dev));
   JG_HIP(hipStreamSynchronize(e->stream));
   return JG_OK;
+}
+
+extern "C" int jg_engine_set_option(jg_engine *e, int key, int64_t value) {
+  JG_REQUIRE(e != nullptr, JG_ERR_INVALID, "jg_engine_set_option: NULL engine");
+  switch (key) {
+    case JG_OPT_STREAM_BYTES:
+      JG_REQUIRE(value >= 4096, JG_ERR_INVALID, "jg_engine_set_option: stream budget %lld < 4096 bytes", (long long)value);
+      e->stream_bytes = value;
+      return JG_OK;
+    default:
+      jg_set_error("jg_engine_set_option: unknown key %d", key);
+      return JG_ERR_INVALID;
+  }
+}
+
+extern "C" int64_t jg_engine_get_stat(const jg_engine *e, int key) {
+  if (e == nullptr) return -1;
+  switch (key) {
+    case JG_STAT_STREAM_GROUPS: return e->streamed_groups;
+    case JG_STAT_STREAM_BYTES: return e->streamed_bytes;
+    case JG_STAT_PEAK_DEVICE_BASES: return e->peak_dev_bases;
+    default: return -1;
+  }
 }
 
 static hipStream_t pick_stream(jg_engine *e, void *stream) {
@@ -135,6 +166,7 @@ extern "C" int jg_profile_enable(jg_engine *e, int on) {
   e->conv_ms = 0.0;
   e->conv_flops = 0.0;
   e->conv_launches = 0;
+  for (int i = 0; i < 4; ++i) { e->cls_ms[i] = 0.0; e->cls_flops[i] = 0.0; e->cls_launches[i] = 0; }
   return JG_OK;
 }
 
@@ -146,6 +178,9 @@ static int drain_profile(jg_engine *e) {
     e->conv_ms += ms;
     e->conv_flops += p.flops;
     e->conv_launches += 1;
+    e->cls_ms[p.cls & 3] += ms;
+    e->cls_flops[p.cls & 3] += p.flops;
+    e->cls_launches[p.cls & 3] += 1;
     e->pool.push_back(p.a);
     e->pool.push_back(p.b);
   }
@@ -162,6 +197,17 @@ extern "C" int jg_profile_read(jg_engine *e, double *conv_ms, int64_t *conv_laun
   if (conv_ms) *conv_ms = e->conv_ms;
   if (conv_launches) *conv_launches = e->conv_launches;
   if (conv_flops) *conv_flops = e->conv_flops;
+  return JG_OK;
+}
+
+extern "C" int jg_profile_read_class(jg_engine *e, int cls, double *ms, int64_t *launches, double *flops) {
+  JG_REQUIRE(e != nullptr && cls >= 0 && cls < 4, JG_ERR_INVALID, "jg_profile_read_class: bad arguments");
+  JG_HIP(hipSetDevice(e->dev));
+  int rc = drain_profile(e);
+  if (rc != JG_OK) return rc;
+  if (ms) *ms = e->cls_ms[cls];
+  if (launches) *launches = e->cls_launches[cls];
+  if (flops) *flops = e->cls_flops[cls];
   return JG_OK;
 }
 
@@ -443,7 +489,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
     ConvHPrep &hp = m->hprep[i];
     hp.out_f16s = !slot_needs_f32(m, i, op.out_buf);
     f32_fmt[op.out_buf] = !hp.out_f16s;
-    if (!hp.out_f16s && getenv("JG_NO_POOL_FUSE") == nullptr) {
+    if (!hp.out_f16s && jg_exp_env("JG_NO_POOL_FUSE") == nullptr) {
       // the only reader of the f32 output is a masked global max pool over the conv's own output mask:
       // reduce in the epilogue instead of storing 4 B per element and reading it back
       int readers = 0, pool_idx = -1;
@@ -615,7 +661,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
       }
       // first layer on ids: the conv is a sum of k table rows T_t[id] = E[id] . W_t (f64 on the
       // host); the kernel's table variant then needs no matrix cores and no acc un-scale
-      static const bool no_lut = getenv("JG_NO_LUT") != nullptr;
+      static const bool no_lut = jg_exp_env("JG_NO_LUT") != nullptr;
       if (m->f16_eligible && !no_lut && op.in_buf == JG_BUF_IDS &&
           (op.in_mask == JG_BUF_IDS || op.in_mask < 0) && op.cout <= 128 &&
           jg_conv_lut_supports(op.k, op.dilation, m->vocab)) {
@@ -697,13 +743,13 @@ static void free_workspace(jg_model *m) {
     if (m->msk[i]) (void)hipFree(m->msk[i]);
     if (m->nmd_part[i]) (void)hipFree(m->nmd_part[i]);
     m->act[i] = nullptr; m->msk[i] = nullptr; m->nmd_part[i] = nullptr;
+    m->act_cap[i] = m->msk_cap[i] = m->nmd_cap[i] = 0;
   }
   for (int i = 0; i < JG_MAX_VECS; ++i) {
     if (m->vec[i]) (void)hipFree(m->vec[i]);
     m->vec[i] = nullptr;
+    m->vec_cap[i] = 0;
   }
-  m->cap_chunk = 0;
-  m->cap_l = 0;
 }
 
 extern "C" int jg_model_destroy(jg_model *m) {
@@ -730,29 +776,42 @@ extern "C" int jg_model_destroy(jg_model *m) {
   return JG_OK;
 }
 
+// Workspace for `chunk` windows of `l` codons per frame.  Buffers are kept as long as they are large enough
+// (the short-contig pass calls with a different l for every batch: commands/predict.py:236-245), and grow to the
+// largest request seen.
 static int ensure_workspace(jg_model *m, int64_t chunk, int l) {
-  if (chunk <= m->cap_chunk && l == m->cap_l) return JG_OK;
-  JG_HIP(hipStreamSynchronize(m->e->stream));
-  free_workspace(m);
   int64_t nmd_elems[JG_MAX_BUFS];
   int rc = plan_shapes(m, l, m->act_elems, m->msk_elems, nmd_elems, m->vec_w, nullptr);
   if (rc != JG_OK) return rc;
+  bool fits = true;
   for (int i = 0; i < JG_MAX_BUFS; ++i) {
     m->nmd_part_elems[i] = nmd_elems[i];
-    if (m->act_elems[i] > 0)
-      JG_HIP(hipMalloc(&m->act[i], (size_t)(chunk * m->act_elems[i]) * sizeof(float)));
-    if (m->msk_elems[i] > 0) JG_HIP(hipMalloc(&m->msk[i], (size_t)(chunk * m->msk_elems[i])));
-    if (nmd_elems[i] > 0)
-      JG_HIP(hipMalloc(&m->nmd_part[i], (size_t)(chunk * nmd_elems[i]) * sizeof(float)));
+    fits &= chunk * m->act_elems[i] <= m->act_cap[i] && chunk * m->msk_elems[i] <= m->msk_cap[i] &&
+            chunk * nmd_elems[i] <= m->nmd_cap[i];
+  }
+  for (int i = 0; i < JG_MAX_VECS; ++i) fits &= chunk * m->vec_w[i] <= m->vec_cap[i];
+  if (fits) return JG_OK;
+  JG_HIP(hipStreamSynchronize(m->e->stream));
+  int64_t want_act[JG_MAX_BUFS], want_msk[JG_MAX_BUFS], want_nmd[JG_MAX_BUFS], want_vec[JG_MAX_VECS];
+  for (int i = 0; i < JG_MAX_BUFS; ++i) {
+    want_act[i] = std::max(m->act_cap[i], chunk * m->act_elems[i]);
+    want_msk[i] = std::max(m->msk_cap[i], chunk * m->msk_elems[i]);
+    want_nmd[i] = std::max(m->nmd_cap[i], chunk * nmd_elems[i]);
+  }
+  for (int i = 0; i < JG_MAX_VECS; ++i) want_vec[i] = std::max(m->vec_cap[i], chunk * (int64_t)m->vec_w[i]);
+  free_workspace(m);
+  for (int i = 0; i < JG_MAX_BUFS; ++i) {
+    if (want_act[i] > 0) JG_HIP(hipMalloc(&m->act[i], (size_t)want_act[i] * sizeof(float)));
+    if (want_msk[i] > 0) JG_HIP(hipMalloc(&m->msk[i], (size_t)want_msk[i]));
+    if (want_nmd[i] > 0) JG_HIP(hipMalloc(&m->nmd_part[i], (size_t)want_nmd[i] * sizeof(float)));
+    m->act_cap[i] = want_act[i]; m->msk_cap[i] = want_msk[i]; m->nmd_cap[i] = want_nmd[i];
   }
   for (int i = 0; i < JG_MAX_VECS; ++i)
-    if (m->vec_w[i] > 0) {
-      JG_HIP(hipMalloc(&m->vec[i], (size_t)(chunk * m->vec_w[i]) * sizeof(float)));
-      JG_HIP(hipMemsetAsync(m->vec[i], 0, (size_t)(chunk * m->vec_w[i]) * sizeof(float),
-                            m->e->stream));
+    if (want_vec[i] > 0) {
+      JG_HIP(hipMalloc(&m->vec[i], (size_t)want_vec[i] * sizeof(float)));
+      JG_HIP(hipMemsetAsync(m->vec[i], 0, (size_t)want_vec[i] * sizeof(float), m->e->stream));
+      m->vec_cap[i] = want_vec[i];
     }
-  m->cap_chunk = chunk;
-  m->cap_l = l;
   return JG_OK;
 }
 
@@ -814,7 +873,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           int strips_per_win = in.frames * a.tiles_m * 2;        // partial rows (128-position strips) per window
           {
             // window-packed tiling when the frames fill their own 256-position tiles badly (e.g. 665 codons)
-            static const bool no_flat = getenv("JG_NO_FLAT") != nullptr;
+            static const bool no_flat = jg_exp_env("JG_NO_FLAT") != nullptr;
             const int halo = (op.k - 1) * op.dilation;
             const int gap = std::max(pl, halo - pl);
             const int fp = lo + gap;
@@ -862,8 +921,10 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
             a.lut_vocab = m->vocab;
             a.epi = hp.d_epi_lut;
           }
+          pe.cls = hp.d_lut != nullptr ? JG_PROF_TABLE : JG_PROF_MFMA_F16X3;
           rc = jg_launch_conv_f16(e, a, s);
         } else {
+          pe.cls = JG_PROF_MFMA_F32;
           ConvArgs a;
           memset(&a, 0, sizeof(a));
           a.x = op.in_buf == JG_BUF_IDS ? nullptr : m->act[op.in_buf];
@@ -1197,6 +1258,139 @@ extern "C" int jg_encode(jg_engine *e, const uint8_t *bases, int64_t n_bases, in
   return rc;
 }
 
+// ---- streamed ingest -------------------------------------------------------------------------
+// Host-resident bases larger than the engine's stream budget never exist on the device as a whole: the
+// (start-sorted) window list is cut into groups whose base span fits the budget; a group's span is copied
+// into one of two pinned staging buffers and sent to one of two device buffers on the copy stream while the
+// previous group is being encoded and classified on the compute stream.
+static int stream_setup(jg_engine *e, int64_t span_cap) {
+  if (e->copy_stream == nullptr) JG_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i)
+    if (e->h2d_done[i] == nullptr) JG_HIP(hipEventCreateWithFlags(&e->h2d_done[i], hipEventDisableTiming));
+  if (span_cap > e->pin_cap) {
+    for (int i = 0; i < 2; ++i) {
+      if (e->pin[i]) JG_HIP(hipHostFree(e->pin[i]));
+      e->pin[i] = nullptr;
+      JG_HIP(hipHostMalloc(&e->pin[i], (size_t)span_cap, hipHostMallocDefault));
+    }
+    e->pin_cap = span_cap;
+  }
+  if (span_cap > e->dbase_cap) {
+    for (int i = 0; i < 2; ++i) {
+      if (e->dbase[i]) JG_HIP(hipFree(e->dbase[i]));
+      e->dbase[i] = nullptr;
+      JG_HIP(hipMalloc(&e->dbase[i], (size_t)span_cap));
+    }
+    e->dbase_cap = span_cap;
+  }
+  return JG_OK;
+}
+
+struct StreamGroup {
+  int64_t w0, w1;      // windows [w0, w1)
+  int64_t b0, b1;      // base span [b0, b1) they touch
+};
+
+static int predict_streamed(jg_model *m, const uint8_t *bases, int64_t n_bases, const int64_t *win_start,
+                            const int32_t *win_len, int64_t n_win, int32_t fsize, const uint8_t *lut65,
+                            int32_t flags, int32_t l_pad, float *prediction, float *reliability,
+                            float *embedding, float *nmd, int32_t *counts, int out_loc, int32_t chunk,
+                            hipStream_t s) {
+  jg_engine *e = m->e;
+  const int64_t budget = e->stream_bytes;
+  std::vector<StreamGroup> groups;
+  int64_t span_cap = 0, win_cap = 0;
+  {
+    StreamGroup g{0, 0, win_start[0], win_start[0]};
+    for (int64_t i = 0; i < n_win; ++i) {
+      const int64_t b1 = std::max(g.b1, win_start[i] + win_len[i]);
+      if (i > g.w0 && b1 - g.b0 > budget) {
+        g.w1 = i;
+        groups.push_back(g);
+        g = StreamGroup{i, i, win_start[i], win_start[i] + win_len[i]};
+      } else {
+        g.b1 = b1;
+      }
+    }
+    g.w1 = n_win;
+    groups.push_back(g);
+    for (const StreamGroup &q : groups) {
+      span_cap = std::max(span_cap, q.b1 - q.b0);
+      win_cap = std::max(win_cap, q.w1 - q.w0);
+    }
+  }
+  span_cap = (span_cap + 4095) / 4096 * 4096;
+  int rc = stream_setup(e, std::max<int64_t>(span_cap, 4096));
+  if (rc != JG_OK) return rc;
+  if ((rc = grow(&m->d_ids, &m->d_ids_cap, win_cap * 6 * (int64_t)l_pad)) != JG_OK) return rc;
+  if ((rc = grow(&m->d_win, &m->d_win_cap, win_cap * 12)) != JG_OK) return rc;
+  if (counts != nullptr && out_loc == JG_PTR_HOST)
+    if ((rc = grow(&m->d_counts, &m->d_counts_cap, win_cap * 16)) != JG_OK) return rc;
+  JG_HIP(hipMemcpyAsync(m->d_lut, lut65, 65, hipMemcpyHostToDevice, s));
+  std::vector<int64_t> rebased((size_t)win_cap);
+  e->streamed_groups = (int64_t)groups.size();
+  e->streamed_bytes = 0;
+  e->peak_dev_bases = 2 * e->dbase_cap;
+  auto stage = [&](size_t gi) -> int {      // host span -> pinned -> device buffer gi % 2 (copy stream)
+    const StreamGroup &g = groups[gi];
+    const int b = (int)(gi & 1);
+    // both buffers of parity b are free: group gi - 2 (their last user) was synchronised at the end of its turn
+    JG_HIP(hipSetDevice(e->dev));
+    memcpy(e->pin[b], bases + g.b0, (size_t)(g.b1 - g.b0));
+    JG_HIP(hipMemcpyAsync(e->dbase[b], e->pin[b], (size_t)(g.b1 - g.b0), hipMemcpyHostToDevice, e->copy_stream));
+    JG_HIP(hipEventRecord(e->h2d_done[b], e->copy_stream));
+    e->streamed_bytes += g.b1 - g.b0;
+    return JG_OK;
+  };
+  if ((rc = stage(0)) != JG_OK) return rc;
+  const int w_pred = jg_model_vec_width(m, 0), w_rel = jg_model_vec_width(m, 1);
+  const int w_emb = jg_model_vec_width(m, 2), w_nmd = jg_model_vec_width(m, 3);
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    const StreamGroup &g = groups[gi];
+    const int b = (int)(gi & 1);
+    const int64_t nw = g.w1 - g.w0;
+    // the next group's span is staged by a helper thread while this group is encoded and classified
+    int stage_rc = JG_OK;
+    std::string stage_err;
+    std::thread stager;
+    if (gi + 1 < groups.size())
+      stager = std::thread([&, gi]() {
+        stage_rc = stage(gi + 1);
+        if (stage_rc != JG_OK) stage_err = jg_last_error();
+      });
+    struct Joiner {
+      std::thread &t;
+      ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{stager};
+    for (int64_t i = 0; i < nw; ++i) rebased[(size_t)i] = win_start[g.w0 + i] - g.b0;
+    char *dw = static_cast<char *>(m->d_win);
+    JG_HIP(hipMemcpyAsync(dw, rebased.data(), (size_t)nw * 8, hipMemcpyHostToDevice, s));
+    JG_HIP(hipMemcpyAsync(dw + win_cap * 8, win_len + g.w0, (size_t)nw * 4, hipMemcpyHostToDevice, s));
+    JG_HIP(hipStreamSynchronize(s));          // `rebased` is reused by the next group (pageable source)
+    JG_HIP(hipStreamWaitEvent(s, e->h2d_done[b], 0));
+    int32_t *d_counts = counts == nullptr ? nullptr : (out_loc == JG_PTR_HOST ? m->d_counts : counts + g.w0 * 4);
+    rc = jg_launch_encode(static_cast<const uint8_t *>(e->dbase[b]), reinterpret_cast<const int64_t *>(dw),
+                          reinterpret_cast<const int32_t *>(dw + win_cap * 8), nw, fsize, m->d_lut, flags, l_pad,
+                          m->d_ids, d_counts, s);
+    if (rc != JG_OK) return rc;
+    rc = forward_device_ids(m, m->d_ids, nw, l_pad, prediction ? prediction + g.w0 * w_pred : nullptr,
+                            reliability ? reliability + g.w0 * w_rel : nullptr,
+                            embedding ? embedding + g.w0 * w_emb : nullptr, nmd ? nmd + g.w0 * w_nmd : nullptr,
+                            out_loc, chunk, s);
+    if (rc != JG_OK) return rc;
+    if (counts != nullptr && out_loc == JG_PTR_HOST)
+      JG_HIP(hipMemcpyAsync(counts + g.w0 * 4, d_counts, (size_t)nw * 16, hipMemcpyDeviceToHost, s));
+    JG_HIP(hipStreamSynchronize(s));
+    if (stager.joinable()) stager.join();
+    if (stage_rc != JG_OK) {
+      jg_set_error("%s", stage_err.c_str());
+      return stage_rc;
+    }
+  }
+  (void)n_bases;
+  return JG_OK;
+}
+
 extern "C" int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_bases, int bases_loc,
                                   const int64_t *win_start, const int32_t *win_len, int win_loc,
                                   int64_t n_win, int32_t fsize, const uint8_t *lut65,
@@ -1210,6 +1404,30 @@ extern "C" int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_b
   jg_engine *e = m->e;
   JG_HIP(hipSetDevice(e->dev));
   hipStream_t s = pick_stream(e, stream);
+  e->streamed_groups = 0;
+  e->streamed_bytes = 0;
+  e->peak_dev_bases = bases_loc == JG_PTR_HOST ? n_bases : 0;
+  if (bases_loc == JG_PTR_HOST && win_loc == JG_PTR_HOST && n_bases > e->stream_bytes) {
+    // streamed ingest needs a start-sorted window list (the fragmenter's FASTA order is) inside the buffer
+    bool sorted = true;
+    int longest = 0;
+    for (int64_t i = 0; i < n_win; ++i) {
+      JG_REQUIRE(win_start[i] >= 0 && win_len[i] >= 0 && win_start[i] + win_len[i] <= n_bases, JG_ERR_INVALID,
+                 "encode: window %lld [%lld, +%d) outside the %lld-byte base buffer", (long long)i,
+                 (long long)win_start[i], win_len[i], (long long)n_bases);
+      sorted &= i == 0 || win_start[i] >= win_start[i - 1];
+      longest = std::max(longest, std::min(win_len[i], fsize));
+    }
+    if (sorted) {
+      const int off3 = (fsize % 3 == 0) ? -2 : ((fsize % 3 == 1) ? -1 : 0);
+      const int usable = longest - 5 + off3;
+      const int need = usable > 0 ? (usable + 2) / 3 : 0;
+      JG_REQUIRE(fsize >= 3 && l_pad >= need && l_pad >= 1, JG_ERR_INVALID,
+                 "encode: l_pad=%d is smaller than the %d codons the longest window yields (fsize %d)", l_pad, need, fsize);
+      return predict_streamed(m, bases, n_bases, win_start, win_len, n_win, fsize, lut65, soft_mask, l_pad,
+                              prediction, reliability, embedding, nmd, counts, out_loc, chunk, s);
+    }
+  }
   std::vector<void *> to_free;
   int rc = grow(&m->d_ids, &m->d_ids_cap, n_win * 6 * (int64_t)l_pad);
   if (rc != JG_OK) return rc;

@@ -9,6 +9,19 @@
 
 void jg_set_error(const char *fmt, ...);
 
+// Experiment switches (JG_DBG ablation mask, JG_NO_LUT, JG_NO_FLAT, JG_NO_POOL_FUSE, JG_ONE_WG) exist only in the
+// `make exp` build (libjaeger_hip_exp.so, -DJG_EXPERIMENT): the shipped library never reads them, so that a stray
+// variable in a user's environment cannot change results.
+#include <stdlib.h>
+static inline const char *jg_exp_env(const char *name) {
+#ifdef JG_EXPERIMENT
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 #define JG_HIP(call)                                                                 \
   do {                                                                               \
     hipError_t err_ = (call);                                                        \
@@ -122,6 +135,7 @@ struct EltArgs {
 struct ProfEvent {
   hipEvent_t a, b;
   double flops;
+  int cls = 0;      // JG_PROF_*: which kernel family the launch belongs to
 };
 
 struct jg_engine {
@@ -133,7 +147,18 @@ struct jg_engine {
   std::vector<hipEvent_t> pool;   // recycled events
   double conv_ms = 0.0, conv_flops = 0.0;
   int64_t conv_launches = 0;
+  double cls_ms[4] = {}, cls_flops[4] = {};     // the same split by kernel family (JG_PROF_*)
+  int64_t cls_launches[4] = {};
   int n_cu = 256;
+  // streamed ingest of host-resident bases (jg_predict_windows): spans above `stream_bytes` go through two pinned
+  // staging buffers and two device buffers on a copy stream, record group by record group
+  int64_t stream_bytes = (int64_t)256 << 20;
+  hipStream_t copy_stream = nullptr;
+  void *pin[2] = {nullptr, nullptr};
+  void *dbase[2] = {nullptr, nullptr};
+  int64_t pin_cap = 0, dbase_cap = 0;
+  hipEvent_t h2d_done[2] = {nullptr, nullptr};
+  int64_t streamed_groups = 0, streamed_bytes = 0, peak_dev_bases = 0;   // statistics of the last call (jg_engine_get_stat)
 };
 
 struct ConvHPrep {          // per CONV op: split-f16 operands (built at model creation)
@@ -169,8 +194,7 @@ struct jg_model {
   int64_t n_w = 0;
   int vocab = 0;
   // workspace (grown on demand)
-  int64_t cap_chunk = 0;
-  int cap_l = 0;
+  int64_t act_cap[JG_MAX_BUFS] = {}, msk_cap[JG_MAX_BUFS] = {}, nmd_cap[JG_MAX_BUFS] = {}, vec_cap[JG_MAX_VECS] = {};  // elements allocated
   float *act[JG_MAX_BUFS] = {};
   int64_t act_elems[JG_MAX_BUFS] = {}; // per window
   uint8_t *msk[JG_MAX_BUFS] = {};

@@ -61,7 +61,7 @@ bool jg_conv_f16_has_pattern(unsigned ep, bool first_layer) {
 // JG_DBG ablation mask: read at every launch, so that an experiment can warm up on real data and then
 // switch (bench.py --timed-dbg)
 static int jg_dbg_env(void) {
-  const char *ev = getenv("JG_DBG");
+  const char *ev = jg_exp_env("JG_DBG");
   return ev ? atoi(ev) : 0;
 }
 

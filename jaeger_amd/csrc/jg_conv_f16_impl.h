@@ -938,7 +938,7 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   // two 4-wave workgroups per CU when their LDS fits (<= 80 KB each): one's epilogue and stores overlap
   // the other's matrix-core steps.  (Forcing the two out of phase - by dispatch order or by a per-CU
   // arrival ticket - was measured and changes nothing; neither does storing each block early.)
-  static const bool one_wg = getenv("JG_ONE_WG") != nullptr;      // experiment switch: one workgroup per CU
+  static const bool one_wg = jg_exp_env("JG_ONE_WG") != nullptr;      // experiment switch: one workgroup per CU
   int grid = ((smem <= 80 * 1024 && !one_wg) ? 2 : 1) * e->n_cu;
   if (grid > n_pairs) grid = n_pairs;
   ConvHArgs b = a;

@@ -72,6 +72,16 @@ class HipDevice:
     def sync(self):
         L.check(self.lib.jg_engine_sync(self.handle), "jg_engine_sync")
 
+    def set_stream_bytes(self, nbytes: int):
+        """Host base buffers above ``nbytes`` are streamed through pinned staging buffers (JG_OPT_STREAM_BYTES)."""
+        L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_STREAM_BYTES, int(nbytes)), "jg_engine_set_option")
+
+    def stream_stats(self) -> dict:
+        """Streaming statistics of the last ``jg_predict_windows`` call on this engine."""
+        g = lambda k: int(self.lib.jg_engine_get_stat(self.handle, k))  # noqa: E731
+        return {"groups": g(L.JG_STAT_STREAM_GROUPS), "bytes": g(L.JG_STAT_STREAM_BYTES),
+                "peak_device_bases": g(L.JG_STAT_PEAK_DEVICE_BASES)}
+
     # raw device memory -------------------------------------------------------
     def alloc(self, nbytes: int) -> int:
         p = C.c_void_p()
@@ -108,7 +118,11 @@ class HipDevice:
     def profile_read(self) -> dict:
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
         L.check(self.lib.jg_profile_read(self.handle, C.byref(ms), C.byref(n), C.byref(fl)))
-        return {"conv_ms": ms.value, "conv_launches": n.value, "conv_flops": fl.value}
+        out = {"conv_ms": ms.value, "conv_launches": n.value, "conv_flops": fl.value}
+        for cls, name in enumerate(("mfma_f16x3", "mfma_f32", "table", "fused_small")):
+            L.check(self.lib.jg_profile_read_class(self.handle, cls, C.byref(ms), C.byref(n), C.byref(fl)))
+            out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value}
+        return out
 
     def encode(self, bases: np.ndarray, win_start: np.ndarray, win_len: np.ndarray, fsize: int,
                lut: np.ndarray, flags: int = 0, l_pad: int | None = None):

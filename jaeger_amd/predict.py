@@ -142,13 +142,21 @@ def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None,
     if not padded:
         out = engine.predict_windows(fa.bases, starts, table.length, fsize, pre_cased=pre_cased, want=want)
     else:
+        # the short-contig pass: one whole-contig window per record.  The selected records are compacted into a
+        # buffer of their own once, so that a batch of 96 windows uploads the few hundred kB it covers and not the
+        # whole FASTA image (a 2 Gbp assembly with 1 M short contigs would otherwise move 2 GB per batch)
+        wl = table.length.astype(np.int64)
+        cstart = np.cumsum(wl) - wl
+        gather = np.repeat(starts - cstart, wl) + np.arange(int(wl.sum()), dtype=np.int64)
+        compact = fa.bases[gather]
         off3 = (-2, -1, 0)[fsize % 3]
         parts = []
         for i in range(0, len(table), batch):
             sl = slice(i, i + batch)
             lmax = int(max(0, -(-(int(table.length[sl].max()) - 5 + off3) // 3)))
-            parts.append(engine.predict_windows(fa.bases, starts[sl], table.length[sl], fsize, l_pad=max(lmax, 1),
-                                                pre_cased=pre_cased, want=want))
+            c0, c1 = int(cstart[i]), int(cstart[sl][-1] + wl[sl][-1])
+            parts.append(engine.predict_windows(compact[c0:c1], cstart[sl] - c0, table.length[sl], fsize,
+                                                l_pad=max(lmax, 1), pre_cased=pre_cased, want=want))
         out = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
     counts = out.pop("counts")
     out.update(frag.window_metadata(table, names, counts))

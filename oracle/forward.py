@@ -39,6 +39,8 @@ _ACT_ALIASES = {"relu", "gelu", "sigmoid", "softmax", "tanh"}
 # --------------------------------------------------------------------------
 def gelu_tanh(x):
     """tf.nn.gelu(approximate=True), layers.py:29."""
+    if FAST:
+        return F.gelu(x, approximate="tanh")
     return 0.5 * x * (1.0 + torch.tanh(0.7978845608028654 * (x + 0.044715 * x * x * x)))
 
 
@@ -71,10 +73,18 @@ def same_pad(length: int, k: int, stride: int, dilation: int) -> tuple[int, int,
     return l_out, total // 2, total - total // 2
 
 
+#: False = the checker's default: every op spelled out (k shifted sgemm calls per conv, GELU / batch norm as the
+#: reference writes them).  True = the same f32 forward on the fused CPU kernels a TensorFlow-CPU build would run
+#: (oneDNN channels-last convolution, fused tanh-GELU, batch norm as one multiply-add with constant-folded
+#: scale / shift); used by bench.py's cpu_baseline leg, agrees with the default to rounding
+#: (tests/test_oracle_forward.py).
+FAST = False
+
+
 def conv1d_nwc(x, kernel, stride, padding, dilation):
-    """tf.nn.conv1d on (N, L, Cin) with a (k, Cin, Cout) kernel, written as k shifted
-    GEMMs (y[:, m] = sum_t x[:, m*s + t*d - pad_left] @ W[t]) so the CPU baseline runs
-    on the BLAS sgemm path like TensorFlow's oneDNN/Eigen conv does."""
+    """tf.nn.conv1d on (N, L, Cin) with a (k, Cin, Cout) kernel: k shifted GEMMs
+    (y[:, m] = sum_t x[:, m*s + t*d - pad_left] @ W[t]) or, with ``CONV_IMPL = "conv1d"``, the oneDNN
+    convolution behind ``torch.nn.functional.conv1d``."""
     k, cin, cout = kernel.shape
     n, length, _ = x.shape
     if padding == "SAME":
@@ -83,6 +93,12 @@ def conv1d_nwc(x, kernel, stride, padding, dilation):
     else:
         span = dilation * (k - 1) + 1
         l_out = (length - span) // stride + 1 if length >= span else 0
+    if FAST and l_out > 0 and cin > 1:
+        # (N, L, C) contiguous IS the channels-last image of an (N, C, 1, L) tensor: no copies either way
+        x4 = x.contiguous().permute(0, 2, 1).unsqueeze(2)
+        w4 = kernel.permute(2, 1, 0).unsqueeze(2).contiguous(memory_format=torch.channels_last)
+        y = F.conv2d(x4, w4, stride=(1, stride), dilation=(1, dilation))
+        return y[:, :, 0, :l_out].permute(0, 2, 1).contiguous()
     y = None
     for t in range(k):
         start = t * dilation
@@ -124,6 +140,9 @@ def masked_conv1d(x, mask, w: dict, *, kernel_size, strides=1, padding="valid",
 def masked_batchnorm(x, w, eps=1e-5):
     """layers.py:918-938 inference branch: gamma*((x-mm)*rsqrt(mv+eps))+beta."""
     inv_std = torch.rsqrt(w["moving_variance"] + eps)
+    if FAST:
+        scale = w["gamma"] * inv_std
+        return torch.addcmul(w["beta"] - w["moving_mean"] * scale, x, scale)
     return w["gamma"] * ((x - w["moving_mean"]) * inv_std) + w["beta"]
 
 

@@ -1,4 +1,6 @@
 # (ablation masks are applied after a full-kernel warm-up step - bench.py --timed-dbg - so that the timed step reads real activations)
+# ablation switches live in the experiment build only (make -C jaeger_amd/csrc exp)
+export JAEGER_HIP_LIB=${JAEGER_HIP_LIB:-${GRAFT_REPO_ROOT:-.}/jaeger_amd/libjaeger_hip_exp.so}
 # what a one-workgroup-per-CU design could reach: lone workgroup with the epilogue parts removed
 for one in 0 1; do for dbg in 0 64 96 224 1; do
   echo -n "one_wg=$one JG_DBG=$dbg: "

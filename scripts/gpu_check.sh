@@ -1,4 +1,6 @@
 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -3
+# ablation switches live in the experiment build only (make -C jaeger_amd/csrc exp)
+export JAEGER_HIP_LIB=${JAEGER_HIP_LIB:-${GRAFT_REPO_ROOT:-.}/jaeger_amd/libjaeger_hip_exp.so}
 python bench.py --no-cpu-baseline --contigs 3000 --steps 1 2>&1 | tail -1 | cut -c1-400
 JG_NO_LUT=1 python bench.py --no-cpu-baseline --contigs 3000 --steps 1 2>&1 | tail -1 | cut -c1-400
 cd /tmp && export TMPDIR=/tmp

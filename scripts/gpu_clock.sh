@@ -1,4 +1,6 @@
 # effective shader clock per kernel: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel duration.
+# ablation switches live in the experiment build only (make -C jaeger_amd/csrc exp)
+export JAEGER_HIP_LIB=${JAEGER_HIP_LIB:-${GRAFT_REPO_ROOT:-.}/jaeger_amd/libjaeger_hip_exp.so}
 # One warm-up step with the full kernel (real activations in the buffers), then one timed step under the ablation
 # mask: the first half of each kernel's launches is the full kernel, the second half the ablated one.
 cd /tmp && export TMPDIR=/tmp

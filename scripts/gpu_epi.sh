@@ -1,4 +1,6 @@
 # (ablation masks are applied after a full-kernel warm-up step - bench.py --timed-dbg - so that the timed step reads real activations)
+# ablation switches live in the experiment build only (make -C jaeger_amd/csrc exp)
+export JAEGER_HIP_LIB=${JAEGER_HIP_LIB:-${GRAFT_REPO_ROOT:-.}/jaeger_amd/libjaeger_hip_exp.so}
 # epilogue ablations with the matrix cores running (JG_DBG bits: 1 no epilogue at all, 32 no stage arithmetic, 64 no stores, 128 no shortcut loads)
 for dbg in 0 1 32 64 128 96 192 224; do
   echo -n "JG_DBG=$dbg: "

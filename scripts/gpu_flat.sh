@@ -1,4 +1,6 @@
 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -2
+# ablation switches live in the experiment build only (make -C jaeger_amd/csrc exp)
+export JAEGER_HIP_LIB=${JAEGER_HIP_LIB:-${GRAFT_REPO_ROOT:-.}/jaeger_amd/libjaeger_hip_exp.so}
 python - <<'PY'
 import sys, time, numpy as np, warnings, os
 warnings.simplefilter("ignore")

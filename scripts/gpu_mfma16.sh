@@ -1,4 +1,6 @@
 # Build the probe library first (not part of `make`):
+# ablation switches live in the experiment build only (make -C jaeger_amd/csrc exp)
+export JAEGER_HIP_LIB=${JAEGER_HIP_LIB:-${GRAFT_REPO_ROOT:-.}/jaeger_amd/libjaeger_hip_exp.so}
 #   make -C jaeger_amd/csrc -j6 BUILD=build_m16 OUT=$PWD/jaeger_amd/libjaeger_hip_m16.so \
 #     "FLAGS=-O3 -std=c++17 --offload-arch=gfx950 -fPIC -I$PWD/include -I. -Wall -Wno-pass-failed -DJG_MFMA16_PROBE"
 # MFMA-shape probe (timing only): libjaeger_hip_m16.so (-DJG_MFMA16_PROBE) replaces every 32x32x16 MFMA of the main

@@ -1,4 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
+# ablation switches live in the experiment build only (make -C jaeger_amd/csrc exp)
+export JAEGER_HIP_LIB=${JAEGER_HIP_LIB:-${GRAFT_REPO_ROOT:-.}/jaeger_amd/libjaeger_hip_exp.so}
 R=$GRAFT_REPO_ROOT
 rocprofv3 -L 2>/dev/null | grep -o "Name:[[:space:]]*[A-Za-z0-9_]*" | sort -u > $R/gpurun_out/counters.txt
 wc -l $R/gpurun_out/counters.txt

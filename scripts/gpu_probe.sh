@@ -1,4 +1,6 @@
 # VALU-in-the-MFMA-shadow probe: main loop only (timed JG_DBG=1 after a full-kernel warm-up on real data), one or two
+# ablation switches live in the experiment build only (make -C jaeger_amd/csrc exp)
+export JAEGER_HIP_LIB=${JAEGER_HIP_LIB:-${GRAFT_REPO_ROOT:-.}/jaeger_amd/libjaeger_hip_exp.so}
 # workgroups per CU, 60 dummy FMAs per 12 MFMAs.  The probe sits in the one-barrier-per-tap loop: both libraries are
 # built with -DJG_PAIRED=0 (libjaeger_hip_np.so; libjaeger_hip_probe_60_0.so adds -DJG_VALU_PROBE=60).
 for one in 1 0; do

@@ -1,0 +1,179 @@
+"""GPU tests at the sizes of BASELINE.json configs[2] and configs[4], run as the per-rank shard one of the eight
+GPUs would own, through ``predict_windows`` with host buffers:
+
+* oracle parity (logits within 1e-4) on a seeded sample of >= 500 windows drawn across the whole run,
+* full-size invariants: G/C/A/T counts exact, results bit-identical under a different stream budget / windows per
+  pass (chunk invariance implies repeatability: the second run repeats every window in other launch groups),
+* configs[4]: the host-DRAM -> HBM ingest really is streamed (several groups, the device never holds the whole buffer).
+
+Also the N-rank launch of ``bench.py --gpus N`` (two ranks sharing the one GPU of the test box, gloo exchange).
+"""
+import json
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_model_cfg
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+ACGT = np.frombuffer(b"ACGT", np.uint8)
+
+
+@pytest.fixture(scope="module")
+def brain():
+    from jaeger_amd.engine import JaegerHipEngine
+    from oracle import forward as ofwd
+    cfg = load_model_cfg("brain")
+    weights = ofwd.random_weights(cfg, seed=38341)
+    with pytest.warns(UserWarning):
+        eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0)
+    assert eng.model.precision == "f16x3"
+    yield cfg, weights, eng
+    eng.close()
+
+
+def _oracle_check(cfg, weights, bases, starts, lens, fsize, got, sample):
+    from jaeger_amd.engine import frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    windows = [bases[starts[i]:starts[i] + lens[i]].tobytes() for i in sample]
+    ids = oenc.encode_windows(windows, fsize, pad_to=frame_length(fsize))
+    worst = {}
+    for i in range(0, len(sample), 96):
+        ref = ofwd.forward(cfg, weights, ids[i:i + 96])
+        sl = sample[i:i + 96]
+        for k in ("prediction", "reliability"):
+            worst[k] = max(worst.get(k, 0.0), float(np.abs(got[k][sl] - ref[k]).max()))
+    ref_counts = np.array([oenc.window_counts(w) for w in windows], np.int32)
+    np.testing.assert_array_equal(got["counts"][sample], ref_counts)
+    print("oracle parity on", len(sample), "sampled windows:", worst)
+    assert worst["prediction"] < TOL and worst["reliability"] < TOL, worst
+
+
+def test_config3_shard_125k_fragments(brain):
+    """configs[2] per-rank shard: 125 000 fragments of exactly 1 500 bp, one window each, PCG64(seed + 1)."""
+    from jaeger_amd.fragment import build_window_table
+    cfg, weights, eng = brain
+    fsize, n_frag = 1500, 125_000
+    rng = np.random.Generator(np.random.PCG64(20260923 + 1))
+    bases = ACGT[rng.integers(0, 4, fsize * n_frag, dtype=np.uint8)]
+    lengths = np.full(n_frag, fsize, np.int64)
+    table = build_window_table(lengths, fsize, fsize)
+    assert len(table) == n_frag and table.is_last.all()
+    starts = (np.arange(n_frag, dtype=np.int64) * fsize)[table.contig] + table.start
+    want = ("prediction", "reliability")
+    eng.device.set_stream_bytes(256 << 20)
+    got = eng.predict_windows(bases, starts, table.length, fsize, want=want)
+    assert got["prediction"].shape == (n_frag, 6) and np.isfinite(got["prediction"]).all()
+    assert int(got["counts"].sum()) == n_frag * fsize                 # every base is an upper-case A/C/G/T
+    # the gathered (n, 6) f32 logit matrix of the full config is 24 MB; this shard's part is 3 MB
+    assert got["prediction"].nbytes == n_frag * 6 * 4
+    # bit-identical in other launch groups: 1 000 windows per pass and a 16 MiB stream budget (12 groups)
+    eng.device.set_stream_bytes(16 << 20)
+    eng.chunk = 1000
+    try:
+        again = eng.predict_windows(bases, starts, table.length, fsize, want=want)
+        stats = eng.device.stream_stats()
+    finally:
+        eng.chunk = 0
+        eng.device.set_stream_bytes(256 << 20)
+    assert stats["groups"] >= 11 and stats["peak_device_bases"] < 40 << 20
+    for k in ("prediction", "reliability", "counts"):
+        np.testing.assert_array_equal(got[k], again[k])
+    sample = np.sort(np.random.Generator(np.random.PCG64(3)).choice(n_frag, 512, replace=False))
+    _oracle_check(cfg, weights, bases, starts, table.length, fsize, got, sample)
+
+
+def mixed_assembly(rng, total_bp: int):
+    """configs[4] length mixture: by count 70 % log-uniform 1.5-20 kb, 25 % 20-200 kb,
+    5 % 0.2-5 Mb, drawn until ``total_bp`` is reached; bases generated block-wise into one buffer."""
+    lens = []
+    acc = 0
+    while acc < total_bp:
+        u = rng.random(4096)
+        lo = np.where(u < 0.70, 1500.0, np.where(u < 0.95, 20e3, 200e3))
+        hi = np.where(u < 0.70, 20e3, np.where(u < 0.95, 200e3, 5e6))
+        batch = np.exp(rng.uniform(np.log(lo), np.log(hi))).astype(np.int64)
+        for v in batch:
+            lens.append(int(v))
+            acc += int(v)
+            if acc >= total_bp:
+                break
+    lengths = np.asarray(lens, np.int64)
+    bases = np.empty(int(lengths.sum()), np.uint8)
+    step = 1 << 26
+    for o in range(0, bases.size, step):
+        n = min(step, bases.size - o)
+        bases[o:o + n] = ACGT[rng.integers(0, 4, n, dtype=np.uint8)]
+    return lengths, bases
+
+
+def test_config5_shard_mixed_lengths_streamed(brain):
+    """configs[4] per-rank shard: >= 1.25 Gbp of mixed-length contigs incl. 0.2-5 Mb ones, host buffers, streamed."""
+    from jaeger_amd.fragment import build_window_table
+    cfg, weights, eng = brain
+    fsize = 1500
+    rng = np.random.Generator(np.random.PCG64(20260923 + 4))
+    lengths, bases = mixed_assembly(rng, 1_250_000_000)
+    assert bases.size >= 1_250_000_000 and lengths.max() > 1_000_000 and (lengths < 20_000).mean() > 0.6
+    offsets = np.zeros(lengths.size + 1, np.int64)
+    np.cumsum(lengths, out=offsets[1:])
+    table = build_window_table(lengths, fsize, fsize)
+    starts = offsets[table.contig] + table.start
+    n_win = len(table)
+    assert n_win > 800_000
+    want = ("prediction", "reliability")
+    eng.device.set_stream_bytes(256 << 20)
+    got = eng.predict_windows(bases, starts, table.length, fsize, want=want)
+    stats = eng.device.stream_stats()
+    print("streamed ingest:", stats, "windows:", n_win)
+    # streamed: several groups, all bases went through the staging buffers once, and the device held two spans
+    assert stats["groups"] >= 4
+    assert stats["bytes"] <= bases.size and stats["bytes"] >= int(table.length.sum())
+    assert stats["peak_device_bases"] <= 2 * (256 << 20) + 8192 < bases.size // 2
+    assert np.isfinite(got["prediction"]).all()
+    assert int(got["counts"].sum()) == n_win * fsize
+    # other launch groups (64 MiB spans, 1 536 windows per pass): bit-identical
+    eng.device.set_stream_bytes(64 << 20)
+    eng.chunk = 1536
+    try:
+        again = eng.predict_windows(bases, starts, table.length, fsize, want=want)
+        assert eng.device.stream_stats()["groups"] >= 16
+    finally:
+        eng.chunk = 0
+        eng.device.set_stream_bytes(256 << 20)
+    for k in ("prediction", "reliability", "counts"):
+        np.testing.assert_array_equal(got[k], again[k])
+    # sampled oracle parity across the run: windows of short, medium and megabase contigs, first / last windows
+    srng = np.random.Generator(np.random.PCG64(5))
+    sample = set(srng.choice(n_win, 480, replace=False).tolist())
+    big = int(np.argmax(lengths))
+    w_big = np.nonzero(table.contig == big)[0]
+    sample.update([0, n_win - 1, int(w_big[0]), int(w_big[-1]), int(w_big[len(w_big) // 2])])
+    sample.update(np.nonzero(table.is_last == 1)[0][:16].tolist())
+    sample = np.sort(np.fromiter(sample, np.int64))
+    assert len(sample) >= 500
+    _oracle_check(cfg, weights, bases, starts, table.length, fsize, got, sample)
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """``python bench.py --gpus 2`` with no torchrun environment launches two ranks by itself and reports n_gpus 2
+    (here both ranks share the test box's one GPU and exchange over gloo: --oversubscribe)."""
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--oversubscribe", "--contigs", "200", "--steps", "1",
+           "--warmup", "1", "--no-cpu-baseline", "--no-exact-f32"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["windows_per_gpu"] > 0 and line["roofline"]["launches"] > 0
+    # a --gpus that contradicts the torchrun environment is an error, not a silent single-GPU run
+    import os
+    bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                         env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert bad.returncode == 2 and "does not match WORLD_SIZE" in bad.stderr
