@@ -78,5 +78,24 @@ def predict(**kwargs):
     run_core(**kwargs)
 
 
+@main.command("verify-model", help="Compare a SavedModel directory (saved_model.pb + variables) with the layer plan "
+                                   "the MI355X engine compiles - no TensorFlow needed.")
+@click.argument("graph_dir", type=click.Path(exists=True))
+@click.option("--project", type=click.Path(exists=True), default=None, help="the model's *_project.yaml")
+@click.option("--legacy", is_flag=True, help="check against the legacy `default` tower instead of a project.yaml")
+def verify_model_cmd(graph_dir, project, legacy):
+    import sys
+
+    import yaml
+
+    from .plan import build_plan
+    from .verify import report, verify_model
+    if not legacy and project is None:
+        raise click.UsageError("pass --project <name>_project.yaml or --legacy")
+    plan = None if legacy else build_plan(yaml.safe_load(open(project).read())["model"])
+    click.echo(report(graph_dir, plan, legacy))
+    sys.exit(1 if verify_model(graph_dir, plan, legacy) else 0)
+
+
 if __name__ == "__main__":
     main()

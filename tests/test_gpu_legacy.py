@@ -112,3 +112,19 @@ def test_cli_config1_default_model(tmp_path):
     print(got[["contig_id", "length", "prediction", "phage_score", "reliability_score", "window_summary"]])
     assert (out / "test_contigs_phages_jaeger.tsv").exists()
     assert (out / "test_contigs_default_window_scores.npz").exists()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_legacy_gpu_vs_reference_savedmodel(precision):
+    """The HIP legacy path against the reference's OWN graph + weights: logits and embeddings of the bundled
+    ``jaeger_fragment_graph`` SavedModel, executed TF-free (tests/golden/make_golden_savedmodel.py), on the 135
+    windows of test_contigs.fasta.  Gate: 1e-4 absolute against the graph's exact (f64) value."""
+    from jaeger_amd import legacy
+    gold = np.load(GOLDEN / "legacy_savedmodel_logits.npz")
+    eng = legacy.LegacyHipEngine(H5, precision=precision)
+    got = eng.forward_ids(gold["ids"])
+    eng.close()
+    e_out = float(np.abs(got["output"] - gold["output_f64"]).max())
+    e_emb = float(np.abs(got["embedding"] - gold["embedding_f64"]).max())
+    print(f"{precision}: logits {e_out:.2e} (|max| {np.abs(gold['output_f64']).max():.1f}), embedding {e_emb:.2e}")
+    assert e_out < 1e-4 and e_emb < 1e-4

@@ -1,0 +1,136 @@
+"""The float forward pinned to a reference-held artefact: the reference's bundled SavedModel
+(``src/jaeger/data/models/test/jaeger_fragment_graph``, committed as a data fixture) executed WITHOUT TensorFlow by
+``oracle/graphdef.py``; golden logits in ``tests/golden/legacy_savedmodel_logits.npz`` (generator:
+``tests/golden/make_golden_savedmodel.py``)."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+GRAPH = GOLDEN / "legacy_data" / "models" / "test" / "jaeger_fragment_graph"
+H5 = GOLDEN / "legacy_data" / "models" / "default" / "WRes_1024.h5"
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return dict(np.load(GOLDEN / "legacy_savedmodel_logits.npz"))
+
+
+def test_bundle_reader_matches_the_h5_weights():
+    """The SavedModel's variable bundle (TF-free SSTable reader) holds the same 947 036 values as WRes_1024.h5."""
+    from jaeger_amd import legacy
+    from jaeger_amd import savedmodel_lite as S
+    bundle = S.read_bundle(GRAPH / "variables")
+    floats = {k: v for k, v in bundle.items() if v.dtype == np.float32 and k.endswith("VARIABLE_VALUE")}
+    assert sum(v.size for v in floats.values()) == 947_036
+    h5 = legacy.load_legacy_h5(H5)
+    # Keras names differ; match the two sets by value (every tensor of one side appears bit for bit in the other)
+    sigs = {(v.shape, v.tobytes()) for v in floats.values()}
+    for name, arr in h5.items():
+        assert (arr.shape, np.asarray(arr, np.float32).tobytes()) in sigs, name
+
+
+def test_census_of_the_bundled_graph():
+    """SURVEY Appendix D census, reproduced by the committed reader."""
+    from jaeger_amd import savedmodel_lite as S
+    c = S.census(GRAPH)
+    assert c["n_nodes"] == 6324 and c["n_captured_variables"] == 79 and c["n_parameters"] == 947_036
+    assert c["ops"]["Conv2D"] == 72 and c["ops"]["Erfc"] == 104 and c["ops"]["MaxPool"] == 12
+    assert c["ops"]["SpaceToBatchND"] == 66 and c["ops"]["MatMul"] == 3 and c["ops"]["Max"] == 1
+    assert c["gelu_form"] == "erf"
+    assert list(c["batchnorm_eps"].values()) == [72] and abs(list(c["batchnorm_eps"])[0] - 1e-3) < 1e-9
+    assert c["inputs"] == ["inputs", "inputs_1", "inputs_2", "inputs_3", "inputs_4", "inputs_5"]
+
+
+def test_graph_interpreter_reproduces_golden(golden):
+    """Re-executing the committed graph on a few windows gives the committed logits (the fixture is what it says)."""
+    from oracle import graphdef
+    ids = golden["ids"][[0, 67, 134]]
+    feeds = {("inputs" if f == 0 else f"inputs_{f}"): ids[:, f, :].astype(np.float32) for f in range(6)}
+    out = graphdef.run_saved_model(GRAPH, feeds)
+    np.testing.assert_allclose(out["identity_1"], golden["output"][[0, 67, 134]], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(out["identity"], golden["embedding"][[0, 67, 134]], atol=2e-6, rtol=0)
+
+
+def test_legacy_oracle_pinned_to_the_reference_graph(golden):
+    """oracle/legacy.py (the restatement every legacy GPU test is checked against) vs the reference's own graph +
+    weights: conv SAME-pad split, dilations, bias, exact-erf GELU, batch norm eps 1e-3, MaxPool, frame sum, global max,
+    dense stack - within 1e-4 of the graph's exact (f64) value on all 135 windows."""
+    from jaeger_amd import legacy
+    from oracle import legacy as ol
+    w = legacy.load_legacy_h5(H5)
+    ref = ol.forward(w, golden["ids"])
+    e_out = float(np.abs(ref["output"] - golden["output_f64"]).max())
+    e_emb = float(np.abs(ref["embedding"] - golden["embedding_f64"]).max())
+    print(f"oracle/legacy.py vs SavedModel (f64): logits {e_out:.2e} (range {np.abs(golden['output_f64']).max():.1f}), "
+          f"embedding {e_emb:.2e}")
+    assert e_out < TOL and e_emb < TOL
+    # and the graph's own f32 evaluation is as far from its f64 value as the oracle is: the gate is rounding-level
+    assert float(np.abs(golden["output"] - golden["output_f64"]).max()) < TOL
+
+
+def test_modern_conv_semantics_match_tf_ops():
+    """oracle/forward.py's conv (SAME / VALID, stride, dilation) against the TF op chain the SavedModel interpreter
+    implements (ExpandDims -> [SpaceToBatchND] -> Conv2D -> [BatchToSpaceND]), the way tf.nn.conv1d lowers."""
+    import torch
+    from oracle import forward as ofwd
+    from oracle import graphdef as G
+
+    class N:                       # a stand-in NodeDef with the attributes _conv2d reads
+        def __init__(self, padding, strides):
+            self.p, self.s = padding, strides
+        def attr_s(self, k, d=None):
+            return {"padding": self.p, "data_format": "NHWC"}.get(k, d)
+        def attr_ints(self, k):
+            return {"strides": [1, 1, self.s, 1], "dilations": [1, 1, 1, 1]}.get(k, [])
+
+    rng = np.random.default_rng(0)
+    for L, k, s, d, pad in [(50, 5, 1, 3, "SAME"), (51, 7, 1, 1, "SAME"), (40, 3, 2, 1, "SAME"), (41, 3, 2, 1, "SAME"),
+                            (33, 1, 2, 1, "SAME"), (50, 5, 1, 2, "VALID"), (30, 9, 1, 1, "VALID")]:
+        x = rng.standard_normal((3, L, 6)).astype(np.float32)
+        w = rng.standard_normal((k, 6, 4)).astype(np.float32)
+        got = ofwd.conv1d_nwc(torch.from_numpy(x), torch.from_numpy(w), s, pad, d).numpy()
+        x4, w4 = x[:, None, :, :], w[None, :, :, :]
+        if d > 1:                   # tf.nn.convolution lowers dilation to SpaceToBatchND / VALID conv / BatchToSpaceND
+            assert s == 1
+            span = (k - 1) * d
+            pl, pr = (span // 2, span - span // 2) if pad == "SAME" else (0, 0)
+            Lp = L + pl + pr
+            extra = (-Lp) % d
+            xb = G._space_to_batch(x4[:, 0], [d], [[pl, pr + extra]])
+            yb = G._conv2d(xb[:, None], w4, N("VALID", 1))[:, 0]
+            ref = G._batch_to_space(yb, [d], [[0, extra]])
+        else:
+            ref = G._conv2d(x4, w4, N(pad, s))[:, 0]
+        assert got.shape == ref.shape, (L, k, s, d, pad, got.shape, ref.shape)
+        np.testing.assert_allclose(got, ref, atol=1e-5, rtol=0)
+
+
+def test_fast_cpu_mode_agrees_with_the_checker():
+    """bench.py's cpu_baseline runs oracle.forward with FAST = True (oneDNN convs, fused GELU): same results."""
+    from conftest import load_model_cfg
+    from oracle import forward as ofwd
+    cfg = load_model_cfg("brain")
+    w = ofwd.random_weights(cfg, seed=38341)
+    ids = np.random.default_rng(1).integers(0, 65, (4, 6, 120)).astype(np.uint8)
+    ids[:, :, 100:] = 0
+    ref = ofwd.forward(cfg, w, ids)
+    ofwd.FAST = True
+    try:
+        fast = ofwd.forward(cfg, w, ids)
+    finally:
+        ofwd.FAST = False
+    for k in ref:
+        assert float(np.abs(ref[k] - fast[k]).max()) < 1e-4, k
+
+
+def test_verify_model_accepts_the_matching_plan_and_flags_others():
+    from conftest import load_model_cfg
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.verify import verify_model
+    assert verify_model(GRAPH, legacy=True) == []
+    findings = verify_model(GRAPH, build_plan(load_model_cfg("brain")))
+    text = " ".join(findings)
+    assert "variable shapes differ" in text and "GELU form" in text and "epsilons differ" in text
+    assert "no mask comparison ops" in text
