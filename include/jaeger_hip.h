@@ -220,6 +220,12 @@ int jg_fasta_count(const uint8_t *text, int64_t n, int64_t *n_records, int64_t *
 int jg_fasta_parse(const uint8_t *text, int64_t n, int64_t max_records, uint8_t *bases, int64_t *offsets,
                    uint8_t *names, int64_t *name_off, int64_t *n_records, int64_t *n_bases);
 
+/* jg_fasta_index : the records of a file image without extracting them: byte offset of each record's header line
+ *                  (rec_off, max_records + 1 entries, last = n), whitespace-stripped sequence length, names.  Under
+ *                  torchrun rank 0 indexes, every rank parses only the byte ranges of the contigs it owns. */
+int jg_fasta_index(const uint8_t *text, int64_t n, int64_t max_records, int64_t *rec_off, int64_t *seq_len,
+                   uint8_t *names, int64_t *name_off, int64_t *n_records);
+
 /* ---- DUST soft-masking (host only; replaces pydustmasker.DustMasker(seq, window_size=64,
  * score_threshold=20).mask() of seqops/io.py:104-108) -------------------------------------------
  * Upper-cases every record of the base buffer, then lower-cases the symmetric-DUST intervals, in

@@ -86,6 +86,81 @@ def load_fasta(path) -> FastaBatch:
     return FastaBatch(names, text[:nb.value], offsets[:got.value + 1])
 
 
+def _read_text(path) -> np.ndarray:
+    """File image as uint8: a read-only memory map for plain files (pages are touched only where a rank reads its
+    own records), the decompressed stream for ``.gz`` (not seekable: every rank inflates it)."""
+    if str(path).endswith(".gz"):
+        with gzip.open(path, "rb") as fh:
+            return np.frombuffer(fh.read(), np.uint8)
+    import os
+    if os.path.getsize(path) == 0:
+        return np.zeros(0, np.uint8)
+    return np.memmap(path, dtype=np.uint8, mode="r")
+
+
+@dataclass
+class FastaIndex:
+    """Where the records of a FASTA file are, without their sequences (``jg_fasta_index``)."""
+    names: list[str]
+    rec_off: np.ndarray        # int64, len = n_records + 1: byte offset of each header line, last = file size
+    lengths: np.ndarray        # int64 sequence lengths
+
+    def __len__(self) -> int:
+        return len(self.names)
+
+
+def index_fasta(path) -> FastaIndex:
+    import ctypes as C
+
+    from . import _lib as L
+    lib = L.load()
+    text = _read_text(path)
+    ptr = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    n_rec, name_bytes = C.c_int64(), C.c_int64()
+    L.check(lib.jg_fasta_count(ptr(text), text.size, C.byref(n_rec), C.byref(name_bytes)), "jg_fasta_count")
+    n = n_rec.value
+    rec_off, seq_len = np.zeros(n + 1, np.int64), np.zeros(max(n, 1), np.int64)
+    names_buf, name_off = np.zeros(max(name_bytes.value, 1), np.uint8), np.zeros(n + 1, np.int64)
+    got = C.c_int64()
+    L.check(lib.jg_fasta_index(ptr(text), text.size, n, ptr(rec_off), ptr(seq_len), ptr(names_buf), ptr(name_off),
+                               C.byref(got)), "jg_fasta_index")
+    raw, no = names_buf.tobytes(), name_off.tolist()
+    return FastaIndex([raw[no[i]:no[i + 1]].decode() for i in range(got.value)], rec_off[:got.value + 1],
+                      seq_len[:got.value])
+
+
+def load_fasta_records(path, rec_off: np.ndarray, records) -> FastaBatch:
+    """Only the listed records (ascending indices into ``rec_off``) of a FASTA file: their byte ranges are read
+    (adjacent ones merged) and parsed; nothing else of the file is touched."""
+    import ctypes as C
+
+    from . import _lib as L
+    lib = L.load()
+    records = np.asarray(records, np.int64)
+    if records.size == 0:
+        return FastaBatch([], np.zeros(0, np.uint8), np.zeros(1, np.int64))
+    text = _read_text(path)
+    a, b = rec_off[records], rec_off[records + 1]
+    cut = np.nonzero(a[1:] != b[:-1])[0] + 1                  # runs of adjacent records -> one read each
+    run_a, run_b = a[np.concatenate(([0], cut))], b[np.concatenate((cut - 1, [records.size - 1]))]
+    buf = np.empty(int((run_b - run_a).sum()), np.uint8)
+    o = 0
+    for x, y in zip(run_a.tolist(), run_b.tolist()):
+        buf[o:o + (y - x)] = text[x:y]
+        o += y - x
+    ptr = lambda arr: arr.ctypes.data_as(C.c_void_p)  # noqa: E731
+    n = records.size
+    offsets, name_off = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+    names_buf = np.zeros(max(int((np.minimum(b - a, 4096)).sum()), 1), np.uint8)
+    got, nb = C.c_int64(), C.c_int64()
+    L.check(lib.jg_fasta_parse(ptr(buf), buf.size, n, ptr(buf), ptr(offsets), ptr(names_buf), ptr(name_off),
+                               C.byref(got), C.byref(nb)), "jg_fasta_parse")
+    if got.value != n:
+        raise ValueError(f"{path}: expected {n} records in the selected byte ranges, parsed {got.value}")
+    raw, no = names_buf.tobytes(), name_off.tolist()
+    return FastaBatch([raw[no[i]:no[i + 1]].decode() for i in range(n)], buf[:nb.value], offsets)
+
+
 def dust_mask(fa: FastaBatch, window: int = 64, threshold: int = 20, threads: int = 0) -> int:
     """Soft-mask low-complexity intervals of every record in place (``jg_dust_mask``): all bases
     upper-cased, DUST intervals lower-cased - what ``fragment_generator`` does per contig with

@@ -126,7 +126,7 @@ def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None,
                   max_len: int | None = None, dynamic_stride: bool = False,
                   dynamic_stride_threshold: float = 10.0, batch: int = 96, padded: bool = False,
                   subset=None, pre_cased: bool = False,
-                  want=("prediction", "reliability", "embedding", "nmd")) -> dict[str, np.ndarray]:
+                  want=("prediction", "reliability", "embedding", "nmd"), meta: bool = True) -> dict[str, np.ndarray]:
     """Window table + GPU encode/forward for the records of ``fa`` (optionally only those listed in
     ``subset``, kept in that order); returns the dict ``InferModel.predict`` would (model outputs +
     ``meta_0..9``).  ``padded`` reproduces ``padded_batch`` of the short-contig pass: windows run in
@@ -158,6 +158,8 @@ def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None,
             parts.append(engine.predict_windows(compact[c0:c1], cstart[sl] - c0, table.length[sl], fsize,
                                                 l_pad=max(lmax, 1), pre_cased=pre_cased, want=want))
         out = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+    if not meta:                       # sharded runs: rank 0 rebuilds the metadata from its own window table
+        return out
     counts = out.pop("counts")
     out.update(frag.window_metadata(table, names, counts))
     return out
@@ -243,6 +245,176 @@ class _HostPipeline:
         self.thread.join()
 
 
+
+# ---- torchrun: contig-sharded prediction, one gather of f32 rows ---------------------------------------------
+SHARD_STATS: dict = {}        # filled by the sharded path (tests read it): local / total bases of this rank
+
+
+def _coll_device(local_rank: int):
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _bcast(arr: np.ndarray | None, dtype, n: int, dev):
+    """Broadcast a 1-D array from rank 0 (``arr`` is None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(arr, dtype)).to(dev) if arr is not None else \
+        torch.zeros(n, dtype=torch.from_numpy(np.zeros(0, dtype)).dtype, device=dev)
+    dist.broadcast(t, src=0)
+    return t.cpu().numpy()
+
+
+def _place_rows(out: np.ndarray, part: np.ndarray, items: np.ndarray, rows_per_item: np.ndarray, first: np.ndarray):
+    """``part`` holds the rows of ``items`` back to back (``rows_per_item[i]`` each); write them to their global
+    positions ``first[i]...`` (vectorised :func:`jaeger_amd.dist.restore_order`)."""
+    n = rows_per_item[items]
+    total = int(n.sum())
+    if total == 0:
+        return
+    local_first = np.cumsum(n) - n
+    dest = np.repeat(first[items] - local_first, n) + np.arange(total, dtype=np.int64)
+    out[dest] = part[:total]
+
+
+def _predict_sharded(make_engine, input_path, fsize, stride, user_min_len, min_len, dust, common, want, lg,
+                     rank, world, local_rank, log_setup):
+    """Rank 0 indexes the FASTA and broadcasts (record byte offsets, lengths); every rank reads, soft-masks, scans
+    and classifies only the contigs LPT deals it; one padded gather of f32 rows (logits | reliability | G C A T counts
+    [| embedding | nmd]) and one of the int32 repeat table go to rank 0, which rebuilds the window metadata from
+    its own window table and restores FASTA order (long pass before short pass)."""
+    import torch
+    import torch.distributed as dist
+
+    from . import dist as jdist
+    from .termini import repeats_frame, terminal_repeat_table
+    if not dist.is_initialized():
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    dev = _coll_device(local_rank)
+
+    def all_ok(ok: bool) -> bool:
+        t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item()) == 0
+
+    t_ingest = time.time()
+    ix, head = None, np.zeros(2, np.int64)
+    if rank == 0:
+        try:
+            ix = frag.index_fasta(str(input_path))
+            ok = int((ix.lengths >= min_len).sum())
+            lg.info(f"{ok}/{len(ix)} entries in {input_path}")
+            if ok == 0:
+                raise Exception(f"all records in {input_path} are < {min_len}bp")
+            head[:] = (0, len(ix))
+        except Exception as e:
+            lg.error(e)
+            head[:] = (1, 0)
+    head = _bcast(head if rank == 0 else None, np.int64, 2, dev)
+    if head[0] != 0:
+        sys.exit(1)
+    n_rec = int(head[1])
+    rec_off = _bcast(ix.rec_off if rank == 0 else None, np.int64, n_rec + 1, dev)
+    lengths = _bcast(ix.lengths if rank == 0 else None, np.int64, n_rec, dev)
+    groups = [np.sort(g) for g in _shard_records(lengths, fsize, stride, world)]
+    used = lengths >= min_len                                   # contigs that yield a window in either pass
+    mine = groups[rank][used[groups[rank]]]
+    ok, fa, engine, local, rep_local = True, None, None, None, None
+    t_predict = 0.0
+    two_pass = user_min_len is not None and user_min_len < fsize
+    try:
+        fa = frag.load_fasta_records(str(input_path), rec_off, mine)
+        assert np.array_equal(fa.lengths, lengths[mine]), "record lengths changed between index and read"
+        t_ingest = time.time() - t_ingest
+        SHARD_STATS.update(rank=rank, local_bases=int(fa.bases.size), total_bases=int(lengths.sum()),
+                           local_records=len(fa), total_records=n_rec)
+        if dust:
+            t0 = time.time()
+            n_masked = frag.dust_mask(fa)
+            lg.info(f"DUST (window 64, threshold 20): {n_masked} of {fa.bases.size} bases of this rank's "
+                    f"{len(fa)} contigs soft-masked in {time.time() - t0:.2f} s")
+        engine = make_engine()
+        log_setup(engine)
+        t_predict = time.time()
+        kw = dict(common, want=want, meta=False)
+        if two_pass:
+            lg.info(f"Two-pass prediction: long contigs (>= {fsize} bp) then short contigs "
+                    f"({user_min_len}-{fsize - 1} bp)")
+            parts = [predict_batch(engine, fa, fsize, stride, min_len=fsize, max_len=None, **kw),
+                     predict_batch(engine, fa, fsize, stride, min_len=user_min_len, max_len=fsize - 1, padded=True, **kw)]
+        else:
+            parts = [predict_batch(engine, fa, fsize, stride, min_len=min_len, max_len=None, **kw)]
+        cols = [k for k in ("prediction", "reliability", "counts", "embedding", "nmd") if any(k in p for p in parts)]
+        mats = [np.concatenate([np.asarray(p[k], np.float32).reshape(len(p[k]), -1) for k in cols], axis=1)
+                for p in parts if p]
+        widths = {k: next(np.asarray(p[k]).reshape(len(p[k]), -1).shape[1] for p in parts if p) for k in cols}
+        local = np.concatenate(mats, axis=0) if mats else None
+        t_predict = time.time() - t_predict
+        rep_local = terminal_repeat_table(engine.device, fa, fsize)
+    except BaseException as e:               # every rank must reach the collectives below, or the others hang
+        lg.debug(traceback.format_exc())
+        lg.error(f"an error {e} occured during inference on MI355X #{local_rank} (rank {rank})!")
+        ok = False
+    if not all_ok(ok):
+        if engine is not None:
+            engine.close()
+        sys.exit(1)
+    # column layout is the same on every rank (same model); ranks without windows send zero rows
+    wtab = torch.zeros(8, dtype=torch.int64, device=dev)
+    if local is not None:
+        for j, k in enumerate(("prediction", "reliability", "counts", "embedding", "nmd")):
+            wtab[j] = widths.get(k, 0)
+    dist.all_reduce(wtab, op=dist.ReduceOp.MAX)
+    wlist = [int(v) for v in wtab.tolist()[:5]]
+    n_col = sum(wlist)
+    if local is None:
+        local = np.zeros((0, n_col), np.float32)
+    got = jdist.gather_rows(torch.from_numpy(np.ascontiguousarray(local)).to(dev), dst=0)
+    rep = jdist.gather_rows(torch.from_numpy(np.ascontiguousarray(rep_local.reshape(-1, 10))).to(dev), dst=0)
+    class_map = engine.class_map
+    engine.close()
+    if rank != 0:
+        dist.barrier()
+        return None
+    # ---- rank 0: metadata from its own window table, rows back in the reference's emission order -------------
+    passes = [dict(min_len=fsize, max_len=None), dict(min_len=user_min_len, max_len=fsize - 1)] if two_pass else \
+        [dict(min_len=min_len, max_len=None)]
+    tables = [frag.build_window_table(lengths, fsize, stride, common["dynamic_stride"],
+                                      common["dynamic_stride_threshold"], **pk) for pk in passes]
+    per_rec = [np.bincount(t.contig, minlength=n_rec).astype(np.int64) for t in tables]
+    y_pred: dict = {}
+    consumed = [0] * world
+    for t, n_w in zip(tables, per_rec):
+        rows = np.zeros((len(t), n_col), np.float32)
+        first = np.cumsum(n_w) - n_w
+        for q in range(world):
+            items = groups[q][used[groups[q]]]
+            take = int(n_w[items].sum())
+            part = got[q].cpu().numpy()[consumed[q]:consumed[q] + take]
+            _place_rows(rows, part, items, n_w, first)
+            consumed[q] += take
+        out, c0 = {}, 0
+        for k, w in zip(("prediction", "reliability", "counts", "embedding", "nmd"), wlist):
+            if w:
+                out[k] = rows[:, c0:c0 + w]
+            c0 += w
+        counts = np.rint(out.pop("counts")).astype(np.int32)
+        out.update(frag.window_metadata(t, ix.names, counts))
+        y_pred = _concat_predictions(y_pred, out) if len(t) else y_pred
+    res = np.full((n_rec, 10), -1, np.int32)
+    for q in range(world):
+        items = groups[q][used[groups[q]]]
+        res[items] = rep[q].cpu().numpy()
+    term_repeats = repeats_frame(res, ix.names, lengths)
+    lg.info(f"terminal repeats: {int(term_repeats['terminal_repeats'].notna().sum())} of {len(term_repeats)} contigs")
+    dist.barrier()
+    return dict(y_pred=y_pred, term_repeats=term_repeats, class_map=class_map, num=n_rec, t_ingest=t_ingest,
+                t_predict=t_predict)
+
+
 # ---- run_core ---------------------------------------------------------------------------------
 def run_core(**kwargs) -> int:
     """Equivalent of ``commands/predict.py:run_core``; returns the number of table rows written."""
@@ -293,14 +465,16 @@ def run_core(**kwargs) -> int:
     fsize, stride = kwargs.get("fsize", 2000), kwargs.get("stride", 1500)
     user_min_len = kwargs.get("min_len")
     min_len = user_min_len or fsize
-    try:
-        t_ingest = time.time()
-        fa = frag.load_fasta(str(input_path))
-        t_ingest = time.time() - t_ingest
-        num = validate_fasta_entries(fa, min_len=min_len)
-    except Exception as e:
-        lg.error(e)
-        sys.exit(1)
+    fa, num, t_ingest = None, 0, 0.0
+    if world == 1:                      # (under torchrun rank 0 indexes the file and every rank reads its own contigs)
+        try:
+            t_ingest = time.time()
+            fa = frag.load_fasta(str(input_path))
+            t_ingest = time.time() - t_ingest
+            num = validate_fasta_entries(fa, min_len=min_len)
+        except Exception as e:
+            lg.error(e)
+            sys.exit(1)
     table_path, phage_path = out_dir / f"{file_base}.tsv", out_dir / f"{file_base}_phages.tsv"
     if table_path.exists() and not kwargs.get("overwrite"):
         lg.error("output file exists. enable --overwrite option to overwrite the output file.")
@@ -360,11 +534,18 @@ def run_core(**kwargs) -> int:
     common = dict(dynamic_stride=kwargs.get("dynamic_stride", False),
                   dynamic_stride_threshold=kwargs.get("dynamic_stride_threshold", 10.0),
                   batch=kwargs.get("batch", 96), pre_cased=dust, want=want)
-    all_names = fa.names
-    groups, subset = None, None
     term_repeats = None
+    class_map = None
     t_predict = time.time()
-    if world == 1 and not kwargs.get("no_pipeline"):
+    if world > 1:
+        got = _predict_sharded(make_engine, input_path, fsize, stride, user_min_len, min_len, dust, common, want, lg,
+                               rank, world, local_rank, log_setup)
+        if got is None:                 # ranks other than 0 are done after the gather
+            return 0
+        y_pred, term_repeats, class_map = got["y_pred"], got["term_repeats"], got["class_map"]
+        num, t_ingest, t_predict = got["num"], got["t_ingest"], got["t_predict"]
+        engine = None
+    elif not kwargs.get("no_pipeline"):
         # ---- one GPU: DUST, engine set-up and the terminal-repeat scan run beside the forward ---------------
         if two_pass:
             lg.info(f"Two-pass prediction: long contigs (>= {fsize} bp) then short contigs "
@@ -412,8 +593,9 @@ def run_core(**kwargs) -> int:
                 lg.error(f"an error {e} occured during inference on MI355X #{local_rank}!")
                 sys.exit(1)
             y_pred = _concat_predictions(y_pred, y_short)
+        t_predict = time.time() - t_predict
     else:
-        # ---- torchrun: every rank masks the whole input (host threads), owns a contig shard -----------------
+        # ---- one GPU, --no-pipeline: mask, set up, scan and classify one after the other -------------------------
         if dust:
             t_dust = time.time()
             n_masked = frag.dust_mask(fa)
@@ -423,61 +605,31 @@ def run_core(**kwargs) -> int:
             engine = make_engine()
         except Exception as e:
             engine_failed(e, traceback.format_exc())
-        if rank == 0:
-            term_repeats = scan_repeats(engine.device)
+        term_repeats = scan_repeats(engine.device)
         log_setup(engine)
-        if world > 1:
-            import torch
-            import torch.distributed as dist
-            if not dist.is_initialized():
-                torch.cuda.set_device(local_rank)
-                dist.init_process_group("nccl")
-            groups = _shard_records(fa.lengths, fsize, stride, world)
-            subset = np.sort(np.asarray(groups[rank], np.int64))
         try:
             if two_pass:
                 lg.info(f"Two-pass prediction: long contigs (>= {fsize} bp) then short contigs "
                         f"({user_min_len}-{fsize - 1} bp)")
-                y_long = predict_batch(engine, fa, fsize, stride, min_len=fsize, max_len=None, subset=subset, **common)
+                y_long = predict_batch(engine, fa, fsize, stride, min_len=fsize, max_len=None, **common)
                 y_short = predict_batch(engine, fa, fsize, stride, min_len=user_min_len, max_len=fsize - 1,
-                                        padded=True, subset=subset, **common)
+                                        padded=True, **common)
                 y_pred = _concat_predictions(y_long, y_short)
             else:
-                y_pred = predict_batch(engine, fa, fsize, stride, min_len=min_len, max_len=None, subset=subset, **common)
+                y_pred = predict_batch(engine, fa, fsize, stride, min_len=min_len, max_len=None, **common)
         except Exception as e:
             lg.debug(traceback.format_exc())
             lg.error(f"an error {e} occured during inference on MI355X #{local_rank}!")
             sys.exit(1)
-
-    t_predict = time.time() - t_predict
+        t_predict = time.time() - t_predict
+    if class_map is None:
+        class_map = engine.class_map
     t_post = time.time()
-    if world > 1:
-        import torch.distributed as dist
-        objs = [None] * world if rank == 0 else None
-        dist.gather_object(y_pred, objs, dst=0)
-        if rank != 0:
-            dist.barrier()
-            return 0
-        # restore the reference's emission order: FASTA order within each pass
-        blocks = {}
-        for yr in objs:
-            if not yr:
-                continue
-            ends = np.nonzero(np.asarray(yr["meta_2"]) == 1)[0] + 1
-            begins = np.concatenate(([0], ends[:-1]))
-            for b, e in zip(begins, ends):
-                blocks[(int(yr["meta_4"][b]) >= fsize, yr["meta_0"][b])] = (yr, b, e)
-        hdr = [n.strip().replace(",", "___") for n in all_names]
-        ordered = [blocks[(True, h)] for h in hdr if (True, h) in blocks] + \
-                  [blocks[(False, h)] for h in hdr if (False, h) in blocks]
-        keys = objs[0].keys() if objs[0] else next(o for o in objs if o).keys()
-        y_pred = {k: np.concatenate([yr[k][b:e] for yr, b, e in ordered], axis=0) for k in keys}
-        dist.barrier()
 
     from .postprocess import pred_to_dict, write_output       # pandas: imported beside the forward (termini, above)
-    data, data_full = pred_to_dict(y_pred, class_map=engine.class_map, fsize=fsize, term_repeats=term_repeats,
+    data, data_full = pred_to_dict(y_pred, class_map=class_map, fsize=fsize, term_repeats=term_repeats,
                                    want_full=bool(kwargs.get("window_scores")), **crf_kw)
-    n_written = write_output(data, labels=engine.class_map.get("class"), indices=engine.class_map.get("index"),
+    n_written = write_output(data, labels=class_map.get("class"), indices=class_map.get("index"),
                              output_table_path=table_path, output_phage_table_path=phage_path,
                              reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))
     lg.info(f"processed {n_written}/{num} sequences")
@@ -496,5 +648,6 @@ def run_core(**kwargs) -> int:
     lg.info(f"wall time(s) : {t_all:.2f}  ({len(y_pred['meta_2'])} windows; FASTA ingest {t_ingest:.2f} s, "
             f"encode+forward {t_predict:.2f} s = {n_bp / 1e6 / max(t_predict, 1e-9):.1f} Mbp/s, aggregation+TSV "
             f"{time.time() - t_post:.2f} s; end to end {n_bp / 1e6 / max(t_all, 1e-9):.1f} Mbp/s)")
-    engine.close()
+    if engine is not None:
+        engine.close()
     return n_written

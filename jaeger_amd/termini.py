@@ -16,9 +16,9 @@ import pandas as pd
 from . import _lib as L
 
 
-def scan_for_terminal_repeats(device, fa, fsize: int) -> pd.DataFrame:
-    """``device``: :class:`~jaeger_amd.engine.HipDevice`; ``fa``: FastaBatch.  One row per record with
-    ``len >= fsize`` (the reference's filter, termini.py:164-168)."""
+def terminal_repeat_table(device, fa, fsize: int) -> np.ndarray:
+    """(n_records, 10) int32 from ``jg_terminal_repeats``: per record DTR then ITR (score, alignment length, query gaps,
+    end in the query, end in the reference); -1 rows for records shorter than ``fsize``."""
     n = len(fa)
     res = np.full((max(n, 1), 10), -1, np.int32)
     bases = np.ascontiguousarray(fa.bases, np.uint8)
@@ -26,8 +26,12 @@ def scan_for_terminal_repeats(device, fa, fsize: int) -> pd.DataFrame:
     ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     L.check(device.lib.jg_terminal_repeats(device.handle, ptr(bases), bases.size, L.JG_PTR_HOST, ptr(offsets), n,
                                            int(fsize), ptr(res)), "jg_terminal_repeats")
-    res = res[:n]
-    keep = np.nonzero(res[:, 0] >= 0)[0]
+    return res[:n]
+
+
+def repeats_frame(res: np.ndarray, names: list[str], lengths: np.ndarray) -> pd.DataFrame:
+    """Decision rule (termini.py:137-154, :58-63) over a :func:`terminal_repeat_table`; one row per scanned record."""
+    keep = np.nonzero(res[:, 0] >= 0)[0] if len(res) else np.zeros(0, np.int64)
     d_score, d_len, d_fg = res[keep, 0], res[keep, 1], res[keep, 2]
     i_score, i_len = res[keep, 5], res[keep, 6]
     found = (i_len > 12) | (d_len > 12)
@@ -41,9 +45,15 @@ def scan_for_terminal_repeats(device, fa, fsize: int) -> pd.DataFrame:
     length[~found] = np.nan
     score = np.where(is_itr, i_score, d_score).astype(np.float64)
     score[~found] = np.nan
-    lengths = fa.lengths
+    lengths = np.asarray(lengths)
     return pd.DataFrame({
-        "contig_id": [fa.names[i].strip().replace(",", "___") for i in keep.tolist()],
+        "contig_id": [names[i].strip().replace(",", "___") for i in keep.tolist()],
         "repeat_length": length, "score": score, "terminal_repeats": kind,
         "seq_len": lengths[keep] if keep.size else np.array([], np.int64),
     })
+
+
+def scan_for_terminal_repeats(device, fa, fsize: int) -> pd.DataFrame:
+    """``device``: :class:`~jaeger_amd.engine.HipDevice`; ``fa``: FastaBatch.  One row per record with
+    ``len >= fsize`` (the reference's filter, termini.py:164-168)."""
+    return repeats_frame(terminal_repeat_table(device, fa, fsize), fa.names, fa.lengths)

@@ -10,8 +10,30 @@ if str(ROOT) not in sys.path:
 GOLDEN = ROOT / "tests" / "golden"
 
 
+def _cpu_quota() -> int:
+    """Cores this container may actually use (cgroup CPU quota; a GPU box shows 256 cores and grants 16)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # the CPU oracle (torch) otherwise starts one thread per VISIBLE core and the threads preempt each other
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(_cpu_quota(), 32)))
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")

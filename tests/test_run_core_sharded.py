@@ -1,7 +1,9 @@
 """The torchrun path of ``run_core`` on CPU: world_size 2 over gloo with a stand-in engine (deterministic logits
 computed from the window bases on the host - the GPU engine itself is covered by the -m gpu tests).  Contig
 sharding (LPT), the object gather, the restoration of the reference's emission order (FASTA order, long pass before
-short pass) and the TSV must equal a single-process run byte for byte."""
+short pass) and the TSV must equal a single-process run byte for byte.  Under torchrun rank 0 indexes the FASTA,
+every rank reads / masks / classifies only its own contigs (asserted: no rank holds the whole base buffer), one
+gather of f32 rows + one of the int32 repeat table; duplicate record names survive (order is by record index)."""
 import os
 import socket
 import sys
@@ -57,7 +59,7 @@ def _write_fasta(path, seed=5):
             seq = "".join(rng.choice(list("ACGT"), n))
             if i == 3:
                 seq = seq[:500] + "AT" * 60 + seq[620:]          # a low-complexity stretch for DUST
-            fh.write(f">ctg_{i} len={n}\n")
+            fh.write(f">{'ctg_dup' if i in (9, 11) else f'ctg_{i}'} len={n}\n")     # two records share a name
             for j in range(0, n, 60):
                 fh.write(seq[j:j + 60] + "\n")
     return lens
@@ -74,6 +76,8 @@ def _run(out_dir, fasta, model_root, min_len, no_pipeline=True):
     T.scan_for_terminal_repeats = lambda device, fa, fsize: pd.DataFrame(
         {"contig_id": [n.strip().replace(",", "___") for n, ln in zip(fa.names, fa.lengths.tolist()) if ln >= fsize],
          "terminal_repeats": None, "repeat_length": np.nan})
+    T.terminal_repeat_table = lambda device, fa, fsize: np.where(
+        (fa.lengths >= fsize)[:, None], np.zeros((len(fa), 10), np.int32), np.int32(-1)).astype(np.int32)
     return run_core(input=str(fasta), output=str(out_dir), model_path=str(model_root), fsize=1500, stride=1500,
                     min_len=min_len, batch=2, dustmask=True, rc=0.1, pc=1, overwrite=True, verbose=1,
                     no_pipeline=no_pipeline)
@@ -87,6 +91,10 @@ def _worker(rank, world, port, tmp, min_len):
                       LOCAL_RANK=str(rank))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _run(Path(tmp) / "sharded", Path(tmp) / "in.fasta", Path(tmp) / "m", min_len)
+    import json
+
+    import jaeger_amd.predict as P
+    (Path(tmp) / f"shard_stats_{rank}.json").write_text(json.dumps(P.SHARD_STATS))
     dist.destroy_process_group()
 
 
@@ -99,7 +107,7 @@ def test_sharded_run_core_equals_single_process(tmp_path, min_len, monkeypatch):
         monkeypatch.delenv(k, raising=False)
     import jaeger_amd.engine as E
     import jaeger_amd.termini as T
-    keep = (E.JaegerHipEngine, E.HipDevice, T.scan_for_terminal_repeats)
+    keep = (E.JaegerHipEngine, E.HipDevice, T.scan_for_terminal_repeats, T.terminal_repeat_table)
     try:
         n_single = _run(tmp_path / "single", tmp_path / "in.fasta", tmp_path / "m", min_len)
         # the single-GPU host pipeline (worker thread owns the engine, record groups masked beside the forward)
@@ -107,7 +115,7 @@ def test_sharded_run_core_equals_single_process(tmp_path, min_len, monkeypatch):
         monkeypatch.setattr(P, "_record_groups", lambda fa, **k: [(0, 4), (4, 5), (5, 11), (11, len(fa))])
         n_piped = _run(tmp_path / "piped", tmp_path / "in.fasta", tmp_path / "m", min_len, no_pipeline=False)
     finally:
-        E.JaegerHipEngine, E.HipDevice, T.scan_for_terminal_repeats = keep
+        E.JaegerHipEngine, E.HipDevice, T.scan_for_terminal_repeats, T.terminal_repeat_table = keep
     assert n_piped == n_single
     assert (tmp_path / "piped" / "38341_1.4M" / "in.tsv").read_text() == \
         (tmp_path / "single" / "38341_1.4M" / "in.tsv").read_text()
@@ -120,7 +128,15 @@ def test_sharded_run_core_equals_single_process(tmp_path, min_len, monkeypatch):
     sharded = (tmp_path / "sharded" / "38341_1.4M" / "in.tsv").read_text()
     assert n_single > 0 and single == sharded
     ids = [ln.split("\t")[0] for ln in single.splitlines()[1:]]
-    long_first = [f"ctg_{i}" for i in (0, 3, 7, 9, 10, 11, 12, 14)]
+    long_first = [f"ctg_{i}" for i in (0, 3, 7, 10, 12, 14)]
+    assert ids.count("ctg_dup") >= 2                                # both records that share a name are reported
+    ids = [i for i in ids if i != "ctg_dup"]
+    # per-rank ingest: each rank parsed only its own contigs, together they cover the used ones exactly once
+    import json
+    stats = [json.loads((tmp_path / f"shard_stats_{r}.json").read_text()) for r in range(2)]
+    total = stats[0]["total_bases"]
+    assert all(0 < st["local_bases"] < total for st in stats), stats
+    assert sum(st["local_bases"] for st in stats) <= total and stats[0]["total_records"] == 15
     assert ids[:len(long_first)] == long_first                      # FASTA order, long pass first
     if min_len is not None:
         assert set(ids[len(long_first):]) <= {"ctg_1", "ctg_2", "ctg_4", "ctg_5", "ctg_8", "ctg_13"}
