@@ -10,6 +10,7 @@
 #include <thread>
 
 #include "jg_common.h"
+#include "jg_small.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -435,6 +436,187 @@ static bool slot_needs_f32(const jg_model *m, size_t i, int buf) {
   return false;
 }
 
+
+// ---------------------------------------------------------------------------
+// fused small-window network (jg_small.hip): does the op program match the family, and its operands
+//   [MASK] CONV(ids, k0, E -> 32)  { [MASK] CONV(k 3, 32 -> 32, SAME) } x 2 | 4   POOL(avg | max)   ...heads
+// every conv's stages being  [BIAS] [BN]  [ADD]  GELU(tanh)  [ [BN] GELU(tanh) ]
+// ---------------------------------------------------------------------------
+static void free_small(jg_model *m) {
+  if (m->small == nullptr) return;
+  JgSmallNet *sn = m->small;
+  if (sn->d_lut) (void)hipFree(sn->d_lut);
+  if (sn->d_epi) (void)hipFree(sn->d_epi);
+  if (sn->d_part) (void)hipFree(sn->d_part);
+  if (sn->d_wfrag) (void)hipFree(sn->d_wfrag);
+  delete sn;
+  m->small = nullptr;
+}
+
+static int prepare_small(jg_model *m, const float *weights) {
+  std::vector<int> convs;
+  int pool_op = -1;
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    const jg_op &op = m->ops[i];
+    if (op.kind == JG_OP_MASK) continue;
+    if (op.kind == JG_OP_CONV) { convs.push_back((int)i); continue; }
+    if (op.kind == JG_OP_POOL) { pool_op = (int)i; break; }
+    return JG_OK;                                   // anything else in front of the pool: not this family
+  }
+  const int nc = (int)convs.size() - 1;
+  if (pool_op < 0 || nc < 1 || !jg_small_supports(nc, m->ops[convs[0]].k, m->vocab)) return JG_OK;
+  const jg_op &c0 = m->ops[convs[0]];
+  if (c0.in_buf != JG_BUF_IDS || c0.cout != 32 || c0.stride != 1 || c0.dilation != 1 || c0.mask_mode != JG_MASK_ANY ||
+      !(c0.in_mask == JG_BUF_IDS || c0.in_mask == JG_BUF_NONE))
+    return JG_OK;
+  const bool use_mask = c0.in_mask == JG_BUF_IDS;
+  for (int q = 1; q <= nc; ++q) {
+    const jg_op &c = m->ops[convs[q]];
+    if (c.in_buf != m->ops[convs[q - 1]].out_buf || c.k != 3 || c.cin != 32 || c.cout != 32 || c.stride != 1 ||
+        c.dilation != 1 || c.padding != JG_PAD_SAME || c.mask_mode != JG_MASK_ANY || (c.in_mask >= 0) != use_mask)
+      return JG_OK;
+    if (use_mask && c.in_mask != m->ops[convs[q - 1]].out_mask) return JG_OK;
+  }
+  const jg_op &pl = m->ops[pool_op];
+  if (pl.in_buf != m->ops[convs[nc]].out_buf || !(pl.arg == JG_POOL_AVG || pl.arg == JG_POOL_MAX) ||
+      (pl.in_mask >= 0) != use_mask || (use_mask && pl.in_mask != m->ops[convs[nc]].out_mask))
+    return JG_OK;
+  // no later op may read an activation slot (the kernel never writes them)
+  for (size_t i = (size_t)pool_op + 1; i < m->ops.size(); ++i) {
+    const int k = m->ops[i].kind;
+    if (k == JG_OP_CONV || k == JG_OP_MASK || k == JG_OP_POOL || k == JG_OP_ELTWISE || k == JG_OP_MAXPOOL1D ||
+        k == JG_OP_FRAMESUM || k == JG_OP_NMD_FINAL)
+      return JG_OK;
+  }
+  JgSmallNet *sn = new JgSmallNet();
+  for (JgSmallLayer &ly : sn->layer) ly.add = ly.aff2 = ly.save = ly.pad_ = 0;
+  std::vector<float> epi((size_t)(nc + 1) * 4 * 32, 0.f);
+  std::vector<double> wscale((size_t)nc + 1, 1.0);
+  bool ok = true;
+  // split-f16 weight fragments of the k = 3 convs
+  std::vector<uint16_t> frag((size_t)nc * 12 * 64 * 8, 0);
+  for (int q = 1; q <= nc && ok; ++q) {
+    const jg_op &c = m->ops[convs[q]];
+    const float *w = weights + c.w_off;               // (3, 32, 32) f32 (cin even, cout multiple of 32: no padding)
+    float maxabs = 0.f;
+    for (int e = 0; e < 3 * 32 * 32; ++e) maxabs = std::max(maxabs, fabsf(w[e]));
+    int sexp = 0;
+    if (maxabs > 0.f) {
+      int e2;
+      frexpf(maxabs, &e2);
+      sexp = 3 - e2;                                  // scaled max in [4, 8): the lo halves stay normal
+    }
+    const float sc = ldexpf(1.f, sexp);
+    wscale[(size_t)q] = ldexp(1.0, -sexp);
+    for (int t = 0; t < 3; ++t)
+      for (int cc = 0; cc < 2; ++cc)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int co = lane & 31, ci = cc * 16 + (lane >> 5) * 8 + j;
+            const float v = w[((size_t)t * 32 + ci) * 32 + co] * sc;
+            const float hi = f16_value(v);
+            const size_t base = ((((size_t)(q - 1) * 3 + t) * 2 + cc) * 2) * 64 * 8;
+            frag[base + (size_t)lane * 8 + j] = f16_bits(hi);
+            frag[base + 64 * 8 + (size_t)lane * 8 + j] = f16_bits(v - hi);
+          }
+  }
+  // epilogue parameters: fold BIAS / BN chains (f64), match  affine [ADD] GELU [affine GELU]
+  for (int q = 0; q <= nc && ok; ++q) {
+    const jg_op &c = m->ops[convs[q]];
+    std::vector<double> s1(32, wscale[(size_t)q]), t1(32, 0.0), s2(32, 1.0), t2(32, 0.0);
+    int st = 0;
+    auto fold = [&](std::vector<double> &sc, std::vector<double> &sh) {
+      bool any = false;
+      for (; st < c.n_stages; ++st) {
+        const jg_stage &g = c.stages[st];
+        if (g.kind == JG_ST_BIAS) {
+          for (int n = 0; n < 32; ++n) sh[n] += (double)weights[g.p0 + n];
+        } else if (g.kind == JG_ST_BN) {
+          for (int n = 0; n < 32; ++n) {
+            const double mu = weights[g.p0 + n], is = weights[g.p1 + n], ga = weights[g.p2 + n], be = weights[g.p3 + n];
+            sc[n] = sc[n] * is * ga;
+            sh[n] = (sh[n] - mu) * is * ga + be;
+          }
+        } else break;
+        any = true;
+      }
+      return any;
+    };
+    fold(s1, t1);
+    JgSmallLayer &ly = sn->layer[q];
+    if (st < c.n_stages && c.stages[st].kind == JG_ST_ADD) {
+      // the shortcut must be the output of an earlier layer of this chain, and the only one alive
+      int src = -1;
+      for (int r = q - 1; r >= 0; --r)
+        if (m->ops[convs[r]].out_buf == c.stages[st].arg) { src = r; break; }
+      if (src < 0) { ok = false; break; }
+      bool clobbered = false;
+      for (int r = src + 1; r < q; ++r) clobbered |= m->ops[convs[r]].out_buf == c.stages[st].arg;
+      if (clobbered) { ok = false; break; }
+      sn->layer[src].save = 1;
+      ly.add = 1;
+      ++st;
+    }
+    if (!(st < c.n_stages && c.stages[st].kind == JG_ST_ACT && c.stages[st].arg == JG_ACT_GELU_TANH)) { ok = false; break; }
+    ++st;
+    if (st < c.n_stages) {
+      if (!fold(s2, t2)) { ok = false; break; }
+      if (!(st < c.n_stages && c.stages[st].kind == JG_ST_ACT && c.stages[st].arg == JG_ACT_GELU_TANH)) { ok = false; break; }
+      ++st;
+      ly.aff2 = 1;
+    }
+    if (st != c.n_stages) { ok = false; break; }
+    for (int n = 0; n < 32; ++n) {
+      epi[((size_t)q * 4 + 0) * 32 + n] = (float)s1[n];
+      epi[((size_t)q * 4 + 1) * 32 + n] = (float)t1[n];
+      epi[((size_t)q * 4 + 2) * 32 + n] = (float)s2[n];
+      epi[((size_t)q * 4 + 3) * 32 + n] = (float)t2[n];
+    }
+  }
+  // a shortcut saved by layer r is read by exactly the next ADD: saves must not overlap
+  if (ok) {
+    int pending = -1;
+    for (int q = 0; q <= nc; ++q) {
+      if (sn->layer[q].add) pending = -1;
+      if (sn->layer[q].save) {
+        if (pending >= 0) ok = false;
+        pending = q;
+      }
+    }
+  }
+  if (!ok) { delete sn; return JG_OK; }
+  // first-layer table T_t[id] = E[id] . W_t (f64), row `vocab` = zeros (padding), row 0 = zeros when ids mask
+  const int k0 = c0.k, vr = m->vocab + 1, cin_pad = (c0.cin + 1) & ~1;
+  std::vector<float> lut((size_t)k0 * vr * 32, 0.f);
+  const float *emb = weights + c0.b_off, *w0 = weights + c0.w_off;
+  for (int t = 0; t < k0; ++t)
+    for (int id = (use_mask ? 1 : 0); id < m->vocab; ++id)
+      for (int n = 0; n < 32; ++n) {
+        double acc = 0.0;
+        for (int ci = 0; ci < c0.cin; ++ci)
+          acc += (double)emb[(size_t)id * c0.cin + ci] * (double)w0[((size_t)t * cin_pad + ci) * 32 + n];
+        lut[((size_t)t * vr + id) * 32 + n] = (float)acc;
+      }
+  JG_HIP(hipMalloc(reinterpret_cast<void **>(&sn->d_lut), lut.size() * sizeof(float)));
+  JG_HIP(hipMemcpy(sn->d_lut, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
+  JG_HIP(hipMalloc(reinterpret_cast<void **>(&sn->d_epi), epi.size() * sizeof(float)));
+  JG_HIP(hipMemcpy(sn->d_epi, epi.data(), epi.size() * sizeof(float), hipMemcpyHostToDevice));
+  JG_HIP(hipMalloc(reinterpret_cast<void **>(&sn->d_wfrag), frag.size() * 2));
+  JG_HIP(hipMemcpy(sn->d_wfrag, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
+  sn->valid = true;
+  sn->n_conv = nc;
+  sn->k0 = k0;
+  sn->pad_same0 = c0.padding == JG_PAD_SAME;
+  sn->use_mask = use_mask ? 1 : 0;
+  sn->pool_kind = pl.arg;
+  sn->first_op = 0;
+  sn->pool_op = pool_op;
+  sn->flops_per_pos0 = 2.0 * k0 * c0.cin * 32;
+  sn->flops_per_pos = 2.0 * 3 * 32 * 32 * nc;
+  m->small = sn;
+  return JG_OK;
+}
+
 // exact-f32 conv operands: weights grouped by 8 input channels so that a lane fetches the four
 // k-steps of a group with one 16-byte load (see conv_f32_kernel)
 static int prepare_f32(jg_model *m, const float *weights) {
@@ -732,6 +914,11 @@ extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const 
   if (rc != JG_OK) { jg_model_destroy(m); return rc; }
   rc = prepare_f32(m, weights);
   if (rc != JG_OK) { jg_model_destroy(m); return rc; }
+  if (!m->f16_eligible) {          // the 32-channel family has a fused kernel of its own (same split-f16 arithmetic)
+    rc = prepare_small(m, weights);
+    if (rc != JG_OK) { jg_model_destroy(m); return rc; }
+    if (m->small != nullptr) m->f16_eligible = true;
+  }
   m->precision = m->f16_eligible ? 1 : 0;
   *out = m;
   return JG_OK;
@@ -757,6 +944,7 @@ extern "C" int jg_model_destroy(jg_model *m) {
   (void)hipSetDevice(m->e->dev);
   (void)hipStreamSynchronize(m->e->stream);
   free_workspace(m);
+  free_small(m);
   if (m->d_w) (void)hipFree(m->d_w);
   if (m->d_ids) (void)hipFree(m->d_ids);
   if (m->d_counts) (void)hipFree(m->d_counts);
@@ -831,14 +1019,67 @@ static void resolve_stages(const jg_model *m, const jg_op &op, StageArg *dst, in
   }
 }
 
+template <typename T>
+static int grow(T **p, int64_t *cap, int64_t need_bytes) {
+  if (need_bytes <= *cap) return JG_OK;
+  if (*p) JG_HIP(hipFree(*p));
+  *p = nullptr;
+  JG_HIP(hipMalloc(reinterpret_cast<void **>(p), (size_t)need_bytes));
+  *cap = need_bytes;
+  return JG_OK;
+}
+
 // Run the op program over `nw` windows whose ids (nw, 6, l) are on the device.
 static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream_t s) {
   jg_engine *e = m->e;
   Shape sh[JG_MAX_BUFS];
   int mlen[JG_MAX_BUFS] = {};
+  // the 32-channel family: one fused kernel from ids to pooled sums when the rows fit its 160 positions; longer
+  // rows of such a model run layer by layer on the exact-f32 kernels (its convs have no split-f16 operands)
+  int small_L0 = 0, small_pad0 = 0;
+  bool small = false;
+  if (m->precision == 1 && m->small != nullptr) {
+    const jg_op &c0 = m->ops[0].kind == JG_OP_CONV ? m->ops[0] : m->ops[1];
+    conv_geometry(l, c0.k, 1, 1, c0.padding, &small_L0, &small_pad0);
+    small = small_L0 >= 1 && small_L0 <= jg_small_max_positions() && l <= 192;
+  }
+  const int prec = (m->precision == 1 && m->small != nullptr) ? 0 : m->precision;   // arithmetic of the per-layer path
+  if (small) {
+    JgSmallNet *sn = m->small;
+    const int64_t rows = (int64_t)nw * 6;
+    int rc = grow(&sn->d_part, &sn->part_cap, rows * JG_SMALL_PARTW * (int64_t)sizeof(float));
+    if (rc != JG_OK) return rc;
+    JgSmallArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ids = d_ids; a.lut = sn->d_lut; a.wfrag = sn->d_wfrag; a.epi = sn->d_epi; a.part = sn->d_part;
+    a.overflow = m->d_overflow;
+    a.rows = rows; a.L = l; a.L0 = small_L0; a.pad0 = small_pad0; a.vocab = m->vocab;
+    a.use_mask = sn->use_mask; a.pool_kind = sn->pool_kind;
+    for (int q = 0; q < JG_SMALL_MAX_LAYERS; ++q) a.layer[q] = sn->layer[q];
+    ProfEvent pe;
+    if (e->profile) {
+      if ((rc = prof_event(e, &pe.a)) != JG_OK || (rc = prof_event(e, &pe.b)) != JG_OK) return rc;
+      pe.flops = (sn->flops_per_pos0 + sn->flops_per_pos) * (double)rows * small_L0;
+      pe.cls = JG_PROF_FUSED_SMALL;
+      JG_HIP(hipEventRecord(pe.a, s));
+    }
+    rc = jg_launch_small_net(e, a, sn->n_conv, sn->k0, s);
+    if (rc != JG_OK) return rc;
+    if (e->profile) {
+      JG_HIP(hipEventRecord(pe.b, s));
+      e->pending.push_back(pe);
+    }
+  }
   for (size_t i = 0; i < m->ops.size(); ++i) {
     const jg_op &op = m->ops[i];
     int rc = JG_OK;
+    if (small && (int)i < m->small->pool_op) continue;
+    if (small && (int)i == m->small->pool_op) {
+      rc = jg_launch_small_pool_final(m->small->d_part, 6, nw, m->small->pool_kind, m->vec[op.out_vec] + op.vec_off,
+                                      m->vec_w[op.out_vec], s);
+      if (rc != JG_OK) return rc;
+      continue;
+    }
     switch (op.kind) {
       case JG_OP_CONV: {
         Shape in;
@@ -852,7 +1093,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           pe.flops = 2.0 * op.k * op.cin * op.cout * (double)nw * in.frames * lo;
           JG_HIP(hipEventRecord(pe.a, s));
         }
-        if (m->precision == 1) {
+        if (prec == 1) {
           const ConvHPrep &hp = m->hprep[i];
           ConvHArgs a;
           memset(&a, 0, sizeof(a));
@@ -979,7 +1220,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
       case JG_OP_MAXPOOL1D: {
         const Shape in = sh[op.in_buf];
         const int lo = in.L / 2;
-        if (m->precision == 1 && m->hprep[i].pool_f16s)
+        if (prec == 1 && m->hprep[i].pool_f16s)
           rc = jg_launch_maxpool1d_f16s(reinterpret_cast<const uint4 *>(m->act[op.in_buf]), nw * in.frames, in.L, lo,
                                         in.C, reinterpret_cast<uint4 *>(m->act[op.out_buf]), s);
         else
@@ -996,7 +1237,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
       case JG_OP_POOL: {
         const Shape in = sh[op.in_buf];
         const uint8_t *mk = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
-        if (m->precision == 1 && m->pool_fused_by[i] >= 0) {
+        if (prec == 1 && m->pool_fused_by[i] >= 0) {
           rc = jg_launch_pool_final(m->pool_part, m->pool_rows, nw, in.C,
                                     m->vec[op.out_vec] + op.vec_off, m->vec_w[op.out_vec], s);
           break;
@@ -1013,7 +1254,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         // op.arg = partial slot, in_mask = mask the tap used, cout = channels,
         // in_buf = activation slot whose shape gives the position count
         const Shape in = sh[op.in_buf];
-        const int rows_per_win = m->precision == 1
+        const int rows_per_win = prec == 1
                                      ? m->part_rows[op.arg]
                                      : in.frames * ((in.L + jg_conv_tile_m(in.L) - 1) / jg_conv_tile_m(in.L));
         const uint8_t *mk = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
@@ -1118,16 +1359,6 @@ static int forward_device_ids(jg_model *m, const uint8_t *d_ids, int64_t n_win, 
     m->precision = 0;
     m->f16_reason = "an activation left the f16 range at run time";
   }
-  return JG_OK;
-}
-
-template <typename T>
-static int grow(T **p, int64_t *cap, int64_t need_bytes) {
-  if (need_bytes <= *cap) return JG_OK;
-  if (*p) JG_HIP(hipFree(*p));
-  *p = nullptr;
-  JG_HIP(hipMalloc(reinterpret_cast<void **>(p), (size_t)need_bytes));
-  *cap = need_bytes;
   return JG_OK;
 }
 

@@ -182,8 +182,10 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   int dytmask1 = 0, dytmask2 = 0;
 };
 
+struct JgSmallNet;
 struct jg_model {
   jg_engine *e = nullptr;
+  JgSmallNet *small = nullptr;    // fused small-window network (jg_small.hip) when the program matches that family
   std::vector<jg_op> ops;
   std::vector<ConvHPrep> hprep;   // parallel to ops
   int precision = 0;              // 0 = exact f32 MFMA, 1 = split-f16 (f16x3)

@@ -142,7 +142,9 @@ def test_forward_zeus_dyt(precision):
 def test_default_precision_is_f16x3_when_eligible():
     from jaeger_amd.engine import JaegerHipEngine
     from oracle import forward as ofwd
-    for name, want in (("brain", "f16x3"), ("baseline500", "f32")):
+    # brain: split-f16 conv kernels; baseline500: the fused small-window kernel (same arithmetic); nmdmerge500 (NMD
+    # taps on a 32-channel net) has neither and runs on the exact-f32 kernels
+    for name, want in (("brain", "f16x3"), ("baseline500", "f16x3"), ("nmdmerge500", "f32")):
         cfg = load_model_cfg(name)
         eng = JaegerHipEngine(model_cfg=cfg, weights=ofwd.random_weights(cfg))
         assert eng.model.precision == want
@@ -152,8 +154,88 @@ def test_default_precision_is_f16x3_when_eligible():
         eng.close()
 
 
-def test_forward_baseline500():
-    _forward_case("baseline500", 500, 64, 5, n_frac=0.02)
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_forward_baseline500(precision):
+    """BASELINE configs[3]: f16x3 = the fused small-window kernel (ids -> pooled sums in one launch), f32 = the
+    layer-by-layer exact-f32 kernels."""
+    _forward_case("baseline500", 500, 64, 5, n_frac=0.02, precision=precision)
+
+
+def test_forward_baseline500_fused_ragged_and_masked():
+    """The fused kernel on short whole-contig windows (padded rows), N runs, an all-N window, several launch groups."""
+    _forward_case("baseline500", 500, 301, 6, n_frac=0.05, short=True, chunk=64, precision="f16x3")
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = load_model_cfg("baseline500")
+    weights = ofwd.random_weights(cfg, seed=38341)
+    rng = np.random.Generator(np.random.PCG64(12))
+    fsize = 500
+    seq = _random_dna(rng, fsize * 4)
+    seq[fsize:2 * fsize] = ord("N")                      # all masked: the average pool divides by max(count, 1e-7)
+    seq[2 * fsize + 40:2 * fsize + 300] = ord("N")
+    starts = (np.arange(4) * fsize).astype(np.int64)
+    lens = np.array([500, 500, 500, 23], np.int32)       # the last one yields 6 codons per frame: conv0 (k 7, valid) -> 0
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, precision="f16x3")
+    got = eng.predict_windows(seq, starts[:3], lens[:3], fsize)
+    again = eng.predict_windows(seq, starts[:3], lens[:3], fsize)
+    eng.close()
+    ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts[:3], lens[:3])], fsize,
+                              pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    for k, r in ref.items():
+        np.testing.assert_array_equal(got[k], again[k])
+        assert np.abs(got[k] - r).max() <= TOL, k
+    assert not got["embedding"][1].any()
+
+
+def _small_variant(pool="average", blocks=2, k0=7, pad0=None, use_masking=True):
+    import copy
+    cfg = copy.deepcopy(load_model_cfg("baseline500"))
+    rep = cfg["representation_learner"]
+    rep["pooling"] = pool
+    rep["hidden_layers"][0]["config"]["kernel_size"] = k0
+    if pad0 is not None:
+        rep["hidden_layers"][0]["config"]["padding"] = pad0
+    rep["hidden_layers"][3]["config"]["block_size"] = blocks
+    cfg["use_masking"] = use_masking
+    return cfg
+
+
+@pytest.mark.parametrize("kw", [dict(pool="max"), dict(blocks=1), dict(k0=5, pad0="same"), dict(k0=3),
+                                dict(use_masking=False), dict(k0=9, pad0="same", pool="max")])
+def test_forward_small_window_variants(kw):
+    """Variants of the 32-channel family the fused kernel is instantiated for: max pool, one residual block, other
+    first-conv widths / SAME padding, mask-free graphs (model.use_masking: false, builder.py:259)."""
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = _small_variant(**kw)
+    weights = ofwd.random_weights(cfg, seed=7)
+    rng = np.random.Generator(np.random.PCG64(21))
+    fsize, n_win = 500, 40
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.03)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    lens[2::5] = rng.integers(120, fsize, lens[2::5].size)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights)
+    assert eng.model.precision == "f16x3"
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    eng.model.set_precision("f32")
+    exact = eng.predict_windows(seq, starts, lens, fsize)
+    eng.close()
+    ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    for k, r in ref.items():
+        err, err32 = float(np.abs(got[k] - r).max()), float(np.abs(exact[k] - r).max())
+        print(kw, k, f"fused {err:.2e} exact-f32 {err32:.2e}")
+        assert err <= TOL and err32 <= TOL, (k, err, err32)
+
+
+def test_small_window_model_on_longer_rows_runs_layer_by_layer():
+    """Rows beyond the fused kernel's 160 positions (fsize 1000 -> 332 codons) fall back to the per-layer path
+    inside the same model, same results contract."""
+    _forward_case("baseline500", 1000, 9, 8, n_frac=0.02, precision="f16x3")
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
