@@ -1055,6 +1055,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
     a.overflow = m->d_overflow;
     a.rows = rows; a.L = l; a.L0 = small_L0; a.pad0 = small_pad0; a.vocab = m->vocab;
     a.use_mask = sn->use_mask; a.pool_kind = sn->pool_kind;
+    { const char *ev = jg_exp_env("JG_SMALL_DBG"); a.dbg = ev ? atoi(ev) : 0; }
     for (int q = 0; q < JG_SMALL_MAX_LAYERS; ++q) a.layer[q] = sn->layer[q];
     ProfEvent pe;
     if (e->profile) {

@@ -23,6 +23,8 @@ struct JgSmallArgs {
   long rows;
   int L, L0, pad0, vocab;
   int use_mask, pool_kind;
+  int n_conv, k0;       // k = 3 convs behind the first layer; taps of the first layer
+  int dbg;              // experiment build only (JG_SMALL_DBG): ablation mask
   JgSmallLayer layer[JG_SMALL_MAX_LAYERS];
 };
 

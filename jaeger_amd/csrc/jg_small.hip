@@ -21,6 +21,8 @@
 //     accumulates the masked pool instead of storing.
 //
 // Waves never exchange data, so there is no barrier after the tables are loaded.
+#include <stdio.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -79,40 +81,87 @@ __device__ __forceinline__ M192 m_first(int n) {     // bits [0, n)
 }
 __device__ __forceinline__ int m_count(M192 m) { return __popcll(m.w[0]) + __popcll(m.w[1]) + __popcll(m.w[2]); }
 
+// packed f16 pair of two floats (v_cvt_pk_f16_f32, round to nearest even)
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  const half2_t r = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, r);
+}
+// v - f32(hi2.half[H]) in one mixed-precision FMA (as in jg_conv_f16_impl.h)
+template <int H>
+__device__ __forceinline__ float mix_rem(float v, unsigned hi2) {
+  float r;
+  if constexpr (H == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi2), "v"(v));
+  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi2), "v"(v));
+  return r;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// tanh-GELU of two values: the polynomial and the final product as packed f32 instructions (v_pk_mul / v_pk_fma:
+// two elements per issue slot - a lone wave per SIMD issues one vector instruction per 4 cycles, so instruction
+// count is what the epilogue costs), exp2 / rcp per element
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 v) {
+  const f32x2 c0 = {-2.3022082f, -2.3022082f}, c1 = {-0.10294324f, -0.10294324f}, one = {1.0f, 1.0f};
+  const f32x2 t = v * (c0 + c1 * (v * v));
+  f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  e = e + one;
+  const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+  return v * r;
+}
+
 __device__ __forceinline__ float gelu_tanh(float v) {
   const float t = v * (-2.3022082f - 0.10294324f * v * v);   // -2u * log2(e), u = sqrt(2/pi)(v + 0.044715 v^3)
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 // One layer's epilogue over the five accumulator blocks of a row.  Lane (n, h) holds position 32 b + n and channels
 // 8 g + 4 h + i in register 4 g + i of block b.  Compiled per pattern (the activation is always the tanh-GELU):
-//   P2 = false:  x = gelu(acc * s1 + t1 + addf * shortcut)              (addf = 0 or 1: exact either way)
-//   P2 = true :  x = gelu(gelu(...) * s2 + t2)                          (the norm + GELU behind a residual stack)
-// LAST: accumulate the masked pool instead of storing the row.
-template <bool LAST, bool P2>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], const float addf, const int save,
-                                         const float *epi, M192 mout, char *act, int n, int h, float &vmax,
-                                         float (&pool)[16], int pool_kind) {
-  // (the per-channel parameters are re-read from LDS - broadcast reads - for every block: holding them would cost
-  // 64 registers next to the accumulators and the shortcut)
+//   x = gelu(acc * s1 + t1 [+ shortcut: ADD]);  P2: x = gelu(x * s2 + t2) (the norm + GELU behind a residual stack);
+//   SAVE: the result becomes the shortcut of a later layer;  LAST: accumulate the masked pool instead of storing the row.
+// (Run-time flags instead of ADD / SAVE cost 1.5 more vector instructions per element: a "+ 0 * shortcut" and a select.)
+#ifdef JG_SMALL_ABLATE                   /* (make exp EXPFLAGS=-DJG_SMALL_ABLATE: the branches perturb the code they sit in) */
+#define JG_SDBG(bit) (dbg & (bit))      /* JG_SMALL_DBG: 1 no table phase, 2 no MFMA, 4 GELU = identity, 8 no LDS stores */
+#else
+#define JG_SDBG(bit) false
+#endif
+
+template <bool LAST, bool P2, bool ADD, bool SAVE>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], const float *epi, M192 mout, char *act,
+                                         int n, int h, float &vmax, float (&pool)[16], int pool_kind, int dbg) {
+  (void)dbg;
+  // the lane's 16 channels' parameters, read once per layer (broadcast LDS reads; a read per block and channel
+  // group left the wave waiting on LDS latency twenty times a layer)
+  f32x4 s1[4], t1[4], s2[4], t2[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    s1[g] = *reinterpret_cast<const f32x4 *>(epi + 0 * C + g * 8 + h * 4);
+    t1[g] = *reinterpret_cast<const f32x4 *>(epi + 1 * C + g * 8 + h * 4);
+    if constexpr (P2) {
+      s2[g] = *reinterpret_cast<const f32x4 *>(epi + 2 * C + g * 8 + h * 4);
+      t2[g] = *reinterpret_cast<const f32x4 *>(epi + 3 * C + g * 8 + h * 4);
+    }
+  }
+  JG_FENCE();
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const bool keep = (mout.w[b >> 1] >> ((b & 1) * 32 + n)) & 1ull;
     float v[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 s1 = *reinterpret_cast<const f32x4 *>(epi + 0 * C + g * 8 + h * 4);
-      const f32x4 t1 = *reinterpret_cast<const f32x4 *>(epi + 1 * C + g * 8 + h * 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float x = gelu_tanh(acc[b][g * 4 + i] * s1[i] + t1[i] + addf * sc[b][g * 4 + i]);
+      for (int i = 0; i < 4; i += 2) {
+        const int r = g * 4 + i;
+        f32x2 x = f32x2{acc[b][r], acc[b][r + 1]} * f32x2{s1[g][i], s1[g][i + 1]} + f32x2{t1[g][i], t1[g][i + 1]};
+        if constexpr (ADD) x = x + f32x2{sc[b][r], sc[b][r + 1]};
+        if (!JG_SDBG(4)) x = gelu_tanh2(x);
         if constexpr (P2) {
-          const float s2 = epi[2 * C + g * 8 + h * 4 + i], t2 = epi[3 * C + g * 8 + h * 4 + i];
-          x = gelu_tanh(x * s2 + t2);
+          x = x * f32x2{s2[g][i], s2[g][i + 1]} + f32x2{t2[g][i], t2[g][i + 1]};
+          if (!JG_SDBG(4)) x = gelu_tanh2(x);
         }
-        v[g * 4 + i] = x;
+        v[r] = x[0];
+        v[r + 1] = x[1];
       }
     }
-    if (save) {
+    if constexpr (SAVE) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[b][r] = v[r];
     }
@@ -127,26 +176,45 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], co
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        half4 hi, lo;
+        // x = hi + lo: hi = f16(x) by packed converts, lo = f16(x - hi) with the remainder from v_fma_mix_f32 (reads
+        // the f16 half straight out of the packed register)
+        float x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float x = keep ? v[g * 4 + i] : 0.0f;
-          vmax = fmaxf(vmax, fabsf(x));
-          const _Float16 hh = (_Float16)x;
-          hi[i] = hh;
-          lo[i] = (_Float16)(x - (float)hh);
+          x[i] = keep ? v[g * 4 + i] : 0.0f;
+          vmax = fmaxf(vmax, fabsf(x[i]));
         }
+        const unsigned h01 = pk_f16(x[0], x[1]), h23 = pk_f16(x[2], x[3]);
+        const unsigned l01 = pk_f16(mix_rem<0>(x[0], h01), mix_rem<1>(x[1], h01));
+        const unsigned l23 = pk_f16(mix_rem<0>(x[2], h23), mix_rem<1>(x[3], h23));
         char *p = act + (1 + b * 32 + n) * ROWB + (g * 8 + h * 4) * 2;
-        *reinterpret_cast<half4 *>(p) = hi;
-        *reinterpret_cast<half4 *>(p + 64) = lo;
+        if (!JG_SDBG(8)) {
+          *reinterpret_cast<uint2 *>(p) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2 *>(p + 64) = make_uint2(l01, l23);
+        }
       }
     }
     JG_FENCE();      // one block at a time: hoisted loads of later blocks would spill
   }
 }
 
-template <int NC, int K0>
+// experiment build: per-phase shader cycles of every wave (ids, table phase, first epilogue, MFMA, epilogues, pool)
+#ifdef JG_EXPERIMENT
+static __device__ unsigned long long jg_small_stamp[8];
+#define JG_SST_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime()
+#define JG_SST(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
+#define JG_SST_END do { if (lane == 0) for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&jg_small_stamp[q_], st_[q_]); } while (0)
+#else
+#define JG_SST_DECL
+#define JG_SST(i)
+#define JG_SST_END
+#endif
+
+#define JG_EPI_CALL(LASTV, P2V, ADDV, SAVEV) \
+  epilogue<LASTV, P2V, ADDV, SAVEV>(acc, sc, ep, mo, act, n, h, vmax, pool, a.pool_kind, dbg)
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void small_net_kernel(JgSmallArgs a) {
+  const int NC = a.n_conv, K0 = a.k0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, h = lane >> 5;
@@ -182,8 +250,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __syncthreads();
 
   const int L = a.L, L0 = a.L0, pad0 = a.pad0;
+  const int dbg = a.dbg;
+  (void)dbg;
   const M192 valid_in = m_first(L), valid0 = m_first(L0);
   float vmax = 0.0f;
+  JG_SST_DECL;
   for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += (long)gridDim.x * 4) {
     // ---- ids of the row -> LDS, input mask by ballot --------------------------------------------------
     M192 m;
@@ -196,6 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       idbuf[IDM + q] = q < L ? (unsigned char)id : (unsigned char)a.vocab;
     }
     m = m_and(m, valid_in);
+    JG_SST(0);
     // ---- first conv: k0 table rows per output position --------------------------------------------------
     f32x16 acc[NB], sc[NB];
 #pragma unroll
@@ -206,21 +278,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     // (a real loop over the taps: fully unrolled, the compiler issues every table read of the row first and adds
     // last - 560 live registers; one tap of the five blocks per iteration keeps 80 in flight)
+    {
+      const unsigned char *it = idbuf + IDM + n - pad0;
+      int idc[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) idc[b] = it[b * 32];
 #pragma unroll 1
-    for (int t = 0; t < K0; ++t) {
-      const float *lt = lut + t * VR * LUTS + h * 4;
-      const unsigned char *it = idbuf + IDM + n + t - pad0;
+      for (int t = 0; t < (JG_SDBG(1) ? 1 : K0); ++t) {
+        const float *lt = lut + t * VR * LUTS + h * 4;
+        // all twenty 16-byte reads of this tap first, the next tap's ids behind them, the adds last
+        f32x4 v[NB][4];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const float *rp = lt + (int)it[b * 32] * LUTS;
+        for (int b = 0; b < NB; ++b) {
+          const float *rp = lt + idc[b] * LUTS;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 v = *reinterpret_cast<const f32x4 *>(rp + g * 8);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[b][g * 4 + i] += v[i];
+          for (int g = 0; g < 4; ++g) v[b][g] = *reinterpret_cast<const f32x4 *>(rp + g * 8);
         }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) idc[b] = it[b * 32 + t + 1];      // (reads the zero-row margin behind the last tap)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[b][g * 4 + i] += v[b][g][i];
       }
     }
+    JG_SST(1);
     // output mask of the first conv ("any" rule over its k0 taps), positions [0, L0)
     M192 mo = m;
     if (a.use_mask) {
@@ -232,27 +316,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float pool[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) pool[i] = a.pool_kind == JG_POOL_AVG ? 0.0f : -1.0e9f;
-    epilogue<false, false>(acc, sc, 0.0f, a.layer[0].save, epi, mo, act, n, h, vmax, pool, a.pool_kind);
+    {
+      const float *ep = epi;
+      if (a.layer[0].save) JG_EPI_CALL(false, false, false, true);
+      else JG_EPI_CALL(false, false, false, false);
+    }
+    JG_SST(2);
     // ---- k = 3 convolutions on the matrix cores -----------------------------------------------------------
 #pragma unroll 1
     for (int j = 0; j < NC; ++j) {
+      // fragments of block b + 1 are read (12 x 16 B per lane) while block b's 18 MFMAs run: the twelve reads of a
+      // block issued right in front of their MFMAs left the matrix pipe waiting on LDS latency (118 cycles per MFMA)
+      half8 fr[2][12];
+      const char *fp = act + n * ROWB + h * 16;
+#pragma unroll
+      for (int q = 0; q < 12; ++q)
+        fr[0][q] = *reinterpret_cast<const half8 *>(fp + (q >> 2) * ROWB + ((q >> 1) & 1) * 32 + (q & 1) * 64);
+      JG_FENCE();
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
+        if (b + 1 < NB) {
+#pragma unroll
+          for (int q = 0; q < 12; ++q)
+            fr[(b + 1) & 1][q] = *reinterpret_cast<const half8 *>(fp + ((b + 1) * 32 + (q >> 2)) * ROWB +
+                                                                  ((q >> 1) & 1) * 32 + (q & 1) * 64);
+        }
         f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int cc = 0; cc < 2; ++cc) {
-            const char *p = act + (b * 32 + n + t) * ROWB + (cc * 16 + h * 8) * 2;
-            const half8 xh = *reinterpret_cast<const half8 *>(p);
-            const half8 xl = *reinterpret_cast<const half8 *>(p + 64);
+            const half8 xh = fr[b & 1][(t * 2 + cc) * 2], xl = fr[b & 1][(t * 2 + cc) * 2 + 1];
+            if (JG_SDBG(2)) {
+              c[0] += (float)xh[0] + (float)xl[1];
+              continue;
+            }
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t][cc][0], xh, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t][cc][0], xl, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t][cc][1], xh, c, 0, 0, 0);
           }
         acc[b] = c;
-        JG_FENCE();  // one block's twelve fragments in flight at a time
+        JG_FENCE();
       }
+      JG_SST(3);
       {                                     // next layer's weights (layer 0 of the next row after the last one)
         const half8 *wn = wsrc + ((j + 1 == NC ? 0 : j + 1) * 12 << 6);
 #pragma unroll
@@ -264,35 +370,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       if (a.use_mask) mo = m_and(m_or(m_or(m_shl(mo, 1), mo), m_shr(mo, 1)), valid0);
       const float *ep = epi + (j + 1) * 4 * C;
-      const float addf = a.layer[j + 1].add ? 1.0f : 0.0f;
-      const int save = a.layer[j + 1].save, p2 = a.layer[j + 1].aff2;
-      if (j == NC - 1) {
-        if (p2) epilogue<true, true>(acc, sc, addf, save, ep, mo, act, n, h, vmax, pool, a.pool_kind);
-        else epilogue<true, false>(acc, sc, addf, save, ep, mo, act, n, h, vmax, pool, a.pool_kind);
-      } else {
-        if (p2) epilogue<false, true>(acc, sc, addf, save, ep, mo, act, n, h, vmax, pool, a.pool_kind);
-        else epilogue<false, false>(acc, sc, addf, save, ep, mo, act, n, h, vmax, pool, a.pool_kind);
+      {
+        const int add = a.layer[j + 1].add, save = a.layer[j + 1].save, p2 = a.layer[j + 1].aff2;
+        const int code = (j == NC - 1 ? 8 : 0) | (p2 ? 4 : 0) | (add ? 2 : 0) | (save ? 1 : 0);
+        switch (code) {               // wave-uniform: one compiled epilogue per (last, second norm, add, save)
+          case 0: JG_EPI_CALL(false, false, false, false); break;
+          case 1: JG_EPI_CALL(false, false, false, true); break;
+          case 2: JG_EPI_CALL(false, false, true, false); break;
+          case 3: JG_EPI_CALL(false, false, true, true); break;
+          case 4: JG_EPI_CALL(false, true, false, false); break;
+          case 5: JG_EPI_CALL(false, true, false, true); break;
+          case 6: JG_EPI_CALL(false, true, true, false); break;
+          case 7: JG_EPI_CALL(false, true, true, true); break;
+          case 8: case 9: JG_EPI_CALL(true, false, false, false); break;
+          case 10: case 11: JG_EPI_CALL(true, false, true, false); break;
+          case 12: case 13: JG_EPI_CALL(true, true, false, false); break;
+          default: JG_EPI_CALL(true, true, true, false); break;
+        }
       }
+      JG_SST(4);
     }
     // ---- pooled channel sums / maxima of the row: reduce over the 32 lanes that share h --------------------
+    // register-halving butterfly: at each step a lane hands half of its registers to its partner and keeps the sums
+    // of the other half (16 exchanges instead of 16 registers x 5 steps); lane bits 4..1 end up selecting the
+    // register, i.e. the channel 8 g + 4 h + i with 4 g + i = r
+    {
+      const bool avg = a.pool_kind == JG_POOL_AVG;
+      float v8[8], v4[4], v2[2], v1;
+      const bool b16 = n & 16, b8 = n & 8, b4 = n & 4, b2 = n & 2;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float v = pool[i];
-#pragma unroll
-      for (int s = 1; s < 32; s <<= 1) {
-        const float o = __shfl_xor(v, s, 64);
-        v = a.pool_kind == JG_POOL_AVG ? v + o : fmaxf(v, o);
+      for (int i = 0; i < 8; ++i) {
+        const float o = __shfl_xor(b16 ? pool[i] : pool[i + 8], 16, 64), k = b16 ? pool[i + 8] : pool[i];
+        v8[i] = avg ? k + o : fmaxf(k, o);
       }
-      pool[i] = v;
-    }
-    if (n == 0) {
-      float *dst = a.part + row * PARTW;
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4 *>(dst + g * 8 + h * 4) = f32x4{pool[g * 4], pool[g * 4 + 1], pool[g * 4 + 2], pool[g * 4 + 3]};
-      if (h == 0) dst[C] = (float)m_count(mo);
+      for (int i = 0; i < 4; ++i) {
+        const float o = __shfl_xor(b8 ? v8[i] : v8[i + 4], 8, 64), k = b8 ? v8[i + 4] : v8[i];
+        v4[i] = avg ? k + o : fmaxf(k, o);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float o = __shfl_xor(b4 ? v4[i] : v4[i + 2], 4, 64), k = b4 ? v4[i + 2] : v4[i];
+        v2[i] = avg ? k + o : fmaxf(k, o);
+      }
+      {
+        const float o = __shfl_xor(b2 ? v2[0] : v2[1], 2, 64), k = b2 ? v2[1] : v2[0];
+        v1 = avg ? k + o : fmaxf(k, o);
+      }
+      {
+        const float o = __shfl_xor(v1, 1, 64);
+        v1 = avg ? v1 + o : fmaxf(v1, o);
+      }
+      const int r = (b16 ? 8 : 0) | (b8 ? 4 : 0) | (b4 ? 2 : 0) | (b2 ? 1 : 0);
+      float *dst = a.part + row * PARTW;
+      if ((n & 1) == 0) dst[(r >> 2) * 8 + h * 4 + (r & 3)] = v1;
+      if (lane == 0) dst[C] = (float)m_count(mo);
     }
+    JG_SST(5);
   }
+  JG_SST_END;
   if (__any(!(vmax <= 65000.0f)) && lane == 0) atomicOr(a.overflow, 1);
 }
 
@@ -310,17 +446,27 @@ __global__ void small_pool_final_kernel(const float *part, int frames, int n_win
   out[(long)w * out_ld + c] = kind == JG_POOL_AVG ? acc / fmaxf(cnt, 1e-7f) : (cnt > 0.0f ? acc : 0.0f);
 }
 
-template <int NC, int K0>
 int launch(jg_engine *e, const JgSmallArgs &a, int smem, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_net_kernel<NC, K0>),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_net_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const int grid = (int)std::min<long>(e->n_cu, (a.rows + 3) / 4);
-  hipLaunchKernelGGL((small_net_kernel<NC, K0>), dim3((unsigned)grid), dim3(256), (size_t)smem, s, a);
+  hipLaunchKernelGGL(small_net_kernel, dim3((unsigned)grid), dim3(256), (size_t)smem, s, a);
   JG_HIP(hipGetLastError());
+#ifdef JG_EXPERIMENT
+  if (a.dbg & 16) {
+    unsigned long long hst[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    JG_HIP(hipStreamSynchronize(s));
+    JG_HIP(hipMemcpyFromSymbol(hst, HIP_SYMBOL(jg_small_stamp), sizeof(hst)));
+    JG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(jg_small_stamp), z, sizeof(z)));
+    const double w = (double)a.rows;
+    fprintf(stderr, "SMALL STAMP rows=%ld cycles/row: ids %.0f table %.0f epi0 %.0f mfma %.0f epi %.0f pool %.0f\n", a.rows,
+            hst[0] / w, hst[1] / w, hst[2] / w, hst[3] / w, hst[4] / w, hst[5] / w);
+  }
+#endif
   return JG_OK;
 }
 
@@ -331,7 +477,7 @@ int jg_small_lds_bytes(int n_conv, int k0, int vocab) {
 }
 
 bool jg_small_supports(int n_conv, int k0, int vocab) {
-  return (n_conv == 2 || n_conv == 4) && (k0 == 3 || k0 == 5 || k0 == 7 || k0 == 9) && vocab <= 254 &&
+  return n_conv >= 1 && n_conv <= JG_SMALL_MAX_LAYERS - 1 && k0 >= 1 && k0 <= 9 && vocab <= 254 &&
          jg_small_lds_bytes(n_conv, k0, vocab) <= 160 * 1024;
 }
 
@@ -342,14 +488,10 @@ int jg_launch_small_net(jg_engine *e, const JgSmallArgs &a, int n_conv, int k0, 
              JG_ERR_UNSUPPORTED, "small-window kernel: %d convs, k0 = %d, %d output positions are outside its limits", n_conv,
              k0, a.L0);
   if (a.rows == 0) return JG_OK;
-  const int smem = jg_small_lds_bytes(n_conv, k0, a.vocab);
-#define JG_SMALL_CASE(NC, K0) \
-  if (n_conv == NC && k0 == K0) return launch<NC, K0>(e, a, smem, s);
-  JG_SMALL_CASE(4, 7) JG_SMALL_CASE(2, 7) JG_SMALL_CASE(4, 5) JG_SMALL_CASE(2, 5) JG_SMALL_CASE(4, 3) JG_SMALL_CASE(2, 3)
-  JG_SMALL_CASE(4, 9) JG_SMALL_CASE(2, 9)
-#undef JG_SMALL_CASE
-  jg_set_error("small-window kernel: no instantiation for %d convs, k0 = %d", n_conv, k0);
-  return JG_ERR_UNSUPPORTED;
+  JgSmallArgs b = a;
+  b.n_conv = n_conv;
+  b.k0 = k0;
+  return launch(e, b, jg_small_lds_bytes(n_conv, k0, a.vocab), s);
 }
 
 int jg_launch_small_pool_final(const float *part, int frames, int n_win, int kind, float *out, int out_ld, hipStream_t s) {
