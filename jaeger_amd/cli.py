@@ -2,7 +2,7 @@
 (cli.py:122-370) in front of :func:`jaeger_amd.predict.run_core`.
 
 Flags that select machinery outside the MI355X hot path (``--cpu``, ``--onnx``, ``--quantized``,
-``--int8``, ``--prophage``, ``--refine``, ``--getsequences``) are accepted so existing
+``--int8``, ``--refine``, ``--getsequences``) are accepted so existing
 command lines parse, and rejected at run time with an explicit message - there is no silent
 fallback.  Extra flags: ``--exact-f32`` (disable the split-f16 conv path), ``--chunk``.
 """
@@ -36,7 +36,8 @@ def main():
 @click.option("--model_path", type=click.Path(exists=True), default=None,
               help="directory containing model/ with *_project.yaml, *_classes.yaml and weights")
 @click.option("--config", type=click.Path(exists=True), default=None)
-@click.option("-p", "--prophage", is_flag=True, help="[unsupported here]")
+@click.option("-p", "--prophage", is_flag=True, help="write the prophage-segmentation input frames of contigs >= --lc "
+                                                     "(the segmentation / plots themselves are not built here)")
 @click.option("-s", "--sensitivity", type=float, default=1.5)
 @click.option("--lc", type=int, default=500000)
 @click.option("--plot-type", type=click.Choice(["circular", "linear"]), default="circular")

@@ -479,10 +479,10 @@ def run_core(**kwargs) -> int:
     if table_path.exists() and not kwargs.get("overwrite"):
         lg.error("output file exists. enable --overwrite option to overwrite the output file.")
         sys.exit(1)
-    for flag in ("prophage", "refine", "quantized", "onnx", "int8", "cpu", "getsequences"):
+    for flag in ("refine", "quantized", "onnx", "int8", "cpu", "getsequences"):
         if kwargs.get(flag):
             lg.error(f"--{flag} is not available on the MI355X predict path (jaeger_amd has no CPU / "
-                     "alternative-backend fallback; prophage / refinement post-processing is out of scope)")
+                     "alternative-backend fallback; refinement post-processing is out of scope)")
             sys.exit(1)
     # experimental CRF (Viterbi) window decoding (commands/predict.py:288-307)
     crf_kw = {}
@@ -628,7 +628,7 @@ def run_core(**kwargs) -> int:
 
     from .postprocess import pred_to_dict, write_output       # pandas: imported beside the forward (termini, above)
     data, data_full = pred_to_dict(y_pred, class_map=class_map, fsize=fsize, term_repeats=term_repeats,
-                                   want_full=bool(kwargs.get("window_scores")), **crf_kw)
+                                   want_full=bool(kwargs.get("window_scores") or kwargs.get("prophage")), **crf_kw)
     n_written = write_output(data, labels=class_map.get("class"), indices=class_map.get("index"),
                              output_table_path=table_path, output_phage_table_path=phage_path,
                              reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))
@@ -638,6 +638,31 @@ def run_core(**kwargs) -> int:
                  lengths=data_full["lengths"], predictions=np.array(data_full["predictions"], dtype=object),
                  gc_skews=np.array(data_full["gc_skews"], dtype=object),
                  gcs=np.array(data_full["gcs"], dtype=object))
+    if kwargs.get("prophage"):
+        # --- prophage segmentation inputs (commands/predict.py:353-442): the per-contig frames logits_to_df_v2 builds
+        # from the window logits.  The change-point segmentation, boundary refinement and plots that consume them
+        # (ruptures / kneed / pycirclize) are not part of this path; the frames are written for them.
+        try:
+            from .prophage_inputs import logits_to_df_v2
+            frames = logits_to_df_v2(class_map=class_map, cmdline_kwargs=kwargs, headers=data_full["headers"],
+                                     predictions=data_full["predictions"], lengths=data_full["lengths"],
+                                     gc_skews=data_full["gc_skews"], gcs=data_full["gcs"])
+            if frames:
+                pro_dir = out_dir / f"{file_base}_prophages"
+                pro_dir.mkdir(parents=True, exist_ok=True)
+                keys = list(frames)
+                np.savez(pro_dir / f"{file_base}_segmentation_inputs.npz",
+                         contigs=np.array(keys, dtype=object), hosts=np.array([frames[k][1] for k in keys], dtype=object),
+                         lengths=np.array([frames[k][2] for k in keys], np.int64),
+                         columns=np.array(list(frames[keys[0]][0].columns), dtype=object),
+                         tracks=np.array([frames[k][0].to_numpy(np.float64) for k in keys], dtype=object))
+                lg.info(f"prophage segmentation inputs of {len(keys)} contigs (>= {kwargs.get('lc', 500000)} bp) written "
+                        f"to {pro_dir}; the segmentation / plotting step itself is not part of the MI355X path")
+            else:
+                lg.info("no prophage regions found")
+        except Exception as e:
+            lg.error(f"an error {e} occurred during the prophage prediction step")
+            lg.debug(traceback.format_exc())
     headers = y_pred.get("meta_0", np.array([], dtype=object))
     if kwargs.get("save_embedding") and "embedding" in y_pred:
         np.savez(out_dir / f"{file_base}_embedding.npz", embedding=y_pred["embedding"], headers=headers)

@@ -245,3 +245,37 @@ def test_cli_gz_dynamic_stride_exact_f32_small_chunks(tmp_path):
         got = next((tmp_path / "out" / "38341_1.4M").glob("*.tsv"))
     _compare_tsv(got, exp)
     assert "gz_4" not in set(pd.read_csv(got, sep="\t")["contig_id"])            # 1999 bp < --fsize
+
+
+def test_cli_prophage_segmentation_inputs(tmp_path):
+    """-p on the product path (commands/predict.py:353-442): the frames ``logits_to_df_v2`` builds for contigs of at
+    least --lc bases, computed from the GPU logits, against the same function fed with the oracle pipeline's logits
+    (the function itself is pinned to the reference's in tests/test_prophage_inputs.py)."""
+    from jaeger_amd.cli import main
+    from jaeger_amd.fragment import read_fasta
+    from jaeger_amd.postprocess import pred_to_dict
+    from jaeger_amd.prophage_inputs import logits_to_df_v2
+    from oracle import forward as ofwd
+    root = make_model_dir(tmp_path / "m")
+    cfg = load_model_cfg("brain")
+    weights = ofwd.random_weights(cfg, seed=38341)
+    fasta = GOLDEN / "test_contigs.fasta"
+    r = CliRunner().invoke(main, ["predict", "-i", str(fasta), "-o", str(tmp_path / "out"), "--model_path", str(root),
+                                  "--fsize", "1500", "--stride", "1500", "--no-dustmask", "-p", "--lc", "20000"])
+    assert r.exit_code == 0, r.output
+    got = np.load(tmp_path / "out" / "38341_1.4M" / "test_contigs_prophages" / "test_contigs_segmentation_inputs.npz",
+                  allow_pickle=True)
+    records = [(n, s.decode()) for n, s in read_fasta(str(fasta))]
+    _, _, y = _expected(tmp_path, records, cfg, weights, 1500, 1500, None, 96)
+    classes = [c["class"] for c in cfg["class_label_map"]]
+    cm = {"num_classes": len(classes), "class": classes, "index": [c["label"] for c in cfg["class_label_map"]]}
+    _, full = pred_to_dict(y, class_map=cm, fsize=1500, term_repeats=oracle_term_repeats(records, 1500), want_full=True)
+    exp = logits_to_df_v2(class_map=cm, cmdline_kwargs={"lc": 20000, "stride": 1500, "fsize": 1500},
+                          headers=full["headers"], predictions=full["predictions"], lengths=full["lengths"],
+                          gc_skews=full["gc_skews"], gcs=full["gcs"])
+    assert list(got["contigs"]) == list(exp) and len(exp) == 5          # the five contigs of >= 20 kb
+    assert list(got["hosts"]) == [exp[k][1] for k in exp]
+    assert list(got["lengths"]) == [exp[k][2] for k in exp]
+    assert list(got["columns"]) == list(next(iter(exp.values()))[0].columns)
+    for tr, k in zip(got["tracks"], exp):
+        np.testing.assert_allclose(tr, exp[k][0].to_numpy(np.float64), atol=2e-4, rtol=0)

@@ -80,7 +80,7 @@ def _run(out_dir, fasta, model_root, min_len, no_pipeline=True):
         (fa.lengths >= fsize)[:, None], np.zeros((len(fa), 10), np.int32), np.int32(-1)).astype(np.int32)
     return run_core(input=str(fasta), output=str(out_dir), model_path=str(model_root), fsize=1500, stride=1500,
                     min_len=min_len, batch=2, dustmask=True, rc=0.1, pc=1, overwrite=True, verbose=1,
-                    no_pipeline=no_pipeline)
+                    no_pipeline=no_pipeline, prophage=True, lc=4000)
 
 
 def _worker(rank, world, port, tmp, min_len):
@@ -127,6 +127,12 @@ def test_sharded_run_core_equals_single_process(tmp_path, min_len, monkeypatch):
     single = (tmp_path / "single" / "38341_1.4M" / "in.tsv").read_text()
     sharded = (tmp_path / "sharded" / "38341_1.4M" / "in.tsv").read_text()
     assert n_single > 0 and single == sharded
+    # -p: the segmentation-input frames of the contigs >= --lc, identical from one process and from two ranks
+    seg = [np.load(tmp_path / d / "38341_1.4M" / "in_prophages" / "in_segmentation_inputs.npz", allow_pickle=True)
+           for d in ("single", "sharded")]
+    assert list(seg[0]["contigs"]) == list(seg[1]["contigs"]) == ["ctg_0", "ctg_10", "ctg_12", "ctg_14"]
+    for a, b in zip(seg[0]["tracks"], seg[1]["tracks"]):
+        np.testing.assert_array_equal(a, b)
     ids = [ln.split("\t")[0] for ln in single.splitlines()[1:]]
     long_first = [f"ctg_{i}" for i in (0, 3, 7, 10, 12, 14)]
     assert ids.count("ctg_dup") >= 2                                # both records that share a name are reported
