@@ -1123,6 +1123,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
             const int64_t flat_tiles = ((int64_t)nw * wp + 255) / 256;
             const int64_t row_tiles = (int64_t)a.rows * a.tiles_m;
             if (!no_flat && op.k == 5 && op.in_buf != JG_BUF_IDS && hp.d_lut == nullptr && op.stride == 1 && in.L == lo &&
+                jg_conv_f16_has_flat_pattern(hp.ep) &&
                 (int64_t)nw * wp < (1 << 24) && flat_tiles * 100 <= row_tiles * 95) {
               a.flat = 1;
               a.flat_p = fp;

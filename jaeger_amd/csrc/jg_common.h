@@ -251,5 +251,6 @@ int jg_conv_f16_lds_bytes(int k, int dil);
 bool jg_conv_f16_supports(int k, int dil);
 int jg_conv_f16_tile_m(void);
 bool jg_conv_f16_has_pattern(unsigned ep, bool first_layer);
+bool jg_conv_f16_has_flat_pattern(unsigned ep);
 int jg_conv_lut_lds_bytes(int k, int vocab);
 bool jg_conv_lut_supports(int k, int dil, int vocab);

@@ -1020,6 +1020,10 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     case (JG_EP_ACT1 | JG_EP_NORM2_AFF): return launch_ke<K, (JG_EP_ACT1 | JG_EP_NORM2_AFF)>(e, a, s); \
     case (JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2):                                                \
       return launch_ke<K, (JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)>(e, a, s);                     \
+    case (JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1):                                    \
+      return launch_ke<K, (JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1)>(e, a, s);         \
+    case (JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2):     \
+      return launch_ke<K, (JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)>(e, a, s); \
     default: break;                                                                                  \
   }                                                                                                  \
   jg_set_error("conv_f16x3: stage pattern 0x%x has no compiled epilogue", a.ep);                     \

@@ -15,6 +15,11 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include "jg_common.h"
 
 namespace {
@@ -138,6 +143,27 @@ struct Dust {
 }  // namespace
 
 // Upper-case every base, then lower-case the DUST intervals, record by record, in place.
+// cores this process may actually use: the affinity mask, cut down to the cgroup CPU quota (cgroup v2 cpu.max, v1
+// cpu.cfs_quota_us / cpu.cfs_period_us) - a container can see 256 cores and own 16; threads beyond the quota only
+// preempt each other.  Under torchrun every rank masks its own contigs, so the quota is also shared by the ranks.
+static int usable_cores() {
+  int n = 0;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (n <= 0) n = (int)std::thread::hardware_concurrency();
+  long long q = -1, per = -1;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char qs[32] = "";
+    if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0) q = atoll(qs);
+    fclose(f);
+  } else {
+    if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &q) != 1) q = -1; fclose(g); }
+    if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = -1; fclose(g); }
+  }
+  if (q > 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, (q + per / 2) / per));
+  return std::max(1, n);
+}
+
 extern "C" int jg_dust_mask(uint8_t *bases, const int64_t *offsets, int64_t n_records, int32_t window,
                             int32_t threshold, int32_t n_threads, int64_t *n_masked) {
   JG_REQUIRE(bases != nullptr && offsets != nullptr && n_records >= 0 && window >= 4 && window <= 4096 &&
@@ -146,7 +172,7 @@ extern "C" int jg_dust_mask(uint8_t *bases, const int64_t *offsets, int64_t n_re
   for (int64_t r = 0; r < n_records; ++r)
     JG_REQUIRE(offsets[r + 1] >= offsets[r] && offsets[r + 1] - offsets[r] < (int64_t)2000000000,
                JG_ERR_INVALID, "jg_dust_mask: record %lld length out of range", (long long)r);
-  int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+  int nt = n_threads > 0 ? n_threads : usable_cores();
   nt = std::max(1, std::min(nt, 256));
   if ((int64_t)nt > n_records) nt = (int)std::max<int64_t>(1, n_records);
   std::vector<int64_t> masked((size_t)nt, 0);

@@ -300,8 +300,16 @@ class JaegerHipEngine:
         key = self.string_processor_config.get("input_type", "translated")
         for inputs, *meta in dataset:
             ids = np.asarray(inputs.get(key))
-            if ids.ndim != 3:
-                raise ValueError("JaegerHipEngine.predict expects (B, 6, L) id tensors (seq_onehot=False)")
+            if ids.ndim == 4:
+                # seq_onehot=True batches (B, 6, L, D) (seqops/encode.py:297-302): class c -> device id c + 1, an
+                # all-zero row (invalid codon / padding: what Masking(0.0) masks, builder.py:850-852) -> 0
+                if not self.string_processor_config.get("seq_onehot"):
+                    raise ValueError("one-hot batch given to a model that takes codon ids")
+                ids = np.where(ids.any(axis=-1), ids.argmax(axis=-1) + 1, 0)
+            elif ids.ndim != 3:
+                raise ValueError("JaegerHipEngine.predict expects (B, 6, L) id or (B, 6, L, D) one-hot tensors")
+            elif self.string_processor_config.get("seq_onehot"):
+                raise ValueError("id batch given to a model that takes one-hot input")
             out = self.model.forward(ids.astype(np.uint8), chunk=self.chunk)
             for k, v in out.items():
                 acc[k].append(v)

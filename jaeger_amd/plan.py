@@ -80,6 +80,7 @@ class ResBlock:
     bn3: Norm | None
     activation: str = "gelu"       # layers.py:1781
     use_masking: bool = True
+    nmd: "Nmd | None" = None       # return_nmd (last block of a stack): bn2's NMD side output (layers.py:1896-1899)
 
 
 @dataclass
@@ -107,6 +108,10 @@ class ModelPlan:
     use_masking: bool = True
     string_processor: dict = field(default_factory=dict)
     class_label_map: list[dict] = field(default_factory=list)
+    # "embedding" = Embedding(vocab, E, mask_zero) on ids; "onehot_dense" = one-hot input -> Masking(0) -> bias-free
+    # Dense(E); "onehot" = the one-hot rows themselves (embedding_size 0) (builder.py:844-880).  The one-hot forms
+    # are the same gather with table row 0 = zeros (the all-zero one-hot row of an invalid codon, masked by Masking)
+    embedding_kind: str = "embedding"
 
     @property
     def nmd_dim(self) -> int:
@@ -114,8 +119,9 @@ class ModelPlan:
 
 
 def _norm(name: str, kind: str, channels: int, cfg: dict, use_masking: bool) -> Norm:
-    if cfg.get("return_nmd"):
-        raise UnsupportedLayer(f"{name}: return_nmd=True norms are not supported; use an 'nmd' layer")
+    if cfg.get("return_nmd") and kind != "masked_batchnorm":
+        # MaskedDYT / MaskedLayerNormalization raise on return_nmd=True (layers.py:307-311, 398-402)
+        raise UnsupportedLayer(f"{name}: return_nmd=True is only defined for masked_batchnorm")
     eps = {"masked_batchnorm": 1e-5, "masked_layernorm": 1e-3, "masked_dyt": 0.0}[kind]
     return Norm(name, kind, channels, float(cfg.get("epsilon", eps)), use_masking)
 
@@ -140,7 +146,16 @@ def _block(layers: list[dict], prefix: str, cin: int, use_masking_default: bool,
             cin = int(cfg["filters"])
         elif name in _NORMS:
             um = bool(cfg.get("use_masking", use_masking_default)) if name == "masked_batchnorm" else True
-            out.append(_norm(p, name, cin, cfg, um))
+            norm = _norm(p, name, cin, cfg, um)
+            if cfg.get("return_nmd"):
+                # MaskedBatchNorm(return_nmd=True) also returns the masked per-example channel mean of its INPUT
+                # minus its own moving_mean (layers.py:943-954): an NMD tap in front of the norm that shares the
+                # norm's moving_mean and epsilon
+                if nmd_dims is None:
+                    raise UnsupportedLayer(f"{p}: return_nmd norm outside the representation learner")
+                out.append(Nmd(p, cin, norm.epsilon))
+                nmd_dims.append(cin)
+            out.append(norm)
         elif name == "nmd":
             if nmd_dims is None:
                 raise UnsupportedLayer(f"{p}: nmd layer outside the representation learner")
@@ -150,8 +165,6 @@ def _block(layers: list[dict], prefix: str, cin: int, use_masking_default: bool,
             kind = name if name in _ACT_ALIASES else cfg.get("activation")   # builder.py:1022-1023
             out.append(Act(str(kind).lower()))
         elif name == "residual_block":
-            if cfg.get("return_nmd"):
-                raise UnsupportedLayer(f"{p}: return_nmd residual blocks are not supported")
             um = bool(cfg.get("use_masking", use_masking_default))
             filters = int(cfg["filters"])
             k = int(cfg.get("kernel_size", 3))                 # layers.py:1788
@@ -173,8 +186,16 @@ def _block(layers: list[dict], prefix: str, cin: int, use_masking_default: bool,
                 if bypass:
                     c3 = Conv(f"{bp}/conv3", 1, cin, filters, stride, pad, dil, bias, None, um, "any")
                     b3 = _norm(f"{bp}/bn3", nt, filters, {}, um)
-                out.append(ResBlock(bp, c1, _norm(f"{bp}/bn1", nt, filters, {}, um), c2,
-                                    _norm(f"{bp}/bn2", nt, filters, {}, um), c3, b3, act, um))
+                blk = ResBlock(bp, c1, _norm(f"{bp}/bn1", nt, filters, {}, um), c2,
+                               _norm(f"{bp}/bn2", nt, filters, {}, um), c3, b3, act, um)
+                if cfg.get("return_nmd") and j == int(cfg.get("block_size", 1)) - 1:   # layers.py:2682-2686
+                    if nt != "masked_batchnorm":
+                        raise ValueError(f"{p}: return_nmd=True is only supported with norm_type='masked_batchnorm'")
+                    if nmd_dims is None:
+                        raise UnsupportedLayer(f"{p}: return_nmd block outside the representation learner")
+                    blk.nmd = Nmd(f"{bp}/bn2", filters, blk.bn2.epsilon)
+                    nmd_dims.append(filters)
+                out.append(blk)
                 cin = filters
         elif name == "dense":
             out.append(Dense(p, cin, int(cfg["units"]), bool(cfg.get("use_bias", True)),
@@ -231,8 +252,10 @@ def build_plan(model_cfg: dict) -> ModelPlan:
         raise UnsupportedLayer(f"input_type {sp['input_type']!r}: only 'translated' models are supported")
     if sp.get("ngram_width", 3) != 3:
         raise UnsupportedLayer("dicodon (ngram_width 6) encodings are not supported")
-    if not emb.get("use_embedding_layer", False) or sp.get("seq_onehot"):
-        raise UnsupportedLayer("only use_embedding_layer=true / seq_onehot=false models are supported")
+    use_emb = bool(emb.get("use_embedding_layer", False))
+    if use_emb == bool(sp.get("seq_onehot")):
+        # Embedding needs ids, the Dense / pass-through branch needs one-hot rows (builder.py:856-880)
+        raise UnsupportedLayer("use_embedding_layer and seq_onehot must be opposite (ids -> Embedding, one-hot -> Dense)")
     if emb.get("use_positional_embeddings", False):
         raise UnsupportedLayer("positional embeddings are not supported")
     for section in ("representation_learner", "classifier"):
@@ -242,6 +265,12 @@ def build_plan(model_cfg: dict) -> ModelPlan:
         pass  # training-only head, not part of the serving graph outputs
     use_masking = bool(model_cfg.get("use_masking", True))          # builder.py:259
     e = int(emb.get("embedding_size", 4))
+    kind = "embedding"
+    if not use_emb:
+        depth = max(sp["codon_id"]) + 1                        # one_hot depth (seqops/encode.py:297-302)
+        kind = "onehot_dense" if e > 0 else "onehot"
+        e = e if e > 0 else depth
+        sp["vocab_size"] = depth + 1                           # ids on the device: 0 = invalid / padding, id + 1 else
     nmd_dims: list[int] = []
     rep_cfg = model_cfg["representation_learner"]
     rep, rep_c = _block(rep_cfg.get("hidden_layers", []), "rep", e, use_masking, nmd_dims)
@@ -254,7 +283,7 @@ def build_plan(model_cfg: dict) -> ModelPlan:
     plan = ModelPlan(vocab=sp["vocab_size"], embedding_dim=e, rep=rep, pooling=pooling,
                      rep_channels=rep_c, classifier=cls, n_classes=n_cls, nmd_dims=nmd_dims,
                      use_masking=use_masking, string_processor=sp,
-                     class_label_map=list(model_cfg.get("class_label_map", []) or []))
+                     class_label_map=list(model_cfg.get("class_label_map", []) or []), embedding_kind=kind)
     rel = model_cfg.get("reliability_model")
     if rel is not None and nmd_dims:
         merge = rel.get("merge") or {}
@@ -280,7 +309,11 @@ def build_plan(model_cfg: dict) -> ModelPlan:
 
 def weight_shapes(plan: ModelPlan) -> dict[str, tuple]:
     """Canonical variable names -> shapes."""
-    out: dict[str, tuple] = {"embedding/embeddings": (plan.vocab, plan.embedding_dim)}
+    out: dict[str, tuple] = {}
+    if plan.embedding_kind == "embedding":
+        out["embedding/embeddings"] = (plan.vocab, plan.embedding_dim)
+    elif plan.embedding_kind == "onehot_dense":
+        out["embedding/kernel"] = (plan.vocab - 1, plan.embedding_dim)      # Dense(E, use_bias=False) on one-hot rows
 
     def norm(n: Norm):
         vars_ = {"masked_batchnorm": ("gamma", "beta", "moving_mean", "moving_variance"),

@@ -246,7 +246,13 @@ class _Compiler:
     def _rep(self):
         plan = self.plan
         layers = plan.rep
-        self.emb_off = self.blob.add(self.w["embedding/embeddings"])
+        if plan.embedding_kind == "embedding":
+            table = self.w["embedding/embeddings"]
+        else:       # one-hot input: row 0 (invalid codon = all-zero one-hot row) is zero, row id + 1 the Dense row / unit row
+            rows = self.w["embedding/kernel"] if plan.embedding_kind == "onehot_dense" else \
+                np.eye(plan.vocab - 1, dtype=np.float32)
+            table = np.concatenate([np.zeros((1, rows.shape[1]), np.float32), np.asarray(rows, np.float32)])
+        self.emb_off = self.blob.add(table)
         buf, mask = L.JG_BUF_IDS, L.JG_BUF_IDS      # Embedding(mask_zero=True), builder.py:858-867
         i = 0
         while i < len(layers):
@@ -284,9 +290,13 @@ class _Compiler:
                     raise UnsupportedLayer(f"{blk.name}: a residual block cannot be the first layer")
                 m2 = self._conv_mask(blk.conv2, m1)
                 b2 = self.bufs.take()
-                st2 = self._base_stages(blk.conv2) + [self._norm_stage(blk.bn2, m2 != L.JG_BUF_NONE),
-                                                      self._stage(L.ST_ADD, arg=shortcut),
-                                                      self._stage(L.ST_ACT, arg=act_code(blk.activation))]
+                st2 = self._base_stages(blk.conv2)
+                if blk.nmd is not None:             # bn2(return_nmd=True): tap on bn2's input, conv2's mask
+                    slot = self.parts.take()
+                    st2.append(self._stage(L.ST_NMD, arg=slot))
+                    pending.append((blk.nmd, slot, m2))
+                st2 += [self._norm_stage(blk.bn2, m2 != L.JG_BUF_NONE), self._stage(L.ST_ADD, arg=shortcut),
+                        self._stage(L.ST_ACT, arg=act_code(blk.activation))]
                 i, m2b = self._fuse_tail(layers, i + 1, st2, m2, blk.conv2.filters, pending)
                 self._emit_conv(blk.conv2, b1, m1, st2, m2, b2)
                 self._flush_nmd(pending, b2)

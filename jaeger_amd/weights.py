@@ -54,7 +54,12 @@ def _layer_order(plan: ModelPlan) -> list[tuple[str, list[str]]]:
     conv, :828-855 batch-norm, :412-429 DyT, :321-331 layer-norm; nmd.py:34-40)."""
     norm_vars = {"masked_batchnorm": ["gamma", "beta", "moving_mean", "moving_variance"],
                  "masked_dyt": ["alpha", "gamma", "beta"], "masked_layernorm": ["gamma", "beta"]}
-    out: list[tuple[str, list[str]]] = [("embedding", ["embeddings"])]
+    out: list[tuple[str, list[str]]] = []
+    if plan.embedding_kind == "embedding":
+        out.append(("embedding", ["embeddings"]))
+    elif plan.embedding_kind == "onehot_dense":
+        out.append(("embedding", ["kernel"]))              # Dense(E, use_bias=False) on the one-hot rows
+    norm_names = {l.name for seq in (plan.rep,) for l in seq if isinstance(l, Norm)}
 
     def conv(c: Conv):
         out.append((c.name, ["kernel", "bias"] if c.use_bias else ["kernel"]))
@@ -66,7 +71,8 @@ def _layer_order(plan: ModelPlan) -> list[tuple[str, list[str]]]:
             elif isinstance(layer, Norm):
                 out.append((layer.name, norm_vars[layer.kind]))
             elif isinstance(layer, Nmd):
-                out.append((layer.name, ["moving_mean"]))
+                if layer.name not in norm_names:           # (a return_nmd norm's tap shares the norm's own variables)
+                    out.append((layer.name, ["moving_mean"]))
             elif isinstance(layer, ResBlock):       # sublayer creation order, layers.py:1839-1876
                 conv(layer.conv1)
                 conv(layer.conv2)

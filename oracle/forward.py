@@ -233,6 +233,13 @@ def _norm_vars(norm_type: str, c: int) -> dict[str, tuple]:
     raise ValueError(norm_type)
 
 
+def onehot_depth(model_cfg: dict) -> int:
+    """max(codon_id) + 1 (seqops/encode.py:297-302)."""
+    from jaeger_amd import maps
+    name = (model_cfg.get("string_processor", {}) or {}).get("codon_id", "CODON_ID")
+    return max(maps.NAMED_MAPS[name]) + 1
+
+
 def vocab_size(model_cfg: dict) -> int:
     """len(codon_id)+1 (inference.py:449): every id map has 64 entries."""
     return 65
@@ -253,6 +260,8 @@ def _block_specs(prefix: str, layers: list[dict], cin: int, specs: dict,
         elif name in ("masked_batchnorm", "masked_dyt", "masked_layernorm"):
             for v, shp in _norm_vars(name, cin).items():
                 specs[f"{p}/{v}"] = shp
+            if cfg.get("return_nmd") and nmd_dims is not None:
+                nmd_dims.append(cin)
         elif name == "nmd":
             specs[f"{p}/moving_mean"] = (cin,)
             if nmd_dims is not None:
@@ -281,6 +290,8 @@ def _block_specs(prefix: str, layers: list[dict], cin: int, specs: dict,
                     for v, shp in _norm_vars(nt, co).items():
                         specs[f"{bp}/bn3/{v}"] = shp
                 cin = co
+            if cfg.get("return_nmd") and nmd_dims is not None:
+                nmd_dims.append(co)
         elif name == "dense":
             specs[f"{p}/kernel"] = (cin, cfg["units"])
             if cfg.get("use_bias", True):
@@ -301,8 +312,11 @@ def weight_specs(model_cfg: dict) -> dict[str, tuple]:
     if emb.get("use_embedding_layer", False):
         specs["embedding/embeddings"] = (vocab_size(model_cfg), e)
         cin = e
-    else:
-        raise ValueError("oracle: only use_embedding_layer=true models are restated")
+    else:                                   # one-hot rows -> Masking -> bias-free Dense(E), or straight through (E = 0)
+        depth = onehot_depth(model_cfg)
+        if e > 0:
+            specs["embedding/kernel"] = (depth, e)
+        cin = e if e > 0 else depth
     nmd_dims: list[int] = []
     rep_out = _block_specs("rep", model_cfg["representation_learner"]["hidden_layers"], cin,
                            specs, nmd_dims)
@@ -359,8 +373,8 @@ def _norm(norm_type, x, mask, w, use_masking=True):
     raise ValueError(norm_type)
 
 
-def _residual_block(x, mask, weights, bp, cfg, first: bool, use_masking, dtype):
-    """layers.py:1882-1915."""
+def _residual_block(x, mask, weights, bp, cfg, first: bool, use_masking, dtype, nmd_out=None):
+    """layers.py:1882-1915.  ``nmd_out`` (a list): bn2 runs with return_nmd=True and appends its side output."""
     k = cfg.get("kernel_size", 3)
     stride = cfg.get("strides", 1)
     d = cfg.get("dilation_rate", 1)
@@ -375,6 +389,8 @@ def _residual_block(x, mask, weights, bp, cfg, first: bool, use_masking, dtype):
     h = activation(act, _norm(nt, h, m1, _sub(weights, f"{bp}/bn1", dtype)))
     h, m2 = masked_conv1d(h, m1, _sub(weights, f"{bp}/conv2", dtype), strides=1, **conv)
     m2 = m2 if use_masking else None
+    if nmd_out is not None:                      # MaskedBatchNorm(return_nmd=True), layers.py:943-954
+        nmd_out.append(nmd_vector(h, m2, _sub(weights, f"{bp}/bn2", dtype)["moving_mean"]))
     h = _norm(nt, h, m2, _sub(weights, f"{bp}/bn2", dtype))
     if (cfg.get("use_1x1conv", False) and first) or stride > 1:
         c3 = dict(conv, kernel_size=1)
@@ -407,7 +423,10 @@ def _run_block(x, mask, layers, prefix, weights, model_cfg, dtype, pooling=None)
             mask = om if cfg["use_masking"] else None
         elif name in ("masked_batchnorm", "masked_dyt", "masked_layernorm"):
             if cfg.get("return_nmd"):
-                raise ValueError("oracle: return_nmd norms are not restated; use an nmd layer")
+                if name != "masked_batchnorm":
+                    raise ValueError("return_nmd=True is only defined for masked_batchnorm")   # layers.py:307, 398
+                # layers.py:943-954: masked mean of the norm's input minus its moving_mean (eps = the norm's 1e-5)
+                nmds.append(nmd_vector(x, mask, _sub(weights, p, dtype)["moving_mean"]))
             x = _norm(name, x, mask, _sub(weights, p, dtype))
             if name == "masked_batchnorm" and not cfg["use_masking"]:
                 mask = None
@@ -417,11 +436,10 @@ def _run_block(x, mask, layers, prefix, weights, model_cfg, dtype, pooling=None)
             x = activation(name if name in _ACT_ALIASES else cfg.get("activation"), x)
         elif name == "residual_block":
             um = cfg["use_masking"]
-            if cfg.get("return_nmd"):
-                raise ValueError("oracle: return_nmd residual blocks are not restated")
-            for j in range(cfg.get("block_size", 1)):
-                x, mask = _residual_block(x, mask if um else None, weights, f"{p}/block{j}",
-                                          cfg, j == 0, um, dtype)
+            nb = cfg.get("block_size", 1)
+            for j in range(nb):                 # return_nmd only reaches the last block of a stack (layers.py:2682-2686)
+                x, mask = _residual_block(x, mask if um else None, weights, f"{p}/block{j}", cfg, j == 0, um, dtype,
+                                          nmd_out=nmds if (cfg.get("return_nmd") and j == nb - 1) else None)
         elif name == "dense":
             w = _sub(weights, p, dtype)
             x = x @ w["kernel"]
@@ -449,11 +467,18 @@ def forward(model_cfg: dict, weights: dict[str, Any], ids: np.ndarray,
     the SavedModel (builder.py:796-836): prediction, embedding[, nmd, reliability]."""
     idt = torch.as_tensor(np.asarray(ids).astype(np.int64))
     emb_cfg = model_cfg["embedding"]
-    if not emb_cfg.get("use_embedding_layer", False):
-        raise ValueError("oracle: only use_embedding_layer=true models are restated")
-    table = torch.as_tensor(weights["embedding/embeddings"]).to(dtype)
-    x = table[idt]                                         # Embedding(mask_zero=True)
-    mask = (idt != 0).to(dtype)                            # builder.py:858-867
+    if emb_cfg.get("use_embedding_layer", False):
+        table = torch.as_tensor(weights["embedding/embeddings"]).to(dtype)
+        x = table[idt]                                     # Embedding(mask_zero=True)
+        mask = (idt != 0).to(dtype)                        # builder.py:858-867
+    else:
+        # seq_onehot=True (builder.py:844-880): the encoder emits one_hot(codon_id, depth) with an all-zero row for an
+        # invalid codon (encode.py:297-302); device ids are codon_id + 1, so the row is one_hot(id - 1); Masking(0.0)
+        # masks rows that are entirely zero; Dense(E, use_bias=False) (or nothing for embedding_size 0) follows
+        depth = onehot_depth(model_cfg)
+        onehot = torch.nn.functional.one_hot(torch.clamp(idt - 1, min=0), depth).to(dtype) * (idt != 0).unsqueeze(-1)
+        mask = (onehot != 0).any(dim=-1).to(dtype)
+        x = onehot @ torch.as_tensor(weights["embedding/kernel"]).to(dtype) if "embedding/kernel" in weights else onehot
     rep = model_cfg["representation_learner"]
     emb, nmds = _run_block(x, mask, rep["hidden_layers"], "rep", weights, model_cfg, dtype,
                            pooling=rep.get("pooling"))

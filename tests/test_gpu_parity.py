@@ -529,3 +529,59 @@ def test_forward_nmdmerge500():
     """The fourth conv-family architecture of the reference's train_config (nn_config_500bp_nmd_merge.yaml):
     500-bp windows, NMD merge + reliability head on a narrow network (exact-f32 path)."""
     _forward_case("nmdmerge500", 500, 48, 6, n_frac=0.02)
+
+
+def test_forward_return_nmd_norm_and_blocks():
+    """return_nmd=True on a batch norm and on residual stacks (layers.py:943-954, 1896-1899; used by
+    train_config/nn_config.yaml:205): the NMD side outputs come from the norms' own moving means, on the
+    split-f16 kernels (the tap sits in front of the norm and of the residual add)."""
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    from test_plan_program import _return_nmd_variant
+    cfg = _return_nmd_variant()
+    weights = ofwd.random_weights(cfg, seed=5)
+    rng = np.random.Generator(np.random.PCG64(31))
+    for fsize, n_win in ((1500, 7), (2000, 5)):             # 2000: the window-packed launch is not compiled for this
+        seq = _random_dna(rng, fsize * n_win, n_frac=0.02)  # pattern, the row-tiled one takes over
+        starts = (np.arange(n_win) * fsize).astype(np.int64)
+        lens = np.full(n_win, fsize, np.int32)
+        eng = JaegerHipEngine(model_cfg=cfg, weights=weights)
+        assert eng.model.precision == "f16x3"
+        got = eng.predict_windows(seq, starts, lens, fsize)
+        eng.close()
+        ids = oenc.encode_windows([seq[s:s + fsize].tobytes() for s in starts], fsize, pad_to=frame_length(fsize))
+        ref = ofwd.forward(cfg, weights, ids)
+        for k, r in ref.items():
+            tol = TOL if k in ("prediction", "reliability") else TOL * max(1.0, float(np.abs(r).max()) / 8)
+            assert float(np.abs(got[k] - r).max()) <= tol, (fsize, k)
+
+
+@pytest.mark.parametrize("embedding_size", [64, 0])
+def test_forward_onehot_translated_input(embedding_size):
+    """seq_onehot=True models: ``predict(dataset)`` takes the (B, 6, L, D) one-hot batches the reference's encoder
+    emits in that mode (seqops/encode.py:297-302), the fused window path encodes on the GPU as always."""
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    from test_plan_program import _onehot_variant
+    cfg = _onehot_variant(embedding_size)
+    weights = ofwd.random_weights(cfg, seed=9)
+    rng = np.random.Generator(np.random.PCG64(41))
+    fsize, n_win = 500, 24
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.03)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights)
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    ids = oenc.encode_windows([seq[s:s + fsize].tobytes() for s in starts], fsize, pad_to=frame_length(fsize))
+    onehot = (np.arange(64)[None, None, None, :] == (ids.astype(np.int64) - 1)[..., None]).astype(np.float32)
+    dataset = [({"translated": onehot[i:i + 10]},) for i in range(0, n_win, 10)]
+    via_api = eng.predict(dataset)
+    with pytest.raises(ValueError):
+        eng.predict([({"translated": ids[:2]},)])
+    eng.close()
+    ref = ofwd.forward(cfg, weights, ids)
+    for k, r in ref.items():
+        assert float(np.abs(got[k] - r).max()) <= TOL, k
+        np.testing.assert_array_equal(via_api[k], got[k])

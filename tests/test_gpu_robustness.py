@@ -22,13 +22,13 @@ def _cases(base, rng):
         w = {k: v.copy() for k, v in base.items()}
         for k in w:
             leaf = k.rsplit("/", 1)[1]
-            if leaf == "kernel" and k.startswith("rep/") and w[k].ndim == 3:
+            if leaf == "kernel" and k.startswith("rep/") and w[k].ndim == 3 and not (compensate and "/block" not in k):
                 if heavy:
                     t = rng.standard_t(2.5, w[k].shape).astype(np.float32)
                     w[k] = (t * np.abs(base[k]).mean() * 0.8).astype(np.float32)
                 w[k] = w[k] * np.float32(kernel_s)
                 if compensate:          # the norm behind the conv sees moving statistics scaled alike: same function,
-                    pre = k.rsplit("/", 2)   # conv outputs kernel_s times larger before the affine
+                    # conv outputs kernel_s times larger before the affine
                     for cand in (k.replace("conv1/kernel", "bn1/"), k.replace("conv2/kernel", "bn2/")):
                         if cand != k and cand + "moving_mean" in w:
                             w[cand + "moving_mean"] = base[cand + "moving_mean"] * np.float32(kernel_s)

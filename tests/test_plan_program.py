@@ -151,3 +151,102 @@ def test_layernorm_cuts_the_epilogue_into_an_elementwise_op():
     assert st(convs[2]) == [L.ST_BIAS] and st(elts[1]) == [L.ST_LN, L.ST_ADD, L.ST_ACT]             # block conv2
     assert st(elts[3]) == [L.ST_LN, L.ST_ADD, L.ST_ACT, L.ST_NMD, L.ST_BN, L.ST_ACT]                # end of a stack
     assert all(e.in_buf == e.out_buf and st(e)[0] == L.ST_LN and L.ST_LN not in st(e)[1:] for e in elts)
+
+
+def _return_nmd_variant():
+    """brain with its four `nmd` layers replaced by return_nmd=True on the first batch norm and on the three
+    residual stacks (train_config/nn_config.yaml:205 uses the block form)."""
+    import copy
+    cfg = copy.deepcopy(load_model_cfg("brain"))
+    hl = cfg["representation_learner"]["hidden_layers"]
+    new, first_bn = [], True
+    for layer in hl:
+        if layer["name"] == "nmd":
+            continue
+        layer = copy.deepcopy(layer)
+        layer.setdefault("config", {})
+        if layer["name"] == "masked_batchnorm" and first_bn:
+            layer["config"]["return_nmd"] = True
+            first_bn = False
+        if layer["name"] == "residual_block":
+            layer["config"]["return_nmd"] = True
+        new.append(layer)
+    cfg["representation_learner"]["hidden_layers"] = new
+    return cfg
+
+
+def test_return_nmd_norms_and_blocks_compile():
+    """MaskedBatchNorm(return_nmd=True) = an NMD tap on the norm's input sharing its moving_mean (layers.py:943-954);
+    ResidualBlockStack(return_nmd=True) = that tap on the LAST block's bn2 (layers.py:1896-1899, 2682-2686)."""
+    from jaeger_amd import _lib as L
+    from jaeger_amd.plan import Nmd, ResBlock, build_plan, weight_shapes
+    from jaeger_amd.program import compile_plan
+    from jaeger_amd.weights import random_weights
+    cfg = _return_nmd_variant()
+    plan = build_plan(cfg)
+    assert plan.nmd_dims == [128, 128, 128, 128]
+    blocks = [l for l in plan.rep if isinstance(l, ResBlock)]
+    assert [b.nmd is not None for b in blocks] == [False, True] * 3          # only the last block of each stack
+    assert isinstance(plan.rep[1], Nmd) and plan.rep[1].name == plan.rep[2].name   # shares the norm's moving_mean
+    assert not any(k.endswith("/moving_mean") and "nmd" in k for k in weight_shapes(plan))
+    prog = compile_plan(plan, random_weights(plan))
+    taps = [op for op in prog.ops if op.kind == L.OP_CONV and any(op.stages[j].kind == L.ST_NMD for j in range(op.n_stages))]
+    finals = [op for op in prog.ops if op.kind == L.OP_NMD_FINAL]
+    assert len(taps) == 4 and len(finals) == 4 and [f.vec_off for f in finals] == [0, 128, 256, 384]
+    # the tap sits in front of the norm and of the residual add
+    st = [taps[1].stages[j].kind for j in range(taps[1].n_stages)]
+    assert st[:5] == [L.ST_BIAS, L.ST_NMD, L.ST_BN, L.ST_ADD, L.ST_ACT]
+    # oracle: same outputs as explicit nmd layers carrying the norms' moving means
+    import numpy as np
+    from oracle import forward as ofwd
+    w = ofwd.random_weights(cfg, seed=3)
+    ids = np.random.default_rng(0).integers(0, 65, (3, 6, 60)).astype(np.uint8)
+    out = ofwd.forward(cfg, w, ids)
+    assert out["nmd"].shape == (3, 512) and out["reliability"].shape == (3, 1)
+    with pytest.raises(Exception):
+        bad = _return_nmd_variant()
+        bad["representation_learner"]["hidden_layers"][3]["config"]["norm_type"] = "masked_dyt"
+        build_plan(bad)
+
+
+def _onehot_variant(embedding_size):
+    import copy
+    cfg = copy.deepcopy(load_model_cfg("baseline500"))
+    cfg["embedding"].update(use_embedding_layer=False, embedding_size=embedding_size, input_shape=[6, None, 64])
+    cfg["string_processor"]["seq_onehot"] = True
+    return cfg
+
+
+@pytest.mark.parametrize("embedding_size", [64, 0])
+def test_onehot_translated_input_compiles_to_the_same_gather(embedding_size):
+    """seq_onehot=True (one-hot rows -> Masking -> bias-free Dense, builder.py:869-880) is an id gather with a zero
+    row for invalid codons; embedding_size 0 feeds the one-hot rows straight into the first conv."""
+    from jaeger_amd.plan import build_plan, weight_shapes
+    from jaeger_amd.program import compile_plan
+    from jaeger_amd.weights import random_weights
+    from oracle import forward as ofwd
+    cfg = _onehot_variant(embedding_size)
+    plan = build_plan(cfg)
+    assert plan.embedding_kind == ("onehot_dense" if embedding_size else "onehot") and plan.vocab == 65
+    assert plan.embedding_dim == (embedding_size or 64) and plan.string_processor["seq_onehot"] is True
+    shapes = weight_shapes(plan)
+    assert ("embedding/kernel" in shapes) == bool(embedding_size) and "embedding/embeddings" not in shapes
+    w = random_weights(plan)
+    prog = compile_plan(plan, w)
+    assert prog.ops[1].cin == (embedding_size or 64)
+    assert set(ofwd.weight_specs(cfg)) == set(shapes)
+    # oracle: identical to the Embedding form whose table is [0; kernel]
+    ids = np.random.default_rng(2).integers(0, 65, (3, 6, 40)).astype(np.uint8)
+    got = ofwd.forward(cfg, w, ids)
+    emb_cfg = copy.deepcopy(load_model_cfg("baseline500"))
+    emb_cfg["embedding"]["embedding_size"] = embedding_size or 64
+    rows = w["embedding/kernel"] if embedding_size else np.eye(64, dtype=np.float32)
+    w2 = dict(w, **{"embedding/embeddings": np.concatenate([np.zeros((1, rows.shape[1]), np.float32), rows])})
+    w2.pop("embedding/kernel", None)
+    ref = ofwd.forward(emb_cfg, w2, ids)
+    for k in ref:
+        np.testing.assert_allclose(got[k], ref[k], atol=1e-6)
+    with pytest.raises(Exception):
+        bad = _onehot_variant(64)
+        bad["string_processor"]["seq_onehot"] = False
+        build_plan(bad)
