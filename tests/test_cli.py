@@ -50,7 +50,7 @@ def test_cli_defaults_and_required():
         assert flag in r.output
 
 
-@pytest.mark.parametrize("flag", ["--cpu", "--onnx", "--prophage", "--refine", "--quantized"])
+@pytest.mark.parametrize("flag", ["--cpu", "--onnx", "--refine", "--quantized"])
 def test_cli_rejects_out_of_scope_flags(tmp_path, flag):
     root = make_model_dir(tmp_path / "m")
     r = CliRunner().invoke(main, ["predict", "-i", str(GOLDEN / "test_contigs.fasta"), "-o", str(tmp_path / "out"),
