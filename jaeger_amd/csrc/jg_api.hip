@@ -423,20 +423,6 @@ static inline uint16_t f16_bits(float x) {
 }
 static inline float f16_value(float x) { return (float)(_Float16)x; }
 
-// which later op needs slot `buf` (written by op `i`) in plain f32?
-static bool slot_needs_f32(const jg_model *m, size_t i, int buf) {
-  for (size_t j = i + 1; j < m->ops.size(); ++j) {
-    const jg_op &o = m->ops[j];
-    if ((o.kind == JG_OP_POOL || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_FRAMESUM) && o.in_buf == buf)
-      return true;       // (MAXPOOL1D has an F16S form)
-    if ((o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D ||
-         o.kind == JG_OP_FRAMESUM) && o.out_buf == buf)
-      return false;   // overwritten
-  }
-  return false;
-}
-
-
 // ---------------------------------------------------------------------------
 // fused small-window network (jg_small.hip): does the op program match the family, and its operands
 //   [MASK] CONV(ids, k0, E -> 32)  { [MASK] CONV(k 3, 32 -> 32, SAME) } x 2 | 4   POOL(avg | max)   ...heads
@@ -641,59 +627,22 @@ static int prepare_f16(jg_model *m, const float *weights) {
   m->pool_fused_by.assign(m->ops.size(), -1);
   m->f16_eligible = true;
   m->f16_reason.clear();
-  auto fail = [&](const char *why) { m->f16_eligible = false; m->f16_reason = why; };
-  bool f32_fmt[JG_MAX_BUFS] = {};   // current format of each slot while walking the program
-  for (size_t i = 0; i < m->ops.size() && m->f16_eligible; ++i) {
+  // Pass A - every conv on its own: can it run on the split-f16 kernel (stride 1, taps / dilation inside the tiling,
+  // 128 output channels, a compiled epilogue pattern)?  Ineligible convs (strided, 1x1 bypass, other widths) keep the
+  // exact-f32 kernel inside an otherwise split-f16 program; pass B below places the layout conversions between them.
+  std::string first_reason;
+  auto fail = [&](const char *why) { if (first_reason.empty()) first_reason = why; };
+  for (size_t i = 0; i < m->ops.size(); ++i) {
     const jg_op &op = m->ops[i];
-    if (op.kind == JG_OP_ELTWISE) {
-      fail("program has standalone elementwise ops");
-      break;
-    }
-    if (op.kind == JG_OP_MAXPOOL1D) {                 // legacy tower: pooled in the F16S form
-      if (op.in_buf < 0 || f32_fmt[op.in_buf]) { fail("maxpool input produced in f32"); break; }
-      m->hprep[i].pool_f16s = true;
-      f32_fmt[op.out_buf] = false;
-      continue;
-    }
-    if (op.kind == JG_OP_FRAMESUM) {
-      if (op.in_buf < 0 || !f32_fmt[op.in_buf]) { fail("frame sum needs an f32 input"); break; }
-      f32_fmt[op.out_buf] = true;
-      continue;
-    }
     if (op.kind != JG_OP_CONV) continue;
-    if (op.stride != 1) { fail("strided conv"); break; }
-    if (!jg_conv_f16_supports(op.k, op.dilation)) { fail("taps / dilation outside the split-f16 tiling"); break; }
-    if (op.cout % 16 != 0 || (op.cout + 31) / 32 * 32 != 128) { fail("conv width is not 128 channels"); break; }
-    if (op.in_buf >= 0 && f32_fmt[op.in_buf]) { fail("conv input produced in f32"); break; }
-    for (int s = 0; s < op.n_stages; ++s)
-      if (op.stages[s].kind == JG_ST_ADD && f32_fmt[op.stages[s].arg]) fail("shortcut produced in f32");
-    if (!m->f16_eligible) break;
     ConvHPrep &hp = m->hprep[i];
-    hp.out_f16s = !slot_needs_f32(m, i, op.out_buf);
-    f32_fmt[op.out_buf] = !hp.out_f16s;
-    if (!hp.out_f16s && jg_exp_env("JG_NO_POOL_FUSE") == nullptr) {
-      // the only reader of the f32 output is a masked global max pool over the conv's own output mask:
-      // reduce in the epilogue instead of storing 4 B per element and reading it back
-      int readers = 0, pool_idx = -1;
-      for (size_t j = i + 1; j < m->ops.size(); ++j) {
-        const jg_op &o = m->ops[j];
-        const bool reads = ((o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D ||
-                             o.kind == JG_OP_FRAMESUM || o.kind == JG_OP_POOL) && o.in_buf == op.out_buf);
-        bool adds = false;
-        if (o.kind == JG_OP_CONV)
-          for (int q = 0; q < o.n_stages; ++q) adds |= o.stages[q].kind == JG_ST_ADD && o.stages[q].arg == op.out_buf;
-        if (reads || adds) {
-          ++readers;
-          if (o.kind == JG_OP_POOL && o.arg == JG_POOL_MAX && o.in_mask == op.out_mask) pool_idx = (int)j;
-          else pool_idx = -2;
-        }
-        if ((o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE) && o.out_buf == op.out_buf) break;   // overwritten
-      }
-      if (readers == 1 && pool_idx >= 0) {
-        hp.pool_op = pool_idx;
-        m->pool_fused_by[(size_t)pool_idx] = (int)i;
-      }
-    }
+    hp.f16_ok = false;
+    if (op.stride != 1) { fail("strided conv"); continue; }
+    if (!jg_conv_f16_supports(op.k, op.dilation)) { fail("taps / dilation outside the split-f16 tiling"); continue; }
+    if (op.cout % 16 != 0 || (op.cout + 31) / 32 * 32 != 128) { fail("conv width is not 128 channels"); continue; }
+    if (op.in_buf != JG_BUF_IDS && op.cin % 16 != 0) { fail("conv input width is not a multiple of 16"); continue; }
+    bool conv_ok = true;
+    auto cfail = [&](const char *why) { conv_ok = false; fail(why); };
     const int cin16 = (op.cin + 15) / 16 * 16, cin_pad = (op.cin + 1) & ~1, cout_pad = 128;
     hp.cc_in = cin16 / 16;
     const float *w = weights + op.w_off;   // (k, cin_pad, cout_pad32) f32
@@ -731,7 +680,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
         for (int c = 0; c < op.cin; ++c) {
           const float v = emb[(size_t)id * op.cin + c];
           const float hi = f16_value(v);
-          if (!(fabsf(v) <= 65000.f)) fail("embedding value outside the f16 range");
+          if (!(fabsf(v) <= 65000.f)) cfail("embedding value outside the f16 range");
           const int cc = c / 16, hh = (c % 16) / 8, j = c % 8;
           eh[(((size_t)id * hp.cc_in + cc) * 4 + 0 * 2 + hh) * 8 + j] = f16_bits(hi);
           eh[(((size_t)id * hp.cc_in + cc) * 4 + 1 * 2 + hh) * 8 + j] = f16_bits(v - hi);
@@ -756,7 +705,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
         std::fill(sh.begin(), sh.end(), 0.0);
         pending = false;
       };
-      for (int q = 0; q < op.n_stages && m->f16_eligible; ++q) {
+      for (int q = 0; q < op.n_stages && conv_ok; ++q) {
         const jg_stage &st = op.stages[q];
         auto vecp = [&](int64_t off) { return weights + off; };
         if (st.kind == JG_ST_BIAS) {
@@ -774,7 +723,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
           continue;
         }
         flush();
-        if (hp.n_hst >= JG_MAX_STAGES) { fail("epilogue too long"); break; }
+        if (hp.n_hst >= JG_MAX_STAGES) { cfail("epilogue too long"); break; }
         HStageArg h{0, st.arg, st.f0, 0};
         switch (st.kind) {
           case JG_ST_DYT:
@@ -789,15 +738,15 @@ static int prepare_f16(jg_model *m, const float *weights) {
             break;
           case JG_ST_NMD: h.kind = JG_HST_NMD; hp.nmd_slot = st.arg; break;
           case JG_ST_MASKMUL: h.kind = JG_HST_MASKMUL; break;
-          default: fail("epilogue stage not supported by the split-f16 kernel"); break;
+          default: cfail("epilogue stage not supported by the split-f16 kernel"); break;
         }
         hp.hst[hp.n_hst++] = h;
       }
-      if (m->f16_eligible) {
-        if (pending && hp.n_hst >= JG_MAX_STAGES) fail("epilogue too long");
+      if (conv_ok) {
+        if (pending && hp.n_hst >= JG_MAX_STAGES) cfail("epilogue too long");
         else flush();
       }
-      if (hp.n_epi_rows > JG_EPI_ROWS) fail("more norm stages than the split-f16 epilogue table holds");
+      if (hp.n_epi_rows > JG_EPI_ROWS) cfail("more norm stages than the split-f16 epilogue table holds");
       // match the stage list against the compiled pattern
       //   affine [nmd] [norm1] [add] [gelu] [nmd] [norm2] [gelu]
       {
@@ -833,18 +782,18 @@ static int prepare_f16(jg_model *m, const float *weights) {
         // Only compiled stage patterns run on the split-f16 path: the interpreted epilogue was measured
         // 12x slower than the compiled ones (and 3x slower than the exact-f32 kernels), so anything else
         // stays on the exact-f32 path.
-        if (m->f16_eligible && !jg_conv_f16_has_pattern(hp.ep, op.in_buf == JG_BUF_IDS)) {
-          fail("a conv's stage list is not one of the compiled split-f16 epilogue patterns");
+        if (conv_ok && !jg_conv_f16_has_pattern(hp.ep, op.in_buf == JG_BUF_IDS)) {
+          cfail("a conv's stage list is not one of the compiled split-f16 epilogue patterns");
         }
       }
-      if (m->f16_eligible) {
+      if (conv_ok) {
         JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_epi), tab.size() * sizeof(float)));
         JG_HIP(hipMemcpy(hp.d_epi, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
       }
       // first layer on ids: the conv is a sum of k table rows T_t[id] = E[id] . W_t (f64 on the
       // host); the kernel's table variant then needs no matrix cores and no acc un-scale
       static const bool no_lut = jg_exp_env("JG_NO_LUT") != nullptr;
-      if (m->f16_eligible && !no_lut && op.in_buf == JG_BUF_IDS &&
+      if (conv_ok && !no_lut && op.in_buf == JG_BUF_IDS &&
           (op.in_mask == JG_BUF_IDS || op.in_mask < 0) && op.cout <= 128 &&
           jg_conv_lut_supports(op.k, op.dilation, m->vocab)) {
         const float *emb = weights + op.b_off;   // (vocab, cin)
@@ -865,6 +814,113 @@ static int prepare_f16(jg_model *m, const float *weights) {
         JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_epi_lut), tab_lut.size() * sizeof(float)));
         JG_HIP(hipMemcpy(hp.d_epi_lut, tab_lut.data(), tab_lut.size() * sizeof(float), hipMemcpyHostToDevice));
       }
+    }
+    hp.f16_ok = conv_ok;
+  }
+  // Pass B - tensor formats.  Walk the program with the format of every activation slot (f32 rows or F16S items):
+  // split-f16 convs read and write F16S (f32 when the next reader needs it, or no tensor at all when only a max pool
+  // reads it), everything else works on f32; where a reader meets the other format, a layout conversion is queued in
+  // front of it (run_chunk converts into a scratch tensor and swaps the slot's pointer).
+  int n_ok = 0, n_conv = 0;
+  for (size_t i = 0; i < m->ops.size(); ++i)
+    if (m->ops[i].kind == JG_OP_CONV) { ++n_conv; n_ok += m->hprep[i].f16_ok ? 1 : 0; }
+  if (n_ok == 0) {
+    m->f16_eligible = false;
+    m->f16_reason = first_reason.empty() ? "program has no convolution" : first_reason;
+    return JG_OK;
+  }
+  m->f16_mixed = n_ok < n_conv;
+  bool is_f32[JG_MAX_BUFS] = {};
+  auto wants_f16s = [&](size_t j, int buf) {          // does op j read `buf` as an F16S tensor?
+    const jg_op &o = m->ops[j];
+    if (o.kind == JG_OP_MAXPOOL1D && o.in_buf == buf) return true;
+    if (o.kind != JG_OP_CONV || !m->hprep[j].f16_ok) return false;
+    if (o.in_buf == buf) return true;
+    for (int q = 0; q < o.n_stages; ++q)
+      if (o.stages[q].kind == JG_ST_ADD && o.stages[q].arg == buf) return true;
+    return false;
+  };
+  auto reads = [&](size_t j, int buf) {
+    const jg_op &o = m->ops[j];
+    if ((o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM ||
+         o.kind == JG_OP_POOL || o.kind == JG_OP_NMD_FINAL) && o.in_buf == buf)
+      return o.kind != JG_OP_NMD_FINAL;               // (NMD_FINAL only takes the slot's shape)
+    if (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE)
+      for (int q = 0; q < o.n_stages; ++q)
+        if (o.stages[q].kind == JG_ST_ADD && o.stages[q].arg == buf) return true;
+    return false;
+  };
+  auto writes = [&](size_t j, int buf) {
+    const jg_op &o = m->ops[j];
+    return (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM) &&
+           o.out_buf == buf;
+  };
+  auto need = [&](size_t i, int buf, bool want_f32) {   // queue a conversion in front of op i if the slot is in the other format
+    if (buf < 0 || is_f32[buf] == want_f32) return;
+    ConvHPrep &hp = m->hprep[i];
+    if (hp.n_cvt < 3) {
+      hp.cvt_slot[hp.n_cvt] = buf;
+      hp.cvt_to_f32[hp.n_cvt] = want_f32;
+      ++hp.n_cvt;
+    }
+    is_f32[buf] = want_f32;
+    m->needs_cvt = true;
+  };
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    const jg_op &op = m->ops[i];
+    ConvHPrep &hp = m->hprep[i];
+    switch (op.kind) {
+      case JG_OP_CONV: {
+        const bool f16 = hp.f16_ok;
+        need(i, op.in_buf, !f16);
+        for (int q = 0; q < op.n_stages; ++q)
+          if (op.stages[q].kind == JG_ST_ADD) need(i, op.stages[q].arg, !f16);
+        if (!f16) { is_f32[op.out_buf] = true; break; }
+        // output format: what the first reader wants
+        bool first_f16s = false, any_reader = false;
+        for (size_t j = i + 1; j < m->ops.size(); ++j) {
+          if (reads(j, op.out_buf)) { first_f16s = wants_f16s(j, op.out_buf); any_reader = true; break; }
+          if (writes(j, op.out_buf)) break;
+        }
+        hp.out_f16s = any_reader && first_f16s;
+        is_f32[op.out_buf] = !hp.out_f16s;
+        if (!hp.out_f16s && jg_exp_env("JG_NO_POOL_FUSE") == nullptr) {
+          // the only reader of the f32 output is a masked global max pool over the conv's own output mask:
+          // reduce in the epilogue instead of storing 4 B per element and reading it back
+          int readers = 0, pool_idx = -1;
+          for (size_t j = i + 1; j < m->ops.size(); ++j) {
+            const jg_op &o = m->ops[j];
+            if (reads(j, op.out_buf)) {
+              ++readers;
+              if (o.kind == JG_OP_POOL && o.arg == JG_POOL_MAX && o.in_mask == op.out_mask) pool_idx = (int)j;
+              else pool_idx = -2;
+            }
+            if (writes(j, op.out_buf)) break;
+          }
+          if (readers == 1 && pool_idx >= 0) {
+            hp.pool_op = pool_idx;
+            m->pool_fused_by[(size_t)pool_idx] = (int)i;
+          }
+        }
+      } break;
+      case JG_OP_ELTWISE:
+        need(i, op.in_buf, true);
+        for (int q = 0; q < op.n_stages; ++q)
+          if (op.stages[q].kind == JG_ST_ADD) need(i, op.stages[q].arg, true);
+        is_f32[op.out_buf] = true;
+        break;
+      case JG_OP_MAXPOOL1D:
+        hp.pool_f16s = op.in_buf >= 0 && !is_f32[op.in_buf];
+        is_f32[op.out_buf] = !hp.pool_f16s;
+        break;
+      case JG_OP_FRAMESUM:
+        need(i, op.in_buf, true);
+        is_f32[op.out_buf] = true;
+        break;
+      case JG_OP_POOL:
+        if (m->pool_fused_by[i] < 0) need(i, op.in_buf, true);
+        break;
+      default: break;
     }
   }
   return JG_OK;
@@ -937,6 +993,9 @@ static void free_workspace(jg_model *m) {
     m->vec[i] = nullptr;
     m->vec_cap[i] = 0;
   }
+  if (m->cvt_scratch) (void)hipFree(m->cvt_scratch);
+  m->cvt_scratch = nullptr;
+  m->cvt_cap = 0;
 }
 
 extern "C" int jg_model_destroy(jg_model *m) {
@@ -978,6 +1037,10 @@ static int ensure_workspace(jg_model *m, int64_t chunk, int l) {
             chunk * nmd_elems[i] <= m->nmd_cap[i];
   }
   for (int i = 0; i < JG_MAX_VECS; ++i) fits &= chunk * m->vec_w[i] <= m->vec_cap[i];
+  int64_t cvt_need = 0;
+  if (m->needs_cvt)
+    for (int i = 0; i < JG_MAX_BUFS; ++i) cvt_need = std::max(cvt_need, chunk * m->act_elems[i]);
+  fits &= cvt_need <= m->cvt_cap;
   if (fits) return JG_OK;
   JG_HIP(hipStreamSynchronize(m->e->stream));
   int64_t want_act[JG_MAX_BUFS], want_msk[JG_MAX_BUFS], want_nmd[JG_MAX_BUFS], want_vec[JG_MAX_VECS];
@@ -987,7 +1050,12 @@ static int ensure_workspace(jg_model *m, int64_t chunk, int l) {
     want_nmd[i] = std::max(m->nmd_cap[i], chunk * nmd_elems[i]);
   }
   for (int i = 0; i < JG_MAX_VECS; ++i) want_vec[i] = std::max(m->vec_cap[i], chunk * (int64_t)m->vec_w[i]);
+  const int64_t want_cvt = std::max(m->cvt_cap, cvt_need);
   free_workspace(m);
+  if (want_cvt > 0) {
+    JG_HIP(hipMalloc(reinterpret_cast<void **>(&m->cvt_scratch), (size_t)want_cvt * sizeof(float)));
+    m->cvt_cap = want_cvt;
+  }
   for (int i = 0; i < JG_MAX_BUFS; ++i) {
     if (want_act[i] > 0) JG_HIP(hipMalloc(&m->act[i], (size_t)want_act[i] * sizeof(float)));
     if (want_msk[i] > 0) JG_HIP(hipMalloc(&m->msk[i], (size_t)want_msk[i]));
@@ -1075,6 +1143,21 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
     const jg_op &op = m->ops[i];
     int rc = JG_OK;
     if (small && (int)i < m->small->pool_op) continue;
+    if (prec == 1) {
+      // layout conversions queued by the format plan: into the scratch tensor, then the slot takes the scratch's
+      // place (same bytes per element in both layouts)
+      const ConvHPrep &hq = m->hprep[i];
+      for (int q = 0; q < hq.n_cvt; ++q) {
+        const int slot = hq.cvt_slot[q];
+        const Shape &t = sh[slot];
+        const int64_t rows = (int64_t)nw * t.frames;
+        if (hq.cvt_to_f32[q]) rc = jg_launch_f16s_to_f32(reinterpret_cast<const uint4 *>(m->act[slot]), rows, t.L, t.C, m->cvt_scratch, s);
+        else rc = jg_launch_f32_to_f16s(m->act[slot], rows, t.L, t.C, reinterpret_cast<uint4 *>(m->cvt_scratch), s);
+        if (rc != JG_OK) return rc;
+        std::swap(m->act[slot], m->cvt_scratch);
+        std::swap(m->act_cap[slot], m->cvt_cap);
+      }
+    }
     if (small && (int)i == m->small->pool_op) {
       rc = jg_launch_small_pool_final(m->small->d_part, 6, nw, m->small->pool_kind, m->vec[op.out_vec] + op.vec_off,
                                       m->vec_w[op.out_vec], s);
@@ -1094,7 +1177,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           pe.flops = 2.0 * op.k * op.cin * op.cout * (double)nw * in.frames * lo;
           JG_HIP(hipEventRecord(pe.a, s));
         }
-        if (prec == 1) {
+        if (prec == 1 && m->hprep[i].f16_ok) {
           const ConvHPrep &hp = m->hprep[i];
           ConvHArgs a;
           memset(&a, 0, sizeof(a));
@@ -1185,6 +1268,8 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           a.cout = op.cout; a.cout_pad = (op.cout + 31) / 32 * 32;
           a.k = op.k; a.stride = op.stride; a.dil = op.dilation; a.pad_left = pl;
           a.tiles_m = (lo + jg_conv_tile_m(lo) - 1) / jg_conv_tile_m(lo);
+          for (int q = 0; q < op.n_stages; ++q)
+            if (op.stages[q].kind == JG_ST_NMD) m->part_rows[op.stages[q].arg] = in.frames * a.tiles_m;
           resolve_stages(m, op, a.st, &a.n_stages);
           rc = jg_launch_conv(e, a, s);
         }
@@ -1212,6 +1297,9 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         a.mask = op.out_mask >= 0 ? m->msk[op.out_mask] : nullptr;
         a.n_pos = (int64_t)nw * in.frames * in.L;
         a.c = in.C;
+        for (int q = 0; q < op.n_stages; ++q)
+          if (op.stages[q].kind == JG_ST_NMD)
+            m->part_rows[op.stages[q].arg] = in.frames * ((in.L + jg_conv_tile_m(in.L) - 1) / jg_conv_tile_m(in.L));
         resolve_stages(m, op, a.st, &a.n_stages);
         if (a.n_stages > 0 && a.st[0].kind == JG_ST_LN)
           rc = jg_launch_layernorm(a, nw * in.frames, in.L, (in.L + jg_conv_tile_m(in.L) - 1) / jg_conv_tile_m(in.L), s);
@@ -1256,9 +1344,10 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         // op.arg = partial slot, in_mask = mask the tap used, cout = channels,
         // in_buf = activation slot whose shape gives the position count
         const Shape in = sh[op.in_buf];
-        const int rows_per_win = prec == 1
-                                     ? m->part_rows[op.arg]
-                                     : in.frames * ((in.L + jg_conv_tile_m(in.L) - 1) / jg_conv_tile_m(in.L));
+        // partial rows per window as the tap that filled the slot laid them out (a conv records it; an element-wise
+        // LayerNorm tap uses the f32 tiling of the slot)
+        const int rows_f32 = in.frames * ((in.L + jg_conv_tile_m(in.L) - 1) / jg_conv_tile_m(in.L));
+        const int rows_per_win = m->part_rows[op.arg] > 0 ? m->part_rows[op.arg] : rows_f32;
         const uint8_t *mk = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
         rc = jg_launch_nmd_final(m->nmd_part[op.arg], rows_per_win, mk, in.frames * in.L,
                                  m->d_w + op.b_off, op.f0, nw, op.cout, m->vec[op.out_vec],

@@ -177,6 +177,10 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   int pool_op = -1;         // index of the OP_POOL (masked max) fused into this conv's epilogue, or -1
   int act_kind = JG_ACT_GELU_TANH;   // activation of the op's ACT stages (the compiled patterns allow one kind per op)
   bool pool_f16s = false;   // (MAXPOOL1D ops) input and output are F16S tensors
+  bool f16_ok = false;      // (CONV ops) runs on the split-f16 kernel when the model is in split-f16 mode
+  int n_cvt = 0;            // layout conversions queued in front of this op (any op kind): slot, direction
+  int cvt_slot[3] = {-1, -1, -1};
+  bool cvt_to_f32[3] = {false, false, false};
   unsigned ep = JG_EP_GENERIC;
   float alpha1 = 0.f, alpha2 = 0.f;
   int dytmask1 = 0, dytmask2 = 0;
@@ -190,6 +194,10 @@ struct jg_model {
   std::vector<ConvHPrep> hprep;   // parallel to ops
   int precision = 0;              // 0 = exact f32 MFMA, 1 = split-f16 (f16x3)
   bool f16_eligible = false;
+  bool f16_mixed = false;         // some convs stay on the exact-f32 kernel inside the split-f16 program
+  bool needs_cvt = false;         // the program holds F16S <-> f32 layout conversions (needs the scratch tensor)
+  float *cvt_scratch = nullptr;
+  int64_t cvt_cap = 0;
   std::string f16_reason;         // why the fast path is unavailable
   int *d_overflow = nullptr;
   float *d_w = nullptr;
@@ -242,6 +250,8 @@ int jg_launch_maxpool1d(const float *x, const uint8_t *mask_in, int rows, int L_
                         float *y, uint8_t *mask_out, hipStream_t s);
 int jg_launch_pool_final(const float *part, int rows_per_win, int n_win, int c, float *out, int out_ld,
                          hipStream_t s);
+int jg_launch_f32_to_f16s(const float *x, int64_t rows, int L, int c, uint4 *y, hipStream_t s);
+int jg_launch_f16s_to_f32(const uint4 *x, int64_t rows, int L, int c, float *y, hipStream_t s);
 int jg_launch_maxpool1d_f16s(const uint4 *x, int rows, int L_in, int L_out, int c, uint4 *y, hipStream_t s);
 int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,
                        hipStream_t s);

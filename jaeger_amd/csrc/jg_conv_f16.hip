@@ -39,10 +39,10 @@ int jg_conv_f16_tile_m(void) { return HM; }
 // stage patterns with a compiled epilogue (keep in step with the instantiation sets in jg_conv_f16_impl.h);
 // a first-layer conv may end up on the table variant, which carries a subset
 bool jg_conv_f16_has_pattern(unsigned ep, bool first_layer) {
-  const unsigned lut[] = {JG_EP_ACT1, JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ACT1,
+  const unsigned lut[] = {0u, JG_EP_NMD1, JG_EP_ACT1, JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ACT1,
                           JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1,
                           JG_EP_ACT1 | JG_EP_NORM2_AFF};
-  const unsigned all[] = {JG_EP_ACT1, JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ACT1,
+  const unsigned all[] = {0u, JG_EP_NMD1, JG_EP_ACT1, JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ACT1,
                           JG_EP_ADD | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1,
                           JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2,
                           JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2,

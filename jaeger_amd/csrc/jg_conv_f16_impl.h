@@ -980,6 +980,8 @@ int launch_lut_e(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
 int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   switch (a.ep) {
 #define JG_CASE(ep) case (ep): return launch_lut_e<(ep)>(e, a, s);
+    JG_CASE(0u)
+    JG_CASE(JG_EP_NMD1)
     JG_CASE(JG_EP_ACT1)
     JG_CASE(JG_EP_NORM1_AFF | JG_EP_ACT1)
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ACT1)
@@ -999,6 +1001,8 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
 // instantiated ~45 times, split over four objects so that they compile in parallel) ---------------
 #define JG_ROW_CASES(K)                                                                              \
   switch (a.ep) {                                                                                    \
+    case 0u: return launch_ke<K, 0u>(e, a, s);           /* plain affine: a LayerNorm follows */      \
+    case (JG_EP_NMD1): return launch_ke<K, (JG_EP_NMD1)>(e, a, s);                                   \
     case (JG_EP_ACT1): return launch_ke<K, (JG_EP_ACT1)>(e, a, s);                                   \
     case (JG_EP_NORM1_AFF | JG_EP_ACT1): return launch_ke<K, (JG_EP_NORM1_AFF | JG_EP_ACT1)>(e, a, s); \
     case (JG_EP_NORM1_DYT | JG_EP_ACT1): return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ACT1)>(e, a, s); \

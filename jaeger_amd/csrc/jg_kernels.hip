@@ -908,6 +908,74 @@ __global__ __launch_bounds__(256) void maxpool1d_f16s_kernel(const uint4 *__rest
   }
 }
 
+// ---- layout conversions between f32 rows (rows, L, c) and F16S items [row][c/16][hi|lo][h][L][8 halfs] ------------
+// (mixed programs: a conv the split-f16 tiling does not cover - strided, 1x1, other widths - or a LayerNorm runs on
+// f32 tensors between split-f16 convs).  One thread per (row, position, 8-channel group): 32 B of f32 <-> a hi and a
+// lo item; 16 consecutive lanes cover one position's 128 channels (coalesced on the f32 side).
+__global__ __launch_bounds__(256) void f32_to_f16s_kernel(const float *__restrict__ x, int64_t total, int L, int groups,
+                                                          uint4 *__restrict__ y) {
+  for (int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int g = (int)(idx % groups);
+    const int64_t rp = idx / groups;                 // row * L + pos
+    const int64_t row = rp / L;
+    const int pos = (int)(rp - row * L);
+    const float4 a = reinterpret_cast<const float4 *>(x)[idx * 2], b = reinterpret_cast<const float4 *>(x)[idx * 2 + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    jg_half8 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const _Float16 hv = (_Float16)v[q];
+      hi[q] = hv;
+      lo[q] = (_Float16)(v[q] - (float)hv);
+    }
+    const int64_t rc = row * (groups / 2) + (g >> 1);
+    const int h = g & 1;
+    y[(rc * 4 + h) * (int64_t)L + pos] = *reinterpret_cast<const uint4 *>(&hi);
+    y[(rc * 4 + 2 + h) * (int64_t)L + pos] = *reinterpret_cast<const uint4 *>(&lo);
+  }
+}
+
+__global__ __launch_bounds__(256) void f16s_to_f32_kernel(const uint4 *__restrict__ x, int64_t total, int L, int groups,
+                                                          float *__restrict__ y) {
+  for (int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int g = (int)(idx % groups);
+    const int64_t rp = idx / groups;
+    const int64_t row = rp / L;
+    const int pos = (int)(rp - row * L);
+    const int64_t rc = row * (groups / 2) + (g >> 1);
+    const int h = g & 1;
+    const uint4 uh = x[(rc * 4 + h) * (int64_t)L + pos], ul = x[(rc * 4 + 2 + h) * (int64_t)L + pos];
+    const jg_half8 hi = *reinterpret_cast<const jg_half8 *>(&uh), lo = *reinterpret_cast<const jg_half8 *>(&ul);
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (float)hi[q] + (float)lo[q];
+    reinterpret_cast<float4 *>(y)[idx * 2] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4 *>(y)[idx * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+static int cvt_launch(bool to_f16s, const void *x, int64_t rows, int L, int c, void *y, hipStream_t s) {
+  JG_REQUIRE(c % 16 == 0, JG_ERR_UNSUPPORTED, "layout conversion: c=%d must be a multiple of 16", c);
+  const int64_t total = rows * L * (c / 8);
+  if (total == 0) return JG_OK;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (to_f16s)
+    hipLaunchKernelGGL(f32_to_f16s_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float *>(x), total, L,
+                       c / 8, static_cast<uint4 *>(y));
+  else
+    hipLaunchKernelGGL(f16s_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint4 *>(x), total, L,
+                       c / 8, static_cast<float *>(y));
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+int jg_launch_f32_to_f16s(const float *x, int64_t rows, int L, int c, uint4 *y, hipStream_t s) {
+  return cvt_launch(true, x, rows, L, c, y, s);
+}
+int jg_launch_f16s_to_f32(const uint4 *x, int64_t rows, int L, int c, float *y, hipStream_t s) {
+  return cvt_launch(false, x, rows, L, c, y, s);
+}
+
 int jg_launch_maxpool1d_f16s(const uint4 *x, int rows, int L_in, int L_out, int c, uint4 *y, hipStream_t s) {
   JG_REQUIRE(c % 16 == 0, JG_ERR_UNSUPPORTED, "maxpool1d_f16s: c=%d must be a multiple of 16", c);
   const int64_t total = (int64_t)rows * (c / 16) * 2 * L_out;

@@ -387,8 +387,9 @@ def test_f16_range_guard_falls_back_to_exact_f32():
 @pytest.mark.parametrize("mode", ["majority", "strict"])
 def test_forward_variant_mask_modes_and_strided_block(mode):
     """Mask rules other than "any" on the first conv (layers.py:1226-1255), a residual block with strides 2 (1x1
-    bypass conv + norm, layers.py:1827-1915: sequence length 498 -> 249) and one with use_1x1conv: the strided
-    convs and their masks run on the exact-f32 kernels, the rest of the network stays where it was."""
+    bypass conv + norm, layers.py:1827-1915: sequence length 498 -> 249) and one with use_1x1conv: the strided and
+    1x1 convs run on the exact-f32 kernel INSIDE the split-f16 program (layout conversions between them), every
+    other conv stays on the split-f16 kernel."""
     import copy
 
     from jaeger_amd.engine import JaegerHipEngine, frame_length
@@ -408,19 +409,25 @@ def test_forward_variant_mask_modes_and_strided_block(mode):
     lens = np.full(n_win, fsize, np.int32)
     lens[2::4] = rng.integers(fsize // 3, fsize, lens[2::4].size)            # ragged windows: padded frames
     eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0)
+    assert eng.model.precision == "f16x3"
     got = eng.predict_windows(seq, starts, lens, fsize)
+    again = eng.predict_windows(seq, starts, lens, fsize)
+    eng.model.set_precision("f32")
+    exact = eng.predict_windows(seq, starts, lens, fsize)
     eng.close()
     ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
     ref = ofwd.forward(cfg, weights, ids)
     for k in ("prediction", "reliability"):
         assert got[k].shape == ref[k].shape
+        np.testing.assert_array_equal(got[k], again[k])
         assert float(np.abs(got[k] - ref[k]).max()) <= TOL, (mode, k, float(np.abs(got[k] - ref[k]).max()))
+        assert float(np.abs(exact[k] - ref[k]).max()) <= TOL, (mode, k, "exact-f32")
 
 
 def test_forward_variant_layernorm():
     """MaskedLayerNormalization (layers.py:293-382) as the residual blocks' norm_type and as standalone layers: a
-    per-position reduction over the channels, run by the LayerNorm kernel behind the exact-f32 convs (a program with
-    element-wise ops is not eligible for the split-f16 path), NMD taps behind it included."""
+    per-position reduction over the channels, run by the LayerNorm kernel on f32 rows behind the split-f16 convs (which
+    then write f32 and whose successors get an f32 -> F16S conversion), NMD taps behind it included."""
     import copy
 
     from jaeger_amd.engine import JaegerHipEngine, frame_length
@@ -444,7 +451,7 @@ def test_forward_variant_layernorm():
     lens = np.full(n_win, fsize, np.int32)
     lens[1::3] = rng.integers(fsize // 2, fsize, lens[1::3].size)
     eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0)
-    assert eng.model.precision == "f32"
+    assert eng.model.precision == "f16x3"
     got = eng.predict_windows(seq, starts, lens, fsize)
     eng.close()
     ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
