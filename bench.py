@@ -299,8 +299,18 @@ def main():
         # dominant kernel = the matrix-core convolutions of the arithmetic in use (the first layer's table-lookup
         # kernel is reported beside it, not folded in: it runs no MFMA)
         dom = prof["mfma_f16x3"] if mode == "f16x3" else prof["mfma_f32"]
+        dom_name = "conv_f32_kernel" if mode == "f32" else "conv_f16x3_kernel (matrix-core convs only)"
+        mfma_share = 1.0
+        if prof["fused_small"]["launches"] and prof["fused_small"]["ms"] > dom["ms"]:
+            # the 32-channel family: ONE fused kernel from ids to pooled sums.  Its first conv is table lookups (no
+            # matrix-core work), so the MFMA roofline is quoted on the k = 3 convs' share of the algorithmic FLOPs
+            from jaeger_amd.plan import conv_flops_per_position
+            rows = conv_flops_per_position(build_plan(cfg))
+            fl = [2.0 * k * ci * co for _, k, ci, co, _, _ in rows]
+            mfma_share = sum(fl[1:]) / sum(fl)
+            dom, dom_name = prof["fused_small"], "small_net_kernel (fused ids -> pooled sums; MFMA share = its k=3 convs)"
         dom_s = dom["ms"] / 1e3
-        ach = dom["flops"] / dom_s / 1e12 if dom_s > 0 else 0.0
+        ach = dom["flops"] * mfma_share / dom_s / 1e12 if dom_s > 0 else 0.0
         # roofline: algorithmic (f32-equivalent) conv FLOP/s against the matrix-core peak the kernel can reach:
         # exact-f32 MFMA, or the f16 MFMA peak / 3 for the split-f16 scheme
         peak = F32_MFMA_PEAK_TFLOPS if mode == "f32" else F16_MFMA_PEAK_TFLOPS / 3.0
@@ -308,10 +318,13 @@ def main():
         # inside the process); the committed summary applies to the default configuration only
         traffic = None
         try:
-            pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())["conv_f16x3_kernel"]
+            pmc_all = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+            pmc = pmc_all["conv_f16x3_kernel"]
             if args.config == "default" and mode == pmc["precision"] and fsize == pmc["fsize"] \
                     and args.chunk in (0, pmc["chunk"]):
                 traffic = pmc["traffic_bytes_per_launch"]
+            if args.config == "baseline500" and mode == "f16x3" and args.chunk == 0 and args.fsize is None:
+                traffic = pmc_all["small_net_kernel"]["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         all_s = prof["conv_ms"] / 1e3
@@ -332,7 +345,7 @@ def main():
                                   "per window) are computed but not copied out in the timed region"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1),
                          "unit": "TFLOP/s", "frac": round(ach / peak, 4) if peak else 0.0, "traffic": traffic,
-                         "kernel": "conv_f32_kernel" if mode == "f32" else "conv_f16x3_kernel (matrix-core convs only)",
+                         "kernel": dom_name,
                          "launches": int(dom["launches"]),
                          "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                          "all_convs_incl_table_kernel": {

@@ -444,7 +444,7 @@ static int prepare_small(jg_model *m, const float *weights) {
   int pool_op = -1;
   for (size_t i = 0; i < m->ops.size(); ++i) {
     const jg_op &op = m->ops[i];
-    if (op.kind == JG_OP_MASK) continue;
+    if (op.kind == JG_OP_MASK || op.kind == JG_OP_NMD_FINAL) continue;     // (NMD finishes: matched to taps below)
     if (op.kind == JG_OP_CONV) { convs.push_back((int)i); continue; }
     if (op.kind == JG_OP_POOL) { pool_op = (int)i; break; }
     return JG_OK;                                   // anything else in front of the pool: not this family
@@ -475,7 +475,7 @@ static int prepare_small(jg_model *m, const float *weights) {
       return JG_OK;
   }
   JgSmallNet *sn = new JgSmallNet();
-  for (JgSmallLayer &ly : sn->layer) ly.add = ly.aff2 = ly.save = ly.pad_ = 0;
+  for (JgSmallLayer &ly : sn->layer) ly.add = ly.aff2 = ly.save = ly.tap = 0;
   std::vector<float> epi((size_t)(nc + 1) * 4 * 32, 0.f);
   std::vector<double> wscale((size_t)nc + 1, 1.0);
   bool ok = true;
@@ -551,6 +551,14 @@ static int prepare_small(jg_model *m, const float *weights) {
       ++st;
       ly.aff2 = 1;
     }
+    if (st < c.n_stages && c.stages[st].kind == JG_ST_NMD && st == c.n_stages - 1) {
+      // a tap behind the layer's last stage: masked channel sums of the layer's output, finished by the NMD_FINAL op
+      // that reads this partial slot (the program's slot number is kept to find it)
+      ly.tap = ++sn->n_taps;
+      sn->tap_part_slot[ly.tap] = c.stages[st].arg;
+      sn->tap_conv_op[ly.tap] = convs[q];
+      ++st;
+    }
     if (st != c.n_stages) { ok = false; break; }
     for (int n = 0; n < 32; ++n) {
       epi[((size_t)q * 4 + 0) * 32 + n] = (float)s1[n];
@@ -570,7 +578,17 @@ static int prepare_small(jg_model *m, const float *weights) {
       }
     }
   }
+  // every NMD_FINAL in front of the pool must finish one of the taps (the one most recently written to its slot)
+  for (int i = 0; i < pool_op && ok; ++i) {
+    if (m->ops[(size_t)i].kind != JG_OP_NMD_FINAL) continue;
+    int tap = 0;
+    for (int t = 1; t <= sn->n_taps; ++t)
+      if (sn->tap_part_slot[t] == m->ops[(size_t)i].arg && sn->tap_conv_op[t] < i) tap = t;
+    if (tap == 0 || m->ops[(size_t)i].cout != 32) ok = false;
+  }
+  if (sn->n_taps > JG_SMALL_MAX_LAYERS) ok = false;
   if (!ok) { delete sn; return JG_OK; }
+  sn->n_slots = 1 + sn->n_taps;
   // first-layer table T_t[id] = E[id] . W_t (f64), row `vocab` = zeros (padding), row 0 = zeros when ids mask
   const int k0 = c0.k, vr = m->vocab + 1, cin_pad = (c0.cin + 1) & ~1;
   std::vector<float> lut((size_t)k0 * vr * 32, 0.f);
@@ -1115,14 +1133,14 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
   if (small) {
     JgSmallNet *sn = m->small;
     const int64_t rows = (int64_t)nw * 6;
-    int rc = grow(&sn->d_part, &sn->part_cap, rows * JG_SMALL_PARTW * (int64_t)sizeof(float));
+    int rc = grow(&sn->d_part, &sn->part_cap, rows * sn->n_slots * JG_SMALL_PARTW * (int64_t)sizeof(float));
     if (rc != JG_OK) return rc;
     JgSmallArgs a;
     memset(&a, 0, sizeof(a));
     a.ids = d_ids; a.lut = sn->d_lut; a.wfrag = sn->d_wfrag; a.epi = sn->d_epi; a.part = sn->d_part;
     a.overflow = m->d_overflow;
     a.rows = rows; a.L = l; a.L0 = small_L0; a.pad0 = small_pad0; a.vocab = m->vocab;
-    a.use_mask = sn->use_mask; a.pool_kind = sn->pool_kind;
+    a.use_mask = sn->use_mask; a.pool_kind = sn->pool_kind; a.n_slots = sn->n_slots;
     { const char *ev = jg_exp_env("JG_SMALL_DBG"); a.dbg = ev ? atoi(ev) : 0; }
     for (int q = 0; q < JG_SMALL_MAX_LAYERS; ++q) a.layer[q] = sn->layer[q];
     ProfEvent pe;
@@ -1142,7 +1160,18 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
   for (size_t i = 0; i < m->ops.size(); ++i) {
     const jg_op &op = m->ops[i];
     int rc = JG_OK;
-    if (small && (int)i < m->small->pool_op) continue;
+    if (small && (int)i < m->small->pool_op) {
+      if (op.kind == JG_OP_NMD_FINAL) {             // finish the tap the fused kernel accumulated for this slot
+        const JgSmallNet *sn = m->small;
+        int tap = 0;
+        for (int t = 1; t <= sn->n_taps; ++t)
+          if (sn->tap_part_slot[t] == op.arg && sn->tap_conv_op[t] < (int)i) tap = t;
+        rc = jg_launch_small_pool_final(sn->d_part, 6, sn->n_slots, tap, nw, 2, m->d_w + op.b_off, op.f0,
+                                        m->vec[op.out_vec] + op.vec_off, m->vec_w[op.out_vec], s);
+        if (rc != JG_OK) return rc;
+      }
+      continue;
+    }
     if (prec == 1) {
       // layout conversions queued by the format plan: into the scratch tensor, then the slot takes the scratch's
       // place (same bytes per element in both layouts)
@@ -1159,8 +1188,8 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
       }
     }
     if (small && (int)i == m->small->pool_op) {
-      rc = jg_launch_small_pool_final(m->small->d_part, 6, nw, m->small->pool_kind, m->vec[op.out_vec] + op.vec_off,
-                                      m->vec_w[op.out_vec], s);
+      rc = jg_launch_small_pool_final(m->small->d_part, 6, m->small->n_slots, 0, nw, m->small->pool_kind, nullptr, 0.f,
+                                      m->vec[op.out_vec] + op.vec_off, m->vec_w[op.out_vec], s);
       if (rc != JG_OK) return rc;
       continue;
     }

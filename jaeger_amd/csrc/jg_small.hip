@@ -126,7 +126,8 @@ __device__ __forceinline__ float gelu_tanh(float v) {
 
 template <bool LAST, bool P2, bool ADD, bool SAVE>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], const float *epi, M192 mout, char *act,
-                                         int n, int h, float &vmax, float (&pool)[16], int pool_kind, int dbg) {
+                                         int n, int h, float &vmax, float (&pool)[16], int pool_kind, int dbg,
+                                         const int tap, float (&tapv)[16]) {
   (void)dbg;
   // the lane's 16 channels' parameters, read once per layer (broadcast LDS reads; a read per block and channel
   // group left the wave waiting on LDS latency twenty times a layer)
@@ -164,6 +165,10 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], co
     if constexpr (SAVE) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[b][r] = v[r];
+    }
+    if (tap) {                      // NMD tap behind the layer's last stage: masked channel sums of its output
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tapv[r] += keep ? v[r] : 0.0f;
     }
     if constexpr (LAST) {
       if (pool_kind == JG_POOL_AVG) {
@@ -211,7 +216,43 @@ static __device__ unsigned long long jg_small_stamp[8];
 #endif
 
 #define JG_EPI_CALL(LASTV, P2V, ADDV, SAVEV) \
-  epilogue<LASTV, P2V, ADDV, SAVEV>(acc, sc, ep, mo, act, n, h, vmax, pool, a.pool_kind, dbg)
+  epilogue<LASTV, P2V, ADDV, SAVEV>(acc, sc, ep, mo, act, n, h, vmax, pool, a.pool_kind, dbg, tap, tapv)
+
+// Reduce a lane's 16 channel values over the 32 lanes that share h and store the row's 32 channel totals + the mask
+// count.  Register-halving butterfly: at each step a lane hands half of its registers to its partner and keeps the
+// sums of the other half (16 exchanges instead of 16 registers x 5 steps); lane bits 4..1 end up selecting the
+// register, i.e. the channel 8 g + 4 h + i with 4 g + i = r.
+__device__ __forceinline__ void row_reduce_store(const float (&p)[16], const bool avg, float *dst, const int count,
+                                                 const int n, const int h, const int lane) {
+  float v8[8], v4[4], v2[2], v1;
+  const bool b16 = n & 16, b8 = n & 8, b4 = n & 4, b2 = n & 2;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float o = __shfl_xor(b16 ? p[i] : p[i + 8], 16, 64), k = b16 ? p[i + 8] : p[i];
+    v8[i] = avg ? k + o : fmaxf(k, o);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float o = __shfl_xor(b8 ? v8[i] : v8[i + 4], 8, 64), k = b8 ? v8[i + 4] : v8[i];
+    v4[i] = avg ? k + o : fmaxf(k, o);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float o = __shfl_xor(b4 ? v4[i] : v4[i + 2], 4, 64), k = b4 ? v4[i + 2] : v4[i];
+    v2[i] = avg ? k + o : fmaxf(k, o);
+  }
+  {
+    const float o = __shfl_xor(b2 ? v2[0] : v2[1], 2, 64), k = b2 ? v2[1] : v2[0];
+    v1 = avg ? k + o : fmaxf(k, o);
+  }
+  {
+    const float o = __shfl_xor(v1, 1, 64);
+    v1 = avg ? v1 + o : fmaxf(v1, o);
+  }
+  const int r = (b16 ? 8 : 0) | (b8 ? 4 : 0) | (b4 ? 2 : 0) | (b2 ? 1 : 0);
+  if ((n & 1) == 0) dst[(r >> 2) * 8 + h * 4 + (r & 3)] = v1;
+  if (lane == 0) dst[C] = (float)count;
+}
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void small_net_kernel(JgSmallArgs a) {
   const int NC = a.n_conv, K0 = a.k0;
@@ -316,10 +357,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float pool[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) pool[i] = a.pool_kind == JG_POOL_AVG ? 0.0f : -1.0e9f;
+    float tapv[16];
+    float *prow = a.part + row * (long)a.n_slots * PARTW;
     {
       const float *ep = epi;
+      const int tap = a.layer[0].tap;
+      if (tap) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tapv[i] = 0.0f;
+      }
       if (a.layer[0].save) JG_EPI_CALL(false, false, false, true);
       else JG_EPI_CALL(false, false, false, false);
+      if (tap) row_reduce_store(tapv, true, prow + tap * PARTW, m_count(mo), n, h, lane);
     }
     JG_SST(2);
     // ---- k = 3 convolutions on the matrix cores -----------------------------------------------------------
@@ -372,6 +421,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const float *ep = epi + (j + 1) * 4 * C;
       {
         const int add = a.layer[j + 1].add, save = a.layer[j + 1].save, p2 = a.layer[j + 1].aff2;
+        const int tap = a.layer[j + 1].tap;
+        if (tap) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) tapv[i] = 0.0f;
+        }
         const int code = (j == NC - 1 ? 8 : 0) | (p2 ? 4 : 0) | (add ? 2 : 0) | (save ? 1 : 0);
         switch (code) {               // wave-uniform: one compiled epilogue per (last, second norm, add, save)
           case 0: JG_EPI_CALL(false, false, false, false); break;
@@ -387,45 +441,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           case 12: case 13: JG_EPI_CALL(true, true, false, false); break;
           default: JG_EPI_CALL(true, true, true, false); break;
         }
+        if (tap) row_reduce_store(tapv, true, prow + tap * PARTW, m_count(mo), n, h, lane);
       }
       JG_SST(4);
     }
-    // ---- pooled channel sums / maxima of the row: reduce over the 32 lanes that share h --------------------
-    // register-halving butterfly: at each step a lane hands half of its registers to its partner and keeps the sums
-    // of the other half (16 exchanges instead of 16 registers x 5 steps); lane bits 4..1 end up selecting the
-    // register, i.e. the channel 8 g + 4 h + i with 4 g + i = r
-    {
-      const bool avg = a.pool_kind == JG_POOL_AVG;
-      float v8[8], v4[4], v2[2], v1;
-      const bool b16 = n & 16, b8 = n & 8, b4 = n & 4, b2 = n & 2;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float o = __shfl_xor(b16 ? pool[i] : pool[i + 8], 16, 64), k = b16 ? pool[i + 8] : pool[i];
-        v8[i] = avg ? k + o : fmaxf(k, o);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float o = __shfl_xor(b8 ? v8[i] : v8[i + 4], 8, 64), k = b8 ? v8[i + 4] : v8[i];
-        v4[i] = avg ? k + o : fmaxf(k, o);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float o = __shfl_xor(b4 ? v4[i] : v4[i + 2], 4, 64), k = b4 ? v4[i + 2] : v4[i];
-        v2[i] = avg ? k + o : fmaxf(k, o);
-      }
-      {
-        const float o = __shfl_xor(b2 ? v2[0] : v2[1], 2, 64), k = b2 ? v2[1] : v2[0];
-        v1 = avg ? k + o : fmaxf(k, o);
-      }
-      {
-        const float o = __shfl_xor(v1, 1, 64);
-        v1 = avg ? v1 + o : fmaxf(v1, o);
-      }
-      const int r = (b16 ? 8 : 0) | (b8 ? 4 : 0) | (b4 ? 2 : 0) | (b2 ? 1 : 0);
-      float *dst = a.part + row * PARTW;
-      if ((n & 1) == 0) dst[(r >> 2) * 8 + h * 4 + (r & 3)] = v1;
-      if (lane == 0) dst[C] = (float)m_count(mo);
-    }
+    // ---- pooled channel sums / maxima of the row -----------------------------------------------------------
+    row_reduce_store(pool, a.pool_kind == JG_POOL_AVG, prow, m_count(mo), n, h, lane);
     JG_SST(5);
   }
   JG_SST_END;
@@ -434,16 +455,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 // pooled vector of a window from the partial rows of its frames: masked average (layers.py:460-480) or masked
 // maximum with the all-masked -> 0 rule (layers.py:517-529)
-__global__ void small_pool_final_kernel(const float *part, int frames, int n_win, int kind, float *out, int out_ld) {
+// kind JG_POOL_AVG / JG_POOL_MAX as above; kind 2 = NMD vector: sum / (count + eps) - moving_mean (nmd.py:52-77)
+__global__ void small_pool_final_kernel(const float *part, int frames, int n_slots, int slot, int n_win, int kind,
+                                        const float *moving_mean, float eps, float *out, int out_ld) {
   const int w = blockIdx.x * (blockDim.x / C) + threadIdx.x / C, c = threadIdx.x % C;
   if (w >= n_win) return;
-  float acc = kind == JG_POOL_AVG ? 0.0f : -1.0e9f, cnt = 0.0f;
+  float acc = kind == JG_POOL_MAX ? -1.0e9f : 0.0f, cnt = 0.0f;
   for (int f = 0; f < frames; ++f) {
-    const float *p = part + ((long)w * frames + f) * PARTW;
-    acc = kind == JG_POOL_AVG ? acc + p[c] : fmaxf(acc, p[c]);
+    const float *p = part + (((long)w * frames + f) * n_slots + slot) * PARTW;
+    acc = kind == JG_POOL_MAX ? fmaxf(acc, p[c]) : acc + p[c];
     cnt += p[C];
   }
-  out[(long)w * out_ld + c] = kind == JG_POOL_AVG ? acc / fmaxf(cnt, 1e-7f) : (cnt > 0.0f ? acc : 0.0f);
+  float r;
+  if (kind == JG_POOL_AVG) r = acc / fmaxf(cnt, 1e-7f);
+  else if (kind == JG_POOL_MAX) r = cnt > 0.0f ? acc : 0.0f;
+  else r = acc / (cnt + eps) - moving_mean[c];
+  out[(long)w * out_ld + c] = r;
 }
 
 int launch(jg_engine *e, const JgSmallArgs &a, int smem, hipStream_t s) {
@@ -494,11 +521,12 @@ int jg_launch_small_net(jg_engine *e, const JgSmallArgs &a, int n_conv, int k0, 
   return launch(e, b, jg_small_lds_bytes(n_conv, k0, a.vocab), s);
 }
 
-int jg_launch_small_pool_final(const float *part, int frames, int n_win, int kind, float *out, int out_ld, hipStream_t s) {
+int jg_launch_small_pool_final(const float *part, int frames, int n_slots, int slot, int n_win, int kind,
+                               const float *moving_mean, float eps, float *out, int out_ld, hipStream_t s) {
   if (n_win == 0) return JG_OK;
   const int per = 256 / C;
   hipLaunchKernelGGL(small_pool_final_kernel, dim3((unsigned)((n_win + per - 1) / per)), dim3(256), 0, s, part, frames,
-                     n_win, kind, out, out_ld);
+                     n_slots, slot, n_win, kind, moving_mean, eps, out, out_ld);
   JG_HIP(hipGetLastError());
   return JG_OK;
 }

@@ -142,16 +142,19 @@ def test_forward_zeus_dyt(precision):
 def test_default_precision_is_f16x3_when_eligible():
     from jaeger_amd.engine import JaegerHipEngine
     from oracle import forward as ofwd
-    # brain: split-f16 conv kernels; baseline500: the fused small-window kernel (same arithmetic); nmdmerge500 (NMD
-    # taps on a 32-channel net) has neither and runs on the exact-f32 kernels
-    for name, want in (("brain", "f16x3"), ("baseline500", "f16x3"), ("nmdmerge500", "f32")):
+    # brain: split-f16 conv kernels; baseline500 / nmdmerge500: the fused small-window kernel (same arithmetic)
+    for name in ("brain", "baseline500", "nmdmerge500"):
         cfg = load_model_cfg(name)
         eng = JaegerHipEngine(model_cfg=cfg, weights=ofwd.random_weights(cfg))
-        assert eng.model.precision == want
-        if want == "f32":
-            with pytest.raises(Exception):
-                eng.model.set_precision("f16x3")
+        assert eng.model.precision == "f16x3"
         eng.close()
+    # a 32-channel net whose first-layer table does not fit LDS has neither and says so
+    cfg = _small_variant(k0=9, pad0="same")
+    eng = JaegerHipEngine(model_cfg=cfg, weights=ofwd.random_weights(cfg))
+    assert eng.model.precision == "f32"
+    with pytest.raises(Exception):
+        eng.model.set_precision("f16x3")
+    eng.close()
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
@@ -532,10 +535,12 @@ def test_engine_predict_dataset_duck_type(tmp_path):
         assert got[f"meta_{j}"].tolist() == [r[j + 1] for r in rows]
 
 
-def test_forward_nmdmerge500():
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_forward_nmdmerge500(precision):
     """The fourth conv-family architecture of the reference's train_config (nn_config_500bp_nmd_merge.yaml):
-    500-bp windows, NMD merge + reliability head on a narrow network (exact-f32 path)."""
-    _forward_case("nmdmerge500", 500, 48, 6, n_frac=0.02)
+    500-bp windows, NMD merge + reliability head on a narrow network.  f16x3 = the fused small-window kernel with its
+    two NMD taps (masked channel sums of a layer's output next to the pool), f32 = layer by layer."""
+    _forward_case("nmdmerge500", 500, 48, 6, n_frac=0.02, short=True, precision=precision)
 
 
 def test_forward_return_nmd_norm_and_blocks():
