@@ -545,8 +545,8 @@ static int prepare_small(jg_model *m, const float *weights) {
     }
     if (!(st < c.n_stages && c.stages[st].kind == JG_ST_ACT && c.stages[st].arg == JG_ACT_GELU_TANH)) { ok = false; break; }
     ++st;
-    if (st < c.n_stages) {
-      if (!fold(s2, t2)) { ok = false; break; }
+    if (st < c.n_stages && (c.stages[st].kind == JG_ST_BIAS || c.stages[st].kind == JG_ST_BN)) {
+      fold(s2, t2);
       if (!(st < c.n_stages && c.stages[st].kind == JG_ST_ACT && c.stages[st].arg == JG_ACT_GELU_TANH)) { ok = false; break; }
       ++st;
       ly.aff2 = 1;

@@ -354,10 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int t = 0; t < K0; ++t) mo = m_or(mo, t >= pad0 ? m_shr(m, t - pad0) : m_shl(m, pad0 - t));
     }
     mo = m_and(mo, valid0);
-    float pool[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) pool[i] = a.pool_kind == JG_POOL_AVG ? 0.0f : -1.0e9f;
-    float tapv[16];
+    float pool[16], tapv[16];       // (pool is initialised right in front of the last layer: live there only)
     float *prow = a.part + row * (long)a.n_slots * PARTW;
     {
       const float *ep = epi;
@@ -425,6 +422,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (tap) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) tapv[i] = 0.0f;
+        }
+        if (j == NC - 1) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) pool[i] = a.pool_kind == JG_POOL_AVG ? 0.0f : -1.0e9f;
         }
         const int code = (j == NC - 1 ? 8 : 0) | (p2 ? 4 : 0) | (add ? 2 : 0) | (save ? 1 : 0);
         switch (code) {               // wave-uniform: one compiled epilogue per (last, second norm, add, save)
