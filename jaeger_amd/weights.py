@@ -90,11 +90,14 @@ _BLOCK_SUBLAYERS = ("conv1", "conv2", "conv3", "bn1", "bn2", "bn3")
 
 
 def _natural_key(path: tuple[str, ...]):
-    """Keras de-duplicates auto names as ``name``, ``name_1``, ``name_2`` ...: sort by (base, index)."""
+    """Keras de-duplicates auto names as ``name``, ``name_1``, ``name_2`` ... and a ResidualBlockStack names its
+    blocks ``rep_residual_block_<i>_<j>`` (layers.py:2676-2692): every digit run compares as a number (``_10`` after
+    ``_2``), a name without a suffix sorts in front of its ``_1``."""
+    import re
     key = []
     for comp in path:
-        base, _, idx = comp.rpartition("_")
-        key.append((base, int(idx)) if base and idx.isdigit() else (comp, -1))
+        toks = [(1, int(t), "") if t.isdigit() else (0, 0, t) for t in re.split(r"(\d+)", comp) if t != ""]
+        key.append(tuple(toks))
     return key
 
 
