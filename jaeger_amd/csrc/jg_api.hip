@@ -607,6 +607,7 @@ static int prepare_small(jg_model *m, const float *weights) {
   JG_HIP(hipMemcpy(sn->d_epi, epi.data(), epi.size() * sizeof(float), hipMemcpyHostToDevice));
   JG_HIP(hipMalloc(reinterpret_cast<void **>(&sn->d_wfrag), frag.size() * 2));
   JG_HIP(hipMemcpy(sn->d_wfrag, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
+
   sn->valid = true;
   sn->n_conv = nc;
   sn->k0 = k0;

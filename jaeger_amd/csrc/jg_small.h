@@ -16,7 +16,8 @@ struct JgSmallLayer {
 struct JgSmallArgs {
   const uint8_t *ids;   // (rows, L) codon ids
   const float *lut;     // [k0][vocab + 1][32] first-layer table (row `vocab` = zeros: padding)
-  const uint4 *wfrag;   // [n_conv][3 taps][2 chunks][hi|lo][64 lanes] MFMA A-fragments (8 halfs each)
+  const uint4 *wfrag;   // [n_conv][3 taps][2 chunks][hi|lo][64 lanes] 32x32x16 A-fragments (8 halfs each): one wave per row
+
   const float *epi;     // [layers][s1 | t1 | s2 | t2][32]
   float *part;          // [rows][n_slots][JG_SMALL_PARTW]: slot 0 pool, slots 1.. NMD taps
   int *overflow;

@@ -21,6 +21,12 @@
 //     accumulates the masked pool instead of storing.
 //
 // Waves never exchange data, so there is no barrier after the tables are loaded.
+//
+// (A variant with TWO waves per row image - waves w and w + 4 on one SIMD, 80 positions each on 16x16x32 MFMAs, two
+// workgroup barriers per layer - was built and measured in round 2: bit-identical results, 4 % slower, and the same
+// cycles per element in every vector-bound phase with half the elements per wave.  The epilogue is bound by the SIMD's
+// vector THROUGHPUT - about 4 cycles per wave64 instruction and 16 per exp2 / rcp - not by a lone wave's issue rate,
+// so a second wave per SIMD buys nothing here; commit history holds the kernel.)
 #include <stdio.h>
 
 #include <algorithm>
