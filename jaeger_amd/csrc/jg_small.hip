@@ -26,7 +26,7 @@
 // workgroup barriers per layer - was built and measured in round 2: bit-identical results, 4 % slower, and the same
 // cycles per element in every vector-bound phase with half the elements per wave.  The epilogue is bound by the SIMD's
 // vector THROUGHPUT - about 4 cycles per wave64 instruction and 16 per exp2 / rcp - not by a lone wave's issue rate,
-// so a second wave per SIMD buys nothing here; commit history holds the kernel.)
+// so a second wave per SIMD buys nothing here; the variant was dropped, DESIGN.md section 3.2 has its cycle stamps.)
 #include <stdio.h>
 
 #include <algorithm>
