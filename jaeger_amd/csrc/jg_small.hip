@@ -130,10 +130,10 @@ __device__ __forceinline__ float gelu_tanh(float v) {
 #define JG_SDBG(bit) false
 #endif
 
-template <bool LAST, bool P2, bool ADD, bool SAVE>
+template <bool LAST, bool P2, bool ADD, bool SAVE, bool TAP>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], const float *epi, M192 mout, char *act,
                                          int n, int h, float &vmax, float (&pool)[16], int pool_kind, int dbg,
-                                         const int tap, float (&tapv)[16]) {
+                                         float (&tapv)[16]) {
   (void)dbg;
   // the lane's 16 channels' parameters, read once per layer (broadcast LDS reads; a read per block and channel
   // group left the wave waiting on LDS latency twenty times a layer)
@@ -151,6 +151,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], co
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const bool keep = (mout.w[b >> 1] >> ((b & 1) * 32 + n)) & 1ull;
+    const unsigned km = keep ? 0xffffffffu : 0u;
     float v[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -172,7 +173,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], co
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[b][r] = v[r];
     }
-    if (tap) {                      // NMD tap behind the layer's last stage: masked channel sums of its output
+    if constexpr (TAP) {            // NMD tap behind the layer's last stage: masked channel sums of its output
 #pragma unroll
       for (int r = 0; r < 16; ++r) tapv[r] += keep ? v[r] : 0.0f;
     }
@@ -189,15 +190,15 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], co
       for (int g = 0; g < 4; ++g) {
         // x = hi + lo: hi = f16(x) by packed converts, lo = f16(x - hi) with the remainder from v_fma_mix_f32 (reads
         // the f16 half straight out of the packed register)
-        float x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          x[i] = keep ? v[g * 4 + i] : 0.0f;
-          vmax = fmaxf(vmax, fabsf(x[i]));
-        }
-        const unsigned h01 = pk_f16(x[0], x[1]), h23 = pk_f16(x[2], x[3]);
-        const unsigned l01 = pk_f16(mix_rem<0>(x[0], h01), mix_rem<1>(x[1], h01));
-        const unsigned l23 = pk_f16(mix_rem<0>(x[2], h23), mix_rem<1>(x[3], h23));
+        // (the range guard watches the unmasked values: one v_max3 per two elements; the mask is applied to the packed
+        // halves - four v_and per four elements and plane instead of a select per element)
+        const float *x = &v[g * 4];
+        vmax = fmaxf(fmaxf(vmax, fabsf(x[0])), fabsf(x[1]));
+        vmax = fmaxf(fmaxf(vmax, fabsf(x[2])), fabsf(x[3]));
+        unsigned h01 = pk_f16(x[0], x[1]), h23 = pk_f16(x[2], x[3]);
+        unsigned l01 = pk_f16(mix_rem<0>(x[0], h01), mix_rem<1>(x[1], h01));
+        unsigned l23 = pk_f16(mix_rem<0>(x[2], h23), mix_rem<1>(x[3], h23));
+        h01 &= km; h23 &= km; l01 &= km; l23 &= km;
         char *p = act + (1 + b * 32 + n) * ROWB + (g * 8 + h * 4) * 2;
         if (!JG_SDBG(8)) {
           *reinterpret_cast<uint2 *>(p) = make_uint2(h01, h23);
@@ -221,8 +222,19 @@ static __device__ unsigned long long jg_small_stamp[8];
 #define JG_SST_END
 #endif
 
-#define JG_EPI_CALL(LASTV, P2V, ADDV, SAVEV) \
-  epilogue<LASTV, P2V, ADDV, SAVEV>(acc, sc, ep, mo, act, n, h, vmax, pool, a.pool_kind, dbg, tap, tapv)
+// (a run-time tap flag inside the block loop cost 8 % of the kernel - the sixteen tap registers stayed allocated in
+// every variant - so the tap is a template parameter like the other stage flags)
+#define JG_EPI_CALL(LASTV, P2V, ADDV, SAVEV)                                                                  \
+  do {                                                                                                        \
+    float tapv[16];                                                                                           \
+    if (TAPS && tap) {                                                                                        \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) tapv[i_] = 0.0f;                                      \
+      epilogue<LASTV, P2V, ADDV, SAVEV, true>(acc, sc, ep, mo, act, n, h, vmax, pool, a.pool_kind, dbg, tapv); \
+      row_reduce_store(tapv, true, prow + tap * PARTW, m_count(mo), n, h, lane);                              \
+    } else {                                                                                                  \
+      epilogue<LASTV, P2V, ADDV, SAVEV, false>(acc, sc, ep, mo, act, n, h, vmax, pool, a.pool_kind, dbg, tapv); \
+    }                                                                                                         \
+  } while (0)
 
 // Reduce a lane's 16 channel values over the 32 lanes that share h and store the row's 32 channel totals + the mask
 // count.  Register-halving butterfly: at each step a lane hands half of its registers to its partner and keeps the
@@ -260,6 +272,8 @@ __device__ __forceinline__ void row_reduce_store(const float (&p)[16], const boo
   if (lane == 0) dst[C] = (float)count;
 }
 
+// TAPS = false: the model has no NMD taps - the tap paths (24 more inlined epilogues, 17 more registers) are compiled out
+template <bool TAPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void small_net_kernel(JgSmallArgs a) {
   const int NC = a.n_conv, K0 = a.k0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -360,18 +374,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int t = 0; t < K0; ++t) mo = m_or(mo, t >= pad0 ? m_shr(m, t - pad0) : m_shl(m, pad0 - t));
     }
     mo = m_and(mo, valid0);
-    float pool[16], tapv[16];       // (pool is initialised right in front of the last layer: live there only)
+    float pool[16];                 // (initialised right in front of the last layer: live there only)
     float *prow = a.part + row * (long)a.n_slots * PARTW;
     {
       const float *ep = epi;
-      const int tap = a.layer[0].tap;
-      if (tap) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) tapv[i] = 0.0f;
-      }
+      const int tap = TAPS ? a.layer[0].tap : 0;
       if (a.layer[0].save) JG_EPI_CALL(false, false, false, true);
       else JG_EPI_CALL(false, false, false, false);
-      if (tap) row_reduce_store(tapv, true, prow + tap * PARTW, m_count(mo), n, h, lane);
     }
     JG_SST(2);
     // ---- k = 3 convolutions on the matrix cores -----------------------------------------------------------
@@ -424,11 +433,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const float *ep = epi + (j + 1) * 4 * C;
       {
         const int add = a.layer[j + 1].add, save = a.layer[j + 1].save, p2 = a.layer[j + 1].aff2;
-        const int tap = a.layer[j + 1].tap;
-        if (tap) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) tapv[i] = 0.0f;
-        }
+        const int tap = TAPS ? a.layer[j + 1].tap : 0;
         if (j == NC - 1) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) pool[i] = a.pool_kind == JG_POOL_AVG ? 0.0f : -1.0e9f;
@@ -448,7 +453,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           case 12: case 13: JG_EPI_CALL(true, true, false, false); break;
           default: JG_EPI_CALL(true, true, true, false); break;
         }
-        if (tap) row_reduce_store(tapv, true, prow + tap * PARTW, m_count(mo), n, h, lane);
       }
       JG_SST(4);
     }
@@ -483,12 +487,15 @@ __global__ void small_pool_final_kernel(const float *part, int frames, int n_slo
 int launch(jg_engine *e, const JgSmallArgs &a, int smem, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_net_kernel),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_net_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_net_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const int grid = (int)std::min<long>(e->n_cu, (a.rows + 3) / 4);
-  hipLaunchKernelGGL(small_net_kernel, dim3((unsigned)grid), dim3(256), (size_t)smem, s, a);
+  if (a.n_slots > 1) hipLaunchKernelGGL(small_net_kernel<true>, dim3((unsigned)grid), dim3(256), (size_t)smem, s, a);
+  else hipLaunchKernelGGL(small_net_kernel<false>, dim3((unsigned)grid), dim3(256), (size_t)smem, s, a);
   JG_HIP(hipGetLastError());
 #ifdef JG_EXPERIMENT
   if (a.dbg & 16) {
