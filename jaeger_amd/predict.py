@@ -292,7 +292,9 @@ def _predict_sharded(make_engine, input_path, fsize, stride, user_min_len, min_l
     if not dist.is_initialized():
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        # RCCL ("nccl") when GPUs are there; JAEGER_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
+        dist.init_process_group(os.environ.get("JAEGER_DIST_BACKEND") or
+                                ("nccl" if torch.cuda.is_available() else "gloo"))
     dev = _coll_device(local_rank)
 
     def all_ok(ok: bool) -> bool:

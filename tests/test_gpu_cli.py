@@ -279,3 +279,43 @@ def test_cli_prophage_segmentation_inputs(tmp_path):
     assert list(got["columns"]) == list(next(iter(exp.values()))[0].columns)
     for tr, k in zip(got["tracks"], exp):
         np.testing.assert_allclose(tr, exp[k][0].to_numpy(np.float64), atol=2e-4, rtol=0)
+
+
+def _sharded_worker(rank, world, port, fasta, out, root):
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", JAEGER_DIST_BACKEND="gloo")       # both ranks on the box's one GPU
+    from jaeger_amd.predict import run_core
+    run_core(input=str(fasta), output=str(out), model_path=str(root), fsize=1500, stride=1500, min_len=700, batch=4,
+             dustmask=True, rc=0.1, pc=3, overwrite=True, verbose=1, save_embedding=True)
+
+
+def test_cli_sharded_two_ranks_real_engine(tmp_path):
+    """The torchrun path with the real engine: two ranks (sharing the test box's GPU, gloo exchange) index / read /
+    mask / scan / classify their own contigs, rank 0 gathers f32 rows and writes the tables - byte-identical to the
+    single-process run of the same command (two-pass mode, DUST on, embeddings saved)."""
+    import socket
+
+    import torch.multiprocessing as mp
+    from jaeger_amd.cli import main
+    root = make_model_dir(tmp_path / "m")
+    fasta = GOLDEN / "test_contigs.fasta"
+    r = CliRunner().invoke(main, ["predict", "-i", str(fasta), "-o", str(tmp_path / "single"), "--model_path", str(root),
+                                  "--fsize", "1500", "--stride", "1500", "--min-len", "700", "--batch", "4",
+                                  "--save-embedding"])
+    assert r.exit_code == 0, r.output
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_worker, args=(2, port, fasta, tmp_path / "sharded", root), nprocs=2, join=True)
+    a = (tmp_path / "single" / "38341_1.4M" / "test_contigs.tsv").read_text()
+    b = (tmp_path / "sharded" / "38341_1.4M" / "test_contigs.tsv").read_text()
+    assert a == b and len(a.splitlines()) == 10
+    ea = np.load(tmp_path / "single" / "38341_1.4M" / "test_contigs_embedding.npz", allow_pickle=True)
+    eb = np.load(tmp_path / "sharded" / "38341_1.4M" / "test_contigs_embedding.npz", allow_pickle=True)
+    assert list(ea["headers"]) == list(eb["headers"])
+    np.testing.assert_array_equal(ea["embedding"], eb["embedding"])
