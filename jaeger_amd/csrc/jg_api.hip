@@ -278,6 +278,12 @@ static int validate_program(const jg_model *m) {
       JG_REQUIRE(op.b_off < 0 || off_ok(op.b_off, op.cout), JG_ERR_INVALID,
                  "op %zu: dense bias outside the weight blob", i);
     }
+    {   // NMD taps per op: the conv kernels carry two accumulators, the element-wise / LayerNorm kernels one
+      int n_nmd = 0;
+      for (int s = 0; s < op.n_stages; ++s) n_nmd += op.stages[s].kind == JG_ST_NMD;
+      JG_REQUIRE(n_nmd <= (op.kind == JG_OP_CONV ? 2 : 1), JG_ERR_UNSUPPORTED,
+                 "op %zu: %d NMD taps in one stage list (at most %d)", i, n_nmd, op.kind == JG_OP_CONV ? 2 : 1);
+    }
     for (int s = 0; s < op.n_stages; ++s) {
       const jg_stage &st = op.stages[s];
       const int64_t c = op.cout;

@@ -43,8 +43,11 @@ __device__ __forceinline__ float jg_apply_act(float v, int act) {
 // Apply the fused stage list to 4 consecutive channels n..n+3 of one position.
 // `o` = flat element offset of channel n in the (rows, L_out, cout) output,
 // `mk` = output mask of the position (1 when the op carries no mask).
+// Up to two NMD taps per stage list (a return_nmd norm's tap in front of the norm and an nmd layer behind the block):
+// the first accumulates into nmd_acc, the second into nmd_acc2.
 __device__ __forceinline__ float4 jg_apply_stages(float4 v, const StageArg *st, int n_stages, int n,
-                                                  size_t o, float mk, float4 *nmd_acc) {
+                                                  size_t o, float mk, float4 *nmd_acc, float4 *nmd_acc2 = nullptr) {
+  bool tapped = false;
   for (int s = 0; s < n_stages; ++s) {
     const StageArg &g = st[s];
     switch (g.kind) {
@@ -84,10 +87,12 @@ __device__ __forceinline__ float4 jg_apply_stages(float4 v, const StageArg *st, 
         v.z = jg_apply_act(v.z, g.arg);
         v.w = jg_apply_act(v.w, g.arg);
         break;
-      case JG_ST_NMD:
-        nmd_acc->x += v.x * mk; nmd_acc->y += v.y * mk;
-        nmd_acc->z += v.z * mk; nmd_acc->w += v.w * mk;
-        break;
+      case JG_ST_NMD: {
+        float4 *acc = (tapped && nmd_acc2 != nullptr) ? nmd_acc2 : nmd_acc;
+        acc->x += v.x * mk; acc->y += v.y * mk;
+        acc->z += v.z * mk; acc->w += v.w * mk;
+        tapped = true;
+      } break;
       case JG_ST_MASKMUL:
         v.x *= mk; v.y *= mk; v.z *= mk; v.w *= mk;
         break;
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
   constexpr int RSTEP = NT / QN;      // rows advanced per iteration
   const int q = tid % QN, r0 = tid / QN;
   const int n = n_blk + q * 4;
-  float4 nmd_acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 nmd_acc = make_float4(0.f, 0.f, 0.f, 0.f), nmd_acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (n < a.cout) {
     for (int ml = r0; ml < BM; ml += RSTEP) {
       const int m = m0 + ml;
@@ -378,23 +383,20 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
       const float mk = a.mask_out != nullptr ? (a.mask_out[pos] != 0 ? 1.f : 0.f) : 1.f;
       const size_t o = pos * a.cout + n;
       float4 v = *reinterpret_cast<const float4 *>(smem + ml * LDC + q * 4);
-      v = jg_apply_stages(v, a.st, a.n_stages, n, o, mk, &nmd_acc);
+      v = jg_apply_stages(v, a.st, a.n_stages, n, o, mk, &nmd_acc, &nmd_acc2);
       *reinterpret_cast<float4 *>(a.y + o) = v;
     }
   }
-  // NMD tap: deterministic in-block reduction over the RSTEP row groups, one
-  // partial per (row, tile) written to the stage's partial-sum buffer.
-  bool has_nmd = false;
-  float *nmd_out = nullptr;
+  // NMD taps (up to two per conv): deterministic in-block reduction over the RSTEP row groups, one partial per
+  // (row, tile) written to each stage's partial-sum buffer.
+  float *nmd_out[2] = {nullptr, nullptr};
+  int n_taps = 0;
   for (int s = 0; s < a.n_stages; ++s)
-    if (a.st[s].kind == JG_ST_NMD) {
-      has_nmd = true;
-      nmd_out = const_cast<float *>(a.st[s].p0);
-    }
-  if (has_nmd) {
+    if (a.st[s].kind == JG_ST_NMD && n_taps < 2) nmd_out[n_taps++] = const_cast<float *>(a.st[s].p0);
+  for (int tp = 0; tp < n_taps; ++tp) {
     __syncthreads();
     float4 *red = reinterpret_cast<float4 *>(smem);
-    red[r0 * QN + q] = nmd_acc;
+    red[r0 * QN + q] = tp == 0 ? nmd_acc : nmd_acc2;
     __syncthreads();
     if (r0 == 0 && n < a.cout) {
       float4 sacc = red[q];
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
         const float4 t4 = red[g * QN + q];
         sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w;
       }
-      *reinterpret_cast<float4 *>(nmd_out + ((size_t)row * a.tiles_m + tile) * a.cout + n) = sacc;
+      *reinterpret_cast<float4 *>(nmd_out[tp] + ((size_t)row * a.tiles_m + tile) * a.cout + n) = sacc;
     }
   }
 }

@@ -11,6 +11,7 @@ C-ABI in ``include/jaeger_hip.h``; there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from collections import defaultdict
 from pathlib import Path
 from typing import Any, Iterable
@@ -61,9 +62,13 @@ class HipDevice:
         self.handle = C.c_void_p()
         L.check(self.lib.jg_engine_create(int(device_id), C.byref(self.handle)), "jg_engine_create")
         self.device_id = device_id
+        self._models = weakref.WeakSet()      # models living on this engine: destroyed before it, whatever the order
+                                              # in which the garbage collector finalises a cycle that holds both
 
     def close(self):
         if getattr(self, "handle", None):
+            for mdl in list(getattr(self, "_models", ())):
+                mdl.close()
             self.lib.jg_engine_destroy(self.handle)
             self.handle = None
 
@@ -153,10 +158,12 @@ class HipModel:
                                          program.vocab, C.byref(self.handle)), "jg_model_create")
         self.widths = {name: self.lib.jg_model_vec_width(self.handle, i)
                        for i, name in enumerate(("prediction", "reliability", "embedding", "nmd"))}
+        device._models.add(self)
 
     def close(self):
         if getattr(self, "handle", None):
-            self.lib.jg_model_destroy(self.handle)
+            if getattr(self.dev, "handle", None):     # (an engine that is already gone took its models with it)
+                self.lib.jg_model_destroy(self.handle)
             self.handle = None
 
     __del__ = close
