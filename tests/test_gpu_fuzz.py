@@ -71,6 +71,29 @@ def random_model(rng):
                                                   {"name": "dense", "config": {"units": 1, "activation": None}}]
     base["reliability_model"].pop("input_shape", None)
     base["reliability_model"]["mode"] = "nmd"
+    if rng.random() < 0.25:
+        base["reliability_model"]["mode"] = "nmd_plus_signals"
+        base["reliability_model"]["signals"] = [str(x) for x in rng.permutation(["max_prob", "entropy", "energy", "margin",
+                                                                                "nmd_norm"])[:int(rng.integers(1, 6))]]
+    if rng.random() < 0.2:
+        base["use_masking"] = False
+    if rng.random() < 0.2:                                   # hidden dense layer in the classifier
+        base["classifier"]["hidden_layers"] = [{"name": "dense", "config": {"units": 24, "activation": "gelu"}},
+                                               {"name": "dense", "config": {"units": 6, "activation": None}}]
+    if rng.random() < 0.15:                                  # translated one-hot input
+        base["embedding"].update(use_embedding_layer=False, embedding_size=int(rng.choice([0, 32])),
+                                 input_shape=[6, None, 64])
+        base["string_processor"]["seq_onehot"] = True
+    if rng.random() < 0.15 and width == 32:                  # the small-window family shape: k = 3 blocks, batch norms
+        layers = [layers[0], {"name": "masked_batchnorm", "config": {}}, {"name": "activation", "config": {"activation": "gelu"}},
+                  {"name": "residual_block", "config": {"filters": 32, "kernel_size": 3,
+                                                        "block_size": int(rng.integers(1, 3))}},
+                  {"name": "masked_batchnorm", "config": {}}, {"name": "activation", "config": {"activation": "gelu"}}]
+        if rng.random() < 0.5:
+            layers.append({"name": "nmd", "config": {}})
+        else:
+            base.pop("reliability_model", None)
+        base["representation_learner"]["hidden_layers"] = layers
     return base
 
 
