@@ -1062,15 +1062,22 @@ static int ensure_workspace(jg_model *m, int64_t chunk, int l) {
             chunk * nmd_elems[i] <= m->nmd_cap[i];
   }
   for (int i = 0; i < JG_MAX_VECS; ++i) fits &= chunk * m->vec_w[i] <= m->vec_cap[i];
+  // programs with layout conversions swap a slot's tensor with the scratch tensor: every activation slot and the
+  // scratch then need the LARGEST slot's size (a smaller buffer would otherwise wander into a larger slot - found by
+  // the architecture fuzz on a net with two strided blocks)
   int64_t cvt_need = 0;
-  if (m->needs_cvt)
+  if (m->needs_cvt) {
     for (int i = 0; i < JG_MAX_BUFS; ++i) cvt_need = std::max(cvt_need, chunk * m->act_elems[i]);
+    for (int i = 0; i < JG_MAX_BUFS; ++i)
+      if (m->act_elems[i] > 0) fits &= cvt_need <= m->act_cap[i];
+  }
   fits &= cvt_need <= m->cvt_cap;
   if (fits) return JG_OK;
   JG_HIP(hipStreamSynchronize(m->e->stream));
   int64_t want_act[JG_MAX_BUFS], want_msk[JG_MAX_BUFS], want_nmd[JG_MAX_BUFS], want_vec[JG_MAX_VECS];
   for (int i = 0; i < JG_MAX_BUFS; ++i) {
     want_act[i] = std::max(m->act_cap[i], chunk * m->act_elems[i]);
+    if (m->needs_cvt && m->act_elems[i] > 0) want_act[i] = std::max(want_act[i], cvt_need);
     want_msk[i] = std::max(m->msk_cap[i], chunk * m->msk_elems[i]);
     want_nmd[i] = std::max(m->nmd_cap[i], chunk * nmd_elems[i]);
   }

@@ -107,7 +107,8 @@ def test_random_architecture(seed):
     rng = np.random.Generator(np.random.PCG64(1000 + seed))
     cfg = random_model(rng)
     weights = ofwd.random_weights(cfg, seed=seed)
-    fsize, n_win = int(rng.choice([450, 600, 900])), 7
+    # 2000-2500 bp: the window-packed tiling of the k = 5 convs; small chunks: several launch groups per call
+    fsize, n_win = int(rng.choice([450, 600, 900, 900, 1500, 2000, 2500])), 7
     seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=fsize * n_win).copy()
     for s in rng.integers(0, seq.size, 6):
         seq[s:s + rng.integers(1, 30)] = ord("N")
@@ -122,7 +123,7 @@ def test_random_architecture(seed):
     from jaeger_amd.plan import UnsupportedLayer
     try:
         with pytest.warns(UserWarning):
-            eng = JaegerHipEngine(model_cfg=cfg, weights=weights)
+            eng = JaegerHipEngine(model_cfg=cfg, weights=weights, chunk=int(rng.choice([0, 0, 3, 5])))
     except (UnsupportedLayer, JaegerHipError) as e:        # a loud refusal is fine; a wrong number is not
         pytest.skip(f"architecture refused: {e}")
     modes = [eng.model.precision] + (["f32"] if eng.model.precision != "f32" else [])
