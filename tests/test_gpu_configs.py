@@ -177,3 +177,34 @@ def test_bench_gpus_flag_spawns_ranks():
     bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4"], capture_output=True, text=True,
                          env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=120)
     assert bad.returncode == 2 and "does not match WORLD_SIZE" in bad.stderr
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_streamed_ingest_random_window_tables(brain, seed):
+    """Streamed vs whole-buffer ingest on random start-sorted window tables (overlapping strides, ragged lengths,
+    windows touching both ends of the buffer) under tiny stream budgets: bit-identical outputs, bounded device bases."""
+    cfg, weights, eng = brain
+    rng = np.random.Generator(np.random.PCG64(900 + seed))
+    fsize = int(rng.choice([600, 900, 1500]))
+    n_bases = int(rng.integers(40_000, 400_000))
+    bases = ACGT[rng.integers(0, 4, n_bases, dtype=np.uint8)]
+    bases[rng.integers(0, n_bases, 50)] = ord("N")
+    n_win = int(rng.integers(5, 120))
+    starts = np.sort(rng.integers(0, n_bases - fsize, n_win)).astype(np.int64)
+    starts[0], starts[-1] = 0, n_bases - fsize
+    lens = np.full(n_win, fsize, np.int32)
+    lens[rng.random(n_win) < 0.2] = rng.integers(fsize // 2, fsize)
+    want = ("prediction", "reliability")
+    eng.device.set_stream_bytes(1 << 30)
+    whole = eng.predict_windows(bases, starts, lens, fsize, want=want)
+    assert eng.device.stream_stats()["groups"] == 0
+    budget = int(rng.choice([4096, 8192, 32768]))          # < n_bases: always streamed
+    eng.device.set_stream_bytes(budget)
+    try:
+        streamed = eng.predict_windows(bases, starts, lens, fsize, want=want)
+        stats = eng.device.stream_stats()
+    finally:
+        eng.device.set_stream_bytes(256 << 20)
+    assert stats["groups"] >= 2 and stats["bytes"] >= int(lens.sum()) // 2
+    for k in ("prediction", "reliability", "counts"):
+        np.testing.assert_array_equal(whole[k], streamed[k])
