@@ -652,9 +652,11 @@ static int prepare_f16(jg_model *m, const float *weights) {
   m->pool_fused_by.assign(m->ops.size(), -1);
   m->f16_eligible = true;
   m->f16_reason.clear();
-  // Pass A - every conv on its own: can it run on the split-f16 kernel (stride 1, taps / dilation inside the tiling,
-  // 128 output channels, a compiled epilogue pattern)?  Ineligible convs (strided, 1x1 bypass, other widths) keep the
-  // exact-f32 kernel inside an otherwise split-f16 program; pass B below places the layout conversions between them.
+  // Pass A - every conv on its own: can it run on the split-f16 kernel (taps / dilation inside the tiling, a compiled
+  // epilogue pattern; 32, 64 or a multiple of 128 output channels - narrow convs on 64- / 32-channel workgroup tiles,
+  // wider ones as one launch per 128 channels; stride 2 as the stride-1 conv whose even outputs are kept)?  Ineligible
+  // convs (1x1 bypass, other strides or widths) keep the exact-f32 kernel inside an otherwise split-f16 program; pass B
+  // below places the layout conversions between them.
   std::string first_reason;
   auto fail = [&](const char *why) { if (first_reason.empty()) first_reason = why; };
   for (size_t i = 0; i < m->ops.size(); ++i) {
@@ -662,14 +664,25 @@ static int prepare_f16(jg_model *m, const float *weights) {
     if (op.kind != JG_OP_CONV) continue;
     ConvHPrep &hp = m->hprep[i];
     hp.f16_ok = false;
-    if (op.stride != 1) { fail("strided conv"); continue; }
+    if (op.stride != 1 && !(op.stride == 2 && op.k == 5 && op.in_buf != JG_BUF_IDS)) { fail("strided conv"); continue; }
     if (!jg_conv_f16_supports(op.k, op.dilation)) { fail("taps / dilation outside the split-f16 tiling"); continue; }
-    if (op.cout % 16 != 0 || (op.cout + 31) / 32 * 32 != 128) { fail("conv width is not 128 channels"); continue; }
+    const bool narrow = op.cout == 32 || op.cout == 64;
+    if (op.cout % 16 != 0 || !(narrow || (op.cout > 64 && op.cout <= 128) || op.cout % 128 == 0)) {
+      fail("conv width is not 32, 64, 80..128 or a multiple of 128 channels");
+      continue;
+    }
+    // only the k = 5 kernels are built with run-time output geometry (other widths than 128, stride 2); a first conv of
+    // up to 128 channels runs as the table variant, which has it too (checked below: no table -> 128 channels only)
+    if (op.in_buf != JG_BUF_IDS && op.k != 5 && op.cout != 128) { fail("conv width is not 128 channels (k = 7 / 9)"); continue; }
+    if (op.in_buf == JG_BUF_IDS && op.cout > 128) { fail("first conv wider than 128 channels"); continue; }
     if (op.in_buf != JG_BUF_IDS && op.cin % 16 != 0) { fail("conv input width is not a multiple of 16"); continue; }
     bool conv_ok = true;
     auto cfail = [&](const char *why) { conv_ok = false; fail(why); };
     const int cin16 = (op.cin + 15) / 16 * 16, cin_pad = (op.cin + 1) & ~1, cout_pad = 128;
     hp.cc_in = cin16 / 16;
+    hp.n_half = (op.cout + 127) / 128;
+    hp.cw = (narrow && op.in_buf != JG_BUF_IDS) ? op.cout : 128;    // (a first conv runs as the table variant: 128-wide)
+    const int cwide = hp.n_half * 128;                                // channels incl. zero padding
     const float *w = weights + op.w_off;   // (k, cin_pad, cout_pad32) f32
     const int cout_pad32 = (op.cout + 31) / 32 * 32;
     float maxabs = 0.f;
@@ -683,15 +696,18 @@ static int prepare_f16(jg_model *m, const float *weights) {
     const float wscale = ldexpf(1.f, sexp);
     hp.acc_scale = ldexpf(1.f, -sexp);
     const int kc_total = cin16 / 8;
-    const size_t n_items = (size_t)2 * op.k * kc_total * cout_pad;
+    const size_t half_items = (size_t)2 * op.k * kc_total * cout_pad;     // one 128-channel half: [plane][tap][kc][128]
+    const size_t n_items = half_items * hp.n_half;
+    hp.wh_half_items = (int64_t)half_items;
     std::vector<uint16_t> wh(n_items * 8, 0);
     for (int t = 0; t < op.k; ++t)
       for (int c = 0; c < op.cin; ++c)
         for (int n = 0; n < op.cout; ++n) {
           const float v = w[((size_t)t * cin_pad + c) * cout_pad32 + n] * wscale;
           const float hi = f16_value(v);
-          const size_t item = (((size_t)0 * op.k + t) * kc_total + c / 8) * cout_pad + n;
-          const size_t item_lo = (((size_t)1 * op.k + t) * kc_total + c / 8) * cout_pad + n;
+          const size_t base = (size_t)(n / 128) * half_items;
+          const size_t item = base + (((size_t)0 * op.k + t) * kc_total + c / 8) * cout_pad + n % 128;
+          const size_t item_lo = base + (((size_t)1 * op.k + t) * kc_total + c / 8) * cout_pad + n % 128;
           wh[item * 8 + c % 8] = f16_bits(hi);
           wh[item_lo * 8 + c % 8] = f16_bits(v - hi);
         }
@@ -715,8 +731,8 @@ static int prepare_f16(jg_model *m, const float *weights) {
     }
     // compact epilogue: fold acc un-scale, bias and batch-norm chains into per-channel affines
     {
-      std::vector<float> tab;                       // [n_hst][2][128]
-      std::vector<double> sc(128, (double)hp.acc_scale), sh(128, 0.0);
+      std::vector<float> tab;                       // [n_epi_rows][2][cwide]; uploaded as [half][n_epi_rows][2][128]
+      std::vector<double> sc(cwide, (double)hp.acc_scale), sh(cwide, 0.0);
       bool pending = true;                          // an affine (the un-scale) is always pending first
       hp.n_hst = 0;
       hp.n_epi_rows = 0;
@@ -724,8 +740,8 @@ static int prepare_f16(jg_model *m, const float *weights) {
         if (!pending) return;
         HStageArg h{JG_HST_AFFINE, 0, 0.f, hp.n_epi_rows++};
         hp.hst[hp.n_hst++] = h;
-        for (int n = 0; n < 128; ++n) tab.push_back((float)sc[n]);
-        for (int n = 0; n < 128; ++n) tab.push_back((float)sh[n]);
+        for (int n = 0; n < cwide; ++n) tab.push_back((float)sc[n]);
+        for (int n = 0; n < cwide; ++n) tab.push_back((float)sh[n]);
         std::fill(sc.begin(), sc.end(), 1.0);
         std::fill(sh.begin(), sh.end(), 0.0);
         pending = false;
@@ -754,8 +770,8 @@ static int prepare_f16(jg_model *m, const float *weights) {
           case JG_ST_DYT:
             h.kind = JG_HST_DYT;
             h.pad_ = hp.n_epi_rows++;
-            for (int n = 0; n < 128; ++n) tab.push_back(n < op.cout ? vecp(st.p2)[n] : 0.f);
-            for (int n = 0; n < 128; ++n) tab.push_back(n < op.cout ? vecp(st.p3)[n] : 0.f);
+            for (int n = 0; n < cwide; ++n) tab.push_back(n < op.cout ? vecp(st.p2)[n] : 0.f);
+            for (int n = 0; n < cwide; ++n) tab.push_back(n < op.cout ? vecp(st.p3)[n] : 0.f);
             break;
           case JG_ST_ADD: h.kind = JG_HST_ADD; hp.add_slot = st.arg; break;
           case JG_ST_ACT:
@@ -810,10 +826,19 @@ static int prepare_f16(jg_model *m, const float *weights) {
         if (conv_ok && !jg_conv_f16_has_pattern(hp.ep, op.in_buf == JG_BUF_IDS)) {
           cfail("a conv's stage list is not one of the compiled split-f16 epilogue patterns");
         }
+        if (conv_ok && op.in_buf != JG_BUF_IDS && (op.cout != 128 || op.stride != 1) && !jg_conv_f16_has_narrow_pattern(hp.ep))
+          cfail("the stage list of a conv of other than 128 channels / stride 1 is not one of the patterns compiled for it");
+        if (conv_ok && op.stride == 2 && (hp.ep & (JG_EP_ADD | JG_EP_NMD1 | JG_EP_NMD2)))
+          cfail("strided conv with a shortcut or an NMD tap in its epilogue");
       }
       if (conv_ok) {
-        JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_epi), tab.size() * sizeof(float)));
-        JG_HIP(hipMemcpy(hp.d_epi, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<float> th(tab.size());                 // [half][row][2][128]
+        const int nr = hp.n_epi_rows;
+        for (int hf = 0; hf < hp.n_half; ++hf)
+          for (int r = 0; r < nr * 2; ++r)
+            for (int n = 0; n < 128; ++n) th[((size_t)hf * nr * 2 + r) * 128 + n] = tab[(size_t)r * cwide + hf * 128 + n];
+        JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_epi), th.size() * sizeof(float)));
+        JG_HIP(hipMemcpy(hp.d_epi, th.data(), th.size() * sizeof(float), hipMemcpyHostToDevice));
       }
       // first layer on ids: the conv is a sum of k table rows T_t[id] = E[id] . W_t (f64 on the
       // host); the kernel's table variant then needs no matrix cores and no acc un-scale
@@ -839,6 +864,8 @@ static int prepare_f16(jg_model *m, const float *weights) {
         JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_epi_lut), tab_lut.size() * sizeof(float)));
         JG_HIP(hipMemcpy(hp.d_epi_lut, tab_lut.data(), tab_lut.size() * sizeof(float), hipMemcpyHostToDevice));
       }
+      if (conv_ok && op.in_buf == JG_BUF_IDS && hp.d_lut == nullptr && op.cout != 128)
+        cfail("first conv without the table variant is not 128 channels wide");
     }
     hp.f16_ok = conv_ok;
   }
@@ -1235,10 +1262,14 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           a.overflow = m->d_overflow;
           a.rows = nw * in.frames;
           a.L_in = in.L; a.L_out = lo;
-          a.cc_in = hp.cc_in; a.cout = op.cout; a.cout_pad = 128;
+          a.cc_in = hp.cc_in; a.cout = op.cout; a.cout_pad = op.cout;
           a.k = op.k; a.dil = op.dilation; a.pad_left = pl;
-          a.tiles_m = (lo + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m();
-          int strips_per_win = in.frames * a.tiles_m * 2;        // partial rows (128-position strips) per window
+          a.cw = hp.cw;
+          a.ostride = op.stride;
+          a.L_res = op.stride == 2 ? 2 * lo - 1 : lo;
+          a.tiles_m = (a.L_res + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m();
+          const int strips = hp.cw == 128 ? 2 : 4;               // wave strips per 256-position tile
+          int strips_per_win = in.frames * a.tiles_m * strips;   // partial rows (128- / 64-position strips) per window
           {
             // window-packed tiling when the frames fill their own 256-position tiles badly (e.g. 665 codons)
             static const bool no_flat = jg_exp_env("JG_NO_FLAT") != nullptr;
@@ -1249,7 +1280,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
             const int64_t flat_tiles = ((int64_t)nw * wp + 255) / 256;
             const int64_t row_tiles = (int64_t)a.rows * a.tiles_m;
             if (!no_flat && op.k == 5 && op.in_buf != JG_BUF_IDS && hp.d_lut == nullptr && op.stride == 1 && in.L == lo &&
-                jg_conv_f16_has_flat_pattern(hp.ep) &&
+                (op.cout == 128 ? jg_conv_f16_has_flat_pattern(hp.ep) : jg_conv_f16_has_narrow_pattern(hp.ep)) &&
                 (int64_t)nw * wp < (1 << 24) && flat_tiles * 100 <= row_tiles * 95) {
               a.flat = 1;
               a.flat_p = fp;
@@ -1258,7 +1289,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
               a.flat_tiles = (int)flat_tiles;
               a.flat_inv_p = 1.0f / (float)fp;
               a.flat_inv_wp = 1.0f / (float)wp;
-              strips_per_win = wp / 128;
+              strips_per_win = wp / (256 / strips);
             }
           }
           if (hp.nmd_slot >= 0) m->part_rows[hp.nmd_slot] = strips_per_win;
@@ -1275,7 +1306,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           if (hp.add_slot >= 0) a.addh = reinterpret_cast<const uint4 *>(m->act[hp.add_slot]);
           if (hp.nmd_slot >= 0) a.nmd_out = m->nmd_part[hp.nmd_slot];
           if (hp.pool_op >= 0) {
-            const int64_t need = (int64_t)a.rows * a.tiles_m * 2 * op.cout;
+            const int64_t need = (int64_t)a.rows * a.tiles_m * strips * op.cout;
             if (need > m->pool_part_cap) {
               JG_HIP(hipStreamSynchronize(s));
               if (m->pool_part) (void)hipFree(m->pool_part);
@@ -1289,9 +1320,16 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
             a.lut = hp.d_lut;
             a.lut_vocab = m->vocab;
             a.epi = hp.d_epi_lut;
+            a.lut_one_half = op.cout <= 64 ? 1 : 0;
           }
           pe.cls = hp.d_lut != nullptr ? JG_PROF_TABLE : JG_PROF_MFMA_F16X3;
           rc = jg_launch_conv_f16(e, a, s);
+          for (int hf = 1; hf < hp.n_half && rc == JG_OK; ++hf) {      // wider than 128 channels: one launch per 128
+            a.ch0 = hf * 128;
+            a.wh = hp.d_wh + (int64_t)hf * hp.wh_half_items;
+            a.epi = hp.d_epi + (int64_t)hf * hp.n_epi_rows * 2 * 128;
+            rc = jg_launch_conv_f16(e, a, s);
+          }
         } else {
           pe.cls = JG_PROF_MFMA_F32;
           ConvArgs a;
@@ -1310,7 +1348,10 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           a.cin = op.cin; a.cin_pad = (op.cin + 7) / 8 * 8;
           a.cout = op.cout; a.cout_pad = (op.cout + 31) / 32 * 32;
           a.k = op.k; a.stride = op.stride; a.dil = op.dilation; a.pad_left = pl;
-          a.tiles_m = (lo + jg_conv_tile_m(lo) - 1) / jg_conv_tile_m(lo);
+          {
+            const int tm_ = jg_conv_tile_m_for(lo, op.k, op.cin, op.stride, op.dilation);
+            a.tiles_m = (lo + tm_ - 1) / tm_;
+          }
           for (int q = 0; q < op.n_stages; ++q)
             if (op.stages[q].kind == JG_ST_NMD) m->part_rows[op.stages[q].arg] = in.frames * a.tiles_m;
           resolve_stages(m, op, a.st, &a.n_stages);

@@ -102,7 +102,12 @@ struct ConvHArgs {
   float *pool_out;         // fused masked max-pool partials, same geometry; when set the output is not stored
   int *overflow;           // set to 1 when an output leaves the f16 range
   int rows, L_in, L_out;
-  int cc_in, cout, cout_pad;
+  int cc_in, cout, cout_pad;   // cout_pad: output channels rounded up to 16 (F16S chunks of y / addh)
+  int ch0;                     // first output channel of this launch (convs wider than 128 run one launch per 128)
+  int cw;                      // channel width of a workgroup tile: 128, 64 or 32 (narrow convs: waves split positions only)
+  int ostride;                 // 1, or 2: the conv is evaluated at stride 1 over L_res positions and even ones are kept
+  int L_res;                   // positions the tiles resolve (= L_out when ostride == 1, 2*L_out - 1 otherwise)
+  int lut_one_half;            // table variant: only the first 64-channel half exists (cout <= 64)
   int k, dil, pad_left, tiles_m;
   // window-packed tiling (see jg_conv_f16_impl.h): frames of a window on one axis, row pitch flat_p, window
   // pitch flat_wp (multiple of 128), flat_tiles tiles of 256; 0 = every row tiled on its own
@@ -162,7 +167,10 @@ struct jg_engine {
 };
 
 struct ConvHPrep {          // per CONV op: split-f16 operands (built at model creation)
-  uint4 *d_wh = nullptr;    // weights [2][k][cin16/8][cout_pad]
+  uint4 *d_wh = nullptr;    // weights [n_half][2][k][cin16/8][128]
+  int n_half = 1;           // launches per conv: one per 128 output channels
+  int cw = 128;             // workgroup tile width (128, or 64 / 32 for narrow convs)
+  int64_t wh_half_items = 0;   // 16-byte items of one half's weight blob
   uint4 *d_embh = nullptr;  // embedding table [vocab][cin16/16][4] (conv on ids only)
   float acc_scale = 1.f;
   int cc_in = 0;
@@ -256,11 +264,13 @@ int jg_launch_maxpool1d_f16s(const uint4 *x, int rows, int L_in, int L_out, int 
 int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,
                        hipStream_t s);
 int jg_conv_tile_m(int l_out);
+int jg_conv_tile_m_for(int l_out, int k, int cin, int stride, int dil);
 int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_lds_bytes(int k, int dil);
 bool jg_conv_f16_supports(int k, int dil);
 int jg_conv_f16_tile_m(void);
 bool jg_conv_f16_has_pattern(unsigned ep, bool first_layer);
 bool jg_conv_f16_has_flat_pattern(unsigned ep);
+bool jg_conv_f16_has_narrow_pattern(unsigned ep);
 int jg_conv_lut_lds_bytes(int k, int vocab);
 bool jg_conv_lut_supports(int k, int dil, int vocab);

@@ -8,6 +8,9 @@ int jg_conv_f16_part_k5(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_k79(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_flat(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s);
+int jg_conv_f16_part_n64(jg_engine *e, const ConvHArgs &a, hipStream_t s);
+int jg_conv_f16_part_n32(jg_engine *e, const ConvHArgs &a, hipStream_t s);
+int jg_conv_f16_part_g128(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 
 namespace {
 constexpr int HM = 256, HN = 128, HT = 256, NT = 1, A_ITERS = 5, W_ITEMS = 2 * 2 * HN, LUT_RS = 68;   // as in jg_conv_f16_impl.h
@@ -73,6 +76,17 @@ bool jg_conv_f16_has_flat_pattern(unsigned ep) {
   return false;
 }
 
+// stage patterns compiled for the run-time-geometry variants (narrow convs of 64 / 32 output channels, the general
+// 128-wide tile: jg_conv_f16_part_n64 / _n32 / _g128, k = 5, both tilings)
+bool jg_conv_f16_has_narrow_pattern(unsigned ep) {
+  const unsigned nar[] = {0u, JG_EP_ACT1, JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_ADD | JG_EP_ACT1,
+                          JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2, JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1,
+                          JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1,
+                          JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2};
+  for (unsigned p : nar) if (p == ep) return true;
+  return false;
+}
+
 // JG_DBG ablation mask: read at every launch, so that an experiment can warm up on real data and then
 // switch (bench.py --timed-dbg)
 static int jg_dbg_env(void) {
@@ -81,9 +95,14 @@ static int jg_dbg_env(void) {
 }
 
 int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
-  JG_REQUIRE(a.cout_pad == HN && a.cout % 16 == 0, JG_ERR_UNSUPPORTED,
-             "conv_f16x3: cout=%d (needs 128 padded, multiple of 16)", a.cout);
+  JG_REQUIRE(a.cout % 16 == 0 && a.cout_pad == a.cout && a.ch0 % HN == 0 && a.ch0 < a.cout &&
+                 (a.cw == HN || ((a.cw == 64 || a.cw == 32) && a.cout <= a.cw && a.ch0 == 0)) &&
+                 (a.ostride == 1 || a.ostride == 2) && a.L_res == (a.ostride == 2 ? 2 * a.L_out - 1 : a.L_out),
+             JG_ERR_UNSUPPORTED, "conv_f16x3: cout=%d ch0=%d tile width %d out-stride %d (L_res %d, L_out %d) outside the kernel",
+             a.cout, a.ch0, a.cw, a.ostride, a.L_res, a.L_out);
   if (a.lut != nullptr) {
+    JG_REQUIRE(a.cw == HN && a.ostride == 1 && a.cout <= HN && (!a.lut_one_half || a.cout <= 64), JG_ERR_UNSUPPORTED,
+               "conv lut: cout=%d outside the table variant", a.cout);
     JG_REQUIRE(a.ids != nullptr && jg_conv_lut_supports(a.k, a.dil, a.lut_vocab), JG_ERR_UNSUPPORTED,
                "conv lut: k=%d dilation=%d vocab=%d outside the table variant's limits", a.k, a.dil, a.lut_vocab);
     if (a.rows == 0 || a.L_out <= 0) return JG_OK;
@@ -97,8 +116,17 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
              "conv_f16x3: activation tensor of %d rows exceeds the 32-bit DMA offset range", a.rows);
   if (a.rows == 0 || a.L_out <= 0) return JG_OK;
   const_cast<ConvHArgs &>(a).dbg = jg_dbg_env();
+  JG_REQUIRE(!a.lut_one_half, JG_ERR_INVALID, "conv_f16x3: lut_one_half without a table");
+  if (a.cw != HN) {
+    JG_REQUIRE(a.k == 5, JG_ERR_UNSUPPORTED, "conv_f16x3: narrow convs are only built for k = 5");
+    return a.cw == 64 ? jg_conv_f16_part_n64(e, a, s) : jg_conv_f16_part_n32(e, a, s);
+  }
+  if (a.cout != HN || a.ostride != 1) {        // (ch0 != 0 implies cout > 128)
+    JG_REQUIRE(a.k == 5, JG_ERR_UNSUPPORTED, "conv_f16x3: cout=%d out-stride %d is only built for k = 5", a.cout, a.ostride);
+    return jg_conv_f16_part_g128(e, a, s);
+  }
   if (a.flat) {
-    JG_REQUIRE(a.k == 5, JG_ERR_UNSUPPORTED, "conv_f16x3: window-packed tiling is only built for k = 5");
+    JG_REQUIRE(a.k == 5 && a.ostride == 1, JG_ERR_UNSUPPORTED, "conv_f16x3: window-packed tiling is only built for k = 5, stride 1");
     return jg_conv_f16_part_flat(e, a, s);
   }
   if (a.k == 5) return jg_conv_f16_part_k5(e, a, s);

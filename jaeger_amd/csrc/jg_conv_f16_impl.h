@@ -50,7 +50,6 @@ constexpr int HT = 256;       // threads: 4 waves, 2 (positions) x 2 (channels),
 constexpr int NT = 1;         // tiles per workgroup pass
 constexpr int A_ITERS = 5;    // 16-B activation pieces per thread per chunk (4*rows_a <= 1280)
 constexpr int W_ITERS = 2;    // 16-B weight items per thread per slice
-constexpr int TM = 4;         // 32-position blocks per wave
 constexpr int W_ITEMS = 2 * 2 * HN;           // 16-B items of one weight slice (chunk, tap): 8 KB
 constexpr int LUT_RS = 68;    // floats per LDS row of the first-layer table (64 + 4: rows 16 apart share banks)
 
@@ -160,7 +159,13 @@ static __device__ unsigned long long jg_stamp_acc[8];
 // table (k * (vocab + 1) rows, row `vocab` = zeros for padding) and its JG_LUT_WAVES (8) waves cover
 // four 256-position tiles per pass: waves {0,1} the first, {2,3} the second, ... - two waves per SIMD
 // share the table, so one's row lookups run under the other's epilogue.  K is unused (taps come from a.k).
-template <int K, unsigned EP, bool LUT = false, bool FLAT = false>
+// CW = channel width of the workgroup tile.  128: waves 2 x 2, 128 positions x 64 channels each, exactly 128 output
+// channels at stride 1 (the residual stacks: no run-time geometry in the epilogue).  129: the same tile with run-time
+// geometry - a channel base (convs wider than 128 run one launch per 128 channels), fewer than 128 real channels,
+// stride 2 evaluated at stride 1 with the odd outputs dropped.  64 / 32 (narrow convs of pyramid-shaped models): waves
+// 4 x 1, 64 positions x 64 / 32 channels each, run-time geometry too - the weight slices and the epilogue table keep
+// their 128-wide (zero-padded) layout, only the matrix-core work and the outputs shrink.
+template <int K, unsigned EP, bool LUT = false, bool FLAT = false, int CW = 128>
 // K = 5 fits two workgroups per CU in LDS (<= 80 KB each): hold the register file to 256 per
 // lane so that both are really resident (without the bound hipcc takes ~340 and the second
 // workgroup of a CU only starts when the first has finished).
@@ -168,15 +173,23 @@ __global__ __launch_bounds__(LUT ? JG_LUT_WAVES * 64 : HT) __attribute__((amdgpu
 void conv_f16x3_kernel(ConvHArgs a) {
   constexpr int NTHR = LUT ? JG_LUT_WAVES * 64 : HT;      // threads of this variant's workgroup
   constexpr int WA = K - 2;                  // weight slices in flight ahead of the matrix cores
+  constexpr bool NARROW = !LUT && (CW == 64 || CW == 32);
+  constexpr bool GEN = LUT || CW != 128;     // run-time output geometry (channel base, real width, out-stride)
+  const int ch0 = GEN ? a.ch0 : 0;
+  const int L_res = GEN ? a.L_res : a.L_out;
+  constexpr int TM = NARROW ? 2 : 4;         // 32-position blocks per wave
+  constexpr int TN = (NARROW && CW == 32) ? 1 : 2;   // 32-channel blocks per wave
+  constexpr int STRIPS = HM / (TM * 32);     // wave strips (partial NMD / pool rows) per tile: 2, or 4 when narrow
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = LUT ? (wid & 1) : (wid >> 1);
-  const int wn = LUT ? (int)(blockIdx.x & 1u) : (wid & 1);
+  const int wm = LUT ? (wid & 1) : (NARROW ? wid : (wid >> 1));
+  const int wn = LUT ? (a.lut_one_half ? 0 : (int)(blockIdx.x & 1u)) : (NARROW ? 0 : (wid & 1));
   const int i = lane & 31, h = lane >> 5;
   // virtual block index / grid / tiles per pass (LUT: two blocks = the two channel halves share one index)
-  const int vb = LUT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
-  const int vgrid = LUT ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+  const int lut_sh = (LUT && !a.lut_one_half) ? 1 : 0;
+  const int vb = (int)(blockIdx.x >> lut_sh);
+  const int vgrid = (int)(gridDim.x >> lut_sh);
   constexpr int TPER = LUT ? JG_LUT_WAVES / 2 : NT;       // tiles per pass (LUT: two waves per 256-position tile)
   const int tsub = LUT ? (wid >> 1) : 0;
   // LDS carve (16-byte units)
@@ -331,12 +344,12 @@ void conv_f16x3_kernel(ConvHArgs a) {
       if ((a_pk[it] >> 20) < NT && !((x_ok >> it) & 1u)) A[tid + it * HT] = make_uint4(0u, 0u, 0u, 0u);
   };
 
-  f32x16 acc[TM][2];        // [tm: position block][tn: channel block]
+  f32x16 acc[TM][TN];       // [tm: position block][tn: channel block]
   auto zero_acc = [&]() {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
   };
@@ -403,7 +416,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
           const int rowi = stage[tm * 32 + i + t * a.dil];
           const float *r = Tl + (t * (a.lut_vocab + 1) + rowi) * LUT_RS;
 #pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
+          for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const float4 v = *reinterpret_cast<const float4 *>(r + tn * 32 + 8 * g);
@@ -427,9 +440,9 @@ void conv_f16x3_kernel(ConvHArgs a) {
         const int ncc = last_chunk ? 0 : cc + 1;
         auto taps = [&](int t, auto &&mid, bool has_mid = true) {
           const uint4 *B = Wbuf + t * W_ITEMS + w_frag;
-          half8 wh[2], wl[2];
+          half8 wh[TN], wl[TN];
 #pragma unroll
-          for (int tn = 0; tn < 2; ++tn) {
+          for (int tn = 0; tn < TN; ++tn) {
             const uint4 vh = B[tn * 32];
             const uint4 vl = B[2 * HN + tn * 32];
             wh[tn] = *reinterpret_cast<const half8 *>(&vh);
@@ -448,7 +461,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
             for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
-              for (int tn = 0; tn < 2; ++tn) {
+              for (int tn = 0; tn < TN; ++tn) {
                 f32x16 &c = acc[tp * 2 + tq][tn];
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tn], xl[tq], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[tn], xh[tq], c, 0, 0, 0);
@@ -535,9 +548,9 @@ void conv_f16x3_kernel(ConvHArgs a) {
         // -- matrix-core work: one tap of one 16-channel chunk ----------------------------------
         if (!(a.dbg & 2)) {
           const uint4 *B = Wbuf + t * W_ITEMS + w_frag;
-          half8 wh[2], wl[2];
+          half8 wh[TN], wl[TN];
 #pragma unroll
-          for (int tn = 0; tn < 2; ++tn) {
+          for (int tn = 0; tn < TN; ++tn) {
             const uint4 vh = B[tn * 32];
             const uint4 vl = B[2 * HN + tn * 32];
             wh[tn] = *reinterpret_cast<const half8 *>(&vh);
@@ -556,7 +569,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
             for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
-              for (int tn = 0; tn < 2; ++tn) {
+              for (int tn = 0; tn < TN; ++tn) {
                 // weights are the MFMA A operand: acc rows = channels, cols = positions
                 f32x16 &c = acc[tp * 2 + tq][tn];
 #ifdef JG_MFMA16_PROBE
@@ -609,7 +622,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
 
     // ---- pass finished: fused epilogue straight from the accumulators ----------------------
     if (a.dbg & 1) {
-      if (acc[0][0][0] + acc[1][1][3] + acc[2][1][7] + acc[3][0][9] == 12345.678f) a.overflow[0] = 2;
+      if (acc[0][0][0] + acc[1][TN - 1][3] + acc[TM - 1][TN - 1][7] + acc[TM - 1][0][9] == 12345.678f) a.overflow[0] = 2;
     } else {
       JG_PRIO_EPI();
       float vmax = 0.f;             // running max |output|: f16-range guard
@@ -630,13 +643,19 @@ void conv_f16x3_kernel(ConvHArgs a) {
       };
       auto item4 = [&](int row, int mc, int nb, int j) -> unsigned {
         // hi-plane item of group 2j + h (uint4 units); lo plane = + 2*L_out
-        const int G = (nb >> 3) + 2 * j + h;
+        const int G = ((nb + ch0) >> 3) + 2 * j + h;
         return (unsigned)(((row * (a.cout_pad >> 4) + (G >> 1)) * 4 + (G & 1)) * a.L_out + mc);
       };
       // this lane's output position in block tm: row, clamped position, alive
       auto out_pos = [&](const Tile &tile, int tm, int &row, int &mc) -> bool {
         int p;
-        const bool live = resolve(tile, (wm * TM + tm) * 32 + i, a.L_out, row, p);
+        bool live = resolve(tile, (wm * TM + tm) * 32 + i, L_res, row, p);
+        if constexpr (GEN) {
+          if (a.ostride == 2) {           // stride-2 conv evaluated at stride 1: odd positions are dropped
+            live = live && !(p & 1);
+            p >>= 1;
+          }
+        }
         mc = live ? p : 0;
         if constexpr (FLAT) {
           if (!live) row = min(max(row, 0), a.rows - 1);
@@ -651,7 +670,8 @@ void conv_f16x3_kernel(ConvHArgs a) {
         if (a.addh != nullptr && !(a.dbg & 128)) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const unsigned it4 = item4(orow, mc, nb, j);
+            // (a 16-channel chunk past the tensor's width - zero-padded weights - reads the last real chunk: unused)
+            const unsigned it4 = item4(orow, mc, (!GEN || nb + ch0 + 16 * j < a.cout) ? nb : 0, j);
             uint4 vh = a.addh[it4];                        // whole item of group 2j+h
             uint4 vl = a.addh[it4 + 2u * (unsigned)a.L_out];
             // give each lane back its own 4 channels of groups 2j and 2j+1
@@ -807,6 +827,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
             uint4 *yh = reinterpret_cast<uint4 *>(a.y);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+              if (GEN && nb + ch0 + 16 * j >= a.cout) continue;     // zero-padded channels of a narrow conv
               const unsigned it4 = item4(orow, mc, nb, j);
               typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
               const u32x4 vhi = {__float_as_uint(x[4 * j]), __float_as_uint(x[4 * j + 1]),
@@ -819,10 +840,10 @@ void conv_f16x3_kernel(ConvHArgs a) {
               __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)a.L_out));
             }
           } else {
-            float *yf = reinterpret_cast<float *>(a.y) + ((size_t)orow * a.L_out + mc) * a.cout + nb + 4 * h;
+            float *yf = reinterpret_cast<float *>(a.y) + ((size_t)orow * a.L_out + mc) * a.cout + ch0 + nb + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-              if (nb + 8 * g + 4 * h < a.cout)
+              if (ch0 + nb + 8 * g + 4 * h < a.cout)
                 *reinterpret_cast<float4 *>(yf + 8 * g) =
                     make_float4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
           }
@@ -858,8 +879,8 @@ void conv_f16x3_kernel(ConvHArgs a) {
       // where lane i's reduced channel lives, and the partial row of this wave's 128 positions
       auto reduced_slot = [&](const Tile &tile, int tn, int &ch) -> size_t {
         const int r = 8 * (int)((i & 4) != 0) + 4 * (int)((i & 2) != 0) + 2 * (int)((i & 1) != 0) + (int)((i & 8) != 0);
-        ch = (wn * 2 + tn) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-        return ((size_t)tile.T * 2 + wm) * a.cout + ch;     // one partial row per 128-position strip
+        ch = ch0 + (wn * 2 + tn) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        return ((size_t)tile.T * STRIPS + wm) * a.cout + ch;     // one partial row per wave strip (128 / 64 positions)
       };
       auto nmd_flush = [&](const Tile &tile, int tn) {
         const float v = lane_reduce(nmd_acc, [](float x, float y) { return x + y; });
@@ -869,7 +890,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
       };
       const bool has_nmd = EP == JG_EP_GENERIC ? a.nmd_out != nullptr : (EP & (JG_EP_NMD1 | JG_EP_NMD2)) != 0;
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
+      for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) nmd_acc[r] = 0.f;
 #pragma unroll
@@ -888,7 +909,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
           mkv[tm] = (live && mb != 0) ? 1.f : 0.f;
         }
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
+        for (int tn = 0; tn < TN; ++tn) {
           float pa[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) pa[r] = -INFINITY;
@@ -904,8 +925,8 @@ void conv_f16x3_kernel(ConvHArgs a) {
       } else {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-          store_block(acc[tm][0], cur[0], tm, 0);
-          store_block(acc[tm][1], cur[0], tm, 1);
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) store_block(acc[tm][tn], cur[0], tm, tn);
         }
       }
       if (!(vmax <= 65000.0f) && a.overflow != nullptr && a.dbg == 0) atomicOr(a.overflow, 1);
@@ -924,12 +945,12 @@ void conv_f16x3_kernel(ConvHArgs a) {
   JG_ST_END;
 }
 
-template <int K, unsigned EP, bool FLAT = false>
+template <int K, unsigned EP, bool FLAT = false, int CW = 128>
 int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   const int smem = jg_conv_f16_lds_bytes(K, a.dil);
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<K, EP, false, FLAT>),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<K, EP, false, FLAT, CW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -942,7 +963,7 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   int grid = ((smem <= 80 * 1024 && !one_wg) ? 2 : 1) * e->n_cu;
   if (grid > n_pairs) grid = n_pairs;
   ConvHArgs b = a;
-  hipLaunchKernelGGL((conv_f16x3_kernel<K, EP, false, FLAT>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, b);
+  hipLaunchKernelGGL((conv_f16x3_kernel<K, EP, false, FLAT, CW>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, b);
   JG_HIP(hipGetLastError());
 #ifdef JG_STAMP
   {
@@ -971,7 +992,9 @@ int launch_lut_e(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   const int n_tiles = a.rows * a.tiles_m;
   constexpr int tper = JG_LUT_WAVES / 2;
   const int n_pairs = (n_tiles + tper - 1) / tper;
-  const int grid = 2 * (n_pairs < e->n_cu / 2 ? n_pairs : e->n_cu / 2);   // (tile group, channel half); one per CU
+  // (tile group, channel half), one workgroup per CU; a conv of <= 64 channels has only the first half
+  const int grid = a.lut_one_half ? (n_pairs < e->n_cu ? n_pairs : e->n_cu)
+                                  : 2 * (n_pairs < e->n_cu / 2 ? n_pairs : e->n_cu / 2);
   hipLaunchKernelGGL((conv_f16x3_kernel<0, EP, true>), dim3((unsigned)grid), dim3(JG_LUT_WAVES * 64), (size_t)smem, s, a);
   JG_HIP(hipGetLastError());
   return JG_OK;
@@ -1065,4 +1088,34 @@ int jg_conv_f16_part_flat(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
 }
 #elif JG_CONV_PART == 4    // first-layer table variant
 int jg_conv_f16_part_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) { return launch_lut(e, a, s); }
+#elif JG_CONV_PART >= 5 && JG_CONV_PART <= 7   // run-time output geometry, k = 5, both tilings: narrow convs (64 / 32
+                                               // output channels) and the general 128-wide tile (CW = 129)
+#if JG_CONV_PART == 5
+#define JG_NARROW_CW 64
+int jg_conv_f16_part_n64(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+#elif JG_CONV_PART == 6
+#define JG_NARROW_CW 32
+int jg_conv_f16_part_n32(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+#else
+#define JG_NARROW_CW 129
+int jg_conv_f16_part_g128(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+#endif
+  switch (a.ep) {
+#define JG_CASE(ep)                                                          \
+  case (ep):                                                                 \
+    return a.flat ? launch_ke<5, (ep), true, JG_NARROW_CW>(e, a, s) : launch_ke<5, (ep), false, JG_NARROW_CW>(e, a, s);
+    JG_CASE(0u)
+    JG_CASE(JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_AFF | JG_EP_ACT1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)
+    JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1)
+    JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)
+#undef JG_CASE
+    default: break;
+  }
+  jg_set_error("conv_f16x3: stage pattern 0x%x has no compiled narrow-conv epilogue", a.ep);
+  return JG_ERR_UNSUPPORTED;
+}
 #endif

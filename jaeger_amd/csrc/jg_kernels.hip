@@ -416,6 +416,21 @@ int jg_conv_tile_m(int l_out) {
   return (t64 * 10 <= t128 * 9) ? 64 : 128;
 }
 
+// LDS bytes of a BM-position tile: the staged input rows, or the accumulator exchange of the epilogue
+static size_t conv_f32_lds(int bm, int bn, int k, int cin_pad, int stride, int dil) {
+  const size_t rows_in = (size_t)(bm - 1) * stride + (size_t)(k - 1) * dil + 1;
+  const size_t lds_a = rows_in * (cin_pad + 4) * sizeof(float), lds_c = (size_t)bm * (bn + 4) * sizeof(float);
+  return ((lds_a > lds_c ? lds_a : lds_c) + 15) & ~(size_t)15;
+}
+
+// ... of one conv: 64 as well when the input rows of a 128-position tile do not fit the 160 KB of LDS (wide inputs
+// under a long halo or a stride: 256 channels at dilation 8 need 166 KB)
+int jg_conv_tile_m_for(int l_out, int k, int cin, int stride, int dil) {
+  const int cin_pad = (cin + 7) / 8 * 8;
+  if (conv_f32_lds(128, 128, k, cin_pad, stride, dil) > 160 * 1024) return 64;
+  return jg_conv_tile_m(l_out);
+}
+
 template <int WM, int WN, int TM, int TN>
 static int launch_conv_t(const ConvArgs &a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -445,7 +460,7 @@ int jg_launch_conv(jg_engine *e, const ConvArgs &a, hipStream_t s) {
   JG_REQUIRE(a.cin % 4 == 0 && a.cout % 4 == 0, JG_ERR_UNSUPPORTED,
              "conv: cin=%d / cout=%d must be multiples of 4", a.cin, a.cout);
   if (a.rows == 0 || a.L_out <= 0) return JG_OK;
-  const bool bm64 = jg_conv_tile_m(a.L_out) == 64;
+  const bool bm64 = jg_conv_tile_m_for(a.L_out, a.k, a.cin, a.stride, a.dil) == 64;
   JG_REQUIRE(a.tiles_m == (a.L_out + (bm64 ? 63 : 127)) / (bm64 ? 64 : 128), JG_ERR_INVALID,
              "conv: tiles_m=%d does not match the tile size chosen for L_out=%d", a.tiles_m, a.L_out);
   if (a.cout_pad % 128 == 0) return bm64 ? launch_conv_t<2, 2, 1, 2>(a, s) : launch_conv_t<2, 2, 2, 2>(a, s);

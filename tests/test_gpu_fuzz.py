@@ -1,6 +1,6 @@
 """Differential fuzz of the program compiler + format planner + kernels: seeded random conv-family architectures
-(kernel sizes, dilations, strides, widths, norm types, mask modes, 1x1 bypasses, NMD taps in either position,
-return_nmd, pooling) run on the split-f16 / mixed path AND on the exact-f32 path, both against the CPU oracle."""
+(kernel sizes, dilations, strides, widths - constant or changing from block to block like the reference's pyramid
+ResNet, 32 to 256 channels -, norm types, mask modes, 1x1 bypasses, NMD taps in either position, return_nmd, pooling) run on the split-f16 / mixed path AND on the exact-f32 path, both against the CPU oracle."""
 import copy
 
 import numpy as np
@@ -15,6 +15,7 @@ TOL = 1e-4
 def random_model(rng):
     base = copy.deepcopy(load_model_cfg("brain"))
     width = int(rng.choice([128, 128, 128, 64, 32]))
+    pyramid = rng.random() < 0.4                             # widths change from block to block
     emb = int(rng.choice([16, 64, 128]))
     base["embedding"]["embedding_size"] = emb
     layers = []
@@ -42,14 +43,19 @@ def random_model(rng):
 
     tail()
     for _ in range(int(rng.integers(1, 4))):
+        prev_width = width
+        if pyramid and rng.random() < 0.7:
+            width = int(rng.choice([32, 64, 128, 128, 256]))
         if rng.random() < 0.8:
             nt = str(rng.choice(["masked_batchnorm", "masked_batchnorm", "masked_dyt", "masked_layernorm"]))
             cfg = {"filters": width, "kernel_size": int(rng.choice([3, 5, 5, 7])), "block_size": int(rng.integers(1, 3)),
-                   "dilation_rate": int(rng.choice([1, 2, 3])), "strides": int(rng.choice([1, 1, 1, 2])),
+                   "dilation_rate": int(rng.choice([1, 2, 3, 4, 8])), "strides": int(rng.choice([1, 1, 1, 2])),
                    "use_1x1conv": bool(rng.random() < 0.3), "norm_type": nt}
             if nt == "masked_batchnorm" and rng.random() < 0.3:
                 cfg["return_nmd"] = True
                 n_nmd += 1
+            if width != prev_width and cfg["strides"] == 1:
+                cfg["use_1x1conv"] = True                    # (the reference adds x itself otherwise: layers.py:1905-1912)
             layers.append({"name": "residual_block", "config": cfg})
         else:
             layers.append({"name": "masked_conv1d", "config": {"filters": width, "kernel_size": int(rng.choice([1, 3, 5])),
