@@ -142,11 +142,18 @@ int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const float *weig
 int jg_model_destroy(jg_model *m);
 /* Arithmetic of the conv stack: 0 = exact-f32 MFMA, 1 = split-f16 ("f16x3": each f32 operand
  * as an f16 hi/lo pair, three f16 MFMAs per product, f32 accumulate; ~f32 accuracy).  A model
- * starts in mode 1 when every conv is eligible (128 output channels, stride 1), else 0; mode 1
+ * starts in mode 1 when at least one conv is eligible (k = 5: 32, 64, 80..128 or a multiple of 128 output
+ * channels, stride 1 or 2; k = 7 / 9: 128 channels, stride 1; a compiled epilogue pattern), else 0; mode 1
  * falls back to 0 by itself if an activation ever leaves the f16 range.  Replaces the
  * --precision switch of commands/predict.py:604-613 (which trades accuracy; this one does not). */
 int jg_model_set_precision(jg_model *m, int mode);
 int jg_model_get_precision(const jg_model *m);
+/* How the program was placed: JG_MSTAT_CONVS convolutions, JG_MSTAT_CONVS_F16X3 of them on the split-f16 kernels in
+ * mode 1 (the others - 1x1 bypasses, widths or strides outside the kernel - run on the exact-f32 kernel with a layout
+ * conversion either side: JG_MSTAT_LAYOUT_CONVERSIONS), JG_MSTAT_SMALL_FUSED = 1 when the whole conv stack runs as the
+ * fused small-window kernel.  -1 for an unknown key. */
+enum { JG_MSTAT_CONVS = 0, JG_MSTAT_CONVS_F16X3 = 1, JG_MSTAT_LAYOUT_CONVERSIONS = 2, JG_MSTAT_SMALL_FUSED = 3 };
+int64_t jg_model_get_stat(const jg_model *m, int key);
 
 /* ---- hot path ----------------------------------------------------------- */
 /* Replaces fragment_generator's per-window slice + 4x str.count

@@ -18,6 +18,7 @@ JG_PTR_HOST, JG_PTR_DEVICE = 0, 1
 JG_BUF_NONE, JG_BUF_IDS = -1, -2
 JG_OPT_STREAM_BYTES = 1
 JG_STAT_STREAM_GROUPS, JG_STAT_STREAM_BYTES, JG_STAT_PEAK_DEVICE_BASES = 1, 2, 3
+JG_MSTAT_CONVS, JG_MSTAT_CONVS_F16X3, JG_MSTAT_LAYOUT_CONVERSIONS, JG_MSTAT_SMALL_FUSED = 0, 1, 2, 3
 
 # jg_op_kind
 OP_CONV, OP_MASK, OP_POOL, OP_DENSE, OP_ELTWISE, OP_NMD_FINAL, OP_OODSIG, OP_MAXPOOL1D, OP_FRAMESUM = range(1, 10)
@@ -78,6 +79,7 @@ SYMBOLS = {
     "jg_model_destroy": (C.c_int, [_vp]),
     "jg_model_set_precision": (C.c_int, [_vp, C.c_int]),
     "jg_model_get_precision": (C.c_int, [_vp]),
+    "jg_model_get_stat": (C.c_int64, [_vp, C.c_int]),
     "jg_encode": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_int, C.c_int64, C.c_int32, _vp,
                             C.c_int32, C.c_int32, _vp, _vp, C.c_int, _vp]),
     "jg_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, C.c_int,

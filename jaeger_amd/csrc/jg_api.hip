@@ -994,6 +994,24 @@ extern "C" int jg_model_set_precision(jg_model *m, int mode) {
 
 extern "C" int jg_model_get_precision(const jg_model *m) { return m ? m->precision : -1; }
 
+extern "C" int64_t jg_model_get_stat(const jg_model *m, int key) {
+  if (m == nullptr) return -1;
+  int64_t n_conv = 0, n_f16 = 0, n_cvt = 0;
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    n_cvt += m->hprep[i].n_cvt;
+    if (m->ops[i].kind != JG_OP_CONV) continue;
+    ++n_conv;
+    n_f16 += (m->f16_eligible && m->hprep[i].f16_ok) ? 1 : 0;
+  }
+  switch (key) {
+    case JG_MSTAT_CONVS: return n_conv;
+    case JG_MSTAT_CONVS_F16X3: return n_f16;
+    case JG_MSTAT_LAYOUT_CONVERSIONS: return m->f16_eligible ? n_cvt : 0;
+    case JG_MSTAT_SMALL_FUSED: return m->small != nullptr ? 1 : 0;
+    default: return -1;
+  }
+}
+
 extern "C" int jg_model_destroy(jg_model *m);
 extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const float *weights,
                                int64_t n_weights, int32_t vocab, jg_model **out) {

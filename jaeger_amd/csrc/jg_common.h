@@ -61,6 +61,7 @@ struct ConvArgs {
   int cin, cin_pad, cout, cout_pad;
   int k, stride, dil, pad_left;
   int tiles_m;
+  int cchunk;        // input channels staged in LDS per pass (set by the launcher)
   int mask_from_ids; // conv input multiplied by (ids != 0)
   int n_stages;
   StageArg st[JG_MAX_STAGES];

@@ -281,38 +281,11 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
   const int tile = blockIdx.x - row * a.tiles_m;
   const int n_blk = blockIdx.y * BN;
   const int m0 = tile * BM;
-  const int ldr = a.cin_pad + 4;           // cin_pad is a multiple of 8 here
+  const int cch = a.cchunk;                // input channels staged per pass (a multiple of 8; = cin_pad when all fit)
+  const int ldr = cch + 4;
   const int rows_in = (BM - 1) * a.stride + (a.k - 1) * a.dil + 1;
   const int p0 = m0 * a.stride - a.pad_left;
 
-  // ---- stage the input rows ------------------------------------------------
-  {
-    const int c4 = a.cin >> 2;
-    const int total = rows_in * c4;
-    for (int idx = tid; idx < total; idx += NT) {
-      const int r = idx / c4, cq = idx - r * c4;
-      const int p = p0 + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p >= 0 && p < a.L_in) {
-        const size_t pos = (size_t)row * a.L_in + p;
-        if (a.ids != nullptr) {
-          const int id = a.ids[pos];
-          if (id != 0 || !a.mask_from_ids)
-            v = *reinterpret_cast<const float4 *>(a.emb + (size_t)id * a.cin + cq * 4);
-        } else if (a.mask_in == nullptr || a.mask_in[pos] != 0) {
-          v = *reinterpret_cast<const float4 *>(a.x + pos * a.cin + cq * 4);
-        }
-      }
-      *reinterpret_cast<float4 *>(smem + r * ldr + cq * 4) = v;
-    }
-    if (a.cin_pad != a.cin) {  // zero K padding (cin not a multiple of the 8-channel group)
-      for (int r = tid; r < rows_in; r += NT)
-        for (int c = a.cin; c < a.cin_pad; ++c) smem[r * ldr + c] = 0.f;
-    }
-  }
-  __syncthreads();
-
-  // ---- MFMA main loop --------------------------------------------------------
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
@@ -326,18 +299,49 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
   // this lane's weight quads: [tap][group][cout_pad][8], channels 4h..4h+3 of output column n
   const float4 *wq = reinterpret_cast<const float4 *>(a.w8) + ((size_t)n_blk + wn * (TN * 32) + i) * 2 + h;
   const size_t w_group = (size_t)a.cout_pad * 2;                 // float4 units per (tap, group)
-  const int steps = a.k * groups;
+  // Input channels go through LDS in passes of `cch` (one pass unless the rows of a wide input under a long halo or a
+  // stride exceed the 160 KB: 256 channels x 175 rows at k = 7, dilation 8, stride 2)
+  for (int c0 = 0; c0 < a.cin_pad; c0 += cch) {
+  const int cw = min(cch, a.cin_pad - c0);                        // multiple of 8
+  if (c0 != 0) __syncthreads();                                   // every wave is done with the previous pass's rows
+  // ---- stage the input rows (mask multiply / embedding gather / zero K padding fused) -----------------------------
+  {
+    const int c4 = cw >> 2;
+    const int total = rows_in * c4;
+    for (int idx = tid; idx < total; idx += NT) {
+      const int r = idx / c4, cq = idx - r * c4;
+      const int p = p0 + r;
+      const int c = c0 + cq * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p >= 0 && p < a.L_in && c < a.cin) {                    // (cin is a multiple of 4)
+        const size_t pos = (size_t)row * a.L_in + p;
+        if (a.ids != nullptr) {
+          const int id = a.ids[pos];
+          if (id != 0 || !a.mask_from_ids)
+            v = *reinterpret_cast<const float4 *>(a.emb + (size_t)id * a.cin + c);
+        } else if (a.mask_in == nullptr || a.mask_in[pos] != 0) {
+          v = *reinterpret_cast<const float4 *>(a.x + pos * a.cin + c);
+        }
+      }
+      *reinterpret_cast<float4 *>(smem + r * ldr + cq * 4) = v;
+    }
+  }
+  __syncthreads();
+  // ---- MFMA main loop over (tap, 8-channel group of this pass) ---------------------------------------------------
+  const int gpass = cw >> 3, g0 = c0 >> 3;
+  const int steps = a.k * gpass;
   float4 bnext[TN];
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) bnext[tn] = wq[(size_t)tn * 64];
+  for (int tn = 0; tn < TN; ++tn) bnext[tn] = wq[(size_t)g0 * w_group + (size_t)tn * 64];
   int t = 0, g = 0;
   for (int sidx = 0; sidx < steps; ++sidx) {
     float4 bv[TN], av[TM];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) bv[tn] = bnext[tn];
     if (sidx + 1 < steps) {
+      const int gn = g + 1 == gpass ? 0 : g + 1, tnx = g + 1 == gpass ? t + 1 : t;
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) bnext[tn] = wq[(size_t)(sidx + 1) * w_group + (size_t)tn * 64];
+      for (int tn = 0; tn < TN; ++tn) bnext[tn] = wq[(size_t)(tnx * groups + g0 + gn) * w_group + (size_t)tn * 64];
     }
     const float *arow = smem + ((wm * (TM * 32) + i) * a.stride + t * a.dil) * ldr + g * 8 + 4 * h;
 #pragma unroll
@@ -351,7 +355,8 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].z, bv[tn].z, acc[tm][tn], 0, 0, 0);
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].w, bv[tn].w, acc[tm][tn], 0, 0, 0);
       }
-    if (++g == groups) { g = 0; ++t; }
+    if (++g == gpass) { g = 0; ++t; }
+  }
   }
   __syncthreads();  // every wave is done reading the input rows
 
@@ -416,10 +421,10 @@ int jg_conv_tile_m(int l_out) {
   return (t64 * 10 <= t128 * 9) ? 64 : 128;
 }
 
-// LDS bytes of a BM-position tile: the staged input rows, or the accumulator exchange of the epilogue
-static size_t conv_f32_lds(int bm, int bn, int k, int cin_pad, int stride, int dil) {
+// LDS bytes of a BM-position tile: `cch` channels of the staged input rows, or the accumulator exchange of the epilogue
+static size_t conv_f32_lds(int bm, int bn, int k, int cch, int stride, int dil) {
   const size_t rows_in = (size_t)(bm - 1) * stride + (size_t)(k - 1) * dil + 1;
-  const size_t lds_a = rows_in * (cin_pad + 4) * sizeof(float), lds_c = (size_t)bm * (bn + 4) * sizeof(float);
+  const size_t lds_a = rows_in * (cch + 4) * sizeof(float), lds_c = (size_t)bm * (bn + 4) * sizeof(float);
   return ((lds_a > lds_c ? lds_a : lds_c) + 15) & ~(size_t)15;
 }
 
@@ -431,17 +436,23 @@ int jg_conv_tile_m_for(int l_out, int k, int cin, int stride, int dil) {
   return jg_conv_tile_m(l_out);
 }
 
+// input channels staged per pass of that tile: all of them when they fit, else the largest multiple of 8 that does
+// (0: not even 8 channels fit - taps x dilation beyond any model family here)
+static int conv_f32_cchunk(int bm, int k, int cin_pad, int stride, int dil) {
+  const size_t rows_in = (size_t)(bm - 1) * stride + (size_t)(k - 1) * dil + 1;
+  const long fit = (long)((160 * 1024) / (rows_in * sizeof(float))) - 4;
+  if (fit >= cin_pad) return cin_pad;
+  return fit < 8 ? 0 : (int)(fit / 8 * 8);
+}
+
 template <int WM, int WN, int TM, int TN>
 static int launch_conv_t(const ConvArgs &a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  const int rows_in = (BM - 1) * a.stride + (a.k - 1) * a.dil + 1;
-  size_t lds_a = (size_t)rows_in * (a.cin_pad + 4) * sizeof(float);
-  size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
-  size_t smem = lds_a > lds_c ? lds_a : lds_c;
-  smem = (smem + 15) & ~(size_t)15;
-  JG_REQUIRE(smem <= 160 * 1024, JG_ERR_UNSUPPORTED,
-             "conv: k=%d cin=%d stride=%d dil=%d needs %zu B of LDS (>160 KiB)", a.k, a.cin,
-             a.stride, a.dil, smem);
+  ConvArgs b = a;
+  b.cchunk = conv_f32_cchunk(BM, a.k, a.cin_pad, a.stride, a.dil);
+  JG_REQUIRE(b.cchunk >= 8, JG_ERR_UNSUPPORTED, "conv: k=%d stride=%d dil=%d: not even 8 input channels of a tile's %d rows fit LDS",
+             a.k, a.stride, a.dil, (BM - 1) * a.stride + (a.k - 1) * a.dil + 1);
+  const size_t smem = conv_f32_lds(BM, BN, a.k, b.cchunk, a.stride, a.dil);
   auto kern = conv_f32_kernel<WM, WN, TM, TN>;
   static size_t attr_set = 0;
   if (smem > attr_set) {
@@ -450,7 +461,7 @@ static int launch_conv_t(const ConvArgs &a, hipStream_t s) {
     attr_set = 160 * 1024;
   }
   dim3 grid((unsigned)((size_t)a.rows * a.tiles_m), (unsigned)((a.cout + BN - 1) / BN));
-  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, b);
   JG_HIP(hipGetLastError());
   return JG_OK;
 }

@@ -177,6 +177,13 @@ class HipModel:
         L.check(self.lib.jg_model_set_precision(self.handle, {"f32": 0, "f16x3": 1}[mode]),
                 "jg_model_set_precision")
 
+    def placement(self) -> dict:
+        """How the program was placed on the kernels (``jg_model_get_stat``): number of convolutions, how many of them
+        run on the split-f16 kernels in "f16x3" mode, queued F16S <-> f32 layout conversions, fused small-window kernel."""
+        g = lambda k: int(self.lib.jg_model_get_stat(self.handle, k))  # noqa: E731
+        return {"convs": g(L.JG_MSTAT_CONVS), "convs_f16x3": g(L.JG_MSTAT_CONVS_F16X3),
+                "layout_conversions": g(L.JG_MSTAT_LAYOUT_CONVERSIONS), "small_fused": bool(g(L.JG_MSTAT_SMALL_FUSED))}
+
     def flops_per_window(self, l: int) -> float:
         return float(self.lib.jg_model_flops_per_window(self.handle, int(l)))
 

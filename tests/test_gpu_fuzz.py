@@ -90,7 +90,7 @@ def random_model(rng):
         base["embedding"].update(use_embedding_layer=False, embedding_size=int(rng.choice([0, 32])),
                                  input_shape=[6, None, 64])
         base["string_processor"]["seq_onehot"] = True
-    if rng.random() < 0.15 and width == 32:                  # the small-window family shape: k = 3 blocks, batch norms
+    if rng.random() < 0.15 and width == 32 and not pyramid:                  # the small-window family shape: k = 3 blocks, batch norms
         layers = [layers[0], {"name": "masked_batchnorm", "config": {}}, {"name": "activation", "config": {"activation": "gelu"}},
                   {"name": "residual_block", "config": {"filters": 32, "kernel_size": 3,
                                                         "block_size": int(rng.integers(1, 3))}},

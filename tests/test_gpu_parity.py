@@ -79,12 +79,16 @@ def test_encoder_case_flags_and_id_maps(device):
     np.testing.assert_array_equal(ids[2], lit.astype(np.uint8))
 
 
-def _forward_case(name, fsize, n_win, seed, n_frac, chunk=0, short=False, precision=None):
+def _forward_case(name, fsize, n_win, seed, n_frac, chunk=0, short=False, precision=None, gain=None, placement=None):
     from jaeger_amd.engine import JaegerHipEngine, frame_length
     from oracle import encoder as oenc
     from oracle import forward as ofwd
     cfg = load_model_cfg(name)
     weights = ofwd.random_weights(cfg, seed=38341)
+    if gain is not None:            # deep residual pyramids: He-uniform stand-in kernels blow the logits up to +-900
+        for key in weights:
+            if key.startswith("rep/") and key.endswith("/kernel"):
+                weights[key] = weights[key] * np.float32(gain)
     rng = np.random.Generator(np.random.PCG64(seed))
     seq = _random_dna(rng, fsize * n_win, n_frac=n_frac)
     starts = (np.arange(n_win) * fsize).astype(np.int64)
@@ -94,6 +98,9 @@ def _forward_case(name, fsize, n_win, seed, n_frac, chunk=0, short=False, precis
     eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, chunk=chunk, precision=precision)
     if precision is not None:
         assert eng.model.precision == precision
+    if placement is not None and eng.model.precision == "f16x3":
+        got_pl = eng.model.placement()
+        assert {k: got_pl[k] for k in placement} == placement, got_pl
     got = eng.predict_windows(seq, starts, lens, fsize)
     windows = [seq[s:s + n].tobytes() for s, n in zip(starts, lens)]
     ids = oenc.encode_windows(windows, fsize, pad_to=frame_length(fsize))
@@ -137,6 +144,22 @@ def test_forward_brain_2000_short_windows(precision):
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_forward_zeus_dyt(precision):
     _forward_case("zeus", 1500, 6, 4, n_frac=0.01, precision=precision)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_pyramid_resnet(precision):
+    """The reference's pyramid ResNet (train_config/nn_config_baseline.yaml: embedding 192, widths 32 / 64 / 128 / 256,
+    stride-2 blocks with 1x1 bypasses, dilations 1 - 8, 2 000-bp windows).  Split-f16: 32- and 64-channel workgroup tiles,
+    two launches per 256-channel conv, stride-2 convs evaluated at stride 1, window-packed tiles; only the three 1x1
+    bypass convs stay on the exact-f32 kernel.  Exact f32: 64-position tiles where 128 input positions x 256 channels
+    do not fit LDS."""
+    _forward_case("pyramid", 2000, 7, 21, n_frac=0.01, precision=precision, gain=0.85,
+                  placement={"convs": 36, "convs_f16x3": 33, "small_fused": False})
+
+
+def test_forward_pyramid_resnet_short_windows_chunked():
+    _forward_case("pyramid", 2000, 9, 22, n_frac=0.03, short=True, chunk=4, precision="f16x3", gain=0.85)
+    _forward_case("pyramid", 900, 5, 23, n_frac=0.0, precision="f16x3", gain=0.85)
 
 
 def test_default_precision_is_f16x3_when_eligible():
