@@ -174,7 +174,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
   constexpr int NTHR = LUT ? JG_LUT_WAVES * 64 : HT;      // threads of this variant's workgroup
   constexpr int WA = K - 2;                  // weight slices in flight ahead of the matrix cores
   constexpr bool NARROW = !LUT && (CW == 64 || CW == 32);
-  constexpr bool GEN = LUT || CW != 128;     // run-time output geometry (channel base, real width, out-stride)
+  constexpr bool GEN = CW != 128;            // run-time output geometry (channel base, real width, out-stride)
   const int ch0 = GEN ? a.ch0 : 0;
   const int L_res = GEN ? a.L_res : a.L_out;
   constexpr int TM = NARROW ? 2 : 4;         // 32-position blocks per wave
@@ -184,10 +184,10 @@ void conv_f16x3_kernel(ConvHArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = LUT ? (wid & 1) : (NARROW ? wid : (wid >> 1));
-  const int wn = LUT ? (a.lut_one_half ? 0 : (int)(blockIdx.x & 1u)) : (NARROW ? 0 : (wid & 1));
+  const int wn = LUT ? ((GEN && a.lut_one_half) ? 0 : (int)(blockIdx.x & 1u)) : (NARROW ? 0 : (wid & 1));
   const int i = lane & 31, h = lane >> 5;
   // virtual block index / grid / tiles per pass (LUT: two blocks = the two channel halves share one index)
-  const int lut_sh = (LUT && !a.lut_one_half) ? 1 : 0;
+  const int lut_sh = (LUT && !(GEN && a.lut_one_half)) ? 1 : 0;
   const int vb = (int)(blockIdx.x >> lut_sh);
   const int vgrid = (int)(gridDim.x >> lut_sh);
   constexpr int TPER = LUT ? JG_LUT_WAVES / 2 : NT;       // tiles per pass (LUT: two waves per 256-position tile)
@@ -980,12 +980,12 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
 }
 
 #if JG_CONV_PART == 4
-template <unsigned EP>
+template <unsigned EP, int CW>
 int launch_lut_e(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   const int smem = jg_conv_lut_lds_bytes(a.k, a.lut_vocab);
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<0, EP, true>),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<0, EP, true, false, CW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -995,14 +995,15 @@ int launch_lut_e(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   // (tile group, channel half), one workgroup per CU; a conv of <= 64 channels has only the first half
   const int grid = a.lut_one_half ? (n_pairs < e->n_cu ? n_pairs : e->n_cu)
                                   : 2 * (n_pairs < e->n_cu / 2 ? n_pairs : e->n_cu / 2);
-  hipLaunchKernelGGL((conv_f16x3_kernel<0, EP, true>), dim3((unsigned)grid), dim3(JG_LUT_WAVES * 64), (size_t)smem, s, a);
+  hipLaunchKernelGGL((conv_f16x3_kernel<0, EP, true, false, CW>), dim3((unsigned)grid), dim3(JG_LUT_WAVES * 64), (size_t)smem, s, a);
   JG_HIP(hipGetLastError());
   return JG_OK;
 }
 
 int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   switch (a.ep) {
-#define JG_CASE(ep) case (ep): return launch_lut_e<(ep)>(e, a, s);
+  // 128 output channels: no run-time output geometry; fewer: CW = 129 (channel guards, one table half for <= 64)
+#define JG_CASE(ep) case (ep): return a.cout == 128 ? launch_lut_e<(ep), 128>(e, a, s) : launch_lut_e<(ep), 129>(e, a, s);
     JG_CASE(0u)
     JG_CASE(JG_EP_NMD1)
     JG_CASE(JG_EP_ACT1)
