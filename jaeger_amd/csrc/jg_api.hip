@@ -664,8 +664,12 @@ static int prepare_f16(jg_model *m, const float *weights) {
     if (op.kind != JG_OP_CONV) continue;
     ConvHPrep &hp = m->hprep[i];
     hp.f16_ok = false;
-    if (op.stride != 1 && !(op.stride == 2 && op.k == 5 && op.in_buf != JG_BUF_IDS)) { fail("strided conv"); continue; }
-    if (!jg_conv_f16_supports(op.k, op.dilation)) { fail("taps / dilation outside the split-f16 tiling"); continue; }
+    // a 1x1 conv (the bypass of a strided / widening residual block) rides the 5-tap kernel: weights in tap 2, the
+    // matrix-core work of the other taps skipped
+    hp.as_k5 = op.k == 1 && op.in_buf != JG_BUF_IDS;
+    const int kk = hp.as_k5 ? 5 : op.k, kdil = hp.as_k5 ? 1 : op.dilation;
+    if (op.stride != 1 && !(op.stride == 2 && kk == 5 && op.in_buf != JG_BUF_IDS)) { fail("strided conv"); continue; }
+    if (!jg_conv_f16_supports(kk, kdil)) { fail("taps / dilation outside the split-f16 tiling"); continue; }
     const bool narrow = op.cout == 32 || op.cout == 64;
     if (op.cout % 16 != 0 || !(narrow || (op.cout > 64 && op.cout <= 128) || op.cout % 128 == 0)) {
       fail("conv width is not 32, 64, 80..128 or a multiple of 128 channels");
@@ -673,7 +677,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
     }
     // only the k = 5 kernels are built with run-time output geometry (other widths than 128, stride 2); a first conv of
     // up to 128 channels runs as the table variant, which has it too (checked below: no table -> 128 channels only)
-    if (op.in_buf != JG_BUF_IDS && op.k != 5 && op.cout != 128) { fail("conv width is not 128 channels (k = 7 / 9)"); continue; }
+    if (op.in_buf != JG_BUF_IDS && kk != 5 && op.cout != 128) { fail("conv width is not 128 channels (k = 7 / 9)"); continue; }
     if (op.in_buf == JG_BUF_IDS && op.cout > 128) { fail("first conv wider than 128 channels"); continue; }
     if (op.in_buf != JG_BUF_IDS && op.cin % 16 != 0) { fail("conv input width is not a multiple of 16"); continue; }
     bool conv_ok = true;
@@ -696,7 +700,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
     const float wscale = ldexpf(1.f, sexp);
     hp.acc_scale = ldexpf(1.f, -sexp);
     const int kc_total = cin16 / 8;
-    const size_t half_items = (size_t)2 * op.k * kc_total * cout_pad;     // one 128-channel half: [plane][tap][kc][128]
+    const size_t half_items = (size_t)2 * kk * kc_total * cout_pad;       // one 128-channel half: [plane][tap][kc][128]
     const size_t n_items = half_items * hp.n_half;
     hp.wh_half_items = (int64_t)half_items;
     std::vector<uint16_t> wh(n_items * 8, 0);
@@ -706,8 +710,9 @@ static int prepare_f16(jg_model *m, const float *weights) {
           const float v = w[((size_t)t * cin_pad + c) * cout_pad32 + n] * wscale;
           const float hi = f16_value(v);
           const size_t base = (size_t)(n / 128) * half_items;
-          const size_t item = base + (((size_t)0 * op.k + t) * kc_total + c / 8) * cout_pad + n % 128;
-          const size_t item_lo = base + (((size_t)1 * op.k + t) * kc_total + c / 8) * cout_pad + n % 128;
+          const int tk = hp.as_k5 ? 2 : t;                       // (a 1x1 conv's only tap sits in the middle of five)
+          const size_t item = base + (((size_t)0 * kk + tk) * kc_total + c / 8) * cout_pad + n % 128;
+          const size_t item_lo = base + (((size_t)1 * kk + tk) * kc_total + c / 8) * cout_pad + n % 128;
           wh[item * 8 + c % 8] = f16_bits(hi);
           wh[item_lo * 8 + c % 8] = f16_bits(v - hi);
         }
@@ -826,7 +831,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
         if (conv_ok && !jg_conv_f16_has_pattern(hp.ep, op.in_buf == JG_BUF_IDS)) {
           cfail("a conv's stage list is not one of the compiled split-f16 epilogue patterns");
         }
-        if (conv_ok && op.in_buf != JG_BUF_IDS && (op.cout != 128 || op.stride != 1) && !jg_conv_f16_has_narrow_pattern(hp.ep))
+        if (conv_ok && op.in_buf != JG_BUF_IDS && (op.cout != 128 || op.stride != 1 || hp.as_k5) && !jg_conv_f16_has_narrow_pattern(hp.ep))
           cfail("the stage list of a conv of other than 128 channels / stride 1 is not one of the patterns compiled for it");
         if (conv_ok && op.stride == 2 && (hp.ep & (JG_EP_ADD | JG_EP_NMD1 | JG_EP_NMD2)))
           cfail("strided conv with a shortcut or an NMD tap in its epilogue");
@@ -1282,6 +1287,8 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           a.L_in = in.L; a.L_out = lo;
           a.cc_in = hp.cc_in; a.cout = op.cout; a.cout_pad = op.cout;
           a.k = op.k; a.dil = op.dilation; a.pad_left = pl;
+          a.only_tap = -1;
+          if (hp.as_k5) { a.k = 5; a.dil = 1; a.pad_left = 2; a.only_tap = 2; }
           a.cw = hp.cw;
           a.ostride = op.stride;
           a.L_res = op.stride == 2 ? 2 * lo - 1 : lo;
@@ -1291,14 +1298,14 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           {
             // window-packed tiling when the frames fill their own 256-position tiles badly (e.g. 665 codons)
             static const bool no_flat = jg_exp_env("JG_NO_FLAT") != nullptr;
-            const int halo = (op.k - 1) * op.dilation;
-            const int gap = std::max(pl, halo - pl);
+            const int halo = (a.k - 1) * a.dil;
+            const int gap = std::max(a.pad_left, halo - a.pad_left);
             const int fp = lo + gap;
             const int wp = (in.frames * fp + 127) / 128 * 128;
             const int64_t flat_tiles = ((int64_t)nw * wp + 255) / 256;
             const int64_t row_tiles = (int64_t)a.rows * a.tiles_m;
-            if (!no_flat && op.k == 5 && op.in_buf != JG_BUF_IDS && hp.d_lut == nullptr && op.stride == 1 && in.L == lo &&
-                (op.cout == 128 ? jg_conv_f16_has_flat_pattern(hp.ep) : jg_conv_f16_has_narrow_pattern(hp.ep)) &&
+            if (!no_flat && a.k == 5 && op.in_buf != JG_BUF_IDS && hp.d_lut == nullptr && op.stride == 1 && in.L == lo &&
+                ((op.cout == 128 && !hp.as_k5) ? jg_conv_f16_has_flat_pattern(hp.ep) : jg_conv_f16_has_narrow_pattern(hp.ep)) &&
                 (int64_t)nw * wp < (1 << 24) && flat_tiles * 100 <= row_tiles * 95) {
               a.flat = 1;
               a.flat_p = fp;

@@ -439,6 +439,12 @@ void conv_f16x3_kernel(ConvHArgs a) {
         // (t2 t3) at C.
         const int ncc = last_chunk ? 0 : cc + 1;
         auto taps = [&](int t, auto &&mid, bool has_mid = true) {
+          if constexpr (GEN) {
+            if (a.only_tap >= 0 && t != a.only_tap) {     // 1x1 conv on the 5-tap pipeline: this tap's weights are zero
+              if (has_mid) mid();
+              return;
+            }
+          }
           const uint4 *B = Wbuf + t * W_ITEMS + w_frag;
           half8 wh[TN], wl[TN];
 #pragma unroll

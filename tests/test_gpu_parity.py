@@ -150,11 +150,11 @@ def test_forward_zeus_dyt(precision):
 def test_forward_pyramid_resnet(precision):
     """The reference's pyramid ResNet (train_config/nn_config_baseline.yaml: embedding 192, widths 32 / 64 / 128 / 256,
     stride-2 blocks with 1x1 bypasses, dilations 1 - 8, 2 000-bp windows).  Split-f16: 32- and 64-channel workgroup tiles,
-    two launches per 256-channel conv, stride-2 convs evaluated at stride 1, window-packed tiles; only the three 1x1
-    bypass convs stay on the exact-f32 kernel.  Exact f32: 64-position tiles where 128 input positions x 256 channels
+    two launches per 256-channel conv, stride-2 convs evaluated at stride 1, the 1x1 bypass convs as single-tap runs of
+    the 5-tap kernel, window-packed tiles - no conv is left on the exact-f32 kernel, no layout conversion.  Exact f32: 64-position tiles where 128 input positions x 256 channels
     do not fit LDS."""
     _forward_case("pyramid", 2000, 7, 21, n_frac=0.01, precision=precision, gain=0.85,
-                  placement={"convs": 36, "convs_f16x3": 33, "small_fused": False})
+                  placement={"convs": 36, "convs_f16x3": 36, "layout_conversions": 0, "small_fused": False})
 
 
 def test_forward_pyramid_resnet_short_windows_chunked():
