@@ -45,6 +45,11 @@ CONFIGS = {
                          "shard of the 1 M x 1500 bp fragment set"),
     "baseline500": dict(model="baseline500", fsize=500, contigs=1_000_000, seed=20260925, exact=500,
                         label="nn_config_500bp_baseline architecture (seeded random weights)"),
+    # not a BASELINE.json config: the reference's pyramid ResNet (train_config/nn_config_baseline.yaml: widths 32 - 256,
+    # stride-2 blocks, dilations 1 - 8) at its own 2 000-bp crop, on the default workload's contig mixture
+    "pyramid": dict(model="pyramid", fsize=2000, contigs=10_000, seed=20260926, exact=None, gain=0.85,
+                    label="nn_config_baseline architecture (pyramid ResNet 32/64/128/256 channels; seeded random weights, "
+                          "block kernels x0.85)"),
 }
 
 
@@ -217,6 +222,10 @@ def main():
     wl = CONFIGS[args.config]
     cfg = yaml.safe_load((ROOT / "tests" / "golden" / f"{wl['model']}_project.yaml").read_text())["model"]
     weights = random_weights(build_plan(cfg), seed=38341)
+    if wl.get("gain"):                  # He-uniform stand-in kernels blow a 36-conv residual pyramid's logits up to +-900
+        for key in weights:
+            if key.startswith("rep/") and key.endswith("/kernel"):
+                weights[key] = weights[key] * np.float32(wl["gain"])
     import warnings
     warnings.simplefilter("ignore")
     eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=local_rank, chunk=args.chunk,
