@@ -239,6 +239,13 @@ int jg_fasta_index(const uint8_t *text, int64_t n, int64_t max_records, int64_t 
  * place; n_threads <= 0 = all cores.  The buffer is then "pre-cased" for jg_encode (soft_mask bit 0). */
 int jg_dust_mask(uint8_t *bases, const int64_t *offsets, int64_t n_records, int32_t window,
                  int32_t threshold, int32_t n_threads, int64_t *n_masked);
+/* The same masks for DEVICE-resident bases, in place (window <= 64): symmetric DUST evaluated from its definition on the
+ * GPU - every interval of up to window - 2 triplets by dynamic programme, one thread per interval start - bit-identical
+ * to jg_dust_mask.  offsets (n_records + 1 entries) host or device per offsets_loc; n_masked (host, optional) makes the
+ * call synchronous.  jg_predict_windows runs it by itself on the uploaded bases once records are attached to the engine
+ * (jg_engine_set_dust). */
+int jg_dust_mask_device(jg_engine *e, uint8_t *d_bases, int64_t n_bases, const int64_t *offsets, int offsets_loc,
+                        int64_t n_records, int32_t window, int32_t threshold, int64_t *n_masked, void *stream);
 
 /* ---- CRF window decoding (host only; replaces the per-contig loop over postprocess/helpers.py:398-449
  * viterbi_decode that postprocess/collect.py:343-346 runs for `jaeger predict --crf`) ---------------

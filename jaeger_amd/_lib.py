@@ -101,6 +101,8 @@ SYMBOLS = {
     "jg_terminal_repeats": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64, C.c_int32, _vp]),
     "jg_viterbi_decode": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int64, _vp, _vp]),
     "jg_dust_mask": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "jg_dust_mask_device": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, C.c_int64, C.c_int32, C.c_int32,
+                                      C.POINTER(C.c_int64), _vp]),
     "jg_fasta_count": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "jg_fasta_index": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.POINTER(C.c_int64)]),
     "jg_fasta_parse": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.POINTER(C.c_int64),

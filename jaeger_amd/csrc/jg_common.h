@@ -267,6 +267,8 @@ int jg_launch_f16s_to_f32(const uint4 *x, int64_t rows, int L, int c, float *y, 
 int jg_launch_maxpool1d_f16s(const uint4 *x, int rows, int L_in, int L_out, int c, uint4 *y, hipStream_t s);
 int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,
                        hipStream_t s);
+int jg_launch_dust(uint8_t *d_bases, int64_t origin, int64_t span_len, const int64_t *d_rec_off, int64_t n_rec,
+                   int window, int threshold, int64_t own0, int64_t own1, unsigned long long *d_masked, hipStream_t s);
 int jg_conv_tile_m(int l_out);
 int jg_conv_tile_m_for(int l_out, int k, int cin, int stride, int dil);
 int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s);

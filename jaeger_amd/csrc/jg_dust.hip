@@ -7,7 +7,9 @@
 // unsaturated suffix, list of perfect intervals of the current window); an ambiguous base ends the
 // current stretch and the scan restarts behind it.  pydustmasker is not installable here: parity
 // with it is UNPINNED (tests hold the algorithm's defining properties instead).
-// Host code only, one std::thread per slice of records.
+// jg_dust_mask: host code, one std::thread per slice of records.  jg_dust_mask_device (bottom of the file): the same
+// masks from the DEFINITION of symmetric DUST, evaluated on the GPU for device-resident bases - all intervals of up to
+// W - 2 triplets by dynamic programme, one thread per interval start (bit-identical to the host scan, tests/test_gpu_dust.py).
 #include <stdint.h>
 #include <string.h>
 
@@ -205,4 +207,160 @@ extern "C" int jg_dust_mask(uint8_t *bases, const int64_t *offsets, int64_t n_re
     *n_masked = sum;
   }
   return JG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Symmetric DUST on the GPU, by the definition (Morgulis et al. 2006): an interval of l triplets (2 <= l <= W - 2) with
+// repeat count r = sum_t c_t (c_t - 1) / 2 scores r / (l - 1); it is PERFECT when its score exceeds T / 10 and no
+// sub-interval scores higher; the mask is the union of the perfect intervals.  One thread per interval start s walks
+// l = 1 .. W - 2: r grows by the number of earlier occurrences of the new triplet (a 64-entry byte table per thread,
+// LDS, [triplet][thread]); M(s, l) = max(score(s, l), M(s, l - 1), M(s + 1, l - 1)) is the best score of any
+// sub-interval, exchanged with the neighbour through LDS once per step.  Scores are compared as integer fractions
+// (r <= 1 891, l <= 62: exact).  A workgroup owns 256 base positions and computes 64 starts either side of them:
+// an interval that covers an owned position starts at most 63 bases before it, and a start needs its <= 61 right
+// neighbours.  Triplets that hold a non-ACGT byte or straddle a record boundary exist in no interval.  HBM: one byte
+// read (+ a 1.5x halo from L2) and at most one written per base; the kernel is bound by the 62 dependent DP steps
+// (~25 vector instructions each per start).
+namespace {
+
+constexpr int DT = 384, DOWN = 256, DHALO = 64;
+
+__device__ __forceinline__ bool frac_ge(int an, int ad, int bn, int bd) { return an * bd >= bn * ad; }   // an/ad >= bn/bd
+
+__global__ __launch_bounds__(DT) void dust_kernel(uint8_t *bases, int64_t origin, int64_t span_len,
+                                                  const int64_t *rec_off, int64_t n_rec, int lmax, int T,
+                                                  int64_t own0, int64_t own1, unsigned long long *n_masked) {
+  __shared__ uint32_t cnt32[64 * DT / 4];          // byte table [triplet][thread]
+  __shared__ uint8_t code[DT + 68];                // bits 0-2: 0-3 = A C G T, 4 = other; bit 3: last base of its record
+  __shared__ uint8_t tri[DT + 64];                 // triplet code, 0xff = no triplet starts here
+  __shared__ int2 Mbuf[2][DT + 1];
+  __shared__ int endp[DT];
+  uint8_t *cnt = reinterpret_cast<uint8_t *>(cnt32);
+  const int j = threadIdx.x;
+  const int64_t tile0 = own0 + (int64_t)blockIdx.x * DOWN - DHALO;     // global position of thread 0's start
+  for (int q = j; q < DT + 66; q += DT) {
+    const int64_t pos = tile0 + q, loc = pos - origin;
+    int c = 4;
+    if (loc >= 0 && loc < span_len && pos >= rec_off[0] && pos < rec_off[n_rec]) {
+      switch (bases[loc]) {
+        case 'A': case 'a': c = 0; break;
+        case 'C': case 'c': c = 1; break;
+        case 'G': case 'g': c = 2; break;
+        case 'T': case 't': c = 3; break;
+        default: break;
+      }
+      // record of pos: the last r with rec_off[r] <= pos; pos is its last base when pos + 1 == rec_off[r + 1]
+      int64_t lo = 0, hi = n_rec;                   // rec_off[lo] <= pos < rec_off[hi]
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (rec_off[mid] <= pos) lo = mid; else hi = mid;
+      }
+      if (pos + 1 == rec_off[lo + 1]) c |= 8;
+    }
+    code[q] = (uint8_t)c;
+  }
+  for (int q = j; q < 64 * DT / 4; q += DT) cnt32[q] = 0u;
+  Mbuf[0][j] = Mbuf[1][j] = make_int2(-1, 1);
+  if (j == 0) Mbuf[0][DT] = Mbuf[1][DT] = make_int2(-1, 1);
+  __syncthreads();
+  for (int q = j; q < DT + 64; q += DT) {
+    const int a = code[q], b = code[q + 1], c = code[q + 2];
+    const bool ok = (a & 7) < 4 && (b & 7) < 4 && (c & 7) < 4 && !(a & 8) && !(b & 8);
+    tri[q] = ok ? (uint8_t)((a & 3) * 16 + (b & 3) * 4 + (c & 3)) : (uint8_t)0xff;
+  }
+  __syncthreads();
+  bool alive = true;
+  int r = 0, reach = 0;
+  for (int l = 1; l <= lmax; ++l) {
+    const unsigned t = tri[j + l - 1];
+    alive = alive && t != 0xffu;
+    if (alive) {
+      const unsigned c = cnt[t * DT + j];
+      r += (int)c;
+      cnt[t * DT + j] = (uint8_t)(c + 1);
+    }
+    if (l >= 2) {
+      const int2 a = Mbuf[(l - 1) & 1][j], b = Mbuf[(l - 1) & 1][j + 1];
+      int2 m = frac_ge(a.x, a.y, b.x, b.y) ? a : b;           // best score of any proper sub-interval
+      if (alive && frac_ge(r, l - 1, m.x, m.y)) {
+        if (10 * r > T * (l - 1)) reach = l + 2;               // perfect: masks bases [s, s + l + 2)
+        m = make_int2(r, l - 1);
+      }
+      Mbuf[l & 1][j] = m;
+    }
+    __syncthreads();
+  }
+  endp[j] = reach > 0 ? j + reach : 0;
+  __syncthreads();
+  bool masked = false;
+  if (j >= DHALO && j < DHALO + DOWN) {
+    for (int k = 0; k < DHALO; ++k) masked = masked || endp[j - k] > j;
+    const int64_t pos = tile0 + j, loc = pos - origin;
+    if (pos >= own0 && pos < own1 && loc >= 0 && loc < span_len) {
+      const uint8_t b = bases[loc];
+      uint8_t u = (b >= 'a' && b <= 'z') ? (uint8_t)(b - 32) : b;
+      if (masked) u |= 0x20;
+      if (u != b) bases[loc] = u;
+    } else {
+      masked = false;
+    }
+  }
+  const unsigned long long bal = __ballot(masked);
+  if ((j & 63) == 0 && bal != 0ull && n_masked != nullptr) atomicAdd(n_masked, (unsigned long long)__popcll(bal));
+}
+
+}  // namespace
+
+// device-side launch shared with jg_predict_windows (jg_api.hip): rec_off is a DEVICE array of n_rec + 1 global offsets
+int jg_launch_dust(uint8_t *d_bases, int64_t origin, int64_t span_len, const int64_t *d_rec_off, int64_t n_rec,
+                   int window, int threshold, int64_t own0, int64_t own1, unsigned long long *d_masked, hipStream_t s) {
+  JG_REQUIRE(window >= 4 && window <= 64 && threshold > 0, JG_ERR_UNSUPPORTED,
+             "dust (device): window %d outside 4..64 (use the host scan)", window);
+  if (own1 <= own0 || n_rec <= 0) return JG_OK;
+  const int64_t blocks = (own1 - own0 + DOWN - 1) / DOWN;
+  JG_REQUIRE(blocks < (int64_t)2147483647, JG_ERR_UNSUPPORTED, "dust (device): %lld bases in one launch", (long long)(own1 - own0));
+  hipLaunchKernelGGL(dust_kernel, dim3((unsigned)blocks), dim3(DT), 0, s, d_bases, origin, span_len, d_rec_off, n_rec,
+                     window - 2, threshold, own0, own1, d_masked);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+// Soft-mask device-resident bases in place (all records of the buffer): upper-case everything, lower-case the DUST
+// intervals.  offsets: n_records + 1 entries, host or device (offsets_loc).  n_masked (host, optional) forces a sync.
+extern "C" int jg_dust_mask_device(jg_engine *e, uint8_t *d_bases, int64_t n_bases, const int64_t *offsets, int offsets_loc,
+                                   int64_t n_records, int32_t window, int32_t threshold, int64_t *n_masked, void *stream) {
+  JG_REQUIRE(e != nullptr && d_bases != nullptr && offsets != nullptr && n_records >= 0 && n_bases >= 0, JG_ERR_INVALID,
+             "jg_dust_mask_device: bad arguments");
+  JG_HIP(hipSetDevice(e->dev));
+  hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : e->stream;
+  if (n_masked != nullptr) *n_masked = 0;
+  if (n_records == 0 || n_bases == 0) return JG_OK;
+  void *tmp = nullptr;
+  const int64_t *d_off = offsets;
+  if (offsets_loc == JG_PTR_HOST) {
+    JG_REQUIRE(offsets[0] >= 0 && offsets[n_records] <= n_bases, JG_ERR_INVALID, "jg_dust_mask_device: records outside the base buffer");
+    JG_HIP(hipMalloc(&tmp, (size_t)(n_records + 1) * sizeof(int64_t) + 8));
+    JG_HIP(hipMemcpyAsync(tmp, offsets, (size_t)(n_records + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    d_off = static_cast<const int64_t *>(tmp);
+  }
+  unsigned long long *d_cnt = nullptr;
+  int rc = JG_OK;
+  if (n_masked != nullptr) {
+    hipError_t er = hipMalloc(reinterpret_cast<void **>(&d_cnt), sizeof(unsigned long long));
+    if (er == hipSuccess) er = hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s);
+    if (er != hipSuccess) { jg_set_error("jg_dust_mask_device: %s", hipGetErrorString(er)); rc = JG_ERR_NOMEM; }
+  }
+  if (rc == JG_OK) rc = jg_launch_dust(d_bases, 0, n_bases, d_off, n_records, window, threshold, 0, n_bases, d_cnt, s);
+  if (rc == JG_OK && n_masked != nullptr) {
+    unsigned long long h = 0;
+    hipError_t er = hipMemcpyAsync(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (er == hipSuccess) er = hipStreamSynchronize(s);
+    if (er != hipSuccess) { jg_set_error("jg_dust_mask_device: %s", hipGetErrorString(er)); rc = JG_ERR_HIP; }
+    *n_masked = (int64_t)h;
+  } else if (tmp != nullptr) {
+    (void)hipStreamSynchronize(s);                 // the offsets copy is freed below
+  }
+  if (d_cnt) (void)hipFree(d_cnt);
+  if (tmp) (void)hipFree(tmp);
+  return rc;
 }

@@ -108,6 +108,17 @@ class HipDevice:
         L.check(self.lib.jg_memcpy_d2h(self.handle, _ptr(out), C.c_void_p(ptr), out.nbytes), "jg_memcpy_d2h")
         return out
 
+    def dust_mask(self, bases_ptr: int, n_bases: int, offsets: np.ndarray, window: int = 64, threshold: int = 20,
+                  count: bool = True) -> int:
+        """Symmetric-DUST soft-masking of device-resident bases in place (``jg_dust_mask_device``); returns the number
+        of masked bases (``count=False``: asynchronous on the engine stream, returns -1)."""
+        off = np.ascontiguousarray(offsets, np.int64)
+        n = C.c_int64(-1)
+        L.check(self.lib.jg_dust_mask_device(self.handle, C.c_void_p(bases_ptr), int(n_bases), _ptr(off), L.JG_PTR_HOST,
+                                             len(off) - 1, int(window), int(threshold), C.byref(n) if count else None,
+                                             None), "jg_dust_mask_device")
+        return int(n.value)
+
     # timing --------------------------------------------------------------------
     def timer_start(self):
         L.check(self.lib.jg_timer_start(self.handle, None))
