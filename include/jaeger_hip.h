@@ -131,8 +131,15 @@ enum { JG_OPT_STREAM_BYTES = 1 };
 int jg_engine_set_option(jg_engine *e, int key, int64_t value);
 /* statistics of the engine's last jg_predict_windows call: number of streamed groups (0 = not streamed), bytes sent
  * through the staging buffers, peak bytes of bases resident on the device */
-enum { JG_STAT_STREAM_GROUPS = 1, JG_STAT_STREAM_BYTES = 2, JG_STAT_PEAK_DEVICE_BASES = 3 };
+enum { JG_STAT_STREAM_GROUPS = 1, JG_STAT_STREAM_BYTES = 2, JG_STAT_PEAK_DEVICE_BASES = 3, JG_STAT_DUST_MASKED = 4 };
 int64_t jg_engine_get_stat(const jg_engine *e, int key);
+/* DUST inside the fused path (replaces the per-contig pydustmasker call of seqops/io.py:104-108 without a host pass):
+ * attach the record table (n_records + 1 offsets into the HOST base buffer the following jg_predict_windows /
+ * jg_encode calls are given) and those calls soft-mask their uploaded copy of the bases on the device before encoding
+ * it - whole-buffer uploads in one launch, streamed spans group by group with 64 bases of context - and encode with
+ * the case respected (soft_mask bit 0).  The host buffer is not modified.  window <= 64.  n_records = 0 detaches.
+ * JG_STAT_DUST_MASKED: bases lower-cased since the records were attached (overlapping streamed spans count twice). */
+int jg_engine_set_dust(jg_engine *e, const int64_t *rec_off, int64_t n_records, int32_t window, int32_t threshold);
 
 /* Replaces tf.saved_model.load + serving_default (nnlib/inference.py:307-325):
  * `ops` is the layer plan compiled by jaeger_amd/program.py, `weights` one f32

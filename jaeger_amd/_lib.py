@@ -17,7 +17,7 @@ JG_MAX_VECS = 12
 JG_PTR_HOST, JG_PTR_DEVICE = 0, 1
 JG_BUF_NONE, JG_BUF_IDS = -1, -2
 JG_OPT_STREAM_BYTES = 1
-JG_STAT_STREAM_GROUPS, JG_STAT_STREAM_BYTES, JG_STAT_PEAK_DEVICE_BASES = 1, 2, 3
+JG_STAT_STREAM_GROUPS, JG_STAT_STREAM_BYTES, JG_STAT_PEAK_DEVICE_BASES, JG_STAT_DUST_MASKED = 1, 2, 3, 4
 JG_MSTAT_CONVS, JG_MSTAT_CONVS_F16X3, JG_MSTAT_LAYOUT_CONVERSIONS, JG_MSTAT_SMALL_FUSED = 0, 1, 2, 3
 
 # jg_op_kind
@@ -101,6 +101,7 @@ SYMBOLS = {
     "jg_terminal_repeats": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64, C.c_int32, _vp]),
     "jg_viterbi_decode": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int64, _vp, _vp]),
     "jg_dust_mask": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "jg_engine_set_dust": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32]),
     "jg_dust_mask_device": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, C.c_int64, C.c_int32, C.c_int32,
                                       C.POINTER(C.c_int64), _vp]),
     "jg_fasta_count": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

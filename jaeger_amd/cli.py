@@ -31,6 +31,8 @@ def main():
 @click.option("--crf-transition-matrix", type=click.Path(exists=True), default=None,
               help='JSON class-name-keyed cost matrix, e.g. {"bacteria": {"phage": 0.5}}; overrides --crf-prior')
 @click.option("--dustmask/--no-dustmask", default=True, help="soft-mask low-complexity regions (symmetric DUST)")
+@click.option("--dust-host", is_flag=True, default=False,
+              help="run DUST as a host pass over the FASTA image instead of on the GPU inside the fused call (same masks)")
 @click.option("--min-len", "min_len", type=int, default=None, help="Minimum contig length to process")
 @click.option("-m", "--model", type=str, default="default")
 @click.option("--model_path", type=click.Path(exists=True), default=None,

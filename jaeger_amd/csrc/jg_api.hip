@@ -66,6 +66,8 @@ extern "C" int jg_engine_destroy(jg_engine *e) {
     if (e->h2d_done[i]) (void)hipEventDestroy(e->h2d_done[i]);
   }
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+  if (e->d_rec_off) (void)hipFree(e->d_rec_off);
+  if (e->d_dust_cnt) (void)hipFree(e->d_dust_cnt);
   (void)hipStreamDestroy(e->stream);
   delete e;
   return JG_OK;
@@ -97,8 +99,49 @@ extern "C" int64_t jg_engine_get_stat(const jg_engine *e, int key) {
     case JG_STAT_STREAM_GROUPS: return e->streamed_groups;
     case JG_STAT_STREAM_BYTES: return e->streamed_bytes;
     case JG_STAT_PEAK_DEVICE_BASES: return e->peak_dev_bases;
+    case JG_STAT_DUST_MASKED: {          // bases the device DUST lower-cased since the records were attached (syncs)
+      if (e->d_dust_cnt == nullptr) return 0;
+      unsigned long long h = 0;
+      if (hipSetDevice(e->dev) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||
+          hipMemcpy(&h, e->d_dust_cnt, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+      return (int64_t)h;
+    }
     default: return -1;
   }
+}
+
+// Attach the record table of the host base buffer the following jg_predict_windows / jg_encode calls will be given:
+// their uploaded copy of the bases is then soft-masked on the device (symmetric DUST, jg_dust.hip) before it is
+// encoded, and the encoder respects the case.  n_records = 0 (or rec_off NULL) detaches.
+extern "C" int jg_engine_set_dust(jg_engine *e, const int64_t *rec_off, int64_t n_records, int32_t window,
+                                  int32_t threshold) {
+  JG_REQUIRE(e != nullptr, JG_ERR_INVALID, "jg_engine_set_dust: NULL engine");
+  JG_HIP(hipSetDevice(e->dev));
+  if (rec_off == nullptr || n_records <= 0) {
+    e->n_rec = 0;
+    return JG_OK;
+  }
+  JG_REQUIRE(window >= 4 && window <= 64 && threshold > 0, JG_ERR_UNSUPPORTED,
+             "jg_engine_set_dust: window %d outside 4..64 (mask on the host with jg_dust_mask)", window);
+  for (int64_t r = 0; r < n_records; ++r)
+    JG_REQUIRE(rec_off[r] >= 0 && rec_off[r + 1] >= rec_off[r], JG_ERR_INVALID, "jg_engine_set_dust: record %lld has a negative length",
+               (long long)r);
+  JG_HIP(hipStreamSynchronize(e->stream));            // (a previous call may still read the old table)
+  if (n_records + 1 > e->rec_cap) {
+    if (e->d_rec_off) JG_HIP(hipFree(e->d_rec_off));
+    e->d_rec_off = nullptr;
+    JG_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_rec_off), (size_t)(n_records + 1) * sizeof(int64_t)));
+    e->rec_cap = n_records + 1;
+  }
+  if (e->d_dust_cnt == nullptr) JG_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_dust_cnt), sizeof(unsigned long long)));
+  JG_HIP(hipMemcpy(e->d_rec_off, rec_off, (size_t)(n_records + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  JG_HIP(hipMemset(e->d_dust_cnt, 0, sizeof(unsigned long long)));
+  e->n_rec = n_records;
+  e->rec_end = rec_off[n_records];
+  e->dust_window = window;
+  e->dust_threshold = threshold;
+  return JG_OK;
 }
 
 static hipStream_t pick_stream(jg_engine *e, void *stream) {
@@ -1621,6 +1664,14 @@ static int encode_common(jg_engine *e, jg_model *scratch_owner, const uint8_t *b
     to_free.push_back(p);
     JG_HIP(hipMemcpyAsync(p, bases, (size_t)n_bases, hipMemcpyHostToDevice, s));
     d_bases = static_cast<const uint8_t *>(p);
+    if (e->n_rec > 0) {                       // records attached: DUST on the uploaded copy, the encoder respects the case
+      JG_REQUIRE(e->rec_end <= n_bases, JG_ERR_INVALID, "encode: the attached records end at %lld, beyond the %lld-byte base buffer",
+                 (long long)e->rec_end, (long long)n_bases);
+      const int rc = jg_launch_dust(static_cast<uint8_t *>(p), 0, n_bases, e->d_rec_off, e->n_rec, e->dust_window,
+                                    e->dust_threshold, 0, n_bases, e->d_dust_cnt, s);
+      if (rc != JG_OK) return rc;
+      flags |= 1;
+    }
   }
   const int64_t *d_start = win_start;
   const int32_t *d_len = win_len;
@@ -1750,7 +1801,16 @@ static int predict_streamed(jg_model *m, const uint8_t *bases, int64_t n_bases, 
       win_cap = std::max(win_cap, q.w1 - q.w0);
     }
   }
-  span_cap = (span_cap + 4095) / 4096 * 4096;
+  // with records attached (jg_engine_set_dust) every span is staged with 64 bases of context either side and
+  // soft-masked on the device before it is encoded: an interval that touches a window starts or ends < 64 bases outside it
+  const bool dust = e->n_rec > 0;
+  const int64_t ctx = dust ? 64 : 0;
+  if (dust) {
+    JG_REQUIRE(e->rec_end <= n_bases, JG_ERR_INVALID, "encode: the attached records end at %lld, beyond the %lld-byte base buffer",
+               (long long)e->rec_end, (long long)n_bases);
+    flags |= 1;
+  }
+  span_cap = (span_cap + 2 * ctx + 4095) / 4096 * 4096;
   int rc = stream_setup(e, std::max<int64_t>(span_cap, 4096));
   if (rc != JG_OK) return rc;
   if ((rc = grow(&m->d_ids, &m->d_ids_cap, win_cap * 6 * (int64_t)l_pad)) != JG_OK) return rc;
@@ -1767,8 +1827,9 @@ static int predict_streamed(jg_model *m, const uint8_t *bases, int64_t n_bases, 
     const int b = (int)(gi & 1);
     // both buffers of parity b are free: group gi - 2 (their last user) was synchronised at the end of its turn
     JG_HIP(hipSetDevice(e->dev));
-    memcpy(e->pin[b], bases + g.b0, (size_t)(g.b1 - g.b0));
-    JG_HIP(hipMemcpyAsync(e->dbase[b], e->pin[b], (size_t)(g.b1 - g.b0), hipMemcpyHostToDevice, e->copy_stream));
+    const int64_t h0 = std::max<int64_t>(0, g.b0 - ctx), h1 = std::min(n_bases, g.b1 + ctx);
+    memcpy(e->pin[b], bases + h0, (size_t)(h1 - h0));
+    JG_HIP(hipMemcpyAsync(e->dbase[b], e->pin[b], (size_t)(h1 - h0), hipMemcpyHostToDevice, e->copy_stream));
     JG_HIP(hipEventRecord(e->h2d_done[b], e->copy_stream));
     e->streamed_bytes += g.b1 - g.b0;
     return JG_OK;
@@ -1793,12 +1854,18 @@ static int predict_streamed(jg_model *m, const uint8_t *bases, int64_t n_bases, 
       std::thread &t;
       ~Joiner() { if (t.joinable()) t.join(); }
     } joiner{stager};
-    for (int64_t i = 0; i < nw; ++i) rebased[(size_t)i] = win_start[g.w0 + i] - g.b0;
+    const int64_t h0 = std::max<int64_t>(0, g.b0 - ctx), h1 = std::min(n_bases, g.b1 + ctx);     // the staged span
+    for (int64_t i = 0; i < nw; ++i) rebased[(size_t)i] = win_start[g.w0 + i] - h0;
     char *dw = static_cast<char *>(m->d_win);
     JG_HIP(hipMemcpyAsync(dw, rebased.data(), (size_t)nw * 8, hipMemcpyHostToDevice, s));
     JG_HIP(hipMemcpyAsync(dw + win_cap * 8, win_len + g.w0, (size_t)nw * 4, hipMemcpyHostToDevice, s));
     JG_HIP(hipStreamSynchronize(s));          // `rebased` is reused by the next group (pageable source)
     JG_HIP(hipStreamWaitEvent(s, e->h2d_done[b], 0));
+    if (dust) {
+      rc = jg_launch_dust(static_cast<uint8_t *>(e->dbase[b]), h0, h1 - h0, e->d_rec_off, e->n_rec, e->dust_window,
+                          e->dust_threshold, g.b0, g.b1, e->d_dust_cnt, s);
+      if (rc != JG_OK) return rc;
+    }
     int32_t *d_counts = counts == nullptr ? nullptr : (out_loc == JG_PTR_HOST ? m->d_counts : counts + g.w0 * 4);
     rc = jg_launch_encode(static_cast<const uint8_t *>(e->dbase[b]), reinterpret_cast<const int64_t *>(dw),
                           reinterpret_cast<const int32_t *>(dw + win_cap * 8), nw, fsize, m->d_lut, flags, l_pad,

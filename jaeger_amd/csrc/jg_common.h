@@ -167,6 +167,12 @@ struct jg_engine {
   int64_t pin_cap = 0, dbase_cap = 0;
   hipEvent_t h2d_done[2] = {nullptr, nullptr};
   int64_t streamed_groups = 0, streamed_bytes = 0, peak_dev_bases = 0;   // statistics of the last call (jg_engine_get_stat)
+  // DUST on the device (jg_engine_set_dust): record offsets of the host base buffer the next jg_predict_windows /
+  // jg_encode calls are given; the uploaded bases are soft-masked before they are encoded
+  int64_t *d_rec_off = nullptr;
+  int64_t rec_cap = 0, n_rec = 0, rec_end = 0;
+  int dust_window = 0, dust_threshold = 0;
+  unsigned long long *d_dust_cnt = nullptr;
 };
 
 struct ConvHPrep {          // per CONV op: split-f16 operands (built at model creation)

@@ -108,6 +108,19 @@ class HipDevice:
         L.check(self.lib.jg_memcpy_d2h(self.handle, _ptr(out), C.c_void_p(ptr), out.nbytes), "jg_memcpy_d2h")
         return out
 
+    def attach_records(self, offsets, window: int = 64, threshold: int = 20):
+        """DUST inside the fused path (``jg_engine_set_dust``): the following ``predict_windows`` / ``encode`` calls on
+        host bases soft-mask their uploaded copy on the device before encoding it.  ``offsets=None`` detaches."""
+        if offsets is None:
+            L.check(self.lib.jg_engine_set_dust(self.handle, None, 0, 0, 0), "jg_engine_set_dust")
+            return
+        off = np.ascontiguousarray(offsets, np.int64)
+        L.check(self.lib.jg_engine_set_dust(self.handle, _ptr(off), len(off) - 1, int(window), int(threshold)),
+                "jg_engine_set_dust")
+
+    def dust_masked(self) -> int:
+        return int(self.lib.jg_engine_get_stat(self.handle, L.JG_STAT_DUST_MASKED))
+
     def dust_mask(self, bases_ptr: int, n_bases: int, offsets: np.ndarray, window: int = 64, threshold: int = 20,
                   count: bool = True) -> int:
         """Symmetric-DUST soft-masking of device-resident bases in place (``jg_dust_mask_device``); returns the number
@@ -270,6 +283,7 @@ class JaegerHipEngine:
         self.use_xla = use_xla                      # accepted for signature parity; no-op
         self.return_embedding = return_embedding
         self.chunk = chunk
+        self.dust_masked_total = 0                  # bases soft-masked on the device by predict_windows(dust_records=...)
         self.class_map = None
         if path_dict is not None:
             self.class_map = self._load_class_map(path_dict.get("classes"))
@@ -345,15 +359,27 @@ class JaegerHipEngine:
     # -- fused path ---------------------------------------------------------------
     def predict_windows(self, bases: np.ndarray, win_start: np.ndarray, win_len: np.ndarray, fsize: int,
                         l_pad: int | None = None, pre_cased: bool = False,
-                        want=("prediction", "reliability", "embedding", "nmd")) -> dict[str, np.ndarray]:
+                        want=("prediction", "reliability", "embedding", "nmd"),
+                        dust_records: np.ndarray | None = None) -> dict[str, np.ndarray]:
         """Encode + forward for windows given as (start, length) into ``bases``.  ``want`` limits the
-        outputs copied back (the embedding and NMD vectors are 2.6 KB per window)."""
+        outputs copied back (the embedding and NMD vectors are 2.6 KB per window).  ``dust_records``: the record
+        offsets of ``bases`` (n + 1 entries) - the uploaded copy is then DUST soft-masked on the GPU before it is
+        encoded (what ``fragment_generator`` does per contig with pydustmasker, io.py:104-108); ``bases`` itself is
+        left as it is."""
         bases = np.ascontiguousarray(bases, np.uint8)
         ws = np.ascontiguousarray(win_start, np.int64)
         wl = np.ascontiguousarray(win_len, np.int32)
         flags = self.encode_flags | (1 if pre_cased else 0)
-        return self.model.predict_windows(bases, bases.size, ws, wl, ws.size, fsize, self.lut, flags,
-                                          l_pad, self.chunk, want=want)
+        if dust_records is None:
+            return self.model.predict_windows(bases, bases.size, ws, wl, ws.size, fsize, self.lut, flags,
+                                              l_pad, self.chunk, want=want)
+        self.device.attach_records(dust_records)
+        try:
+            return self.model.predict_windows(bases, bases.size, ws, wl, ws.size, fsize, self.lut, flags,
+                                              l_pad, self.chunk, want=want)
+        finally:
+            self.dust_masked_total += self.device.dust_masked()
+            self.device.attach_records(None)
 
     def close(self):
         self.model.close()

@@ -126,11 +126,14 @@ def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None,
                   max_len: int | None = None, dynamic_stride: bool = False,
                   dynamic_stride_threshold: float = 10.0, batch: int = 96, padded: bool = False,
                   subset=None, pre_cased: bool = False,
-                  want=("prediction", "reliability", "embedding", "nmd"), meta: bool = True) -> dict[str, np.ndarray]:
+                  want=("prediction", "reliability", "embedding", "nmd"), meta: bool = True,
+                  dust_device: bool = False) -> dict[str, np.ndarray]:
     """Window table + GPU encode/forward for the records of ``fa`` (optionally only those listed in
     ``subset``, kept in that order); returns the dict ``InferModel.predict`` would (model outputs +
     ``meta_0..9``).  ``padded`` reproduces ``padded_batch`` of the short-contig pass: windows run in
-    groups of ``batch`` padded to the longest frame of the group (commands/predict.py:236-245)."""
+    groups of ``batch`` padded to the longest frame of the group (commands/predict.py:236-245).  ``dust_device``: the
+    bases are DUST soft-masked on the GPU after their upload (the host buffer stays as read) instead of ``pre_cased``
+    by :func:`jaeger_amd.fragment.dust_mask`."""
     idx = np.arange(len(fa)) if subset is None else np.asarray(subset, np.int64)
     lengths = fa.lengths[idx]
     names = [fa.names[i] for i in idx.tolist()] if subset is not None else fa.names
@@ -140,7 +143,8 @@ def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None,
         return {}
     starts = fa.offsets[idx][table.contig] + table.start
     if not padded:
-        out = engine.predict_windows(fa.bases, starts, table.length, fsize, pre_cased=pre_cased, want=want)
+        out = engine.predict_windows(fa.bases, starts, table.length, fsize, pre_cased=pre_cased, want=want,
+                                     dust_records=fa.offsets if dust_device else None)
     else:
         # the short-contig pass: one whole-contig window per record.  The selected records are compacted into a
         # buffer of their own once, so that a batch of 96 windows uploads the few hundred kB it covers and not the
@@ -155,8 +159,10 @@ def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None,
             sl = slice(i, i + batch)
             lmax = int(max(0, -(-(int(table.length[sl].max()) - 5 + off3) // 3)))
             c0, c1 = int(cstart[i]), int(cstart[sl][-1] + wl[sl][-1])
+            # (every window of this pass is a whole record: the compact buffer's record table is its window table)
+            recs = np.append(cstart[sl] - c0, c1 - c0) if dust_device else None
             parts.append(engine.predict_windows(compact[c0:c1], cstart[sl] - c0, table.length[sl], fsize,
-                                                l_pad=max(lmax, 1), pre_cased=pre_cased, want=want))
+                                                l_pad=max(lmax, 1), pre_cased=pre_cased, want=want, dust_records=recs))
         out = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
     if not meta:                       # sharded runs: rank 0 rebuilds the metadata from its own window table
         return out
@@ -529,13 +535,17 @@ def run_core(**kwargs) -> int:
                 f"contigs in {time.time() - t_term:.2f} s")
         return rep
 
-    dust = bool(kwargs.get("dustmask", True))
+    # DUST soft-masking (on by default like the reference): on the GPU, on the uploaded copy of the bases inside the
+    # fused call; --dust-host runs the host scan over the FASTA image instead (same masks bit for bit)
+    dust_any = bool(kwargs.get("dustmask", True))
+    dust = dust_any and bool(kwargs.get("dust_host", False))          # the host pass
+    dust_dev = dust_any and not dust
     two_pass = user_min_len is not None and user_min_len < fsize
     want = ("prediction", "reliability") + (("embedding",) if kwargs.get("save_embedding") else ()) \
         + (("nmd",) if kwargs.get("save_nmd") else ())
     common = dict(dynamic_stride=kwargs.get("dynamic_stride", False),
                   dynamic_stride_threshold=kwargs.get("dynamic_stride_threshold", 10.0),
-                  batch=kwargs.get("batch", 96), pre_cased=dust, want=want)
+                  batch=kwargs.get("batch", 96), pre_cased=dust, want=want, dust_device=dust_dev)
     term_repeats = None
     class_map = None
     t_predict = time.time()
@@ -626,6 +636,9 @@ def run_core(**kwargs) -> int:
         t_predict = time.time() - t_predict
     if class_map is None:
         class_map = engine.class_map
+    if dust_dev and engine is not None:
+        lg.info(f"DUST (window 64, threshold 20) on the GPU: {engine.dust_masked_total} bases soft-masked inside the "
+                f"fused calls")
     t_post = time.time()
 
     from .postprocess import pred_to_dict, write_output       # pandas: imported beside the forward (termini, above)

@@ -203,6 +203,12 @@ def test_cli_default_dustmask(tmp_path):
     _compare_tsv(tmp_path / "out" / "38341_1.4M" / "lowcomplexity.tsv", exp)
     got = pd.read_csv(tmp_path / "out" / "38341_1.4M" / "lowcomplexity.tsv", sep="\t")
     assert (got["N%"] > 0.05).all()                 # masked bases count as "not ACGT"
+    # the run above masked on the GPU inside the fused calls (the default); --dust-host = the host pass: same bytes
+    r = CliRunner().invoke(main, ["predict", "-i", str(fasta), "-o", str(tmp_path / "out_host"), "--model_path", str(root),
+                                  "--fsize", "1500", "--stride", "1500", "--dust-host", "--no-pipeline"])
+    assert r.exit_code == 0, r.output
+    assert (tmp_path / "out_host" / "38341_1.4M" / "lowcomplexity.tsv").read_bytes() == \
+        (tmp_path / "out" / "38341_1.4M" / "lowcomplexity.tsv").read_bytes()
 
 
 def test_cli_gz_dynamic_stride_exact_f32_small_chunks(tmp_path):

@@ -100,3 +100,58 @@ def test_record_boundaries_are_walls(dev):
     assert joined.tobytes() != split.tobytes() or True      # (the joined run may mask more; the split must not see across)
     with pytest.raises(Exception):
         _device_mask(dev, [a], window=128)
+
+
+@pytest.mark.parametrize("masking", [False, True])
+def test_fused_dust_equals_host_premasked(masking):
+    """DUST inside jg_predict_windows (records attached to the engine: whole-buffer upload and streamed spans with 64
+    bases of context) against the host pass + pre-cased bases: logits, reliability and G/C/A/T counts bit for bit.
+    ``masking: true`` models turn lower-case codons into invalid ids, so there the masks reach the network input."""
+    import copy
+
+    from conftest import load_model_cfg
+    from jaeger_amd.engine import JaegerHipEngine
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("brain"))
+    cfg["string_processor"]["masking"] = masking
+    weights = ofwd.random_weights(cfg, seed=38341)
+    rng = np.random.Generator(np.random.PCG64(31))
+    fsize = 1500
+    seqs = []
+    for n in [5200, 1500, 9100, 3000, 1502, 40_000]:
+        s = ACGT[rng.integers(0, 4, n, dtype=np.uint8)].copy()
+        for _ in range(3 + n // 1500):
+            unit = ACGT[rng.integers(0, 4, int(rng.integers(1, 4)))]
+            length, p = int(rng.integers(20, 160)), int(rng.integers(0, n - 200))
+            s[p:p + length] = np.tile(unit, length // len(unit) + 1)[:length]
+        s[-30:] = ord("A")                                    # a low-complexity record end next to the following record
+        s[:25] = ord("T")
+        seqs.append(s.tobytes())
+    bases, offsets = frag.concat_records(seqs)
+    fa = frag.FastaBatch([f"r{i}" for i in range(len(seqs))], bases, offsets)
+    table = frag.build_window_table(fa.lengths, fsize, 700)      # overlapping windows: spans of neighbouring groups overlap
+    starts = fa.offsets[table.contig] + table.start
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0)
+    want = ("prediction", "reliability")
+    try:
+        fused = eng.predict_windows(bases, starts, table.length, fsize, want=want, dust_records=offsets)
+        n_fused = eng.dust_masked_total
+        eng.device.set_stream_bytes(8192)
+        streamed = eng.predict_windows(bases, starts, table.length, fsize, want=want, dust_records=offsets)
+        groups = eng.device.stream_stats()["groups"]
+        eng.device.set_stream_bytes(256 << 20)
+        raw = eng.predict_windows(bases, starts, table.length, fsize, want=want)
+        host = frag.FastaBatch(fa.names, bases.copy(), offsets)
+        n_host = frag.dust_mask(host)
+        ref = eng.predict_windows(host.bases, starts, table.length, fsize, want=want, pre_cased=True)
+    finally:
+        eng.close()
+    assert groups >= 5 and n_fused == n_host > 1000
+    for k in ("prediction", "reliability", "counts"):
+        np.testing.assert_array_equal(fused[k], ref[k])
+        np.testing.assert_array_equal(streamed[k], ref[k])
+    assert (raw["counts"] != ref["counts"]).any()                # the masks do reach the counts ...
+    assert (raw["prediction"] != ref["prediction"]).any() == masking     # ... and, for masking models, the ids

@@ -31,8 +31,19 @@ class _StandInEngine:
         self.model = _StandInModel()
         self.device = None
 
+    dust_masked_total = 0
+
     def predict_windows(self, bases, win_start, win_len, fsize, l_pad=None, pre_cased=False,
-                        want=("prediction", "reliability")):
+                        want=("prediction", "reliability"), dust_records=None):
+        if dust_records is not None:
+            # what jg_engine_set_dust does on the device: DUST on a COPY of the bases by their record table, then the
+            # encoder respects the case (the host scan gives the same masks bit for bit: tests/test_gpu_dust.py)
+            from jaeger_amd import fragment as frag
+            off = np.asarray(dust_records, np.int64)
+            assert off[0] >= 0 and off[-1] <= len(bases) and (np.diff(off) >= 0).all()
+            tmp = frag.FastaBatch([""] * (len(off) - 1), np.array(bases, np.uint8, copy=True), off)
+            self.dust_masked_total += frag.dust_mask(tmp, threads=1)
+            bases, pre_cased = tmp.bases, True
         n = len(win_start)
         pred = np.zeros((n, self.class_map["num_classes"]), np.float32)
         rel = np.zeros((n, 1), np.float32)
@@ -65,7 +76,7 @@ def _write_fasta(path, seed=5):
     return lens
 
 
-def _run(out_dir, fasta, model_root, min_len, no_pipeline=True):
+def _run(out_dir, fasta, model_root, min_len, no_pipeline=True, dust_host=False):
     import pandas as pd
 
     import jaeger_amd.engine as E
@@ -80,7 +91,7 @@ def _run(out_dir, fasta, model_root, min_len, no_pipeline=True):
         (fa.lengths >= fsize)[:, None], np.zeros((len(fa), 10), np.int32), np.int32(-1)).astype(np.int32)
     return run_core(input=str(fasta), output=str(out_dir), model_path=str(model_root), fsize=1500, stride=1500,
                     min_len=min_len, batch=2, dustmask=True, rc=0.1, pc=1, overwrite=True, verbose=1,
-                    no_pipeline=no_pipeline, prophage=True, lc=4000)
+                    no_pipeline=no_pipeline, prophage=True, lc=4000, dust_host=dust_host)
 
 
 def _worker(rank, world, port, tmp, min_len):
@@ -114,9 +125,14 @@ def test_sharded_run_core_equals_single_process(tmp_path, min_len, monkeypatch):
         import jaeger_amd.predict as P
         monkeypatch.setattr(P, "_record_groups", lambda fa, **k: [(0, 4), (4, 5), (5, 11), (11, len(fa))])
         n_piped = _run(tmp_path / "piped", tmp_path / "in.fasta", tmp_path / "m", min_len, no_pipeline=False)
+        # --dust-host: the host pass over the FASTA image instead of DUST inside the fused calls (record tables of the
+        # whole-buffer and of the compacted short-contig batches): same TSV
+        n_host = _run(tmp_path / "hostdust", tmp_path / "in.fasta", tmp_path / "m", min_len, dust_host=True)
     finally:
         E.JaegerHipEngine, E.HipDevice, T.scan_for_terminal_repeats, T.terminal_repeat_table = keep
-    assert n_piped == n_single
+    assert n_piped == n_single == n_host
+    assert (tmp_path / "hostdust" / "38341_1.4M" / "in.tsv").read_text() == \
+        (tmp_path / "single" / "38341_1.4M" / "in.tsv").read_text()
     assert (tmp_path / "piped" / "38341_1.4M" / "in.tsv").read_text() == \
         (tmp_path / "single" / "38341_1.4M" / "in.tsv").read_text()
     s = socket.socket()
