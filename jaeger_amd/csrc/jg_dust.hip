@@ -216,32 +216,49 @@ extern "C" int jg_dust_mask(uint8_t *bases, const int64_t *offsets, int64_t n_re
 // l = 1 .. W - 2: r grows by the number of earlier occurrences of the new triplet (a 64-entry byte table per thread,
 // LDS, [triplet][thread]); M(s, l) = max(score(s, l), M(s, l - 1), M(s + 1, l - 1)) is the best score of any
 // sub-interval, exchanged with the neighbour through LDS once per step.  Scores are compared as integer fractions
-// (r <= 1 891, l <= 62: exact).  A workgroup owns 256 base positions and computes 64 starts either side of them:
+// (r <= 1 891, l <= 62: exact).  A workgroup owns 640 base positions and computes 64 starts either side of them:
 // an interval that covers an owned position starts at most 63 bases before it, and a start needs its <= 61 right
 // neighbours.  Triplets that hold a non-ACGT byte or straddle a record boundary exist in no interval.  HBM: one byte
-// read (+ a 1.5x halo from L2) and at most one written per base; the kernel is bound by the 62 dependent DP steps
-// (~25 vector instructions each per start).
+// read (+ a 1.2x halo from L2) and at most one written per base - 0.8 GB for 400 Mbp, 0.1 ms of HBM time; the kernel
+// is bound by the 62 dependent DP steps (~30 vector / LDS instructions and a barrier each per start: ~30 ms of vector
+// issue for 400 Mbp on 256 CUs).  Measured 39 ms = 10.3 Gbp/s (workgroups of 768 = three waves per SIMD, two per CU;
+// 384 threads: 64 ms, 512: 40, 640: 55, 1 024: 53), the host scan on 16 threads 1.5 Gbp/s.
 namespace {
 
-constexpr int DT = 384, DOWN = 256, DHALO = 64;
+constexpr int DT = 768, DOWN = 640, DHALO = 64;
+constexpr int DPITCH = DT + 4;      // bytes per triplet row of the count table: 97 dwords, so that the rows of different
+                                    // triplets start in different LDS banks
 
 __device__ __forceinline__ bool frac_ge(int an, int ad, int bn, int bd) { return an * bd >= bn * ad; }   // an/ad >= bn/bd
 
 __global__ __launch_bounds__(DT) void dust_kernel(uint8_t *bases, int64_t origin, int64_t span_len,
                                                   const int64_t *rec_off, int64_t n_rec, int lmax, int T,
                                                   int64_t own0, int64_t own1, unsigned long long *n_masked) {
-  __shared__ uint32_t cnt32[64 * DT / 4];          // byte table [triplet][thread]
+  __shared__ uint32_t cnt32[64 * DPITCH / 4];      // byte table [triplet][thread]
   __shared__ uint8_t code[DT + 68];                // bits 0-2: 0-3 = A C G T, 4 = other; bit 3: last base of its record
   __shared__ uint8_t tri[DT + 64];                 // triplet code, 0xff = no triplet starts here
-  __shared__ int2 Mbuf[2][DT + 1];
+  __shared__ short2 Mbuf[2][DT + 1];              // (repeat count <= 1 891, triplets - 1 <= 61)
   __shared__ int endp[DT];
   uint8_t *cnt = reinterpret_cast<uint8_t *>(cnt32);
   const int j = threadIdx.x;
   const int64_t tile0 = own0 + (int64_t)blockIdx.x * DOWN - DHALO;     // global position of thread 0's start
+  // record of the tile's first position inside the records: one (workgroup-uniform) binary search; every position
+  // then walks forward from it - records are mostly far longer than a tile
+  const int64_t first = rec_off[0], last = rec_off[n_rec];
+  int64_t r0 = 0;
+  {
+    const int64_t p0 = tile0 < first ? first : tile0;
+    int64_t lo = 0, hi = n_rec;                     // rec_off[lo] <= p0 < rec_off[hi] (when p0 < last)
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (rec_off[mid] <= p0) lo = mid; else hi = mid;
+    }
+    r0 = lo;
+  }
   for (int q = j; q < DT + 66; q += DT) {
     const int64_t pos = tile0 + q, loc = pos - origin;
     int c = 4;
-    if (loc >= 0 && loc < span_len && pos >= rec_off[0] && pos < rec_off[n_rec]) {
+    if (loc >= 0 && loc < span_len && pos >= first && pos < last) {
       switch (bases[loc]) {
         case 'A': case 'a': c = 0; break;
         case 'C': case 'c': c = 1; break;
@@ -250,18 +267,15 @@ __global__ __launch_bounds__(DT) void dust_kernel(uint8_t *bases, int64_t origin
         default: break;
       }
       // record of pos: the last r with rec_off[r] <= pos; pos is its last base when pos + 1 == rec_off[r + 1]
-      int64_t lo = 0, hi = n_rec;                   // rec_off[lo] <= pos < rec_off[hi]
-      while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (rec_off[mid] <= pos) lo = mid; else hi = mid;
-      }
-      if (pos + 1 == rec_off[lo + 1]) c |= 8;
+      int64_t r = r0;
+      while (r + 1 < n_rec && rec_off[r + 1] <= pos) ++r;
+      if (pos + 1 == rec_off[r + 1]) c |= 8;
     }
     code[q] = (uint8_t)c;
   }
-  for (int q = j; q < 64 * DT / 4; q += DT) cnt32[q] = 0u;
-  Mbuf[0][j] = Mbuf[1][j] = make_int2(-1, 1);
-  if (j == 0) Mbuf[0][DT] = Mbuf[1][DT] = make_int2(-1, 1);
+  for (int q = j; q < 64 * DPITCH / 4; q += DT) cnt32[q] = 0u;
+  Mbuf[0][j] = Mbuf[1][j] = make_short2(-1, 1);
+  if (j == 0) Mbuf[0][DT] = Mbuf[1][DT] = make_short2(-1, 1);
   __syncthreads();
   for (int q = j; q < DT + 64; q += DT) {
     const int a = code[q], b = code[q + 1], c = code[q + 2];
@@ -275,16 +289,16 @@ __global__ __launch_bounds__(DT) void dust_kernel(uint8_t *bases, int64_t origin
     const unsigned t = tri[j + l - 1];
     alive = alive && t != 0xffu;
     if (alive) {
-      const unsigned c = cnt[t * DT + j];
+      const unsigned c = cnt[t * DPITCH + j];
       r += (int)c;
-      cnt[t * DT + j] = (uint8_t)(c + 1);
+      cnt[t * DPITCH + j] = (uint8_t)(c + 1);
     }
     if (l >= 2) {
-      const int2 a = Mbuf[(l - 1) & 1][j], b = Mbuf[(l - 1) & 1][j + 1];
-      int2 m = frac_ge(a.x, a.y, b.x, b.y) ? a : b;           // best score of any proper sub-interval
+      const short2 a = Mbuf[(l - 1) & 1][j], b = Mbuf[(l - 1) & 1][j + 1];
+      short2 m = frac_ge(a.x, a.y, b.x, b.y) ? a : b;         // best score of any proper sub-interval
       if (alive && frac_ge(r, l - 1, m.x, m.y)) {
         if (10 * r > T * (l - 1)) reach = l + 2;               // perfect: masks bases [s, s + l + 2)
-        m = make_int2(r, l - 1);
+        m = make_short2((short)r, (short)(l - 1));
       }
       Mbuf[l & 1][j] = m;
     }
