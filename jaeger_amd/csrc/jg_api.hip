@@ -1088,11 +1088,12 @@ extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const 
   if (rc != JG_OK) { jg_model_destroy(m); return rc; }
   rc = prepare_f32(m, weights);
   if (rc != JG_OK) { jg_model_destroy(m); return rc; }
-  if (!m->f16_eligible) {          // the 32-channel family has a fused kernel of its own (same split-f16 arithmetic)
-    rc = prepare_small(m, weights);
-    if (rc != JG_OK) { jg_model_destroy(m); return rc; }
-    if (m->small != nullptr) m->f16_eligible = true;
-  }
+  // the 32-channel small-window family has a fused kernel of its own (same split-f16 arithmetic): where the program
+  // matches it, it takes precedence over the layer-by-layer placement above (whose narrow-conv kernels would run the
+  // same model several times slower)
+  rc = prepare_small(m, weights);
+  if (rc != JG_OK) { jg_model_destroy(m); return rc; }
+  if (m->small != nullptr) m->f16_eligible = true;
   m->precision = m->f16_eligible ? 1 : 0;
   *out = m;
   return JG_OK;

@@ -184,7 +184,7 @@ def test_default_precision_is_f16x3_when_eligible():
 def test_forward_baseline500(precision):
     """BASELINE configs[3]: f16x3 = the fused small-window kernel (ids -> pooled sums in one launch), f32 = the
     layer-by-layer exact-f32 kernels."""
-    _forward_case("baseline500", 500, 64, 5, n_frac=0.02, precision=precision)
+    _forward_case("baseline500", 500, 64, 5, n_frac=0.02, precision=precision, placement={"small_fused": True})
 
 
 def test_forward_baseline500_fused_ragged_and_masked():
