@@ -128,7 +128,8 @@ PRECISIONS = ["f32", "f16x3"]
 
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_forward_brain_1500(precision):
-    _forward_case("brain", 1500, 10, 1, n_frac=0.0, precision=precision)
+    _forward_case("brain", 1500, 10, 1, n_frac=0.0, precision=precision,
+                  placement={"convs": 13, "convs_f16x3": 13, "layout_conversions": 0, "small_fused": False})
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -143,7 +144,8 @@ def test_forward_brain_2000_short_windows(precision):
 
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_forward_zeus_dyt(precision):
-    _forward_case("zeus", 1500, 6, 4, n_frac=0.01, precision=precision)
+    _forward_case("zeus", 1500, 6, 4, n_frac=0.01, precision=precision,
+                  placement={"convs": 13, "convs_f16x3": 13, "layout_conversions": 0, "small_fused": False})
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -563,7 +565,8 @@ def test_forward_nmdmerge500(precision):
     """The fourth conv-family architecture of the reference's train_config (nn_config_500bp_nmd_merge.yaml):
     500-bp windows, NMD merge + reliability head on a narrow network.  f16x3 = the fused small-window kernel with its
     two NMD taps (masked channel sums of a layer's output next to the pool), f32 = layer by layer."""
-    _forward_case("nmdmerge500", 500, 48, 6, n_frac=0.02, short=True, precision=precision)
+    _forward_case("nmdmerge500", 500, 48, 6, n_frac=0.02, short=True, precision=precision,
+                  placement={"small_fused": True})
 
 
 def test_forward_return_nmd_norm_and_blocks():
