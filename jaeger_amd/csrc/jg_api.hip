@@ -867,6 +867,9 @@ static int prepare_f16(jg_model *m, const float *weights) {
           ok = q == n;
           hp.act_kind = gelu_kind != 0 ? gelu_kind : JG_ACT_GELU_TANH;
         }
+        if (ok && (ep & (JG_EP_NORM1_DYT | JG_EP_NORM2_DYT)) && (ep & (JG_EP_ACT1 | JG_EP_ACT2)) &&
+            hp.act_kind != JG_ACT_GELU_TANH)
+          ok = false;               // the DyT patterns are compiled for the tanh-GELU only
         hp.ep = ok ? ep : JG_EP_GENERIC;
         // Only compiled stage patterns run on the split-f16 path: the interpreted epilogue was measured
         // 12x slower than the compiled ones (and 3x slower than the exact-f32 kernels), so anything else

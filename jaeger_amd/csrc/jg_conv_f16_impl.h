@@ -737,7 +737,10 @@ void conv_f16x3_kernel(ConvHArgs a) {
           }
         };
         auto st_gelu = [&]() {
-          if (a.act_kind == JG_ACT_GELU_TANH) {
+          // DyT patterns (two tanh norms + two activations at a stack end) are compiled for the tanh-GELU only: with
+          // the erf / ReLU alternatives beside it the stack-end pattern spilled 576 bytes per lane and ran 10x slower
+          constexpr bool TANH_ONLY = EP != JG_EP_GENERIC && ((((EP >> 1) & 3) == 2) || (((EP >> 6) & 3) == 2));
+          if (TANH_ONLY || a.act_kind == JG_ACT_GELU_TANH) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = fast_gelu(x[r]);
           } else if (a.act_kind == JG_ACT_GELU_ERF) {    // one activation kind per op: uniform branches

@@ -20,14 +20,20 @@ def run(name, eng, fsize, stride, pw):
     t = time.time(); pw(bases, starts, tab.length, fsize); dt = time.time() - t
     uniq = float(np.minimum(lengths, (lengths - fsize) // stride * stride + fsize).sum()) if stride < fsize else len(tab) * fsize
     print(f"{name:28s} fsize {fsize} stride {stride}: {len(tab)} windows {dt:.2f} s  {len(tab)*fsize/dt/1e6:.1f} Mbp/s of windows ({uniq/dt/1e6:.1f} Mbp/s of unique bases)  [{eng.model.precision}]")
-for name, fsize, stride in (("brain", 1500, 1500), ("brain", 2000, 1500), ("brain", 2000, 2000), ("zeus", 1500, 1500), ("baseline500", 500, 500)):
+for name, fsize, stride in (("brain", 1500, 1500), ("brain", 2000, 1500), ("brain", 2000, 2000), ("zeus", 1500, 1500), ("baseline500", 500, 500),
+                            ("nmdmerge500", 500, 500), ("pyramid", 2000, 2000)):
     cfg = load_model_cfg(name)
-    eng = JaegerHipEngine(model_cfg=cfg, weights=random_weights(build_plan(cfg), 1))
+    wts = random_weights(build_plan(cfg), 1)
+    if name == "pyramid":
+        wts = {k: (v * np.float32(0.85) if k.startswith("rep/") and k.endswith("/kernel") else v) for k, v in wts.items()}
+    eng = JaegerHipEngine(model_cfg=cfg, weights=wts)
+    print("   placement:", eng.model.placement())
     run(name, eng, fsize, stride, lambda b, s, l, f: eng.predict_windows(b, s, l, f, want=("prediction", "reliability")))
     eng.close()
 w = legacy.load_legacy_h5('tests/golden/legacy_data/models/default/WRes_1024.h5')
 for prec in ("f32", "f16x3"):
     eng = legacy.LegacyHipEngine(w, precision=prec)
+    print("   placement:", eng.model.placement())
     run("legacy default", eng, 2000, 1500, eng.predict_windows)
     eng.close()
 PY
