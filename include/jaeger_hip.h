@@ -121,7 +121,7 @@ const char *jg_last_error(void);
 int jg_engine_create(int device_id, jg_engine **out);
 int jg_engine_destroy(jg_engine *e);
 int jg_engine_sync(jg_engine *e);
-/* Engine options.  JG_OPT_STREAM_BYTES: host-resident base buffers larger than this (default 256 MiB) are
+/* Engine options.  JG_OPT_STREAM_BYTES: host-resident base buffers larger than this (default 1 GiB) are
  * streamed by jg_predict_windows - the start-sorted window list is cut into groups whose base span fits the
  * budget, each span goes host -> pinned staging buffer -> device buffer on a copy stream (two of each) while the
  * previous group is encoded and classified; the device never holds more than two spans of bases.  This is the

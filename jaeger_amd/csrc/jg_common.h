@@ -160,7 +160,7 @@ struct jg_engine {
   int n_cu = 256;
   // streamed ingest of host-resident bases (jg_predict_windows): spans above `stream_bytes` go through two pinned
   // staging buffers and two device buffers on a copy stream, record group by record group
-  int64_t stream_bytes = (int64_t)256 << 20;
+  int64_t stream_bytes = (int64_t)1 << 30;
   hipStream_t copy_stream = nullptr;
   void *pin[2] = {nullptr, nullptr};
   void *dbase[2] = {nullptr, nullptr};
