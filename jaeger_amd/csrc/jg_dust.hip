@@ -328,8 +328,8 @@ __global__ __launch_bounds__(DT) void dust_kernel(uint8_t *bases, int64_t origin
 // device-side launch shared with jg_predict_windows (jg_api.hip): rec_off is a DEVICE array of n_rec + 1 global offsets
 int jg_launch_dust(uint8_t *d_bases, int64_t origin, int64_t span_len, const int64_t *d_rec_off, int64_t n_rec,
                    int window, int threshold, int64_t own0, int64_t own1, unsigned long long *d_masked, hipStream_t s) {
-  JG_REQUIRE(window >= 4 && window <= 64 && threshold > 0, JG_ERR_UNSUPPORTED,
-             "dust (device): window %d outside 4..64 (use the host scan)", window);
+  JG_REQUIRE(window >= 4 && window <= 64 && threshold > 0 && threshold <= 1000000, JG_ERR_UNSUPPORTED,
+             "dust (device): window %d outside 4..64 or threshold %d out of range (use the host scan)", window, threshold);
   if (own1 <= own0 || n_rec <= 0) return JG_OK;
   const int64_t blocks = (own1 - own0 + DOWN - 1) / DOWN;
   JG_REQUIRE(blocks < (int64_t)2147483647, JG_ERR_UNSUPPORTED, "dust (device): %lld bases in one launch", (long long)(own1 - own0));
