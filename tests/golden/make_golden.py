@@ -20,8 +20,10 @@ Produces
                           (postprocess/collect.py)
   *.fasta                 the reference's bundled test FASTA files (test data)
   *_project.yaml          `model:` sections of the reference's train_config/*.yaml (configuration data): brain, zeus,
-                          baseline500 and nmdmerge500 = nn_config_500bp_nmd_merge.yaml, written by
-                          yaml.safe_dump({"model": cfg["model"]}, sort_keys=False)
+                          baseline500, nmdmerge500 = nn_config_500bp_nmd_merge.yaml and pyramid =
+                          nn_config_baseline.yaml (its `training:` section is not valid YAML - a stray quote - so
+                          the text is cut in front of it), written by
+                          yaml.safe_dump({"model": cfg["model"]}, sort_keys=False) - see write_project_yamls()
 """
 import hashlib
 import json
@@ -36,6 +38,19 @@ import pandas as pd
 HERE = Path(__file__).resolve().parent
 REF = Path("/root/reference")
 sys.path.insert(0, str(REF / "src"))
+
+
+def write_project_yamls(reference_root, here):
+    """The `model:` sections the tests compile (configuration data, not code)."""
+    import yaml
+    names = {"brain": "nn_config_1500bp_nmd_merge_6_class_brain.yaml", "zeus": "nn_config_1500bp_nmd_merge_6_class_zeus.yaml",
+             "baseline500": "nn_config_500bp_baseline.yaml", "nmdmerge500": "nn_config_500bp_nmd_merge.yaml",
+             "pyramid": "nn_config_baseline.yaml"}
+    for name, fn in names.items():
+        text = (reference_root / "train_config" / fn).read_text()
+        cut = text.find("\ntraining:")
+        cfg = yaml.safe_load(text[:cut] if cut > 0 else text)
+        (here / f"{name}_project.yaml").write_text(yaml.safe_dump({"model": cfg["model"]}, sort_keys=False))
 
 
 def _stub_modules():
@@ -76,6 +91,7 @@ def _stub_modules():
 
 def main():
     _stub_modules()
+    write_project_yamls(REF, HERE)
     from jaeger.dataops import convert
     from jaeger.postprocess import collect
     from jaeger.seqops import crop, io, maps
