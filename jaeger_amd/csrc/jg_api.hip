@@ -1130,6 +1130,7 @@ extern "C" int jg_model_destroy(jg_model *m) {
   if (m->d_ids) (void)hipFree(m->d_ids);
   if (m->d_counts) (void)hipFree(m->d_counts);
   if (m->d_win) (void)hipFree(m->d_win);
+  if (m->d_bases_buf) (void)hipFree(m->d_bases_buf);
   if (m->d_lut) (void)hipFree(m->d_lut);
   if (m->d_overflow) (void)hipFree(m->d_overflow);
   if (m->pool_part) (void)hipFree(m->pool_part);
@@ -1647,7 +1648,8 @@ static int encode_common(jg_engine *e, jg_model *scratch_owner, const uint8_t *b
                          int64_t n_win, int32_t fsize, const uint8_t *lut65, int32_t flags,
                          int32_t l_pad, uint8_t *d_ids, int32_t *d_counts, uint8_t *d_lut,
                          std::vector<void *> &to_free, hipStream_t s) {
-  (void)scratch_owner;
+  // scratch_owner: a model whose grow-only device buffers hold the uploaded bases / window table (no hipMalloc / hipFree
+  // per call); without one (jg_encode) the copies are temporary
   // l_pad must hold the longest frame: known exactly for host-side window tables (the short-contig
   // pass pads to the longest window of a batch, commands/predict.py:236-245), fsize-derived otherwise
   int need = frame_len(fsize);
@@ -1664,8 +1666,14 @@ static int encode_common(jg_engine *e, jg_model *scratch_owner, const uint8_t *b
   const uint8_t *d_bases = bases;
   if (bases_loc == JG_PTR_HOST) {
     void *p = nullptr;
-    JG_HIP(hipMalloc(&p, (size_t)std::max<int64_t>(n_bases, 1)));
-    to_free.push_back(p);
+    if (scratch_owner != nullptr) {
+      const int rc = grow(&scratch_owner->d_bases_buf, &scratch_owner->d_bases_cap, std::max<int64_t>(n_bases, 1));
+      if (rc != JG_OK) return rc;
+      p = scratch_owner->d_bases_buf;
+    } else {
+      JG_HIP(hipMalloc(&p, (size_t)std::max<int64_t>(n_bases, 1)));
+      to_free.push_back(p);
+    }
     JG_HIP(hipMemcpyAsync(p, bases, (size_t)n_bases, hipMemcpyHostToDevice, s));
     d_bases = static_cast<const uint8_t *>(p);
     if (e->n_rec > 0) {                       // records attached: DUST on the uploaded copy, the encoder respects the case
@@ -1686,8 +1694,14 @@ static int encode_common(jg_engine *e, jg_model *scratch_owner, const uint8_t *b
                  JG_ERR_INVALID, "encode: window %lld [%lld, +%d) outside the %lld-byte base buffer",
                  (long long)i, (long long)win_start[i], win_len[i], (long long)n_bases);
     void *p = nullptr;
-    JG_HIP(hipMalloc(&p, (size_t)n_win * 12));
-    to_free.push_back(p);
+    if (scratch_owner != nullptr) {
+      const int rc = grow(&scratch_owner->d_win, &scratch_owner->d_win_cap, n_win * 12);
+      if (rc != JG_OK) return rc;
+      p = scratch_owner->d_win;
+    } else {
+      JG_HIP(hipMalloc(&p, (size_t)n_win * 12));
+      to_free.push_back(p);
+    }
     JG_HIP(hipMemcpyAsync(p, win_start, (size_t)n_win * 8, hipMemcpyHostToDevice, s));
     JG_HIP(hipMemcpyAsync(static_cast<char *>(p) + n_win * 8, win_len, (size_t)n_win * 4,
                           hipMemcpyHostToDevice, s));

@@ -237,6 +237,8 @@ struct jg_model {
   int64_t d_counts_cap = 0;
   void *d_win = nullptr;
   int64_t d_win_cap = 0;
+  void *d_bases_buf = nullptr;     // device copy of a host base buffer (whole-buffer path of jg_predict_windows): kept between
+  int64_t d_bases_cap = 0;         // calls - the short-contig pass makes thousands of 96-window calls
   uint8_t *d_lut = nullptr;
   float *pool_part = nullptr;       // fused max-pool partial rows (split-f16 path)
   int64_t pool_part_cap = 0;
