@@ -115,10 +115,6 @@ __device__ __forceinline__ f32x2 gelu_tanh2(f32x2 v) {
   return v * r;
 }
 
-__device__ __forceinline__ float gelu_tanh(float v) {
-  const float t = v * (-2.3022082f - 0.10294324f * v * v);   // -2u * log2(e), u = sqrt(2/pi)(v + 0.044715 v^3)
-  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
-}
 // One layer's epilogue over the five accumulator blocks of a row.  Lane (n, h) holds position 32 b + n and channels
 // 8 g + 4 h + i in register 4 g + i of block b.  Compiled per pattern (the activation is always the tanh-GELU):
 //   x = gelu(acc * s1 + t1 [+ shortcut: ADD]);  P2: x = gelu(x * s2 + t2) (the norm + GELU behind a residual stack);
