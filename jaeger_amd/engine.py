@@ -378,7 +378,7 @@ class JaegerHipEngine:
             return self.model.predict_windows(bases, bases.size, ws, wl, ws.size, fsize, self.lut, flags,
                                               l_pad, self.chunk, want=want)
         finally:
-            self.dust_masked_total += self.device.dust_masked()
+            self.dust_masked_total += max(0, self.device.dust_masked())
             self.device.attach_records(None)
 
     def close(self):
