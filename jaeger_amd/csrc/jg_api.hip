@@ -707,10 +707,10 @@ static int prepare_f16(jg_model *m, const float *weights) {
     if (op.kind != JG_OP_CONV) continue;
     ConvHPrep &hp = m->hprep[i];
     hp.f16_ok = false;
-    // a 1x1 conv (the bypass of a strided / widening residual block) rides the 5-tap kernel: weights in tap 2, the
-    // matrix-core work of the other taps skipped
-    hp.as_k5 = op.k == 1 && op.in_buf != JG_BUF_IDS;
-    const int kk = hp.as_k5 ? 5 : op.k, kdil = hp.as_k5 ? 1 : op.dilation;
+    // a 1x1 conv (the bypass of a strided / widening residual block) and a 3-tap conv (ResidualBlock's default kernel
+    // size, layers.py:1787) ride the 5-tap kernel: weights in the middle taps, the matrix-core work of the others skipped
+    hp.as_k5 = (op.k == 1 || op.k == 3) && op.in_buf != JG_BUF_IDS;
+    const int kk = hp.as_k5 ? 5 : op.k, kdil = (hp.as_k5 && op.k == 1) ? 1 : op.dilation;
     if (op.stride != 1 && !(op.stride == 2 && kk == 5 && op.in_buf != JG_BUF_IDS)) { fail("strided conv"); continue; }
     if (!jg_conv_f16_supports(kk, kdil)) { fail("taps / dilation outside the split-f16 tiling"); continue; }
     const bool narrow = op.cout == 32 || op.cout == 64;
@@ -753,7 +753,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
           const float v = w[((size_t)t * cin_pad + c) * cout_pad32 + n] * wscale;
           const float hi = f16_value(v);
           const size_t base = (size_t)(n / 128) * half_items;
-          const int tk = hp.as_k5 ? 2 : t;                       // (a 1x1 conv's only tap sits in the middle of five)
+          const int tk = hp.as_k5 ? (5 - op.k) / 2 + t : t;      // (a 1x1 / 3-tap conv's taps sit in the middle of five)
           const size_t item = base + (((size_t)0 * kk + tk) * kc_total + c / 8) * cout_pad + n % 128;
           const size_t item_lo = base + (((size_t)1 * kk + tk) * kc_total + c / 8) * cout_pad + n % 128;
           wh[item * 8 + c % 8] = f16_bits(hi);
@@ -1233,7 +1233,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
   Shape sh[JG_MAX_BUFS];
   int mlen[JG_MAX_BUFS] = {};
   // the 32-channel family: one fused kernel from ids to pooled sums when the rows fit its 160 positions; longer
-  // rows of such a model run layer by layer on the exact-f32 kernels (its convs have no split-f16 operands)
+  // rows of such a model run layer by layer
   int small_L0 = 0, small_pad0 = 0;
   bool small = false;
   if (m->precision == 1 && m->small != nullptr) {
@@ -1241,7 +1241,9 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
     conv_geometry(l, c0.k, 1, 1, c0.padding, &small_L0, &small_pad0);
     small = small_L0 >= 1 && small_L0 <= jg_small_max_positions() && l <= 192;
   }
-  const int prec = (m->precision == 1 && m->small != nullptr) ? 0 : m->precision;   // arithmetic of the per-layer path
+  // arithmetic of the per-layer path (with `small` the convs in front of the pool are skipped; rows too long for the
+  // fused kernel run layer by layer on the narrow split-f16 kernels - 3-tap convs as tap-masked 5-tap ones)
+  const int prec = m->precision;
   if (small) {
     JgSmallNet *sn = m->small;
     const int64_t rows = (int64_t)nw * 6;
@@ -1335,8 +1337,13 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           a.L_in = in.L; a.L_out = lo;
           a.cc_in = hp.cc_in; a.cout = op.cout; a.cout_pad = op.cout;
           a.k = op.k; a.dil = op.dilation; a.pad_left = pl;
-          a.only_tap = -1;
-          if (hp.as_k5) { a.k = 5; a.dil = 1; a.pad_left = 2; a.only_tap = 2; }
+          a.tap_lo = 0; a.tap_hi = op.k - 1;
+          if (hp.as_k5) {              // taps (5 - k) / 2 .. of five: the same input offsets when the left pad grows with them
+            a.k = 5;
+            a.dil = op.k == 1 ? 1 : op.dilation;
+            a.pad_left = pl + (5 - op.k) / 2 * a.dil;
+            a.tap_lo = (5 - op.k) / 2; a.tap_hi = a.tap_lo + op.k - 1;
+          }
           a.cw = hp.cw;
           a.ostride = op.stride;
           a.L_res = op.stride == 2 ? 2 * lo - 1 : lo;

@@ -109,8 +109,9 @@ struct ConvHArgs {
   int ostride;                 // 1, or 2: the conv is evaluated at stride 1 over L_res positions and even ones are kept
   int L_res;                   // positions the tiles resolve (= L_out when ostride == 1, 2*L_out - 1 otherwise)
   int lut_one_half;            // table variant: only the first 64-channel half exists (cout <= 64)
-  int only_tap;                // -1, or the one tap that carries weights (a 1x1 conv run on the 5-tap kernel: the
-                               // matrix-core work of the other taps is skipped)
+  int tap_lo, tap_hi;          // taps tap_lo .. tap_hi of the kernel's five carry weights (0, 4 normally; a 1x1 / 3-tap
+                               // conv rides the 5-tap pipeline with 2, 2 / 1, 3: the matrix-core work of the other taps
+                               // is skipped, their zero weight slices still flow through the DMA ring)
   int k, dil, pad_left, tiles_m;
   // window-packed tiling (see jg_conv_f16_impl.h): frames of a window on one axis, row pitch flat_p, window
   // pitch flat_wp (multiple of 128), flat_tiles tiles of 256; 0 = every row tiled on its own
@@ -179,7 +180,7 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   uint4 *d_wh = nullptr;    // weights [n_half][2][k][cin16/8][128]
   int n_half = 1;           // launches per conv: one per 128 output channels
   int cw = 128;             // workgroup tile width (128, or 64 / 32 for narrow convs)
-  bool as_k5 = false;       // a 1x1 conv carried by the 5-tap kernel (weights in tap 2, pad 2, the other taps skipped)
+  bool as_k5 = false;       // a 1x1 or 3-tap conv carried by the 5-tap kernel (weights in the middle taps, the others skipped)
   int64_t wh_half_items = 0;   // 16-byte items of one half's weight blob
   uint4 *d_embh = nullptr;  // embedding table [vocab][cin16/16][4] (conv on ids only)
   float acc_scale = 1.f;

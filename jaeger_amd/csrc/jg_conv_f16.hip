@@ -100,8 +100,8 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
                  (a.ostride == 1 || a.ostride == 2) && a.L_res == (a.ostride == 2 ? 2 * a.L_out - 1 : a.L_out),
              JG_ERR_UNSUPPORTED, "conv_f16x3: cout=%d ch0=%d tile width %d out-stride %d (L_res %d, L_out %d) outside the kernel",
              a.cout, a.ch0, a.cw, a.ostride, a.L_res, a.L_out);
-  JG_REQUIRE(a.only_tap < 0 || (a.k == 5 && a.only_tap < 5 && a.lut == nullptr), JG_ERR_UNSUPPORTED,
-             "conv_f16x3: single-tap mode is only built into the 5-tap kernel");
+  JG_REQUIRE(a.tap_lo >= 0 && a.tap_lo <= a.tap_hi && a.tap_hi < a.k && ((a.tap_lo == 0 && a.tap_hi == a.k - 1) || (a.k == 5 && a.lut == nullptr)),
+             JG_ERR_UNSUPPORTED, "conv_f16x3: a tap range (%d..%d of %d) is only built into the 5-tap kernel", a.tap_lo, a.tap_hi, a.k);
   if (a.lut != nullptr) {
     JG_REQUIRE(a.cw == HN && a.ostride == 1 && a.cout <= HN && (!a.lut_one_half || a.cout <= 64), JG_ERR_UNSUPPORTED,
                "conv lut: cout=%d outside the table variant", a.cout);
@@ -123,7 +123,7 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_REQUIRE(a.k == 5, JG_ERR_UNSUPPORTED, "conv_f16x3: narrow convs are only built for k = 5");
     return a.cw == 64 ? jg_conv_f16_part_n64(e, a, s) : jg_conv_f16_part_n32(e, a, s);
   }
-  if (a.cout != HN || a.ostride != 1 || a.only_tap >= 0) {        // (ch0 != 0 implies cout > 128)
+  if (a.cout != HN || a.ostride != 1 || a.tap_lo != 0 || a.tap_hi != a.k - 1) {     // (ch0 != 0 implies cout > 128)
     JG_REQUIRE(a.k == 5, JG_ERR_UNSUPPORTED, "conv_f16x3: cout=%d out-stride %d is only built for k = 5", a.cout, a.ostride);
     return jg_conv_f16_part_g128(e, a, s);
   }

@@ -440,7 +440,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
         const int ncc = last_chunk ? 0 : cc + 1;
         auto taps = [&](int t, auto &&mid, bool has_mid = true) {
           if constexpr (GEN) {
-            if (a.only_tap >= 0 && t != a.only_tap) {     // 1x1 conv on the 5-tap pipeline: this tap's weights are zero
+            if (a.tap_lo != 0 && (t < a.tap_lo || t > a.tap_hi)) {   // 1x1 / 3-tap conv on the 5-tap pipeline: this tap's weights are zero
               if (has_mid) mid();
               return;
             }

@@ -164,6 +164,49 @@ def test_forward_pyramid_resnet_short_windows_chunked():
     _forward_case("pyramid", 900, 5, 23, n_frac=0.0, precision="f16x3", gain=0.85)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_small_family_long_windows_layer_by_layer(precision):
+    """The 32-channel family on windows too long for the fused kernel (1 500 bp: 498 codons per frame > 160): layer by
+    layer, the 3-tap convs as tap-masked runs of the narrow 5-tap split-f16 kernel - none is left on the exact-f32 kernel."""
+    _forward_case("baseline500", 1500, 9, 31, n_frac=0.02, short=True, precision=precision,
+                  placement={"convs": 5, "convs_f16x3": 5, "layout_conversions": 0})
+    _forward_case("nmdmerge500", 1500, 6, 32, n_frac=0.0, precision=precision)
+
+
+def test_forward_brain_with_three_tap_blocks():
+    """ResidualBlock's default kernel size is 3 (layers.py:1787): brain with 3-tap blocks (dilations 1 and 3) stays on the
+    split-f16 kernels."""
+    import copy
+
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("brain"))
+    n_blocks = 0
+    for i, layer in enumerate(cfg["representation_learner"]["hidden_layers"]):
+        if layer["name"] == "residual_block":
+            layer["config"].pop("kernel_size", None)                    # -> the default, 3
+            layer["config"]["dilation_rate"] = 3 if n_blocks % 2 else 1
+            n_blocks += 1
+    assert n_blocks >= 2
+    weights = ofwd.random_weights(cfg, seed=38341)
+    rng = np.random.Generator(np.random.PCG64(33))
+    for fsize, n_win in ((1500, 7), (2000, 5)):                          # row-tiled and window-packed launches
+        seq = _random_dna(rng, fsize * n_win, n_frac=0.02)
+        starts = (np.arange(n_win) * fsize).astype(np.int64)
+        lens = np.full(n_win, fsize, np.int32)
+        lens[1] = fsize // 2
+        eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0)
+        pl = eng.model.placement()
+        got = eng.predict_windows(seq, starts, lens, fsize)
+        eng.close()
+        assert pl["convs_f16x3"] == pl["convs"] and pl["layout_conversions"] == 0, pl
+        ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+        ref = ofwd.forward(cfg, weights, ids)
+        for k in ("prediction", "reliability"):
+            assert np.abs(got[k] - ref[k]).max() <= TOL, (fsize, k, np.abs(got[k] - ref[k]).max())
+
+
 def test_default_precision_is_f16x3_when_eligible():
     from jaeger_amd.engine import JaegerHipEngine
     from oracle import forward as ofwd
@@ -173,12 +216,13 @@ def test_default_precision_is_f16x3_when_eligible():
         eng = JaegerHipEngine(model_cfg=cfg, weights=ofwd.random_weights(cfg))
         assert eng.model.precision == "f16x3"
         eng.close()
-    # a 32-channel net whose first-layer table does not fit LDS has neither and says so
+    # a 32-channel net whose first-layer table does not fit LDS is outside the fused kernel (and its first conv outside
+    # the table variant): its 3-tap convs still run on the narrow split-f16 kernels, the first conv on the exact-f32 one
     cfg = _small_variant(k0=9, pad0="same")
     eng = JaegerHipEngine(model_cfg=cfg, weights=ofwd.random_weights(cfg))
-    assert eng.model.precision == "f32"
-    with pytest.raises(Exception):
-        eng.model.set_precision("f16x3")
+    assert eng.model.precision == "f16x3"
+    pl = eng.model.placement()
+    assert not pl["small_fused"] and pl["convs"] == 5 and pl["convs_f16x3"] == 4, pl
     eng.close()
 
 
@@ -260,14 +304,27 @@ def test_forward_small_window_variants(kw):
         assert err <= TOL and err32 <= TOL, (k, err, err32)
 
 
-def test_small_window_table_too_large_for_lds_stays_on_f32():
-    """A 9-tap first conv needs an 85 KB table next to the four row images: outside the fused kernel, loud f32 path."""
-    from jaeger_amd.engine import JaegerHipEngine
+def test_small_window_table_too_large_for_lds_runs_layer_by_layer():
+    """A 9-tap first conv needs an 85 KB table next to the four row images: outside the fused kernel; layer by layer
+    (first conv exact f32, the 3-tap convs on the narrow split-f16 kernel), same results contract."""
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
     from oracle import forward as ofwd
     cfg = _small_variant(k0=9, pad0="same")
-    eng = JaegerHipEngine(model_cfg=cfg, weights=ofwd.random_weights(cfg, seed=7))
-    assert eng.model.precision == "f32"
+    weights = ofwd.random_weights(cfg, seed=7)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights)
+    assert eng.model.precision == "f16x3" and not eng.model.placement()["small_fused"]
+    rng = np.random.Generator(np.random.PCG64(41))
+    fsize, n_win = 500, 12
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.02)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    got = eng.predict_windows(seq, starts, lens, fsize)
     eng.close()
+    ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    for k in ("prediction", "reliability") if "reliability" in ref else ("prediction",):
+        assert np.abs(got[k] - ref[k]).max() <= TOL, k
 
 
 def test_small_window_model_on_longer_rows_runs_layer_by_layer():
