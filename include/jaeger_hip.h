@@ -149,7 +149,7 @@ int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const float *weig
 int jg_model_destroy(jg_model *m);
 /* Arithmetic of the conv stack: 0 = exact-f32 MFMA, 1 = split-f16 ("f16x3": each f32 operand
  * as an f16 hi/lo pair, three f16 MFMAs per product, f32 accumulate; ~f32 accuracy).  A model
- * starts in mode 1 when at least one conv is eligible (k = 1, 3, 5: 32, 64, 80..128 or a multiple of 128 output
+ * starts in mode 1 when at least one conv is eligible (k = 1 .. 5: 32, 64, 80..128 or a multiple of 128 output
  * channels, stride 1 or 2; k = 7 / 9: 128 channels, stride 1; a compiled epilogue pattern) or the program is the
  * 32-channel small-window family (one fused kernel), else 0; mode 1
  * falls back to 0 by itself if an activation ever leaves the f16 range.  Replaces the

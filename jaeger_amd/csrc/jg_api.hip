@@ -709,7 +709,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
     hp.f16_ok = false;
     // a 1x1 conv (the bypass of a strided / widening residual block) and a 3-tap conv (ResidualBlock's default kernel
     // size, layers.py:1787) ride the 5-tap kernel: weights in the middle taps, the matrix-core work of the others skipped
-    hp.as_k5 = (op.k == 1 || op.k == 3) && op.in_buf != JG_BUF_IDS;
+    hp.as_k5 = op.k >= 1 && op.k <= 4 && op.in_buf != JG_BUF_IDS;       // (2- and 4-tap convs the same way)
     const int kk = hp.as_k5 ? 5 : op.k, kdil = (hp.as_k5 && op.k == 1) ? 1 : op.dilation;
     if (op.stride != 1 && !(op.stride == 2 && kk == 5 && op.in_buf != JG_BUF_IDS)) { fail("strided conv"); continue; }
     if (!jg_conv_f16_supports(kk, kdil)) { fail("taps / dilation outside the split-f16 tiling"); continue; }
@@ -753,7 +753,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
           const float v = w[((size_t)t * cin_pad + c) * cout_pad32 + n] * wscale;
           const float hi = f16_value(v);
           const size_t base = (size_t)(n / 128) * half_items;
-          const int tk = hp.as_k5 ? (5 - op.k) / 2 + t : t;      // (a 1x1 / 3-tap conv's taps sit in the middle of five)
+          const int tk = hp.as_k5 ? std::max(1, (5 - op.k) / 2) + t : t;   // (a 1x1 / 3-tap conv's taps sit in the middle of five)
           const size_t item = base + (((size_t)0 * kk + tk) * kc_total + c / 8) * cout_pad + n % 128;
           const size_t item_lo = base + (((size_t)1 * kk + tk) * kc_total + c / 8) * cout_pad + n % 128;
           wh[item * 8 + c % 8] = f16_bits(hi);
@@ -1341,8 +1341,9 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           if (hp.as_k5) {              // taps (5 - k) / 2 .. of five: the same input offsets when the left pad grows with them
             a.k = 5;
             a.dil = op.k == 1 ? 1 : op.dilation;
-            a.pad_left = pl + (5 - op.k) / 2 * a.dil;
-            a.tap_lo = (5 - op.k) / 2; a.tap_hi = a.tap_lo + op.k - 1;
+            a.tap_lo = std::max(1, (5 - op.k) / 2);      // >= 1: tap_lo != 0 is the kernel's "some taps are skipped" flag
+            a.tap_hi = a.tap_lo + op.k - 1;
+            a.pad_left = pl + a.tap_lo * a.dil;
           }
           a.cw = hp.cw;
           a.ostride = op.stride;

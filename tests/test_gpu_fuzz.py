@@ -48,7 +48,7 @@ def random_model(rng):
             width = int(rng.choice([32, 64, 128, 128, 256]))
         if rng.random() < 0.8:
             nt = str(rng.choice(["masked_batchnorm", "masked_batchnorm", "masked_dyt", "masked_layernorm"]))
-            cfg = {"filters": width, "kernel_size": int(rng.choice([3, 5, 5, 7])), "block_size": int(rng.integers(1, 3)),
+            cfg = {"filters": width, "kernel_size": int(rng.choice([2, 3, 4, 5, 5, 5, 7])), "block_size": int(rng.integers(1, 3)),
                    "dilation_rate": int(rng.choice([1, 2, 3, 4, 8])), "strides": int(rng.choice([1, 1, 1, 2])),
                    "use_1x1conv": bool(rng.random() < 0.3), "norm_type": nt}
             if nt == "masked_batchnorm" and rng.random() < 0.3:
