@@ -162,6 +162,9 @@ int jg_model_get_precision(const jg_model *m);
  * fused small-window kernel.  -1 for an unknown key. */
 enum { JG_MSTAT_CONVS = 0, JG_MSTAT_CONVS_F16X3 = 1, JG_MSTAT_LAYOUT_CONVERSIONS = 2, JG_MSTAT_SMALL_FUSED = 3 };
 int64_t jg_model_get_stat(const jg_model *m, int key);
+/* ... and conv by conv, as text (one line each: geometry -> kernel; for a conv on the exact-f32 kernel the rule that kept
+ * it there), NUL-terminated, truncated to cap. */
+int jg_model_describe(const jg_model *m, char *buf, int64_t cap);
 
 /* ---- hot path ----------------------------------------------------------- */
 /* Replaces fragment_generator's per-window slice + 4x str.count

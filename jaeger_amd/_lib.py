@@ -80,6 +80,7 @@ SYMBOLS = {
     "jg_model_set_precision": (C.c_int, [_vp, C.c_int]),
     "jg_model_get_precision": (C.c_int, [_vp]),
     "jg_model_get_stat": (C.c_int64, [_vp, C.c_int]),
+    "jg_model_describe": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "jg_encode": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_int, C.c_int64, C.c_int32, _vp,
                             C.c_int32, C.c_int32, _vp, _vp, C.c_int, _vp]),
     "jg_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, C.c_int,

@@ -701,10 +701,15 @@ static int prepare_f16(jg_model *m, const float *weights) {
   // convs (1x1 bypass, other strides or widths) keep the exact-f32 kernel inside an otherwise split-f16 program; pass B
   // below places the layout conversions between them.
   std::string first_reason;
-  auto fail = [&](const char *why) { if (first_reason.empty()) first_reason = why; };
+  size_t cur = 0;
+  auto fail = [&](const char *why) {
+    if (first_reason.empty()) first_reason = why;
+    if (m->hprep[cur].why_f32.empty()) m->hprep[cur].why_f32 = why;
+  };
   for (size_t i = 0; i < m->ops.size(); ++i) {
     const jg_op &op = m->ops[i];
     if (op.kind != JG_OP_CONV) continue;
+    cur = i;
     ConvHPrep &hp = m->hprep[i];
     hp.f16_ok = false;
     // a 1x1 conv (the bypass of a strided / widening residual block) and a 3-tap conv (ResidualBlock's default kernel
@@ -1044,6 +1049,39 @@ extern "C" int jg_model_set_precision(jg_model *m, int mode) {
 }
 
 extern "C" int jg_model_get_precision(const jg_model *m) { return m ? m->precision : -1; }
+
+// One line per convolution: geometry, the kernel it runs on in mode 1 and, for the exact-f32 ones, why.
+extern "C" int jg_model_describe(const jg_model *m, char *buf, int64_t cap) {
+  JG_REQUIRE(m != nullptr && buf != nullptr && cap > 0, JG_ERR_INVALID, "jg_model_describe: bad arguments");
+  std::string out;
+  char line[512];
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    const jg_op &op = m->ops[i];
+    if (op.kind != JG_OP_CONV) continue;
+    const ConvHPrep &hp = m->hprep[i];
+    const char *where = m->small != nullptr ? "fused small-window kernel"
+                        : (m->f16_eligible && hp.f16_ok)
+                            ? (hp.d_lut != nullptr ? "split-f16 (table lookup)" : hp.as_k5 ? "split-f16 (tap range of the 5-tap kernel)"
+                               : hp.cw != 128 ? "split-f16 (narrow tile)" : "split-f16")
+                            : "exact-f32";
+    static const char *const st_name[] = {"?", "bias", "bn", "dyt", "add", "act", "nmd", "maskmul", "ln"};
+    std::string stages;
+    for (int q = 0; q < op.n_stages; ++q) {
+      const int kd = op.stages[q].kind;
+      stages += (q ? " " : "");
+      stages += (kd >= 1 && kd <= 8) ? st_name[kd] : "?";
+    }
+    snprintf(line, sizeof(line), "op %zu: conv k=%d cin=%d cout=%d stride=%d dilation=%d [%s] -> %s%s%s\n", i, op.k, op.cin,
+             op.cout, op.stride, op.dilation, stages.c_str(), where,
+             (!hp.f16_ok && !hp.why_f32.empty() && m->small == nullptr) ? ": " : "",
+             (!hp.f16_ok && m->small == nullptr) ? hp.why_f32.c_str() : "");
+    out += line;
+  }
+  const size_t n = std::min(out.size(), (size_t)cap - 1);
+  memcpy(buf, out.data(), n);
+  buf[n] = 0;
+  return JG_OK;
+}
 
 extern "C" int64_t jg_model_get_stat(const jg_model *m, int key) {
   if (m == nullptr) return -1;

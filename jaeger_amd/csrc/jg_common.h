@@ -181,6 +181,7 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   int n_half = 1;           // launches per conv: one per 128 output channels
   int cw = 128;             // workgroup tile width (128, or 64 / 32 for narrow convs)
   bool as_k5 = false;       // a 1x1 or 3-tap conv carried by the 5-tap kernel (weights in the middle taps, the others skipped)
+  std::string why_f32;      // (CONV ops that are not f16_ok) what keeps this conv on the exact-f32 kernel
   int64_t wh_half_items = 0;   // 16-byte items of one half's weight blob
   uint4 *d_embh = nullptr;  // embedding table [vocab][cin16/16][4] (conv on ids only)
   float acc_scale = 1.f;

@@ -54,7 +54,9 @@ bool jg_conv_f16_has_pattern(unsigned ep, bool first_layer) {
                           JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2,
                           JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_DYT | JG_EP_ACT2,
                           JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1,
-                          JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2};
+                          JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2,
+                          JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2,
+                          JG_EP_NORM1_DYT};
   if (first_layer) {
     for (unsigned p : lut) if (p == ep) return true;
     return false;      // (a first layer the table variant cannot take also needs one of `all`: same subset)
@@ -71,7 +73,8 @@ bool jg_conv_f16_has_flat_pattern(unsigned ep) {
                            JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2,
                            JG_EP_ACT1 | JG_EP_NORM2_AFF, JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2,
                            JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2,
-                           JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_DYT | JG_EP_ACT2};
+                           JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_DYT | JG_EP_ACT2,
+                           JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2};
   for (unsigned p : flat) if (p == ep) return true;
   return false;
 }
@@ -82,7 +85,9 @@ bool jg_conv_f16_has_narrow_pattern(unsigned ep) {
   const unsigned nar[] = {0u, JG_EP_ACT1, JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_ADD | JG_EP_ACT1,
                           JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2, JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1,
                           JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1,
-                          JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2};
+                          JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2,
+                          JG_EP_NORM1_DYT | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1, JG_EP_NMD1,
+                          JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2};
   for (unsigned p : nar) if (p == ep) return true;
   return false;
 }

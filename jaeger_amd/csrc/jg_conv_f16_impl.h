@@ -1061,6 +1061,11 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
       return launch_ke<K, (JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1)>(e, a, s);         \
     case (JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2):     \
       return launch_ke<K, (JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)>(e, a, s); \
+    case (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2):           /* a tap behind a block, no norm after it */ \
+      return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)>(e, a, s);                           \
+    case (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2):                                    \
+      return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)>(e, a, s);         \
+    case (JG_EP_NORM1_DYT): return launch_ke<K, (JG_EP_NORM1_DYT)>(e, a, s);                         \
     default: break;                                                                                  \
   }                                                                                                  \
   jg_set_error("conv_f16x3: stage pattern 0x%x has no compiled epilogue", a.ep);                     \
@@ -1090,6 +1095,8 @@ int jg_conv_f16_part_flat(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_CASE(JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)
     JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_DYT | JG_EP_ACT2)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
 #undef JG_CASE
     default: break;
   }
@@ -1122,6 +1129,10 @@ int jg_conv_f16_part_g128(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1)
     JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1)
     JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1)
+    JG_CASE(JG_EP_NMD1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
 #undef JG_CASE
     default: break;
   }

@@ -208,6 +208,12 @@ class HipModel:
         return {"convs": g(L.JG_MSTAT_CONVS), "convs_f16x3": g(L.JG_MSTAT_CONVS_F16X3),
                 "layout_conversions": g(L.JG_MSTAT_LAYOUT_CONVERSIONS), "small_fused": bool(g(L.JG_MSTAT_SMALL_FUSED))}
 
+    def describe(self) -> str:
+        """Conv by conv: geometry, the kernel it runs on and - for convs left on the exact-f32 kernel - why (``jg_model_describe``)."""
+        buf = C.create_string_buffer(1 << 16)
+        L.check(self.lib.jg_model_describe(self.handle, buf, len(buf)), "jg_model_describe")
+        return buf.value.decode()
+
     def flops_per_window(self, l: int) -> float:
         return float(self.lib.jg_model_flops_per_window(self.handle, int(l)))
 
