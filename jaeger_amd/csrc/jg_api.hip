@@ -717,7 +717,12 @@ static int prepare_f16(jg_model *m, const float *weights) {
     hp.as_k5 = op.k >= 1 && op.k <= 4 && op.in_buf != JG_BUF_IDS;       // (2- and 4-tap convs the same way)
     const int kk = hp.as_k5 ? 5 : op.k, kdil = (hp.as_k5 && op.k == 1) ? 1 : op.dilation;
     if (op.stride != 1 && !(op.stride == 2 && kk == 5 && op.in_buf != JG_BUF_IDS)) { fail("strided conv"); continue; }
-    if (!jg_conv_f16_supports(kk, kdil)) { fail("taps / dilation outside the split-f16 tiling"); continue; }
+    // (a first conv on ids runs as the table variant whatever its tap count, when the table fits LDS)
+    static const bool no_lut = jg_exp_env("JG_NO_LUT") != nullptr;
+    const bool lut_ok = !no_lut && op.in_buf == JG_BUF_IDS && (op.in_mask == JG_BUF_IDS || op.in_mask < 0) && op.cout <= 128 &&
+                        op.stride == 1 && jg_conv_lut_supports(op.k, op.dilation, m->vocab);
+    const bool mfma_ok = jg_conv_f16_supports(kk, kdil);
+    if (!mfma_ok && !lut_ok) { fail("taps / dilation outside the split-f16 tiling"); continue; }
     const bool narrow = op.cout == 32 || op.cout == 64;
     if (op.cout % 16 != 0 || !(narrow || (op.cout > 64 && op.cout <= 128) || op.cout % 128 == 0)) {
       fail("conv width is not 32, 64, 80..128 or a multiple of 128 channels");
@@ -898,10 +903,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
       }
       // first layer on ids: the conv is a sum of k table rows T_t[id] = E[id] . W_t (f64 on the
       // host); the kernel's table variant then needs no matrix cores and no acc un-scale
-      static const bool no_lut = jg_exp_env("JG_NO_LUT") != nullptr;
-      if (conv_ok && !no_lut && op.in_buf == JG_BUF_IDS &&
-          (op.in_mask == JG_BUF_IDS || op.in_mask < 0) && op.cout <= 128 &&
-          jg_conv_lut_supports(op.k, op.dilation, m->vocab)) {
+      if (conv_ok && lut_ok) {
         const float *emb = weights + op.b_off;   // (vocab, cin)
         const int vr = m->vocab + 1;             // + the all-zero padding row
         std::vector<float> lut((size_t)2 * op.k * vr * 64, 0.f);
@@ -920,8 +922,8 @@ static int prepare_f16(jg_model *m, const float *weights) {
         JG_HIP(hipMalloc(reinterpret_cast<void **>(&hp.d_epi_lut), tab_lut.size() * sizeof(float)));
         JG_HIP(hipMemcpy(hp.d_epi_lut, tab_lut.data(), tab_lut.size() * sizeof(float), hipMemcpyHostToDevice));
       }
-      if (conv_ok && op.in_buf == JG_BUF_IDS && hp.d_lut == nullptr && op.cout != 128)
-        cfail("first conv without the table variant is not 128 channels wide");
+      if (conv_ok && op.in_buf == JG_BUF_IDS && hp.d_lut == nullptr && (op.cout != 128 || !mfma_ok))
+        cfail("first conv without the table variant is not a 128-channel 5- / 7- / 9-tap conv");
     }
     hp.f16_ok = conv_ok;
   }

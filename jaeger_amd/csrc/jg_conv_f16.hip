@@ -87,7 +87,7 @@ bool jg_conv_f16_has_narrow_pattern(unsigned ep) {
                           JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1,
                           JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2,
                           JG_EP_NORM1_DYT | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1, JG_EP_NMD1,
-                          JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2};
+                          JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2, JG_EP_NORM1_DYT, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2};
   for (unsigned p : nar) if (p == ep) return true;
   return false;
 }

@@ -1133,6 +1133,8 @@ int jg_conv_f16_part_g128(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1)
     JG_CASE(JG_EP_NMD1)
     JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
+    JG_CASE(JG_EP_NORM1_DYT)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
 #undef JG_CASE
     default: break;
   }
