@@ -523,6 +523,18 @@ def run_core(**kwargs) -> int:
         lg.info(f"fragment size: {fsize}  stride: {stride}  batch: {kwargs.get('batch', 96)}")
         lg.info(f"model: {model_id}  arithmetic: {engine.model.precision}  device: MI355X #{local_rank} "
                 f"(rank {rank}/{world})")
+        try:                                   # kernel placement (engines of other kinds have none)
+            pl = engine.model.placement()
+            if pl["small_fused"]:
+                lg.info("kernels: fused small-window kernel (ids -> pooled sums in one launch)")
+            elif engine.model.precision == "f16x3":
+                lg.info(f"kernels: {pl['convs_f16x3']} of {pl['convs']} convolutions on the split-f16 kernels"
+                        + (f", {pl['layout_conversions']} layout conversions" if pl["layout_conversions"] else ""))
+                if pl["convs_f16x3"] < pl["convs"]:
+                    slow = [ln for ln in engine.model.describe().splitlines() if "exact-f32" in ln]
+                    lg.warning("convolutions left on the exact-f32 kernel (about 4x slower):\n  " + "\n  ".join(slow))
+        except AttributeError:
+            pass
         msg = _crop_length_warning(sp.get("crop_size_codons"), sp.get("crop_size_nt"), fsize)
         if msg:
             lg.warning(msg)
