@@ -2,7 +2,7 @@
 (cli.py:122-370) in front of :func:`jaeger_amd.predict.run_core`.
 
 Flags that select machinery outside the MI355X hot path (``--cpu``, ``--onnx``, ``--quantized``,
-``--int8``, ``--refine``, ``--getsequences``) are accepted so existing
+``--int8``, ``--refine``) are accepted so existing
 command lines parse, and rejected at run time with an explicit message - there is no silent
 fallback.  Extra flags: ``--exact-f32`` (disable the split-f16 conv path), ``--chunk``.
 """
@@ -48,7 +48,7 @@ def main():
 @click.option("--batch", type=int, default=96, help="batch of the short-contig padded pass")
 @click.option("--workers", type=int, default=4, help="accepted, unused (no host input pipeline)")
 @click.option("--window-scores", is_flag=True)
-@click.option("--getsequences", is_flag=True, help="[unsupported here]")
+@click.option("--getsequences", is_flag=True, help="write the sequences of the phage table to <stem>_phages_jaeger.fasta")
 @click.option("--cpu", is_flag=True, help="[rejected: no CPU fallback]")
 @click.option("--physicalid", type=int, default=0, help="GPU ordinal")
 @click.option("--mem", type=int, default=4, help="accepted, unused")

@@ -453,3 +453,26 @@ def write_output(data: dict, reliability_cutoff: float = 0.5, phage_score=1, **k
     if not phage_df.empty:
         _to_tsv(phage_df, kwargs.get("output_phage_table_path"))
     return len(df)
+
+
+def write_fasta_from_results(input_fasta, output_tsv, output_fasta, width: int = 70) -> int:
+    """``--getsequences`` (postprocess/collect.py:613-639, commands/predict.py:444-456): the records of the input FASTA
+    whose name is a ``contig_id`` of the phage table, as read from the file (original case), ``width`` bases per line.
+    Returns the number of records written."""
+    import os
+
+    from .fragment import load_fasta
+    if not os.path.exists(str(output_tsv)):              # no contig passed the phage filters: an empty FASTA
+        open(str(output_fasta), "wb").close()
+        return 0
+    phages = set(pd.read_table(str(output_tsv))["contig_id"].to_list())
+    fa = load_fasta(str(input_fasta))
+    n = 0
+    with open(str(output_fasta), "wb") as out:
+        for i, name in enumerate(fa.names):
+            if name in phages:
+                out.write(b">" + name.encode() + b"\n")
+                seq = fa.sequence(i)
+                out.write(b"".join(seq[j:j + width] + b"\n" for j in range(0, len(seq), width)))
+                n += 1
+    return n

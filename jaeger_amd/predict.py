@@ -487,7 +487,7 @@ def run_core(**kwargs) -> int:
     if table_path.exists() and not kwargs.get("overwrite"):
         lg.error("output file exists. enable --overwrite option to overwrite the output file.")
         sys.exit(1)
-    for flag in ("refine", "quantized", "onnx", "int8", "cpu", "getsequences"):
+    for flag in ("refine", "quantized", "onnx", "int8", "cpu"):
         if kwargs.get(flag):
             lg.error(f"--{flag} is not available on the MI355X predict path (jaeger_amd has no CPU / "
                      "alternative-backend fallback; refinement post-processing is out of scope)")
@@ -690,6 +690,13 @@ def run_core(**kwargs) -> int:
         except Exception as e:
             lg.error(f"an error {e} occurred during the prophage prediction step")
             lg.debug(traceback.format_exc())
+    if kwargs.get("getsequences"):
+        # --- phage sequences as FASTA (commands/predict.py:444-456) ---
+        from .postprocess import write_fasta_from_results
+        out_fasta = out_dir / f"{file_base}_phages_jaeger.fasta"
+        lg.info(f"generating fasta file {out_fasta}")
+        n_seq = write_fasta_from_results(input_path, phage_path, out_fasta)
+        lg.info(f"{n_seq} phage sequences written")
     headers = y_pred.get("meta_0", np.array([], dtype=object))
     if kwargs.get("save_embedding") and "embedding" in y_pred:
         np.savez(out_dir / f"{file_base}_embedding.npz", embedding=y_pred["embedding"], headers=headers)

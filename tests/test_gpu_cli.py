@@ -177,8 +177,16 @@ def test_cli_default_dustmask(tmp_path):
     cfg = load_model_cfg("brain")
     weights = ofwd.random_weights(cfg, seed=38341)
     r = CliRunner().invoke(main, ["predict", "-i", str(fasta), "-o", str(tmp_path / "out"), "--model_path", str(root),
-                                  "--fsize", "1500", "--stride", "1500"])
+                                  "--fsize", "1500", "--stride", "1500", "--getsequences", "--pc", "0", "--rc", "-100"])
     assert r.exit_code == 0, r.output
+    # --getsequences: the records of the phage table, as read from the file (the GPU-side masking never touches them)
+    ph_path = tmp_path / "out" / "38341_1.4M" / "lowcomplexity_phages.tsv"
+    ph_ids = set(pd.read_csv(ph_path, sep="\t")["contig_id"]) if ph_path.exists() else set()
+    got_fa = (tmp_path / "out" / "38341_1.4M" / "lowcomplexity_phages_jaeger.fasta").read_text()
+    assert [ln[1:] for ln in got_fa.splitlines() if ln.startswith(">")] == [n for n, _ in records if n in ph_ids]
+    for n, s_ in records:
+        if n in ph_ids:
+            assert "".join(got_fa.split(f">{n}\n")[1].split(">")[0].split()) == s_
     masked = [(n, odust.soft_mask(s.encode()).decode()) for n, s in records]
     assert sum(c.islower() for _, s in masked for c in s) > 1200
 

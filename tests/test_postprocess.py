@@ -124,3 +124,15 @@ def test_vectorised_aggregation_equals_per_contig_restatement(n_cls, with_rel, c
         assert [np.asarray(x).ravel().tolist() for x in dp["frag_pred"]] == [np.asarray(x).ravel().tolist() for x in do["frag_pred"]]
         assert len(fp["predictions"]) == len(fo["predictions"]) == n_contigs
         assert all(np.array_equal(a, b) for a, b in zip(fp["gcs"], fo["gcs"]))
+
+
+def test_write_fasta_from_results(tmp_path):
+    """--getsequences (collect.py:613-639): records named in the phage table, as read, 70 bases per line."""
+    from jaeger_amd.postprocess import write_fasta_from_results
+    fasta = tmp_path / "in.fasta"
+    fasta.write_text(">a desc\nACGTacgtNN\nGG\n>b\n" + "ACGT" * 40 + "\n>c,x\nTTTT\n")
+    (tmp_path / "ph.tsv").write_text("contig_id\tlength\nb\t160\na\t12\nc___x\t4\n")
+    n = write_fasta_from_results(fasta, tmp_path / "ph.tsv", tmp_path / "out.fasta")
+    assert n == 2
+    seq_b = "ACGT" * 40
+    assert (tmp_path / "out.fasta").read_text() == ">a\nACGTacgtNNGG\n>b\n" + seq_b[:70] + "\n" + seq_b[70:140] + "\n" + seq_b[140:] + "\n"
