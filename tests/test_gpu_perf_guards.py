@@ -48,18 +48,18 @@ def test_zeus_dyt_epilogues_keep_pace_with_brain():
     zeus, m2 = _rate("zeus", 1500, 6144)
     print(f"brain {brain:.1f} Mbp/s, zeus {zeus:.1f} Mbp/s")
     assert m1 == m2 == "f16x3"
-    assert zeus >= 0.7 * brain, (zeus, brain)          # measured 0.95
+    assert zeus >= 0.5 * brain, (zeus, brain)          # measured 0.95; the spilling epilogue gave 0.27
 
 
 def test_small_window_family_runs_fused():
     fused, m = _rate("baseline500", 500, 98_304)
     layered, _ = _rate("baseline500", 500, 24_576, precision="f32")
     print(f"baseline500 fused {fused:.0f} Mbp/s, exact-f32 layer by layer {layered:.0f} Mbp/s")
-    assert m == "f16x3" and fused >= 3.0 * layered, (fused, layered)        # measured 5 - 6x with host buffers
+    assert m == "f16x3" and fused >= 2.0 * layered, (fused, layered)        # measured 5 - 6x with host buffers; unfused 1.3x
 
 
 def test_pyramid_runs_on_the_split_f16_kernels():
     fast, m = _rate("pyramid", 2000, 6144, gain=0.85)
     exact, _ = _rate("pyramid", 2000, 1536, precision="f32", gain=0.85)
     print(f"pyramid split-f16 {fast:.1f} Mbp/s, exact-f32 {exact:.1f} Mbp/s")
-    assert m == "f16x3" and fast >= 2.5 * exact, (fast, exact)              # measured 4.6x
+    assert m == "f16x3" and fast >= 2.2 * exact, (fast, exact)              # measured 4.6x; with spilling kernels 1.8x
