@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "jg_common.h"
@@ -156,6 +157,7 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
   hipStream_t s = e->stream;
   std::vector<TermJob> jobs;
   std::vector<int64_t> owner;
+  std::vector<uint8_t> ends;          // host bases: only the two scanned ends of every record go to the device
   int max_n = 0;
   for (int64_t r = 0; r < n_records; ++r) {
     const int64_t len = offsets[r + 1] - offsets[r];
@@ -166,18 +168,37 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
     int scan = (int)std::min<int64_t>(std::max<int64_t>((int64_t)((double)len * 0.04), 400), 4000);
     if (scan > len) scan = (int)len;                   // str slicing clamps (termini.py:121-133)
     max_n = std::max(max_n, scan);
+    int64_t q_off = offsets[r], r_off = offsets[r + 1] - scan;
+    if (bases_loc == JG_PTR_HOST) {
+      q_off = (int64_t)ends.size();
+      ends.insert(ends.end(), bases + offsets[r], bases + offsets[r] + scan);
+      r_off = (int64_t)ends.size();
+      ends.insert(ends.end(), bases + offsets[r + 1] - scan, bases + offsets[r + 1]);
+    }
     for (int itr = 0; itr < 2; ++itr) {
-      jobs.push_back(TermJob{offsets[r], offsets[r + 1] - scan, scan, itr});
+      jobs.push_back(TermJob{q_off, r_off, scan, itr});
       owner.push_back(r * 2 + itr);
     }
   }
   if (jobs.empty()) return JG_OK;
   JG_REQUIRE(max_n <= TT * RMAX, JG_ERR_UNSUPPORTED, "jg_terminal_repeats: scan length %d", max_n);
+  {
+    // longest jobs first: a 4 000-base scan costs 100x a 400-base one, and workgroups are dispatched in index order -
+    // in FASTA order the last long jobs run alone at the end of the launch
+    std::vector<size_t> order(jobs.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return jobs[a].n > jobs[b].n; });
+    std::vector<TermJob> sj(jobs.size());
+    std::vector<int64_t> so(jobs.size());
+    for (size_t k = 0; k < order.size(); ++k) { sj[k] = jobs[order[k]]; so[k] = owner[order[k]]; }
+    jobs.swap(sj);
+    owner.swap(so);
+  }
   const uint8_t *d_bases = bases;
   void *tmp_bases = nullptr, *d_jobs = nullptr, *d_out = nullptr;
   if (bases_loc == JG_PTR_HOST) {
-    JG_HIP(hipMalloc(&tmp_bases, (size_t)std::max<int64_t>(n_bases, 1)));
-    JG_HIP(hipMemcpyAsync(tmp_bases, bases, (size_t)n_bases, hipMemcpyHostToDevice, s));
+    JG_HIP(hipMalloc(&tmp_bases, std::max<size_t>(ends.size(), 1)));
+    JG_HIP(hipMemcpyAsync(tmp_bases, ends.data(), ends.size(), hipMemcpyHostToDevice, s));
     d_bases = static_cast<const uint8_t *>(tmp_bases);
   }
   JG_HIP(hipMalloc(&d_jobs, jobs.size() * sizeof(TermJob)));
