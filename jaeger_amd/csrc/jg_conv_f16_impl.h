@@ -31,8 +31,10 @@
 // bias / batch-norm affine, DyT, residual add, GELU, NMD tap, max pool, f16 re-split) needs no
 // cross-lane transpose and reads its per-channel parameters from LDS.
 // Variants of the same kernel (template parameters): LUT - the first layer as table lookups
-// instead of matrix-core work; FLAT - window-packed position tiling.  The instantiations are
-// compiled in four translation units (JG_CONV_PART, see the bottom of this file).
+// instead of matrix-core work; FLAT - window-packed position tiling;
+// CW - the width- / stride-general tiles (64- / 32-channel workgroup tiles, a channel base for convs wider than 128,
+// stride 2, tap ranges for 1- to 4-tap convs).  The instantiations are compiled in seven translation units
+// (JG_CONV_PART, see the bottom of this file).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -1031,7 +1033,7 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
 #endif
 
 // ---- per-translation-unit instantiation sets (JG_CONV_PART selects one; the kernel template is
-// instantiated ~45 times, split over four objects so that they compile in parallel) ---------------
+// instantiated ~200 times, split over seven objects so that they compile in parallel) -------------
 #define JG_ROW_CASES(K)                                                                              \
   switch (a.ep) {                                                                                    \
     case 0u: return launch_ke<K, 0u>(e, a, s);           /* plain affine: a LayerNorm follows */      \
