@@ -190,8 +190,12 @@ void conv_f16x3_kernel(ConvHArgs a) {
   const int i = lane & 31, h = lane >> 5;
   // virtual block index / grid / tiles per pass (LUT: two blocks = the two channel halves share one index)
   const int lut_sh = (LUT && !(GEN && a.lut_one_half)) ? 1 : 0;
-  const int vb = (int)(blockIdx.x >> lut_sh);
   const int vgrid = (int)(gridDim.x >> lut_sh);
+  // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by index, each XCD has its own L2.  Giving the
+  // workgroups of one XCD a contiguous run of tiles keeps neighbouring tiles of a row (shared halo rows, mask bytes) and,
+  // in the table variant, the two channel halves of a tile on one L2.
+  int vb = (int)(blockIdx.x >> lut_sh);
+  if ((vgrid & 7) == 0) vb = (vb & 7) * (vgrid >> 3) + (vb >> 3);
   constexpr int TPER = LUT ? JG_LUT_WAVES / 2 : NT;       // tiles per pass (LUT: two waves per 256-position tile)
   const int tsub = LUT ? (wid >> 1) : 0;
   // LDS carve (16-byte units)
