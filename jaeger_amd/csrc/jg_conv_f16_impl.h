@@ -89,6 +89,15 @@ __device__ __forceinline__ void glds16(const void *sbase, unsigned voff, unsigne
                : "v"(voff), "s"(sbase), "s"(lds_addr)
                : "memory");
 }
+// the same for data that is read once (activation slices): non-temporal, so that the streams do not displace the
+// weight slices every workgroup of the XCD keeps re-reading from L2
+__device__ __forceinline__ void glds16_nt(const void *sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -336,9 +345,9 @@ void conv_f16x3_kernel(ConvHArgs a) {
     // and exists only in the leading wave(s).  The branch around it is wave-uniform on purpose:
     // the counted waits below must know exactly how many DMAs each wave has in flight.
 #pragma unroll
-    for (int it = 0; it < A_ITERS - 1; ++it) glds16(sb, x_voff[it], dst + it * (HT * 16));
+    for (int it = 0; it < A_ITERS - 1; ++it) glds16_nt(sb, x_voff[it], dst + it * (HT * 16));
     if (x_last_wave) {
-      if ((a_pk[A_ITERS - 1] >> 20) < NT) glds16(sb, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
+      if ((a_pk[A_ITERS - 1] >> 20) < NT) glds16_nt(sb, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
     }
   };
   // after a slice's DMA has landed: overwrite padding / masked-out pieces with zeros (by the
@@ -684,8 +693,12 @@ void conv_f16x3_kernel(ConvHArgs a) {
           for (int j = 0; j < 2; ++j) {
             // (a 16-channel chunk past the tensor's width - zero-padded weights - reads the last real chunk: unused)
             const unsigned it4 = item4(orow, mc, (!GEN || nb + ch0 + 16 * j < a.cout) ? nb : 0, j);
-            uint4 vh = a.addh[it4];                        // whole item of group 2j+h
-            uint4 vl = a.addh[it4 + 2u * (unsigned)a.L_out];
+            // (read once, like the activation slices: non-temporal)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 nh = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.addh + it4));   // whole item of group 2j+h
+            const u32x4 nl = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.addh + it4 + 2u * (unsigned)a.L_out));
+            uint4 vh = make_uint4(nh[0], nh[1], nh[2], nh[3]);
+            uint4 vl = make_uint4(nl[0], nl[1], nl[2], nl[3]);
             // give each lane back its own 4 channels of groups 2j and 2j+1
             swap32(vh.x, vh.z); swap32(vh.y, vh.w);
             swap32(vl.x, vl.z); swap32(vl.y, vl.w);
