@@ -320,7 +320,10 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
           if (id != 0 || !a.mask_from_ids)
             v = *reinterpret_cast<const float4 *>(a.emb + (size_t)id * a.cin + c);
         } else if (a.mask_in == nullptr || a.mask_in[pos] != 0) {
-          v = *reinterpret_cast<const float4 *>(a.x + pos * a.cin + c);
+          // (activations are read once per launch: non-temporal, so that they do not displace the weights in L2)
+          typedef float f32x4 __attribute__((ext_vector_type(4)));
+          const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.x + pos * a.cin + c));
+          v = make_float4(t[0], t[1], t[2], t[3]);
         }
       }
       *reinterpret_cast<float4 *>(smem + r * ldr + cq * 4) = v;
@@ -389,7 +392,9 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
       const size_t o = pos * a.cout + n;
       float4 v = *reinterpret_cast<const float4 *>(smem + ml * LDC + q * 4);
       v = jg_apply_stages(v, a.st, a.n_stages, n, o, mk, &nmd_acc, &nmd_acc2);
-      *reinterpret_cast<float4 *>(a.y + o) = v;
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const f32x4 t = {v.x, v.y, v.z, v.w};
+      __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(a.y + o));
     }
   }
   // NMD taps (up to two per conv): deterministic in-block reduction over the RSTEP row groups, one partial per
