@@ -176,7 +176,8 @@ static __device__ unsigned long long jg_stamp_acc[8];
 // stride 2 evaluated at stride 1 with the odd outputs dropped.  64 / 32 (narrow convs of pyramid-shaped models): waves
 // 4 x 1, 64 positions x 64 / 32 channels each, run-time geometry too - the weight slices and the epilogue table keep
 // their 128-wide (zero-padded) layout, only the matrix-core work and the outputs shrink.
-template <int K, unsigned EP, bool LUT = false, bool FLAT = false, int CW = 128>
+// TANH: compiled for the tanh-GELU alone (the residual stacks' hot patterns: half the code, inside the instruction cache).
+template <int K, unsigned EP, bool LUT = false, bool FLAT = false, int CW = 128, bool TANH = false>
 // K = 5 fits two workgroups per CU in LDS (<= 80 KB each): hold the register file to 256 per
 // lane so that both are really resident (without the bound hipcc takes ~340 and the second
 // workgroup of a CU only starts when the first has finished).
@@ -758,7 +759,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
         auto st_gelu = [&]() {
           // DyT patterns (two tanh norms + two activations at a stack end) are compiled for the tanh-GELU only: with
           // the erf / ReLU alternatives beside it the stack-end pattern spilled 576 bytes per lane and ran 10x slower
-          constexpr bool TANH_ONLY = EP != JG_EP_GENERIC && ((((EP >> 1) & 3) == 2) || (((EP >> 6) & 3) == 2));
+          constexpr bool TANH_ONLY = TANH || (EP != JG_EP_GENERIC && ((((EP >> 1) & 3) == 2) || (((EP >> 6) & 3) == 2)));
           if (TANH_ONLY || a.act_kind == JG_ACT_GELU_TANH) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = fast_gelu(x[r]);
@@ -973,12 +974,12 @@ void conv_f16x3_kernel(ConvHArgs a) {
   JG_ST_END;
 }
 
-template <int K, unsigned EP, bool FLAT = false, int CW = 128>
+template <int K, unsigned EP, bool FLAT = false, int CW = 128, bool TANH = false>
 int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   const int smem = jg_conv_f16_lds_bytes(K, a.dil);
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<K, EP, false, FLAT, CW>),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<K, EP, false, FLAT, CW, TANH>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -991,7 +992,7 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   int grid = ((smem <= 80 * 1024 && !one_wg) ? 2 : 1) * e->n_cu;
   if (grid > n_pairs) grid = n_pairs;
   ConvHArgs b = a;
-  hipLaunchKernelGGL((conv_f16x3_kernel<K, EP, false, FLAT, CW>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, b);
+  hipLaunchKernelGGL((conv_f16x3_kernel<K, EP, false, FLAT, CW, TANH>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, b);
   JG_HIP(hipGetLastError());
 #ifdef JG_STAMP
   {
@@ -1055,13 +1056,19 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   switch (a.ep) {                                                                                    \
     case 0u: return launch_ke<K, 0u>(e, a, s);           /* plain affine: a LayerNorm follows */      \
     case (JG_EP_NMD1): return launch_ke<K, (JG_EP_NMD1)>(e, a, s);                                   \
-    case (JG_EP_ACT1): return launch_ke<K, (JG_EP_ACT1)>(e, a, s);                                   \
+    case (JG_EP_ACT1):                                   /* the residual stacks' three hot patterns: tanh-GELU build */ \
+      if (K == 5 && a.act_kind == JG_ACT_GELU_TANH) return launch_ke<K, (JG_EP_ACT1), false, 128, true>(e, a, s); \
+      return launch_ke<K, (JG_EP_ACT1)>(e, a, s);                                                     \
     case (JG_EP_NORM1_AFF | JG_EP_ACT1): return launch_ke<K, (JG_EP_NORM1_AFF | JG_EP_ACT1)>(e, a, s); \
     case (JG_EP_NORM1_DYT | JG_EP_ACT1): return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ACT1)>(e, a, s); \
-    case (JG_EP_ADD | JG_EP_ACT1): return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1)>(e, a, s);           \
+    case (JG_EP_ADD | JG_EP_ACT1):                                                                   \
+      if (K == 5 && a.act_kind == JG_ACT_GELU_TANH) return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1), false, 128, true>(e, a, s); \
+      return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1)>(e, a, s);                                         \
     case (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1):                                                 \
       return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1)>(e, a, s);                      \
     case (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2):                       \
+      if (K == 5 && a.act_kind == JG_ACT_GELU_TANH)                                                  \
+        return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2), false, 128, true>(e, a, s); \
       return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)>(e, a, s); \
     case (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2):     \
       return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2)>(e, a, s); \
@@ -1103,12 +1110,15 @@ int jg_conv_f16_part_k79(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
 int jg_conv_f16_part_flat(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   switch (a.ep) {
 #define JG_CASE(ep) case (ep): return launch_ke<5, (ep), true>(e, a, s);
-    JG_CASE(JG_EP_ACT1)
+#define JG_CASE_HOT(ep)     /* the residual stacks' hot patterns: a tanh-GELU build beside the general one */ \
+  case (ep):                                                                                                  \
+    return a.act_kind == JG_ACT_GELU_TANH ? launch_ke<5, (ep), true, 128, true>(e, a, s) : launch_ke<5, (ep), true>(e, a, s);
+    JG_CASE_HOT(JG_EP_ACT1)
     JG_CASE(JG_EP_NORM1_AFF | JG_EP_ACT1)
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ACT1)
-    JG_CASE(JG_EP_ADD | JG_EP_ACT1)
+    JG_CASE_HOT(JG_EP_ADD | JG_EP_ACT1)
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1)
-    JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)
+    JG_CASE_HOT(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2)
     JG_CASE(JG_EP_ACT1 | JG_EP_NORM2_AFF)
     JG_CASE(JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)
@@ -1117,6 +1127,7 @@ int jg_conv_f16_part_flat(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
 #undef JG_CASE
+#undef JG_CASE_HOT
     default: break;
   }
   jg_set_error("conv_f16x3: stage pattern 0x%x has no compiled window-packed epilogue", a.ep);
