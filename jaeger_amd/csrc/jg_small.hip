@@ -312,14 +312,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const M192 valid_in = m_first(L), valid0 = m_first(L0);
   float vmax = 0.0f;
   JG_SST_DECL;
-  for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += (long)gridDim.x * 4) {
-    // ---- ids of the row -> LDS, input mask by ballot --------------------------------------------------
-    M192 m;
-    const unsigned char *src = a.ids + row * L;
+  // the ids of a wave's NEXT row are requested while it works on the current one (a lone wave per SIMD has nothing else
+  // to cover the HBM latency with)
+  int idn[3];
+  {
+    const long row0 = (long)blockIdx.x * 4 + wave;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int q = j * 64 + lane;
-      const int id = q < L ? (int)src[q] : 0;
+      idn[j] = (row0 < a.rows && q < L) ? (int)a.ids[row0 * L + q] : 0;
+    }
+  }
+  for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += (long)gridDim.x * 4) {
+    // ---- ids of the row -> LDS, input mask by ballot --------------------------------------------------
+    M192 m;
+    const long nrow = row + (long)gridDim.x * 4;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int q = j * 64 + lane;
+      const int id = idn[j];
+      idn[j] = (nrow < a.rows && q < L) ? (int)a.ids[nrow * L + q] : 0;
       m.w[j] = __ballot(a.use_mask ? id != 0 : q < L);
       idbuf[IDM + q] = q < L ? (unsigned char)id : (unsigned char)a.vocab;
     }
