@@ -1009,12 +1009,12 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
 }
 
 #if JG_CONV_PART == 4
-template <unsigned EP, int CW>
+template <unsigned EP, int CW, bool TANH = false>
 int launch_lut_e(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   const int smem = jg_conv_lut_lds_bytes(a.k, a.lut_vocab);
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<0, EP, true, false, CW>),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<0, EP, true, false, CW, TANH>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -1024,7 +1024,7 @@ int launch_lut_e(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   // (tile group, channel half), one workgroup per CU; a conv of <= 64 channels has only the first half
   const int grid = a.lut_one_half ? (n_pairs < e->n_cu ? n_pairs : e->n_cu)
                                   : 2 * (n_pairs < e->n_cu / 2 ? n_pairs : e->n_cu / 2);
-  hipLaunchKernelGGL((conv_f16x3_kernel<0, EP, true, false, CW>), dim3((unsigned)grid), dim3(JG_LUT_WAVES * 64), (size_t)smem, s, a);
+  hipLaunchKernelGGL((conv_f16x3_kernel<0, EP, true, false, CW, TANH>), dim3((unsigned)grid), dim3(JG_LUT_WAVES * 64), (size_t)smem, s, a);
   JG_HIP(hipGetLastError());
   return JG_OK;
 }
@@ -1038,7 +1038,10 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_CASE(JG_EP_ACT1)
     JG_CASE(JG_EP_NORM1_AFF | JG_EP_ACT1)
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ACT1)
-    JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1)
+    case (JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1):       // the brain family's first conv: a tanh-GELU build beside the general one
+      if (a.cout == 128 && a.act_kind == JG_ACT_GELU_TANH) return launch_lut_e<(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1), 128, true>(e, a, s);
+      return a.cout == 128 ? launch_lut_e<(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1), 128>(e, a, s)
+                           : launch_lut_e<(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1), 129>(e, a, s);
     JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1)
     JG_CASE(JG_EP_ACT1 | JG_EP_NORM2_AFF)
 #undef JG_CASE
