@@ -142,27 +142,87 @@ def cpu_baseline(cfg, weights, bases, offsets, fsize, flops_per_window: float, t
                       f"({avail} cores visible, CPU quota {quota})"}
 
 
-def spawn_ranks(n: int, oversubscribe: bool = False) -> int:
-    """``--gpus N`` outside torchrun: N fresh child ranks over RCCL, created before this process initialises HIP."""
+def visible_gpus() -> int:
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (a process that has initialised the GPU must
+    not start other programs on this pool): the *_VISIBLE_DEVICES lists if set, else the KFD topology in sysfs (a node
+    with simd_count > 0 is a GPU), else /dev/dri render nodes."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    nodes = Path("/sys/class/kfd/kfd/topology/nodes")
+    n = 0
+    if nodes.is_dir():
+        for node in nodes.iterdir():
+            try:
+                props = dict(line.split()[:2] for line in (node / "properties").read_text().splitlines() if line.strip())
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                continue
+        return n
+    dri = Path("/dev/dri")
+    return len(list(dri.glob("renderD*"))) if dri.is_dir() else 0
+
+
+def spawn_ranks(n: int, oversubscribe: bool = False, timeout_s: float = 1800.0) -> int:
+    """``--gpus N`` outside torchrun: N fresh child ranks over RCCL.  The parent never initialises HIP (GPUs are counted
+    from sysfs / the environment), children are plain ``subprocess`` launches in a process group of their own; a rank
+    that fails has its stderr surfaced, and a rank that outlives ``timeout_s`` takes the whole group down (exit 124)."""
+    import signal
     import socket
-    import torch
-    have = torch.cuda.device_count()           # counting devices does not initialise the GPU runtime
+    import tempfile
+    have = visible_gpus()
     if have < n and not (oversubscribe and have >= 1):
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
         return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    procs, errs = [], []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % have), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % have), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        err = tempfile.TemporaryFile()
+        errs.append(err)
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out)
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=err,
+                                      start_new_session=True))
+    deadline = time.monotonic() + timeout_s
+    out, timed_out = b"", False
+    try:
+        out = procs[0].communicate(timeout=max(1.0, deadline - time.monotonic()))[0]
+        for p in procs[1:]:
+            p.wait(timeout=max(1.0, deadline - time.monotonic()))
+    except subprocess.TimeoutExpired:
+        timed_out = True
+    # a rank that died leaves the others in a collective: give them a moment, then end every group we started
+    for p in procs:
+        if p.poll() is None:
+            try:
+                p.wait(timeout=0.0 if timed_out else 20.0)
+            except subprocess.TimeoutExpired:
+                timed_out = True
+    for p in procs:
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)          # the exact process group this function created
+            except ProcessLookupError:
+                pass
+            p.wait()
+    rcs = [p.returncode for p in procs]
+    for r, (rc, err) in enumerate(zip(rcs, errs)):
+        err.seek(0)
+        text = err.read().decode(errors="replace")
+        err.close()
+        if rc != 0 and text.strip():
+            sys.stderr.write(f"---- bench.py rank {r} (exit {rc}) stderr ----\n{text[-4000:]}\n")
+    sys.stdout.write(out.decode())
     sys.stdout.flush()
+    if timed_out:
+        print(f"bench.py: ranks still running after {timeout_s:.0f} s were killed", file=sys.stderr)
+        return 124
     return max(abs(rc) for rc in rcs)
 
 
@@ -183,6 +243,17 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="tests only: let the N ranks share the visible GPUs (rank r on GPU r %% visible) and exchange "
                          "over gloo instead of RCCL, so that the N-rank launch can be exercised on a 1-GPU box")
+    ap.add_argument("--rank-timeout", type=float, default=1800.0,
+                    help="--gpus N outside torchrun: seconds after which the child ranks are killed (exit 124)")
+    ap.add_argument("--rank-seed", type=int, default=None,
+                    help="tests only: generate the synthetic contigs of rank R (seed = config seed + R) in a "
+                         "single-rank run")
+    ap.add_argument("--dump-gather", default=None,
+                    help="tests only: rank 0 writes the gathered (or, with one rank, its own) logits of the last step to "
+                         "this .npy file")
+    ap.add_argument("--conv-pc", type=int, choices=[0, 1], default=0,
+                    help="A/B switch: 128-channel five-tap convs on the producer / consumer kernel (1, the default) or "
+                         "on the two-workgroup kernel (0); same results bit for bit")
     ap.add_argument("--timed-dbg", type=int, default=None,
                     help="experiments only (libjaeger_hip_exp.so): set the conv kernel's JG_DBG ablation mask after "
                          "the warm-up steps (the timed steps then read real activations; their results are wrong)")
@@ -190,7 +261,7 @@ def main():
 
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
-        sys.exit(spawn_ranks(args.gpus, args.oversubscribe))
+        sys.exit(spawn_ranks(args.gpus, args.oversubscribe, args.rank_timeout))
     if world_env is not None and int(world_env) != args.gpus:
         print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world_env}", file=sys.stderr)
         sys.exit(2)
@@ -201,6 +272,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("JAEGER_BENCH_FAIL_RANK") == str(rank) and world > 1:      # tests: a rank that dies before the rendezvous
+        raise RuntimeError(f"JAEGER_BENCH_FAIL_RANK={rank}: this rank was told to fail")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -231,6 +304,7 @@ def main():
     eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=local_rank, chunk=args.chunk,
                           precision=args.precision)
     mode = eng.model.precision
+    eng.device.set_conv_pc(bool(args.conv_pc))
     if args.timed_dbg is not None and "_exp" not in _lib.lib_path().name:
         print("bench.py: --timed-dbg needs the experiment build (make -C jaeger_amd/csrc exp; "
               "JAEGER_HIP_LIB=jaeger_amd/libjaeger_hip_exp.so)", file=sys.stderr)
@@ -239,7 +313,7 @@ def main():
     fsize = args.fsize or wl["fsize"]
     n_contigs = args.contigs or wl["contigs"]
     l_pad = frame_length(fsize)
-    rng = np.random.Generator(np.random.PCG64(wl["seed"] + rank))
+    rng = np.random.Generator(np.random.PCG64(wl["seed"] + (rank if args.rank_seed is None else args.rank_seed)))
     lengths, bases = synth_contigs(rng, n_contigs, exact=(fsize if wl["exact"] else None))
     offsets = np.zeros(lengths.size + 1, np.int64)
     np.cumsum(lengths, out=offsets[1:])
@@ -283,8 +357,9 @@ def main():
         os.environ["JG_DBG"] = str(args.timed_dbg)
     eng.device.profile_enable(not args.no_profile)
     t0 = time.perf_counter()
+    gathered = None
     for _ in range(args.steps):
-        step()
+        gathered = step()
     fence()
     dt = time.perf_counter() - t0
     prof = eng.device.profile_read()
@@ -302,6 +377,9 @@ def main():
     else:
         dt_max, bp_total, win_total = dt, float(bp_per_step), float(n_win)
 
+    if rank == 0 and args.dump_gather:
+        parts = [g.cpu().numpy() for g in gathered] if gathered is not None else [d_pred.cpu().numpy()]
+        np.save(args.dump_gather, np.concatenate(parts, axis=0))
     if rank == 0:
         steps = max(args.steps, 1)
         value = bp_total * steps / dt_max / 1e6

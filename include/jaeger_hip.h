@@ -126,8 +126,11 @@ int jg_engine_sync(jg_engine *e);
  * budget, each span goes host -> pinned staging buffer -> device buffer on a copy stream (two of each) while the
  * previous group is encoded and classified; the device never holds more than two spans of bases.  This is the
  * "host-DRAM -> HBM streamed" ingest of BASELINE.json configs[4]; the reference streams Python strings through
- * tf.data instead (commands/predict.py:186-245). */
-enum { JG_OPT_STREAM_BYTES = 1 };
+ * tf.data instead (commands/predict.py:186-245).
+ * JG_OPT_CONV_PC (default 0 while the kernel is being tuned): the 128 -> 128 channel five-tap convs of the residual stacks (layers.py:1882-1915) run on
+ * the producer / consumer kernel (jg_conv_pc.hip); 0 = on the two-workgroup kernel.  Same results bit for bit - the
+ * switch exists for A/B timing and for the test that asserts exactly that. */
+enum { JG_OPT_STREAM_BYTES = 1, JG_OPT_CONV_PC = 2 };
 int jg_engine_set_option(jg_engine *e, int key, int64_t value);
 /* statistics of the engine's last jg_predict_windows call: number of streamed groups (0 = not streamed), bytes sent
  * through the staging buffers, peak bytes of bases resident on the device */

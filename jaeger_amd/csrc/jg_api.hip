@@ -87,6 +87,10 @@ extern "C" int jg_engine_set_option(jg_engine *e, int key, int64_t value) {
       JG_REQUIRE(value >= 4096, JG_ERR_INVALID, "jg_engine_set_option: stream budget %lld < 4096 bytes", (long long)value);
       e->stream_bytes = value;
       return JG_OK;
+    case JG_OPT_CONV_PC:
+      JG_REQUIRE(value == 0 || value == 1, JG_ERR_INVALID, "jg_engine_set_option: JG_OPT_CONV_PC takes 0 or 1, got %lld", (long long)value);
+      e->conv_pc = (int)value;
+      return JG_OK;
     default:
       jg_set_error("jg_engine_set_option: unknown key %d", key);
       return JG_ERR_INVALID;
@@ -965,14 +969,17 @@ static int prepare_f16(jg_model *m, const float *weights) {
     return (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM) &&
            o.out_buf == buf;
   };
+  bool cvt_overflow = false;
   auto need = [&](size_t i, int buf, bool want_f32) {   // queue a conversion in front of op i if the slot is in the other format
     if (buf < 0 || is_f32[buf] == want_f32) return;
     ConvHPrep &hp = m->hprep[i];
-    if (hp.n_cvt < 3) {
-      hp.cvt_slot[hp.n_cvt] = buf;
-      hp.cvt_to_f32[hp.n_cvt] = want_f32;
-      ++hp.n_cvt;
+    if (hp.n_cvt >= 3) {           // table full: the op would read a tensor in the wrong layout - give the fast path up instead
+      cvt_overflow = true;
+      return;
     }
+    hp.cvt_slot[hp.n_cvt] = buf;
+    hp.cvt_to_f32[hp.n_cvt] = want_f32;
+    ++hp.n_cvt;
     is_f32[buf] = want_f32;
     m->needs_cvt = true;
   };
@@ -1032,6 +1039,13 @@ static int prepare_f16(jg_model *m, const float *weights) {
         break;
       default: break;
     }
+  }
+  if (cvt_overflow) {
+    m->f16_eligible = false;
+    m->f16_mixed = false;
+    m->f16_reason = "an op needs more than 3 layout conversions in front of it (mixed split-f16 / f32 program)";
+    for (ConvHPrep &hp : m->hprep) { hp.f16_ok = false; hp.n_cvt = 0; hp.pool_op = -1; }
+    std::fill(m->pool_fused_by.begin(), m->pool_fused_by.end(), -1);
   }
   return JG_OK;
 }
@@ -1335,7 +1349,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         const Shape &t = sh[slot];
         const int64_t rows = (int64_t)nw * t.frames;
         if (hq.cvt_to_f32[q]) rc = jg_launch_f16s_to_f32(reinterpret_cast<const uint4 *>(m->act[slot]), rows, t.L, t.C, m->cvt_scratch, s);
-        else rc = jg_launch_f32_to_f16s(m->act[slot], rows, t.L, t.C, reinterpret_cast<uint4 *>(m->cvt_scratch), s);
+        else rc = jg_launch_f32_to_f16s(m->act[slot], rows, t.L, t.C, reinterpret_cast<uint4 *>(m->cvt_scratch), s, m->d_overflow);
         if (rc != JG_OK) return rc;
         std::swap(m->act[slot], m->cvt_scratch);
         std::swap(m->act_cap[slot], m->cvt_cap);

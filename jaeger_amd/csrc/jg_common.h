@@ -159,6 +159,7 @@ struct jg_engine {
   double cls_ms[4] = {}, cls_flops[4] = {};     // the same split by kernel family (JG_PROF_*)
   int64_t cls_launches[4] = {};
   int n_cu = 256;
+  int conv_pc = 0;                // JG_OPT_CONV_PC: producer / consumer kernel for the 128-channel five-tap convs
   // streamed ingest of host-resident bases (jg_predict_windows): spans above `stream_bytes` go through two pinned
   // staging buffers and two device buffers on a copy stream, record group by record group
   int64_t stream_bytes = (int64_t)1 << 30;
@@ -272,7 +273,7 @@ int jg_launch_maxpool1d(const float *x, const uint8_t *mask_in, int rows, int L_
                         float *y, uint8_t *mask_out, hipStream_t s);
 int jg_launch_pool_final(const float *part, int rows_per_win, int n_win, int c, float *out, int out_ld,
                          hipStream_t s);
-int jg_launch_f32_to_f16s(const float *x, int64_t rows, int L, int c, uint4 *y, hipStream_t s);
+int jg_launch_f32_to_f16s(const float *x, int64_t rows, int L, int c, uint4 *y, hipStream_t s, int *overflow);
 int jg_launch_f16s_to_f32(const uint4 *x, int64_t rows, int L, int c, float *y, hipStream_t s);
 int jg_launch_maxpool1d_f16s(const uint4 *x, int rows, int L_in, int L_out, int c, uint4 *y, hipStream_t s);
 int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,

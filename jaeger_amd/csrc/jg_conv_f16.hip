@@ -11,6 +11,8 @@ int jg_conv_f16_part_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_n64(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_n32(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_g128(jg_engine *e, const ConvHArgs &a, hipStream_t s);
+bool jg_conv_pc_supports(const ConvHArgs &a);                                  // jg_conv_pc.hip
+int jg_conv_pc_launch(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 
 namespace {
 constexpr int HM = 256, HN = 128, HT = 256, NT = 1, A_ITERS = 5, W_ITEMS = 2 * 2 * HN, LUT_RS = 68;   // as in jg_conv_f16_impl.h
@@ -132,6 +134,10 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_REQUIRE(a.k == 5, JG_ERR_UNSUPPORTED, "conv_f16x3: cout=%d out-stride %d is only built for k = 5", a.cout, a.ostride);
     return jg_conv_f16_part_g128(e, a, s);
   }
+  // the residual stacks' 128 -> 128 five-tap convs: producer / consumer kernel (math waves + DMA / epilogue helper waves);
+  // JG_OPT_CONV_PC = 0 keeps them on the two-workgroup kernel below (same results bit for bit)
+  static const bool no_pc = jg_exp_env("JG_NO_PC") != nullptr;
+  if (e->conv_pc && !no_pc && a.dbg == 0 && jg_conv_pc_supports(a)) return jg_conv_pc_launch(e, a, s);
   if (a.flat) {
     JG_REQUIRE(a.k == 5 && a.ostride == 1, JG_ERR_UNSUPPORTED, "conv_f16x3: window-packed tiling is only built for k = 5, stride 1");
     return jg_conv_f16_part_flat(e, a, s);

@@ -1,0 +1,777 @@
+// Producer / consumer form of the split-f16 MaskedConv1D for the 128 -> 128 channel, 5-tap convs of the residual stacks
+// (layers.py:1217-1280 MaskedConv1D.call, layers.py:1882-1915 ResidualBlock.call): the same arithmetic as
+// conv_f16x3_kernel<5, ...> (jg_conv_f16_impl.h) - same operand layouts, same MFMA order per accumulator, same epilogue
+// expressions, bit-identical outputs - with the work of a 256-position x 128-channel tile split by ROLE instead of by
+// time:
+//
+//   * ONE workgroup of 8 waves per CU.  Waves 0-3 are MATH waves (one per SIMD): they read MFMA fragments from the LDS
+//     operand ring and issue matrix-core instructions, nothing else - no DMA issue, no zero-fill, no epilogue.  Fragments
+//     of the next 12-MFMA group are requested before the current group is issued, and a step's barrier is taken BEFORE
+//     the step's last group is issued (its operands are already in registers), so the LDS latency at a step boundary is
+//     covered by 12 MFMAs instead of idling the pipe.
+//   * Waves 4-7 are HELPER waves (the SIMD partners of waves 0-3): they own the DMA ring (global_load_lds, counted
+//     s_waitcnt vmcnt - the two-workgroup kernel's pipeline, unchanged), apply zero padding / input masks in LDS, and run
+//     the fused epilogue of the PREVIOUS tile while the math waves work on the current one: one 32 x 32 accumulator
+//     block per 16-channel chunk (8 blocks, 8 chunks), cut into two halves that sit behind the chunk's first two step
+//     barriers, its stores behind the third.  The epilogue's vector instructions therefore issue beside another wave's
+//     MFMAs on every SIMD all the time, instead of taking the matrix cores away from a whole workgroup for 20 - 40 %
+//     of its life.
+//   * At a tile boundary a math wave hands its 128 accumulator registers to its partner through a 16 KB LDS slot, in two
+//     halves (two extra barriers per tile; the helper keeps them in registers - the slot is a transit buffer).
+//   * Every vector-memory operation a helper issues in steady state is either an LDS-DMA (operands, residual shortcut
+//     items, output-mask bytes) or a store, and sits in front of the step's operand DMAs in issue order, so the counted
+//     waits of the operand ring stay exact and no compiler-inserted vmcnt wait can drain the ring.
+//
+// LDS: operand ring 75 264 B (dilation 3) + epilogue table 4 096 + accumulator transit 65 536 + shortcut staging 17 408.
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#include "jg_common.h"
+#include "jg_conv_dev.h"
+
+namespace {
+
+constexpr int PK = 5;                 // taps
+constexpr int PCC = 8;                // 16-channel input chunks: Cin = 128
+constexpr int PT = 512;               // threads: 4 math + 4 helper waves
+constexpr int X_ITEMS = 1024;         // 16-byte items of one pair's transit slot: 64 registers x 64 lanes x 4 B
+constexpr int S_ITEMS = 4 * 64 + 16;  // 16-byte items of one helper's staging area: 4 shortcut items per lane + 64 mask dwords
+
+#ifndef JG_PC_LATE
+#define JG_PC_LATE 1                  // take a step's barrier before the previous step's last MFMA group is issued
+#endif
+#ifndef JG_PC_PRIO
+#define JG_PC_PRIO 3                  // s_setprio of the math waves (helpers run at 0)
+#endif
+
+#ifdef JG_STAMP
+static __device__ unsigned long long jg_pc_stamp_acc[16];
+#define PC_ST_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime(); const unsigned long long st_t0 = st_t
+#define PC_ST(idx) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[idx] += n_ - st_t; st_t = n_; } while (0)
+#define PC_ST_END(base) do { st_[7] = __builtin_amdgcn_s_memtime() - st_t0; if (lane == 0) { for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&jg_pc_stamp_acc[(base) + q_], st_[q_]); } } while (0)
+#else
+#define PC_ST_DECL
+#define PC_ST(idx)
+#define PC_ST_END(base)
+#endif
+
+__device__ __forceinline__ void lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void bar() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// 4-byte-per-lane global -> LDS DMA of one unsigned byte per lane (zero-extended dword at M0 + lane*4)
+__device__ __forceinline__ void glds_ubyte(const void *sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+
+template <unsigned EP, bool FLAT>
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_pc_kernel(ConvHArgs a) {
+  constexpr bool HAS_ADD = (EP & JG_EP_ADD) != 0;
+  constexpr int NL = (HAS_ADD ? 4 : 0) + 1;            // DMAs of one block's epilogue inputs: shortcut items + mask byte
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_math = wid < 4;
+  const int w4 = wid & 3;                               // pair index: math wave w4 and helper wave w4 + 4 share a SIMD
+  const int wm = w4 >> 1, wn = w4 & 1;                  // the pair's 128-position x 64-channel quarter of the tile
+  const int i = lane & 31, h = lane >> 5;
+  const int vgrid = (int)gridDim.x;
+  int vb = (int)blockIdx.x;
+  if ((vgrid & 7) == 0) vb = (vb & 7) * (vgrid >> 3) + (vb >> 3);     // XCD-aware tile order (see conv_f16x3_kernel)
+  // LDS carve (16-byte units)
+  const int rows_a = HM + (PK - 1) * a.dil;
+  const int a_items = 4 * rows_a;                        // [4 ph][rows_a]
+  uint4 *Abuf = lds;                                     // [2 bufs][a_items]
+  uint4 *Wbuf = lds + 2 * a_items;                       // [5 slots][2 planes][2 h][HN]
+  float *epiL = reinterpret_cast<float *>(Wbuf + PK * W_ITEMS);      // [JG_EPI_ROWS][2][HN]
+  uint4 *Xbuf = Wbuf + PK * W_ITEMS + JG_EPI_ROWS * 2 * HN / 4;      // [4 pairs][X_ITEMS]
+  uint4 *Sbuf = Xbuf + 4 * X_ITEMS;                                   // [4 helpers][S_ITEMS]
+  for (int q = tid; q < a.n_epi_rows * 2 * HN; q += PT) epiL[q] = a.epi[q];   // visible after the first barrier
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+  const int n_tiles = FLAT ? a.flat_tiles : a.rows * a.tiles_m;
+  int my_pairs = 0;
+  if (vb < n_tiles) my_pairs = (n_tiles - 1 - vb) / vgrid + 1;
+  if (my_pairs == 0) return;
+  uint4 *Xp = Xbuf + w4 * X_ITEMS + lane;                // this pair's transit slot, lane column
+  f32x16 acc[4][2];                                      // [tm: position block][tn: channel block]; both roles
+
+  if (is_math) {
+    // =========================================== MATH WAVE ===============================================
+    lgkm0();                                             // the epilogue-table writes above
+    __builtin_amdgcn_s_setprio(JG_PC_PRIO);
+    PC_ST_DECL;
+    const uint4 *Wb = Wbuf + h * HN + wn * 64 + i;       // + t*W_ITEMS + plane*2*HN + tn*32
+    const int x_frag = h * rows_a + wm * 128 + i;        // + plane*2*rows_a + tm*32 + t*dil
+    const int dil = a.dil;
+    struct XF { uint4 h[2], l[2]; };
+    struct WF { uint4 h[2], l[2]; };
+    XF xf[2];
+    WF wf[2];
+    auto ldx = [&](XF &f, const uint4 *A, int t, int tp) {
+#pragma unroll
+      for (int tq = 0; tq < 2; ++tq) {
+        f.h[tq] = A[(tp * 2 + tq) * 32 + t * dil];
+        f.l[tq] = A[2 * rows_a + (tp * 2 + tq) * 32 + t * dil];
+      }
+    };
+    auto ldw = [&](WF &f, int t) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        f.h[tn] = Wb[t * W_ITEMS + tn * 32];
+        f.l[tn] = Wb[t * W_ITEMS + 2 * HN + tn * 32];
+      }
+    };
+    // 12 MFMAs: two position blocks x two channel blocks x (hi.lo, lo.hi, hi.hi), in the order of conv_f16x3_kernel;
+    // ZERO: the block's first product of the tile starts from C = 0 (no accumulator clearing between tiles)
+    auto mm = [&](auto zero_c, const WF &w, const XF &x, int tp) {
+      constexpr bool ZERO = decltype(zero_c)::value;
+#pragma unroll
+      for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          f32x16 &c = acc[tp * 2 + tq][tn];
+          const half8 wh = *reinterpret_cast<const half8 *>(&w.h[tn]), wl = *reinterpret_cast<const half8 *>(&w.l[tn]);
+          const half8 xh = *reinterpret_cast<const half8 *>(&x.h[tq]), xl = *reinterpret_cast<const half8 *>(&x.l[tq]);
+          if constexpr (ZERO) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, z, 0, 0, 0);
+          } else {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, c, 0, 0, 0);
+        }
+    };
+    // accumulator hand-off: blocks tm = 2*half, 2*half + 1 -> the pair's transit slot (register r of lane l lands where
+    // the helper's register r of lane l reads it back)
+    auto xwrite = [&](int half) {
+#pragma unroll
+      for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x16 &c = acc[half * 2 + tq][tn];
+            Xp[((tq * 2 + tn) * 4 + r4) * 64] = make_uint4(__float_as_uint(c[4 * r4]), __float_as_uint(c[4 * r4 + 1]),
+                                                          __float_as_uint(c[4 * r4 + 2]), __float_as_uint(c[4 * r4 + 3]));
+          }
+    };
+    bar();                                               // step A of (pass 0, chunk 0)
+    PC_ST(1);
+    ldw(wf[0], 0);
+    ldx(xf[0], Abuf + x_frag, 0, 0);
+    for (int pass = 0; pass < my_pairs; ++pass) {
+      const bool more = pass + 1 < my_pairs;
+      for (int cp = 0; cp < PCC / 2; ++cp) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {           // chunk cc = 2*cp + half reads activation buffer `half`
+          const uint4 *A = Abuf + half * a_items + x_frag;
+          const uint4 *An = Abuf + (half ^ 1) * a_items + x_frag;
+#pragma unroll
+          for (int g = 0; g < 10; ++g) {                 // group g: tap g/2, position-block pair g%2
+            const int t = g >> 1, tp = g & 1;
+            const bool step_end = g == 3 || g == 7 || g == 9;
+            const bool pass_end = g == 9 && half == 1 && cp == PCC / 2 - 1;      // (cp is a run-time value)
+            auto next_loads = [&]() {                    // fragments of the group after g
+              if (g < 9) {
+                ldx(xf[(g + 1) & 1], A, (g + 1) >> 1, (g + 1) & 1);
+                if (tp == 1) ldw(wf[(half + t + 1) & 1], t + 1);
+              } else {
+                ldx(xf[0], An, 0, 0);
+                ldw(wf[(half ^ 1) & 1], 0);
+              }
+            };
+            if (step_end && JG_PC_LATE && !pass_end) {
+              lgkm0();                                   // this step's last fragments are in registers: the slots may be refilled
+              PC_ST(0);
+              bar();
+              PC_ST(1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(step_end && !JG_PC_LATE) && !pass_end) next_loads();
+            __builtin_amdgcn_sched_barrier(0);
+            if (half == 0 && g < 2) {
+              if (cp == 0) mm(std::true_type{}, wf[(half + t) & 1], xf[g & 1], tp);
+              else mm(std::false_type{}, wf[(half + t) & 1], xf[g & 1], tp);
+            } else {
+              mm(std::false_type{}, wf[(half + t) & 1], xf[g & 1], tp);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (step_end && !JG_PC_LATE && !pass_end) {
+              PC_ST(0);
+              bar();
+              PC_ST(1);
+              next_loads();
+            }
+          }
+        }
+      }
+      // ---- tile finished: hand the accumulators to the helper ----
+      PC_ST(0);
+      xwrite(0);
+      lgkm0();
+      bar();                                             // X1: first half published
+      bar();                                             // X2: the helper has it in registers
+      xwrite(1);
+      lgkm0();
+      bar();                                             // step A of the next pass / X3 after the last one
+      PC_ST(2);
+      if (more) {
+        ldw(wf[0], 0);
+        ldx(xf[0], Abuf + x_frag, 0, 0);
+      }
+    }
+    PC_ST_END(0);
+    return;
+  }
+
+  // ============================================= HELPER WAVE =================================================
+  const int htid = tid - 256;                            // 0..255: the helper threads take the DMA duties of the
+                                                         // two-workgroup kernel's 256 threads one for one
+  const int hw = wid - 4;
+  PC_ST_DECL;
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + hw * 1024);                        // + buf*a_items*16 + it*4096
+  const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + hw * 1024);    // + slot*8192 + it*4096
+  uint4 *Sp = Sbuf + hw * S_ITEMS;                       // this wave's staging: [4 items][64 lanes] + 64 mask dwords
+  const unsigned ldsS = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((Sbuf - lds) + hw * S_ITEMS) * 16u);
+
+  auto resolve = [&](const Tile &tile, int local, int len, int &row, int &p) -> bool {
+    if constexpr (!FLAT) {
+      row = tile.rowblk;
+      p = tile.m0 + local;
+      return tile.valid && p >= 0 && p < len;
+    }
+    const int v = tile.T * HM + local;
+    if (v < 0 || !tile.valid) { row = 0; p = 0; return false; }
+    int g, u, f;
+    udivmod24(v, a.flat_wp, a.flat_inv_wp, g, u);
+    udivmod24(u, a.flat_p, a.flat_inv_p, f, p);
+    row = g * a.flat_frames + f;
+    return f < a.flat_frames && p < len && row < a.rows;
+  };
+  auto tile_of = [&](int pass, Tile &t) {
+    const int T = vb + pass * vgrid;
+    const int Tc = min(T, n_tiles - 1);
+    t.rowblk = Tc / a.tiles_m;
+    t.m0 = (Tc - t.rowblk * a.tiles_m) * HM;
+    t.valid = T < n_tiles;
+    t.T = Tc;
+  };
+  // per-thread activation piece coordinates (as in conv_f16x3_kernel)
+  unsigned a_pk[A_ITERS];
+#pragma unroll
+  for (int it = 0; it < A_ITERS; ++it) {
+    const int q = htid + it * HT;
+    const int ph = q / rows_a;          // >= 4: no piece
+    a_pk[it] = ((unsigned)(ph >> 2) << 20) | ((unsigned)(ph & 3) << 16) | (unsigned)(q - ph * rows_a);
+  }
+  unsigned w_voff[W_ITERS];
+#pragma unroll
+  for (int it = 0; it < W_ITERS; ++it) {
+    const int q = htid + it * HT;          // [plane][h][n]
+    w_voff[it] = (unsigned)((((q >> 8) * PK * PCC * 2 + ((q >> 7) & 1)) * HN + (q & (HN - 1))) * 16);
+  }
+  const uint8_t *bsrc = a.mask_in;
+  unsigned raw[A_ITERS];
+  unsigned x_voff[A_ITERS];
+  unsigned x_ok = 0;
+  auto piece_pos = [&](const Tile &tl, int it, int &pc, bool &inr) -> int {
+    const int a_u = (int)(a_pk[it] >> 20), a_r = (int)(a_pk[it] & 0xffff);
+    int rb, p;
+    inr = resolve(tl, a_r - a.pad_left, a.L_in, rb, p) && a_u < 1;
+    pc = min(max(p, 0), a.L_in - 1);
+    if constexpr (FLAT) rb = min(rb, a.rows - 1);
+    return rb;
+  };
+  auto load_bytes = [&](const Tile &tl) {
+    if (bsrc != nullptr) {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        int pc; bool inr;
+        const int rb = piece_pos(tl, it, pc, inr);
+        raw[it] = bsrc[(size_t)rb * a.L_in + pc];
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) raw[it] = 1;
+    }
+  };
+  // the same bytes for the NEXT tile, without a load the compiler would track (its vmcnt waits would drain the operand
+  // ring): LDS-DMA into the wave's staging area at step A of chunk 6 - in front of that step's operand DMAs, so the step-B
+  // wait covers them - and out of it at step B, before the next block's epilogue inputs are requested
+  auto request_bytes = [&](const Tile &tl) {
+    if (bsrc != nullptr) {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        int pc; bool inr;
+        const int rb = piece_pos(tl, it, pc, inr);
+        glds_ubyte(bsrc, (unsigned)(rb * a.L_in + pc), ldsS + it * 256);
+      }
+    }
+  };
+  auto collect_bytes = [&]() {
+    if (bsrc != nullptr) {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) raw[it] = reinterpret_cast<const unsigned *>(Sp)[it * 64 + lane];
+    }
+  };
+  auto build_pieces = [&](const Tile &tl) {      // consumes raw[] (fetched a chunk ago)
+    x_ok = 0;
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      int pc; bool inr;
+      const int rb = piece_pos(tl, it, pc, inr);
+      const unsigned ph = (a_pk[it] >> 16) & 3;
+      x_voff[it] = (unsigned)(((rb * PCC * 4 + (int)ph) * a.L_in + pc) * 16);
+      if (inr && raw[it] != 0) x_ok |= 1u << it;
+    }
+  };
+  const char *x_base = reinterpret_cast<const char *>(a.xh);
+  const unsigned x_cc_stride = 4u * (unsigned)a.L_in * 16u;   // bytes per chunk
+  const bool x_last_wave = __builtin_amdgcn_readfirstlane((int)((A_ITERS - 1) * HT + hw * 64 < 4 * rows_a)) != 0;
+  auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
+    const char *sb = reinterpret_cast<const char *>(a.wh) + ((size_t)(t * PCC * 2 + cc * 2) * HN) * 16;
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) glds16(sb, w_voff[it], ldsW + t * (W_ITEMS * 16) + it * (HT * 16));
+  };
+  auto issue_x = [&](int cc, int buf) {      // the tile's activation slice of chunk cc
+    const char *sb = x_base + (size_t)cc * x_cc_stride;
+    const unsigned dst = ldsA + buf * (a_items * 16);
+#pragma unroll
+    for (int it = 0; it < A_ITERS - 1; ++it) glds16_nt(sb, x_voff[it], dst + it * (HT * 16));
+    if (x_last_wave) {                        // wave-uniform: the counted waits must know how many DMAs are in flight
+      if ((a_pk[A_ITERS - 1] >> 20) < 1) glds16_nt(sb, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
+    }
+  };
+  auto zero_fill = [&](int buf) {
+    uint4 *A = Abuf + buf * a_items;
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it)
+      if ((a_pk[it] >> 20) < 1 && !((x_ok >> it) & 1u)) A[htid + it * HT] = make_uint4(0u, 0u, 0u, 0u);
+  };
+
+  // ---- epilogue pieces (expressions of conv_f16x3_kernel's compiled patterns, tanh-GELU) -----------------
+  const int L_res = a.L_out;
+  auto item4 = [&](int row, int mc, int nb, int j) -> unsigned {
+    const int G = (nb >> 3) + 2 * j + h;                 // hi-plane item of group 2j + h (uint4 units); lo plane = + 2*L_out
+    return (unsigned)(((row * (a.cout_pad >> 4) + (G >> 1)) * 4 + (G & 1)) * a.L_out + mc);
+  };
+  auto out_pos = [&](const Tile &tile, int tm, int &row, int &mc) -> bool {
+    int p;
+    const bool live = resolve(tile, (wm * 4 + tm) * 32 + i, L_res, row, p);
+    mc = live ? p : 0;
+    if constexpr (FLAT) {
+      if (!live) row = min(max(row, 0), a.rows - 1);
+    }
+    return live;
+  };
+  // request what block (tm, tn) of `tile` needs from memory: NL LDS-DMAs into the wave's staging area
+  auto epi_request = [&](const Tile &tile, int tm, int tn) {
+    const int nb = (wn * 2 + tn) * 32;
+    int orow, mc;
+    out_pos(tile, tm, orow, mc);
+    if constexpr (HAS_ADD) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned it4 = item4(orow, mc, nb, j);
+        glds16_nt(a.addh, it4 * 16u, ldsS + (2 * j) * 1024);
+        glds16_nt(a.addh, (it4 + 2u * (unsigned)a.L_out) * 16u, ldsS + (2 * j + 1) * 1024);
+      }
+    }
+    // (no output mask: any readable byte - the value is ignored)
+    const void *mb = a.mask_out != nullptr ? static_cast<const void *>(a.mask_out) : static_cast<const void *>(a.wh);
+    glds_ubyte(mb, a.mask_out != nullptr ? (unsigned)(orow * a.L_out + mc) : 0u, ldsS + 4 * 1024);
+  };
+  struct Pre {
+    uint2 sh[4], sl[4];
+    float mk;
+    bool live;
+    int orow, mc;
+  };
+  // ... and take it out of the staging area (after the wait that covers those DMAs)
+  auto epi_collect = [&](Pre &p, const Tile &tile, int tm) {
+    p.live = out_pos(tile, tm, p.orow, p.mc);
+    const unsigned mbyte = reinterpret_cast<const unsigned *>(Sp + 4 * 64)[lane];
+    p.mk = (a.mask_out == nullptr || mbyte != 0u) ? 1.f : 0.f;
+    if constexpr (HAS_ADD) {
+      // lane (i, h) staged the whole item of group 2j + h at its position; it needs channels 4h..4h+3 of groups 2j and 2j+1
+      const uint2 *S2 = reinterpret_cast<const uint2 *>(Sp);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          p.sh[2 * j + gg] = S2[((2 * j) * 64 + gg * 32 + i) * 2 + h];
+          p.sl[2 * j + gg] = S2[((2 * j + 1) * 64 + gg * 32 + i) * 2 + h];
+        }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) p.sh[g] = p.sl[g] = make_uint2(0u, 0u);
+    }
+  };
+  float vmax = 0.f;                  // f16-range guard: running max |output| (drops NaN) and "an output is NaN"
+  bool vnan = false;
+  float nmd_acc[16];
+  float mk_tm[4] = {0.f, 0.f, 0.f, 0.f};
+  auto swap32 = [](unsigned &lo_half_keeps, unsigned &hi_half_keeps) {
+    const auto r = __builtin_amdgcn_permlane32_swap(lo_half_keeps, hi_half_keeps, false, false);
+    lo_half_keeps = r[0];
+    hi_half_keeps = r[1];
+  };
+  // half j (channel groups 2j, 2j+1: registers 8j .. 8j+7) of one 32 x 32 block, in place; afterwards registers
+  // 8j..8j+3 hold the hi item and 8j+4..8j+7 the lo item of group 2j + h (F16S outputs)
+  auto epi_half = [&](f32x16 &x, const Pre &p, int tn, int j) {
+    const int nb = (wn * 2 + tn) * 32;
+    auto st_affine = [&](int row) {
+      const float *pr = epiL + (row * 2) * HN + nb + 4 * h;
+#pragma unroll
+      for (int g = 2 * j; g < 2 * j + 2; ++g) {
+        const float4 sc = *reinterpret_cast<const float4 *>(pr + 8 * g);
+        const float4 of = *reinterpret_cast<const float4 *>(pr + HN + 8 * g);
+        x[4 * g + 0] = fmaf(x[4 * g + 0], sc.x, of.x);
+        x[4 * g + 1] = fmaf(x[4 * g + 1], sc.y, of.y);
+        x[4 * g + 2] = fmaf(x[4 * g + 2], sc.z, of.z);
+        x[4 * g + 3] = fmaf(x[4 * g + 3], sc.w, of.w);
+      }
+    };
+    auto st_add = [&]() {
+#pragma unroll
+      for (int g = 2 * j; g < 2 * j + 2; ++g) {
+        x[4 * g + 0] += mix_sum<0>(p.sh[g].x, p.sl[g].x);
+        x[4 * g + 1] += mix_sum<1>(p.sh[g].x, p.sl[g].x);
+        x[4 * g + 2] += mix_sum<0>(p.sh[g].y, p.sl[g].y);
+        x[4 * g + 3] += mix_sum<1>(p.sh[g].y, p.sl[g].y);
+      }
+    };
+    auto st_gelu = [&]() {
+#pragma unroll
+      for (int r = 8 * j; r < 8 * j + 8; ++r) x[r] = fast_gelu(x[r]);
+    };
+    auto st_nmd = [&]() {
+      const float mkl = p.live ? p.mk : 0.f;
+#pragma unroll
+      for (int r = 8 * j; r < 8 * j + 8; ++r) nmd_acc[r] = fmaf(x[r], mkl, nmd_acc[r]);
+    };
+    constexpr int N1 = (EP >> 1) & 3, N2 = (EP >> 6) & 3;
+    static_assert(N1 != 2 && N2 != 2, "DyT patterns are not built into the producer / consumer kernel");
+    st_affine(0);
+    if constexpr (EP & JG_EP_NMD1) st_nmd();
+    if constexpr (N1 == 1) st_affine(1);
+    if constexpr (EP & JG_EP_ADD) st_add();
+    if constexpr (EP & JG_EP_ACT1) st_gelu();
+    if constexpr (EP & JG_EP_NMD2) st_nmd();
+    if constexpr (N2 == 1) st_affine(N1 ? 2 : 1);
+    if constexpr (EP & JG_EP_ACT2) st_gelu();
+    if (a.out_f16s) {
+      uint2 ph[2], pl[2];
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const int g = 2 * j + gg;
+        half4 hh4, ll4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          hh4[q] = (_Float16)x[4 * g + q];
+          vmax = fmaxf(vmax, fabsf(x[4 * g + q]));
+        }
+        vnan = vnan || __builtin_isunordered(x[4 * g + 0], x[4 * g + 1]) || __builtin_isunordered(x[4 * g + 2], x[4 * g + 3]);
+        ph[gg] = *reinterpret_cast<uint2 *>(&hh4);
+        ll4[0] = (_Float16)mix_rem<0>(x[4 * g + 0], ph[gg].x);
+        ll4[1] = (_Float16)mix_rem<1>(x[4 * g + 1], ph[gg].x);
+        ll4[2] = (_Float16)mix_rem<0>(x[4 * g + 2], ph[gg].y);
+        ll4[3] = (_Float16)mix_rem<1>(x[4 * g + 3], ph[gg].y);
+        pl[gg] = *reinterpret_cast<uint2 *>(&ll4);
+      }
+      unsigned h0 = ph[0].x, h1 = ph[0].y, h2 = ph[1].x, h3 = ph[1].y;
+      unsigned l0 = pl[0].x, l1 = pl[0].y, l2 = pl[1].x, l3 = pl[1].y;
+      swap32(h0, h2); swap32(h1, h3);      // -> whole item of group 2j+h
+      swap32(l0, l2); swap32(l1, l3);
+      x[8 * j + 0] = __uint_as_float(h0); x[8 * j + 1] = __uint_as_float(h1);
+      x[8 * j + 2] = __uint_as_float(h2); x[8 * j + 3] = __uint_as_float(h3);
+      x[8 * j + 4] = __uint_as_float(l0); x[8 * j + 5] = __uint_as_float(l1);
+      x[8 * j + 6] = __uint_as_float(l2); x[8 * j + 7] = __uint_as_float(l3);
+    }
+  };
+  auto store_block = [&](const f32x16 &x, const Pre &p, int tn) {
+    const int nb = (wn * 2 + tn) * 32;
+    if (p.live) {
+      if (a.out_f16s) {
+        uint4 *yh = reinterpret_cast<uint4 *>(a.y);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const unsigned it4 = item4(p.orow, p.mc, nb, j);
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 vhi = {__float_as_uint(x[8 * j]), __float_as_uint(x[8 * j + 1]),
+                             __float_as_uint(x[8 * j + 2]), __float_as_uint(x[8 * j + 3])};
+          const u32x4 vlo = {__float_as_uint(x[8 * j + 4]), __float_as_uint(x[8 * j + 5]),
+                             __float_as_uint(x[8 * j + 6]), __float_as_uint(x[8 * j + 7])};
+          __builtin_nontemporal_store(vhi, reinterpret_cast<u32x4 *>(yh + it4));
+          __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)a.L_out));
+        }
+      } else {
+        float *yf = reinterpret_cast<float *>(a.y) + ((size_t)p.orow * a.L_out + p.mc) * a.cout + nb + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4 *>(yf + 8 * g) = make_float4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+      }
+    }
+  };
+#define JG_DPP(v, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), (ctrl), 0xf, 0xf, false))
+  auto lane_reduce = [&](const float (&in)[16], auto op) -> float {
+    const bool b2 = (i & 4) != 0, b1 = (i & 2) != 0, b0 = (i & 1) != 0, b3 = (i & 8) != 0;
+    float s8[8], s4[4], s2[2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {        // partner i ^ 7 (row_half_mirror)
+      const float keep = b2 ? in[8 + q] : in[q], send = b2 ? in[q] : in[8 + q];
+      s8[q] = op(keep, JG_DPP(send, 0x141));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {        // partner i ^ 2 (quad_perm [2,3,0,1])
+      const float keep = b1 ? s8[4 + q] : s8[q], send = b1 ? s8[q] : s8[4 + q];
+      s4[q] = op(keep, JG_DPP(send, 0x4e));
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {        // partner i ^ 1 (quad_perm [1,0,3,2])
+      const float keep = b0 ? s4[2 + q] : s4[q], send = b0 ? s4[q] : s4[2 + q];
+      s2[q] = op(keep, JG_DPP(send, 0xb1));
+    }
+    const float keep1 = b3 ? s2[1] : s2[0], send1 = b3 ? s2[0] : s2[1];
+    const float v = op(keep1, JG_DPP(send1, 0x128));      // partner i ^ 8 (row_ror:8)
+    return op(v, __shfl_xor(v, 16, 32));                  // partner i ^ 16
+  };
+#undef JG_DPP
+  auto reduced_slot = [&](const Tile &tile, int tn, int &ch) -> size_t {
+    const int r = 8 * (int)((i & 4) != 0) + 4 * (int)((i & 2) != 0) + 2 * (int)((i & 1) != 0) + (int)((i & 8) != 0);
+    ch = (wn * 2 + tn) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+    return ((size_t)tile.T * 2 + wm) * a.cout + ch;        // one partial row per wave strip (128 positions)
+  };
+  constexpr bool HAS_NMD = (EP & (JG_EP_NMD1 | JG_EP_NMD2)) != 0;
+  auto nmd_flush = [&](const Tile &tile, int tn) {
+    const float v = lane_reduce(nmd_acc, [](float x, float y) { return x + y; });
+    int ch;
+    const size_t slot = reduced_slot(tile, tn, ch);
+    if (i < 16 && tile.valid) a.nmd_out[slot] = v;
+  };
+  auto pool_reduce = [&](const Tile &tile) {
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      float pa[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pa[r] = -INFINITY;
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pa[r] = mk_tm[tm] != 0.f ? fmaxf(pa[r], acc[tm][tn][r]) : pa[r];
+      const float v = lane_reduce(pa, [](float x, float y) { return fmaxf(x, y); });
+      int ch;
+      const size_t slot = reduced_slot(tile, tn, ch);
+      if (i < 16 && tile.valid) a.pool_out[slot] = v;
+    }
+  };
+  // accumulator hand-off, helper side: registers of blocks tm = 2*half, 2*half + 1 out of the transit slot
+  auto xread = [&](int half) {
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const uint4 v = Xp[((tq * 2 + tn) * 4 + r4) * 64];
+          f32x16 &c = acc[half * 2 + tq][tn];
+          c[4 * r4] = __uint_as_float(v.x); c[4 * r4 + 1] = __uint_as_float(v.y);
+          c[4 * r4 + 2] = __uint_as_float(v.z); c[4 * r4 + 3] = __uint_as_float(v.w);
+        }
+  };
+
+  // ---- prologue: the pipeline of pass 0 ------------------------------------------------------------------------
+  Tile cur, np, et;                  // tile of this pass (operands) / of the next pass / whose accumulators this wave holds
+  tile_of(0, cur);
+  tile_of(1, np);
+  et = cur;
+  load_bytes(cur);
+  build_pieces(cur);                 // the only exposed byte-load latency of the launch
+  issue_x(0, 0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) issue_w(0, t);
+  Pre pre;
+  pre.live = false; pre.mk = 0.f; pre.orow = 0; pre.mc = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) pre.sh[g] = pre.sl[g] = make_uint2(0u, 0u);
+
+  // Pass `my_pairs` is the drain: no operands, no barriers - only the last tile's epilogue, through the same code.
+  for (int pass = 0; pass <= my_pairs; ++pass) {
+    const bool drain = pass == my_pairs;
+    const bool epi = pass > 0;                         // this wave holds a tile's accumulators
+    const bool last_pass = pass == my_pairs - 1;
+    if (epi) {
+      // X1 / X2: first half of the finished tile's accumulators (the step-A wait and zero-fill of this pass's first
+      // chunk are done first, so that the math waves find barrier A right behind X2)
+      if (!drain) { wait_vm<2 * W_ITERS>(); zero_fill(0); lgkm0(); }
+      PC_ST(3);
+      bar();                                           // X1
+      xread(0);
+      lgkm0();
+      bar();                                           // X2
+      PC_ST(2);
+    }
+#pragma unroll
+    for (int cc = 0; cc < PCC; ++cc) {
+      const int abuf = cc & 1;
+      const bool last_chunk = cc == PCC - 1;
+      const bool tail = last_chunk && last_pass;       // nothing is issued behind this chunk
+      const int ncc = last_chunk ? 0 : cc + 1;
+      const int tm = cc & 3, tn = cc >> 2;             // the accumulator block this chunk's steps carry
+      // ---- step A: taps 0, 1 ----
+      if (!drain) {
+        if (!(cc == 0 && epi)) { wait_vm<2 * W_ITERS>(); zero_fill(abuf); lgkm0(); }
+        PC_ST(0);
+        bar();                                         // A (after a pass: also X3 - the second half is in the slot)
+        PC_ST(1);
+      } else if (cc == 0) {
+        PC_ST(0);
+        bar();                                         // X3
+        PC_ST(1);
+        wait_vm<0>();                                  // the first block's staged inputs
+      }
+      if (cc == 0 && epi) xread(1);
+      if (epi) {
+        // stores of the previous block (its registers are final since step B of the previous chunk)
+        if (cc > 0 && a.pool_out == nullptr) store_block(acc[(cc - 1) & 3][(cc - 1) >> 2], pre, (cc - 1) >> 2);
+        if (HAS_NMD && cc == 4) nmd_flush(et, 0);
+      }
+      if (epi) epi_collect(pre, et, tm);               // staged by the DMAs of the previous chunk's step B (covered by wait A)
+      if (!drain) {
+        if (cc == PCC - 2 && !last_pass) { lgkm0(); request_bytes(np); }     // (the staging area was just read out)
+        issue_w(cc, 4);
+        if (!tail) {
+          if (last_chunk) build_pieces(np);
+          issue_x(ncc, abuf ^ 1);
+        }
+      }
+      if (epi) {
+        if (cc == 0 || cc == 4) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) nmd_acc[r] = 0.f;
+        }
+        if (tn == 0) mk_tm[tm] = pre.live ? pre.mk : 0.f;
+        epi_half(acc[tm][tn], pre, tn, 0);
+      }
+      PC_ST(3);
+      // ---- step B: taps 2, 3 ----
+      if (!drain) {
+        if (tail) wait_vm<W_ITERS>();
+        else if (x_last_wave) wait_vm<W_ITERS + A_ITERS>();
+        else wait_vm<W_ITERS + A_ITERS - 1>();
+        PC_ST(0);
+        bar();
+        PC_ST(1);
+      }
+      // inputs of the next block: block cc + 1 of the tile in hand, or block 0 of the tile the math waves are finishing
+      // (pass 0 requests them too - for its own tile, unused - so that the counts below do not depend on the pass)
+      if (!drain && cc == PCC - 2 && !last_pass) { collect_bytes(); lgkm0(); }
+      if (!drain || !last_chunk) {
+        if (last_chunk) epi_request(cur, 0, 0);
+        else epi_request(et, (cc + 1) & 3, (cc + 1) >> 2);
+      }
+      if (!drain && !tail) { issue_w(ncc, 0); issue_w(ncc, 1); }
+      if (epi) epi_half(acc[tm][tn], pre, tn, 1);
+      PC_ST(3);
+      // ---- step C: tap 4 ----
+      if (!drain) {
+        if (tail) wait_vm<0>();
+        else if (x_last_wave) wait_vm<2 * W_ITERS + A_ITERS + NL>();
+        else wait_vm<2 * W_ITERS + A_ITERS - 1 + NL>();
+        PC_ST(0);
+        bar();
+        PC_ST(1);
+      } else {
+        wait_vm<0>();                                  // drain pass: the next block's staged inputs
+      }
+      if (epi && last_chunk) {
+        if (a.pool_out == nullptr) store_block(acc[tm][tn], pre, tn);
+        if (HAS_NMD) nmd_flush(et, 1);
+        if (a.pool_out != nullptr) pool_reduce(et);
+      }
+      if (!drain && !tail) { issue_w(ncc, 2); issue_w(ncc, 3); }
+      PC_ST(3);
+    }
+    if (drain) break;
+    et = cur;
+    cur = np;
+    tile_of(pass + 2, np);
+  }
+  if ((!(vmax <= 65000.0f) || vnan) && a.overflow != nullptr) atomicOr(a.overflow, 1);
+  PC_ST_END(8);
+}
+
+int pc_lds_bytes(int dil) {
+  const int rows_a = HM + (PK - 1) * dil;
+  return (2 * 4 * rows_a + PK * W_ITEMS + 4 * X_ITEMS + 4 * S_ITEMS) * 16 + JG_EPI_ROWS * 2 * HN * 4;
+}
+
+template <unsigned EP, bool FLAT>
+int launch_pc(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  const int smem = pc_lds_bytes(a.dil);
+  static bool attr_set = false;
+  if (!attr_set) {
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pc_kernel<EP, FLAT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int n_tiles = FLAT ? a.flat_tiles : a.rows * a.tiles_m;
+  int grid = e->n_cu;                                   // one 8-wave workgroup per CU
+  if (grid > n_tiles) grid = n_tiles;
+  hipLaunchKernelGGL((conv_pc_kernel<EP, FLAT>), dim3((unsigned)grid), dim3(PT), (size_t)smem, s, a);
+  JG_HIP(hipGetLastError());
+#ifdef JG_STAMP
+  {
+    unsigned long long hh[16], z[16] = {0};
+    JG_HIP(hipStreamSynchronize(s));
+    JG_HIP(hipMemcpyFromSymbol(hh, HIP_SYMBOL(jg_pc_stamp_acc), sizeof(hh)));
+    JG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(jg_pc_stamp_acc), z, sizeof(z)));
+    const double tm = (double)hh[7], th = (double)hh[15];
+    fprintf(stderr, "PCSTAMP ep=0x%x rows=%d grid=%d math: cyc/wave=%.0f mfma+lds=%.3f barrier=%.3f handoff=%.3f | helper: cyc/wave=%.0f "
+            "wait=%.3f barrier=%.3f handoff=%.3f work=%.3f\n", EP, a.rows, grid, tm / (grid * 4.0), hh[0] / tm, hh[1] / tm, hh[2] / tm,
+            th / (grid * 4.0), hh[8] / th, hh[9] / th, hh[10] / th, hh[11] / th);
+  }
+#endif
+  return JG_OK;
+}
+
+}  // namespace
+
+// the stage patterns of the residual stacks (tanh-GELU): plain / + shortcut / stack end with NMD tap, norm and second GELU
+bool jg_conv_pc_supports(const ConvHArgs &a) {
+  if (a.k != PK || a.cc_in != PCC || a.cout != HN || a.cout_pad != HN || a.cw != HN || a.ch0 != 0 || a.ostride != 1 ||
+      a.tap_lo != 0 || a.tap_hi != PK - 1 || a.lut != nullptr || a.ids != nullptr || a.act_kind != JG_ACT_GELU_TANH)
+    return false;
+  if (a.ep != JG_EP_ACT1 && a.ep != (JG_EP_ADD | JG_EP_ACT1) &&
+      a.ep != (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2))
+    return false;
+  if (((a.ep & JG_EP_ADD) != 0) != (a.addh != nullptr)) return false;
+  if (((a.ep & (JG_EP_NMD1 | JG_EP_NMD2)) != 0) != (a.nmd_out != nullptr)) return false;
+  if (4 * (HM + (PK - 1) * a.dil) > A_ITERS * HT || pc_lds_bytes(a.dil) > 160 * 1024) return false;
+  // 32-bit DMA offsets of the shortcut tensor
+  if ((double)a.rows * (a.cout_pad / 16) * 4.0 * a.L_out * 16.0 >= 4.0e9) return false;
+  const int n_tiles = a.flat ? a.flat_tiles : a.rows * a.tiles_m;
+  return n_tiles >= 1;
+}
+
+int jg_conv_pc_launch(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  switch (a.ep) {
+#define JG_CASE(ep) case (ep): return a.flat ? launch_pc<(ep), true>(e, a, s) : launch_pc<(ep), false>(e, a, s);
+    JG_CASE(JG_EP_ACT1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)
+#undef JG_CASE
+    default: break;
+  }
+  jg_set_error("conv_pc: stage pattern 0x%x has no compiled epilogue", a.ep);
+  return JG_ERR_UNSUPPORTED;
+}

@@ -163,6 +163,11 @@ static int usable_cores() {
     if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = -1; fclose(g); }
   }
   if (q > 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, (q + per / 2) / per));
+  // one process per GPU: the ranks of a node share these cores (torchrun / bench.py export LOCAL_WORLD_SIZE)
+  if (const char *lw = getenv("LOCAL_WORLD_SIZE")) {
+    const int ranks = atoi(lw);
+    if (ranks > 1) n = n / ranks;
+  }
   return std::max(1, n);
 }
 

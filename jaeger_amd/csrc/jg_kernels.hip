@@ -945,8 +945,11 @@ __global__ __launch_bounds__(256) void maxpool1d_f16s_kernel(const uint4 *__rest
 // (mixed programs: a conv the split-f16 tiling does not cover - strided, 1x1, other widths - or a LayerNorm runs on
 // f32 tensors between split-f16 convs).  One thread per (row, position, 8-channel group): 32 B of f32 <-> a hi and a
 // lo item; 16 consecutive lanes cover one position's 128 channels (coalesced on the f32 side).
+// Values beyond the f16 range would become hi = +-Inf, lo = -+Inf (a NaN in the next split-f16 conv): `overflow` is raised
+// for any |v| > 65000 or NaN, exactly like the conv epilogue's guard, and the host reruns the chunk in exact f32.
 __global__ __launch_bounds__(256) void f32_to_f16s_kernel(const float *__restrict__ x, int64_t total, int L, int groups,
-                                                          uint4 *__restrict__ y) {
+                                                          uint4 *__restrict__ y, int *__restrict__ overflow) {
+  bool bad = false;
   for (int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int g = (int)(idx % groups);
     const int64_t rp = idx / groups;                 // row * L + pos
@@ -960,12 +963,14 @@ __global__ __launch_bounds__(256) void f32_to_f16s_kernel(const float *__restric
       const _Float16 hv = (_Float16)v[q];
       hi[q] = hv;
       lo[q] = (_Float16)(v[q] - (float)hv);
+      bad = bad || !(fabsf(v[q]) <= 65000.0f);       // (NaN compares false: caught too)
     }
     const int64_t rc = row * (groups / 2) + (g >> 1);
     const int h = g & 1;
     y[(rc * 4 + h) * (int64_t)L + pos] = *reinterpret_cast<const uint4 *>(&hi);
     y[(rc * 4 + 2 + h) * (int64_t)L + pos] = *reinterpret_cast<const uint4 *>(&lo);
   }
+  if (bad && overflow != nullptr) atomicOr(overflow, 1);
 }
 
 __global__ __launch_bounds__(256) void f16s_to_f32_kernel(const uint4 *__restrict__ x, int64_t total, int L, int groups,
@@ -987,7 +992,7 @@ __global__ __launch_bounds__(256) void f16s_to_f32_kernel(const uint4 *__restric
   }
 }
 
-static int cvt_launch(bool to_f16s, const void *x, int64_t rows, int L, int c, void *y, hipStream_t s) {
+static int cvt_launch(bool to_f16s, const void *x, int64_t rows, int L, int c, void *y, hipStream_t s, int *overflow = nullptr) {
   JG_REQUIRE(c % 16 == 0, JG_ERR_UNSUPPORTED, "layout conversion: c=%d must be a multiple of 16", c);
   const int64_t total = rows * L * (c / 8);
   if (total == 0) return JG_OK;
@@ -995,15 +1000,15 @@ static int cvt_launch(bool to_f16s, const void *x, int64_t rows, int L, int c, v
   if (blocks > 256 * 32) blocks = 256 * 32;
   if (to_f16s)
     hipLaunchKernelGGL(f32_to_f16s_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float *>(x), total, L,
-                       c / 8, static_cast<uint4 *>(y));
+                       c / 8, static_cast<uint4 *>(y), overflow);
   else
     hipLaunchKernelGGL(f16s_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint4 *>(x), total, L,
                        c / 8, static_cast<float *>(y));
   JG_HIP(hipGetLastError());
   return JG_OK;
 }
-int jg_launch_f32_to_f16s(const float *x, int64_t rows, int L, int c, uint4 *y, hipStream_t s) {
-  return cvt_launch(true, x, rows, L, c, y, s);
+int jg_launch_f32_to_f16s(const float *x, int64_t rows, int L, int c, uint4 *y, hipStream_t s, int *overflow) {
+  return cvt_launch(true, x, rows, L, c, y, s, overflow);
 }
 int jg_launch_f16s_to_f32(const uint4 *x, int64_t rows, int L, int c, float *y, hipStream_t s) {
   return cvt_launch(false, x, rows, L, c, y, s);

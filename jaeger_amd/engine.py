@@ -81,6 +81,11 @@ class HipDevice:
         """Host base buffers above ``nbytes`` are streamed through pinned staging buffers (JG_OPT_STREAM_BYTES)."""
         L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_STREAM_BYTES, int(nbytes)), "jg_engine_set_option")
 
+    def set_conv_pc(self, on: bool):
+        """128 -> 128 five-tap convs on the producer / consumer kernel (default) or on the two-workgroup kernel
+        (JG_OPT_CONV_PC); the two give the same results bit for bit."""
+        L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_CONV_PC, 1 if on else 0), "jg_engine_set_option")
+
     def stream_stats(self) -> dict:
         """Streaming statistics of the last ``jg_predict_windows`` call on this engine."""
         g = lambda k: int(self.lib.jg_engine_get_stat(self.handle, k))  # noqa: E731

@@ -151,7 +151,13 @@ def load_fasta_records(path, rec_off: np.ndarray, records) -> FastaBatch:
     ptr = lambda arr: arr.ctypes.data_as(C.c_void_p)  # noqa: E731
     n = records.size
     offsets, name_off = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
-    names_buf = np.zeros(max(int((np.minimum(b - a, 4096)).sum()), 1), np.uint8)
+    # names: jg_fasta_parse copies every header's first token with no capacity argument, so the buffer is sized from
+    # the exact upper bound jg_fasta_count computes over these very bytes (the sum of the header-line lengths)
+    cnt, name_bytes = C.c_int64(), C.c_int64()
+    L.check(lib.jg_fasta_count(ptr(buf), buf.size, C.byref(cnt), C.byref(name_bytes)), "jg_fasta_count")
+    if cnt.value != n:
+        raise ValueError(f"{path}: expected {n} records in the selected byte ranges, found {cnt.value}")
+    names_buf = np.zeros(max(name_bytes.value, 1), np.uint8)
     got, nb = C.c_int64(), C.c_int64()
     L.check(lib.jg_fasta_parse(ptr(buf), buf.size, n, ptr(buf), ptr(offsets), ptr(names_buf), ptr(name_off),
                                C.byref(got), C.byref(nb)), "jg_fasta_parse")

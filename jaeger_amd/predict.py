@@ -149,19 +149,25 @@ def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None,
         # the short-contig pass: one whole-contig window per record.  The selected records are compacted into a
         # buffer of their own once, so that a batch of 96 windows uploads the few hundred kB it covers and not the
         # whole FASTA image (a 2 Gbp assembly with 1 M short contigs would otherwise move 2 GB per batch)
+        # (compacted batch by batch, run by run: records are in FASTA order, so adjacent short records merge into one
+        # slice copy - no per-base index array over every short contig of the assembly)
         wl = table.length.astype(np.int64)
         cstart = np.cumsum(wl) - wl
-        gather = np.repeat(starts - cstart, wl) + np.arange(int(wl.sum()), dtype=np.int64)
-        compact = fa.bases[gather]
         off3 = (-2, -1, 0)[fsize % 3]
         parts = []
         for i in range(0, len(table), batch):
             sl = slice(i, i + batch)
             lmax = int(max(0, -(-(int(table.length[sl].max()) - 5 + off3) // 3)))
             c0, c1 = int(cstart[i]), int(cstart[sl][-1] + wl[sl][-1])
+            s_b, l_b = starts[sl], wl[sl]
+            cut = np.nonzero(s_b[1:] != s_b[:-1] + l_b[:-1])[0] + 1          # where a new run of adjacent records starts
+            run_a = s_b[np.concatenate(([0], cut))]
+            run_b = (s_b + l_b)[np.concatenate((cut - 1, [len(s_b) - 1]))]
+            compact = np.concatenate([fa.bases[x:y] for x, y in zip(run_a.tolist(), run_b.tolist())]) \
+                if len(run_a) > 1 else fa.bases[int(run_a[0]):int(run_b[0])]
             # (every window of this pass is a whole record: the compact buffer's record table is its window table)
             recs = np.append(cstart[sl] - c0, c1 - c0) if dust_device else None
-            parts.append(engine.predict_windows(compact[c0:c1], cstart[sl] - c0, table.length[sl], fsize,
+            parts.append(engine.predict_windows(compact, cstart[sl] - c0, table.length[sl], fsize,
                                                 l_pad=max(lmax, 1), pre_cased=pre_cased, want=want, dust_records=recs))
         out = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
     if not meta:                       # sharded runs: rank 0 rebuilds the metadata from its own window table
@@ -335,7 +341,8 @@ def _predict_sharded(make_engine, input_path, fsize, stride, user_min_len, min_l
     two_pass = user_min_len is not None and user_min_len < fsize
     try:
         fa = frag.load_fasta_records(str(input_path), rec_off, mine)
-        assert np.array_equal(fa.lengths, lengths[mine]), "record lengths changed between index and read"
+        if not np.array_equal(fa.lengths, lengths[mine]):
+            raise RuntimeError(f"{input_path}: record lengths changed between the index pass and this rank's read")
         t_ingest = time.time() - t_ingest
         SHARD_STATS.update(rank=rank, local_bases=int(fa.bases.size), total_bases=int(lengths.sum()),
                            local_records=len(fa), total_records=n_rec)

@@ -16,6 +16,7 @@ the reference (``commands/health.py:216-250``) loads the same artefacts through 
 
 from __future__ import annotations
 
+import ast
 from collections import Counter
 from pathlib import Path
 
@@ -72,7 +73,7 @@ def verify_model(graph_dir, plan: ModelPlan | None = None, legacy: bool = False)
         have_dil[int(blk.strip("(),"))] += n // per
     # dilated convs appear either as SpaceToBatchND blocks or as Conv2D dilations attributes
     for key, n in c["conv2d"].items():
-        dil = eval(key)[2]                                   # noqa: S307 - a tuple literal produced by census()
+        dil = ast.literal_eval(key)[2]                       # a tuple literal produced by census()
         if dil and max(dil) > 1:
             have_dil[max(dil)] += n // per
     if have_dil != want_dil:

@@ -58,3 +58,21 @@ def test_large_random_roundtrip(tmp_path):
                 fh.write(s[j:j + w] + (b"\r\n" if i % 7 == 0 else b"\n"))
     fa = _same(p)
     assert [fa.sequence(i) for i in range(300)] == seqs
+
+
+def test_selected_records_with_very_long_header_tokens(tmp_path):
+    """load_fasta_records (the per-rank ingest under torchrun) sizes its name buffer from jg_fasta_count over the
+    selected bytes: header tokens far beyond 4 KB must neither overflow it nor be truncated."""
+    rng = np.random.Generator(np.random.PCG64(10))
+    names = ["short", "x" * 5000, "y" * 70000 + "|tail", "z"]
+    seqs = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].tobytes() for n in (50, 7, 300, 1)]
+    p = tmp_path / "long.fa"
+    with open(p, "wb") as fh:
+        for nm, s in zip(names, seqs):
+            fh.write(b">" + nm.encode() + b" some description\n" + s + b"\n")
+    idx = frag.index_fasta(str(p))
+    assert idx.names == names
+    for sel in ([1, 2], [0, 2, 3], [2], [0, 1, 2, 3]):
+        fb = frag.load_fasta_records(str(p), idx.rec_off, sel)
+        assert fb.names == [names[i] for i in sel]
+        assert [fb.sequence(i) for i in range(len(sel))] == [seqs[i] for i in sel]

@@ -160,6 +160,39 @@ def test_config5_shard_mixed_lengths_streamed(brain):
     _oracle_check(cfg, weights, bases, starts, table.length, fsize, got, sample)
 
 
+def test_bench_two_ranks_gather_equals_single_rank_runs(tmp_path):
+    """BASELINE configs[2] in miniature: rank 0's gathered logits of a 2-rank ``--config frag1m`` launch are, bit for bit,
+    rank 0's own logits followed by rank 1's - each reproduced by a single-rank run on that rank's contig set."""
+    base = [sys.executable, str(ROOT / "bench.py"), "--config", "frag1m", "--contigs", "400", "--steps", "1", "--warmup", "1",
+            "--no-cpu-baseline", "--no-exact-f32"]
+    both = tmp_path / "both.npy"
+    res = subprocess.run(base + ["--gpus", "2", "--oversubscribe", "--dump-gather", str(both)], capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    parts = []
+    for r in (0, 1):
+        one = tmp_path / f"r{r}.npy"
+        res = subprocess.run(base + ["--rank-seed", str(r), "--dump-gather", str(one)], capture_output=True, text=True,
+                             timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        parts.append(np.load(one))
+    got = np.load(both)
+    assert got.shape == (800, parts[0].shape[1]) and parts[0].shape[0] == 400
+    np.testing.assert_array_equal(got, np.concatenate(parts, axis=0))
+    assert np.abs(got).max() > 0
+
+
+def test_bench_failing_rank_is_reported_and_times_out(tmp_path):
+    """A rank that dies surfaces its stderr and a non-zero exit; ranks that hang are killed after --rank-timeout."""
+    import os
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--oversubscribe", "--contigs", "50", "--steps", "1",
+           "--warmup", "0", "--no-cpu-baseline", "--no-exact-f32", "--rank-timeout", "240"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, JAEGER_BENCH_FAIL_RANK="1"))
+    assert res.returncode != 0
+    assert "rank 1" in res.stderr and "JAEGER_BENCH_FAIL_RANK" in res.stderr, res.stderr[-2000:]
+
+
 def test_bench_gpus_flag_spawns_ranks():
     """``python bench.py --gpus 2`` with no torchrun environment launches two ranks by itself and reports n_gpus 2
     (here both ranks share the test box's one GPU and exchange over gloo: --oversubscribe)."""

@@ -380,6 +380,41 @@ def test_f16x3_repeatable(name, fsize, n_win):
     assert bad == 0, f"{bad}/40 repeats differ"
 
 
+@pytest.mark.parametrize("name,fsize,n_win,short", [("brain", 1500, 10, False), ("brain", 1500, 300, True),
+                                                    ("brain", 2000, 48, True), ("brain", 1000, 40, False)])
+def test_producer_consumer_conv_matches_two_workgroup_kernel(name, fsize, n_win, short):
+    """The producer / consumer kernel of the residual stacks (jg_conv_pc.hip) keeps the two-workgroup kernel's
+    arithmetic order: every output must be bit-identical with JG_OPT_CONV_PC off, for row-tiled (1500 bp) and
+    window-packed (2000 / 1000 bp) launches, ragged windows, N runs and several chunkings - and repeatable."""
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = load_model_cfg(name)
+    weights = ofwd.random_weights(cfg, seed=38341)
+    rng = np.random.Generator(np.random.PCG64(77 + fsize))
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.01)
+    lens = np.full(n_win, fsize, np.int32)
+    if short:
+        lens[1::3] = rng.integers(fsize // 2, fsize, lens[1::3].size)
+    windows = [seq[i * fsize:i * fsize + n].tobytes() for i, n in enumerate(lens)]
+    ids = oenc.encode_windows(windows, fsize, pad_to=frame_length(fsize))
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, precision="f16x3")
+    eng.device.set_conv_pc(False)
+    classic = eng.model.forward(ids)
+    eng.device.set_conv_pc(True)
+    bad = 0
+    for rep in range(12):
+        got = eng.model.forward(ids, chunk=(0, 7, 64)[rep % 3])
+        bad += any(not np.array_equal(classic[k], got[k]) for k in classic)
+    assert eng.model.precision == "f16x3"           # the range guard did not trip
+    eng.close()
+    assert bad == 0, f"{bad}/12 runs differ from the two-workgroup kernel"
+    if n_win <= 48:
+        ref = ofwd.forward(cfg, weights, ids)
+        for k in ("prediction", "reliability"):
+            assert np.abs(classic[k] - ref[k]).max() <= TOL, k
+
+
 def test_forward_variant_without_inner_nmd_taps():
     """A 128-channel model whose residual stacks are followed by BN + GELU without an NMD tap
     (stage list conv2: BIAS+BN+ADD+ACT+BN+ACT) must stay on the split-f16 path (compiled pattern) and
