@@ -42,7 +42,10 @@ constexpr int S_ITEMS = 4 * 64 + 16;  // 16-byte items of one helper's staging a
 #define JG_PC_LATE 1                  // take a step's barrier before the previous step's last MFMA group is issued
 #endif
 #ifndef JG_PC_PRIO
-#define JG_PC_PRIO 3                  // s_setprio of the math waves (helpers run at 0)
+#define JG_PC_PRIO 3                  // s_setprio of the math waves
+#endif
+#ifndef JG_PC_HPRIO
+#define JG_PC_HPRIO 0                 // s_setprio of the helper waves
 #endif
 
 #ifdef JG_STAMP
@@ -54,6 +57,11 @@ static __device__ unsigned long long jg_pc_stamp_acc[16];
 #define PC_ST_DECL
 #define PC_ST(idx)
 #define PC_ST_END(base)
+#endif
+#if defined(JG_STAMP) && defined(JG_STAMP_M)
+#define PC_STM(idx) PC_ST(idx)      // math-wave step stamps: every s_memtime drains lgkmcnt, i.e. the fragment lookahead
+#else
+#define PC_STM(idx)
 #endif
 
 __device__ __forceinline__ void lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -133,6 +141,10 @@ void conv_pc_kernel(ConvHArgs a) {
     // ZERO: the block's first product of the tile starts from C = 0 (no accumulator clearing between tiles)
     auto mm = [&](auto zero_c, const WF &w, const XF &x, int tp) {
       constexpr bool ZERO = decltype(zero_c)::value;
+#ifdef JG_PC_NOMFMA            // timing experiment: fragments are still read, the matrix cores stay idle (results are garbage)
+      acc[tp * 2][0][0] += __uint_as_float(w.h[0].x ^ w.l[1].y ^ x.h[0].z ^ x.l[1].w ^ w.h[1].x ^ w.l[0].y ^ x.h[1].z ^ x.l[0].w);
+      return;
+#endif
 #pragma unroll
       for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
@@ -165,7 +177,7 @@ void conv_pc_kernel(ConvHArgs a) {
           }
     };
     bar();                                               // step A of (pass 0, chunk 0)
-    PC_ST(1);
+    PC_STM(1);
     ldw(wf[0], 0);
     ldx(xf[0], Abuf + x_frag, 0, 0);
     for (int pass = 0; pass < my_pairs; ++pass) {
@@ -191,9 +203,9 @@ void conv_pc_kernel(ConvHArgs a) {
             };
             if (step_end && JG_PC_LATE && !pass_end) {
               lgkm0();                                   // this step's last fragments are in registers: the slots may be refilled
-              PC_ST(0);
+              PC_STM(0);
               bar();
-              PC_ST(1);
+              PC_STM(1);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!(step_end && !JG_PC_LATE) && !pass_end) next_loads();
@@ -206,9 +218,9 @@ void conv_pc_kernel(ConvHArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if (step_end && !JG_PC_LATE && !pass_end) {
-              PC_ST(0);
+              PC_STM(0);
               bar();
-              PC_ST(1);
+              PC_STM(1);
               next_loads();
             }
           }
@@ -237,6 +249,7 @@ void conv_pc_kernel(ConvHArgs a) {
   const int htid = tid - 256;                            // 0..255: the helper threads take the DMA duties of the
                                                          // two-workgroup kernel's 256 threads one for one
   const int hw = wid - 4;
+  __builtin_amdgcn_s_setprio(JG_PC_HPRIO);
   PC_ST_DECL;
   const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + hw * 1024);                        // + buf*a_items*16 + it*4096
   const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + hw * 1024);    // + slot*8192 + it*4096
@@ -428,6 +441,9 @@ void conv_pc_kernel(ConvHArgs a) {
   // half j (channel groups 2j, 2j+1: registers 8j .. 8j+7) of one 32 x 32 block, in place; afterwards registers
   // 8j..8j+3 hold the hi item and 8j+4..8j+7 the lo item of group 2j + h (F16S outputs)
   auto epi_half = [&](f32x16 &x, const Pre &p, int tn, int j) {
+#ifdef JG_PC_NOEPI             // timing experiment: no epilogue arithmetic (results are garbage)
+    return;
+#endif
     const int nb = (wn * 2 + tn) * 32;
     auto st_affine = [&](int row) {
       const float *pr = epiL + (row * 2) * HN + nb + 4 * h;
@@ -646,6 +662,7 @@ void conv_pc_kernel(ConvHArgs a) {
         if (HAS_NMD && cc == 4) nmd_flush(et, 0);
       }
       if (epi) epi_collect(pre, et, tm);               // staged by the DMAs of the previous chunk's step B (covered by wait A)
+      PC_ST(4);
       if (!drain) {
         if (cc == PCC - 2 && !last_pass) { lgkm0(); request_bytes(np); }     // (the staging area was just read out)
         issue_w(cc, 4);
@@ -654,6 +671,7 @@ void conv_pc_kernel(ConvHArgs a) {
           issue_x(ncc, abuf ^ 1);
         }
       }
+      PC_ST(3);
       if (epi) {
         if (cc == 0 || cc == 4) {
 #pragma unroll
@@ -662,7 +680,7 @@ void conv_pc_kernel(ConvHArgs a) {
         if (tn == 0) mk_tm[tm] = pre.live ? pre.mk : 0.f;
         epi_half(acc[tm][tn], pre, tn, 0);
       }
-      PC_ST(3);
+      PC_ST(4);
       // ---- step B: taps 2, 3 ----
       if (!drain) {
         if (tail) wait_vm<W_ITERS>();
@@ -680,8 +698,9 @@ void conv_pc_kernel(ConvHArgs a) {
         else epi_request(et, (cc + 1) & 3, (cc + 1) >> 2);
       }
       if (!drain && !tail) { issue_w(ncc, 0); issue_w(ncc, 1); }
-      if (epi) epi_half(acc[tm][tn], pre, tn, 1);
       PC_ST(3);
+      if (epi) epi_half(acc[tm][tn], pre, tn, 1);
+      PC_ST(4);
       // ---- step C: tap 4 ----
       if (!drain) {
         if (tail) wait_vm<0>();
@@ -698,6 +717,7 @@ void conv_pc_kernel(ConvHArgs a) {
         if (HAS_NMD) nmd_flush(et, 1);
         if (a.pool_out != nullptr) pool_reduce(et);
       }
+      PC_ST(4);
       if (!drain && !tail) { issue_w(ncc, 2); issue_w(ncc, 3); }
       PC_ST(3);
     }
@@ -737,8 +757,8 @@ int launch_pc(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(jg_pc_stamp_acc), z, sizeof(z)));
     const double tm = (double)hh[7], th = (double)hh[15];
     fprintf(stderr, "PCSTAMP ep=0x%x rows=%d grid=%d math: cyc/wave=%.0f mfma+lds=%.3f barrier=%.3f handoff=%.3f | helper: cyc/wave=%.0f "
-            "wait=%.3f barrier=%.3f handoff=%.3f work=%.3f\n", EP, a.rows, grid, tm / (grid * 4.0), hh[0] / tm, hh[1] / tm, hh[2] / tm,
-            th / (grid * 4.0), hh[8] / th, hh[9] / th, hh[10] / th, hh[11] / th);
+            "wait=%.3f barrier=%.3f handoff=%.3f dma_issue=%.3f epilogue=%.3f\n", EP, a.rows, grid, tm / (grid * 4.0), hh[0] / tm, hh[1] / tm, hh[2] / tm,
+            th / (grid * 4.0), hh[8] / th, hh[9] / th, hh[10] / th, hh[11] / th, hh[12] / th);
   }
 #endif
   return JG_OK;
