@@ -79,11 +79,12 @@ __device__ __forceinline__ void glds_ubyte(const void *sbase, unsigned voff, uns
                : "memory");
 }
 
-template <unsigned EP, bool FLAT>
+// DIL: the dilation as a compile-time constant - every LDS offset of the fragment reads and of the DMA destinations folds
+// into an instruction immediate (the math waves have no registers to spare for address arithmetic)
+template <unsigned EP, bool FLAT, int DIL>
 __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_pc_kernel(ConvHArgs a) {
   constexpr bool HAS_ADD = (EP & JG_EP_ADD) != 0;
-  constexpr int NL = (HAS_ADD ? 4 : 0) + 1;            // DMAs of one block's epilogue inputs: shortcut items + mask byte
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,17 +92,19 @@ void conv_pc_kernel(ConvHArgs a) {
   const int w4 = wid & 3;                               // pair index: math wave w4 and helper wave w4 + 4 share a SIMD
   const int wm = w4 >> 1, wn = w4 & 1;                  // the pair's 128-position x 64-channel quarter of the tile
   const int i = lane & 31, h = lane >> 5;
+  const int ptid = tid & 255;                           // thread index inside the role (0..255)
   const int vgrid = (int)gridDim.x;
   int vb = (int)blockIdx.x;
   if ((vgrid & 7) == 0) vb = (vb & 7) * (vgrid >> 3) + (vb >> 3);     // XCD-aware tile order (see conv_f16x3_kernel)
   // LDS carve (16-byte units)
-  const int rows_a = HM + (PK - 1) * a.dil;
-  const int a_items = 4 * rows_a;                        // [4 ph][rows_a]
+  constexpr int rows_a = HM + (PK - 1) * DIL;
+  constexpr int a_items = 4 * rows_a;                    // [4 ph][rows_a]
   uint4 *Abuf = lds;                                     // [2 bufs][a_items]
   uint4 *Wbuf = lds + 2 * a_items;                       // [5 slots][2 planes][2 h][HN]
   float *epiL = reinterpret_cast<float *>(Wbuf + PK * W_ITEMS);      // [JG_EPI_ROWS][2][HN]
   uint4 *Xbuf = Wbuf + PK * W_ITEMS + JG_EPI_ROWS * 2 * HN / 4;      // [4 pairs][X_ITEMS]
   uint4 *Sbuf = Xbuf + 4 * X_ITEMS;                                   // [4 helpers][S_ITEMS]
+  unsigned char *Bbuf = reinterpret_cast<unsigned char *>(Sbuf + 4 * S_ITEMS);   // [A_ITERS][256] input-mask bytes of the next tile
   for (int q = tid; q < a.n_epi_rows * 2 * HN; q += PT) epiL[q] = a.epi[q];   // visible after the first barrier
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
   const int n_tiles = FLAT ? a.flat_tiles : a.rows * a.tiles_m;
@@ -111,14 +114,96 @@ void conv_pc_kernel(ConvHArgs a) {
   uint4 *Xp = Xbuf + w4 * X_ITEMS + lane;                // this pair's transit slot, lane column
   f32x16 acc[4][2];                                      // [tm: position block][tn: channel block]; both roles
 
+  auto resolve = [&](const Tile &tile, int local, int len, int &row, int &p) -> bool {
+    if constexpr (!FLAT) {
+      row = tile.rowblk;
+      p = tile.m0 + local;
+      return tile.valid && p >= 0 && p < len;
+    }
+    const int v = tile.T * HM + local;
+    if (v < 0 || !tile.valid) { row = 0; p = 0; return false; }
+    int g, u, f;
+    udivmod24(v, a.flat_wp, a.flat_inv_wp, g, u);
+    udivmod24(u, a.flat_p, a.flat_inv_p, f, p);
+    row = g * a.flat_frames + f;
+    return f < a.flat_frames && p < len && row < a.rows;
+  };
+  auto tile_of = [&](int pass, Tile &t) {
+    const int T = vb + pass * vgrid;
+    const int Tc = min(T, n_tiles - 1);
+    t.rowblk = Tc / a.tiles_m;
+    t.m0 = (Tc - t.rowblk * a.tiles_m) * HM;
+    t.valid = T < n_tiles;
+    t.T = Tc;
+  };
+  // per-thread activation piece coordinates (as in conv_f16x3_kernel): piece q = ptid + it*256 -> (plane/half ph, row r);
+  // ph >= 4: no piece (only the last iteration can run past the slice).  Recomputed where needed: divisions by constants.
+  auto piece_ph = [&](int it) -> int { return (ptid + it * HT) / rows_a; };
+  auto piece_row = [&](int it) -> int { return (ptid + it * HT) % rows_a; };
+  const uint8_t *bsrc = a.mask_in;
+  auto piece_pos = [&](const Tile &tl, int it, int &pc, bool &inr) -> int {
+    int rb, p;
+    inr = resolve(tl, piece_row(it) - a.pad_left, a.L_in, rb, p) && piece_ph(it) < 4;
+    pc = min(max(p, 0), a.L_in - 1);
+    if constexpr (FLAT) rb = min(rb, a.rows - 1);
+    return rb;
+  };
+
   if (is_math) {
     // =========================================== MATH WAVE ===============================================
+    // MFMA stream + the operand ring of conv_f16x3_kernel (same slots, same issue points, same counted waits); no
+    // epilogue.  Nothing else this wave issues touches vector memory, so the counts are exact.
     lgkm0();                                             // the epilogue-table writes above
     __builtin_amdgcn_s_setprio(JG_PC_PRIO);
     PC_ST_DECL;
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);                       // + buf*a_items*16 + it*4096
+    const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + wid * 1024);   // + slot*8192 + it*4096
+    unsigned w_voff[W_ITERS];
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) {
+      const int q = ptid + it * HT;          // [plane][h][n]
+      w_voff[it] = (unsigned)((((q >> 8) * PK * PCC * 2 + ((q >> 7) & 1)) * HN + (q & (HN - 1))) * 16);
+    }
+    unsigned raw[A_ITERS];
+    unsigned x_voff[A_ITERS];
+    unsigned x_ok = 0;
+    auto build_pieces = [&](const Tile &tl) {      // consumes raw[]
+      x_ok = 0;
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        int pc; bool inr;
+        const int rb = piece_pos(tl, it, pc, inr);
+        const int ph = piece_ph(it) & 3;
+        x_voff[it] = (unsigned)(((rb * PCC * 4 + ph) * a.L_in + pc) * 16);
+        if (inr && raw[it] != 0) x_ok |= 1u << it;
+      }
+    };
+    const char *x_base = reinterpret_cast<const char *>(a.xh);
+    const unsigned x_cc_stride = 4u * (unsigned)a.L_in * 16u;   // bytes per chunk
+    const bool x_last_wave = __builtin_amdgcn_readfirstlane((int)((A_ITERS - 1) * HT + wid * 64 < 4 * rows_a)) != 0;
+    auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
+      const char *sb = reinterpret_cast<const char *>(a.wh) + ((size_t)(t * PCC * 2 + cc * 2) * HN) * 16;
+#pragma unroll
+      for (int it = 0; it < W_ITERS; ++it) glds16(sb, w_voff[it], ldsW + t * (W_ITEMS * 16) + it * (HT * 16));
+    };
+    auto issue_x = [&](int cc, int buf) {      // the tile's activation slice of chunk cc
+      const char *sb = x_base + (size_t)cc * x_cc_stride;
+      const unsigned dst = ldsA + buf * (a_items * 16);
+#pragma unroll
+      for (int it = 0; it < A_ITERS - 1; ++it) glds16_nt(sb, x_voff[it], dst + it * (HT * 16));
+      if (x_last_wave) {                        // wave-uniform: the counted waits must know how many DMAs are in flight
+        if (piece_ph(A_ITERS - 1) < 4) glds16_nt(sb, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
+      }
+    };
+    auto zero_fill = [&](int buf) {
+      uint4 *A = Abuf + buf * a_items;
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it)
+        if (piece_ph(it) < 4 && !((x_ok >> it) & 1u)) A[ptid + it * HT] = make_uint4(0u, 0u, 0u, 0u);
+    };
     const uint4 *Wb = Wbuf + h * HN + wn * 64 + i;       // + t*W_ITEMS + plane*2*HN + tn*32
     const int x_frag = h * rows_a + wm * 128 + i;        // + plane*2*rows_a + tm*32 + t*dil
-    const int dil = a.dil;
+    constexpr int dil = DIL;
     struct XF { uint4 h[2], l[2]; };
     struct WF { uint4 h[2], l[2]; };
     XF xf[2];
@@ -176,8 +261,29 @@ void conv_pc_kernel(ConvHArgs a) {
                                                           __float_as_uint(c[4 * r4 + 2]), __float_as_uint(c[4 * r4 + 3]));
           }
     };
+    // ---- prologue: the pipeline of pass 0 ----
+    Tile cur, np;
+    tile_of(0, cur);
+    tile_of(1, np);
+    if (bsrc != nullptr) {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        int pc; bool inr;
+        const int rb = piece_pos(cur, it, pc, inr);
+        raw[it] = bsrc[(size_t)rb * a.L_in + pc];
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) raw[it] = 1;
+    }
+    build_pieces(cur);                 // the only exposed byte-load latency of the launch
+    issue_x(0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) issue_w(0, t);
+    wait_vm<2 * W_ITERS>();
+    zero_fill(0);
+    lgkm0();
     bar();                                               // step A of (pass 0, chunk 0)
-    PC_STM(1);
     ldw(wf[0], 0);
     ldx(xf[0], Abuf + x_frag, 0, 0);
     for (int pass = 0; pass < my_pairs; ++pass) {
@@ -185,14 +291,40 @@ void conv_pc_kernel(ConvHArgs a) {
       for (int cp = 0; cp < PCC / 2; ++cp) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {           // chunk cc = 2*cp + half reads activation buffer `half`
+          const int cc = 2 * cp + half;
+          const bool last_chunk = half == 1 && cp == PCC / 2 - 1;
+          const bool tail = last_chunk && !more;          // nothing is issued behind this chunk
+          const int ncc = last_chunk ? 0 : cc + 1;
           const uint4 *A = Abuf + half * a_items + x_frag;
           const uint4 *An = Abuf + (half ^ 1) * a_items + x_frag;
 #pragma unroll
           for (int g = 0; g < 10; ++g) {                 // group g: tap g/2, position-block pair g%2
             const int t = g >> 1, tp = g & 1;
             const bool step_end = g == 3 || g == 7 || g == 9;
-            const bool pass_end = g == 9 && half == 1 && cp == PCC / 2 - 1;      // (cp is a run-time value)
-            auto next_loads = [&]() {                    // fragments of the group after g
+            const bool pass_end = g == 9 && last_chunk;
+            if (step_end && !pass_end) {
+              // the next step's operands: counted wait, padding / mask zeros, publish.  Taken BEFORE this step's last
+              // group is issued - its fragments are in registers (lgkmcnt 0), so the slots may be refilled - and the
+              // first fragments of the next step are requested under those 12 MFMAs.
+              if (g == 3) {
+                if (tail) wait_vm<W_ITERS>();
+                else if (x_last_wave) wait_vm<W_ITERS + A_ITERS>();
+                else wait_vm<W_ITERS + A_ITERS - 1>();
+              } else if (g == 7) {
+                if (tail) wait_vm<0>();
+                else if (x_last_wave) wait_vm<2 * W_ITERS + A_ITERS>();
+                else wait_vm<2 * W_ITERS + A_ITERS - 1>();
+              } else {
+                wait_vm<2 * W_ITERS>();
+                zero_fill(half ^ 1);
+              }
+              lgkm0();
+              PC_STM(0);
+              bar();
+              PC_STM(1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!pass_end) {                             // fragments of the group after g
               if (g < 9) {
                 ldx(xf[(g + 1) & 1], A, (g + 1) >> 1, (g + 1) & 1);
                 if (tp == 1) ldw(wf[(half + t + 1) & 1], t + 1);
@@ -200,15 +332,7 @@ void conv_pc_kernel(ConvHArgs a) {
                 ldx(xf[0], An, 0, 0);
                 ldw(wf[(half ^ 1) & 1], 0);
               }
-            };
-            if (step_end && JG_PC_LATE && !pass_end) {
-              lgkm0();                                   // this step's last fragments are in registers: the slots may be refilled
-              PC_STM(0);
-              bar();
-              PC_STM(1);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(step_end && !JG_PC_LATE) && !pass_end) next_loads();
             __builtin_amdgcn_sched_barrier(0);
             if (half == 0 && g < 2) {
               if (cp == 0) mm(std::true_type{}, wf[(half + t) & 1], xf[g & 1], tp);
@@ -217,12 +341,25 @@ void conv_pc_kernel(ConvHArgs a) {
               mm(std::false_type{}, wf[(half + t) & 1], xf[g & 1], tp);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (step_end && !JG_PC_LATE && !pass_end) {
-              PC_STM(0);
-              bar();
-              PC_STM(1);
-              next_loads();
+            // keep the ring full: issued behind the step's first 12 MFMAs, so the issue cost runs under matrix-core time
+            if (g == 0) {
+              issue_w(cc, 4);
+              if (!tail) {
+                if (last_chunk) {
+                  if (bsrc != nullptr) {
+#pragma unroll
+                    for (int it = 0; it < A_ITERS; ++it) raw[it] = Bbuf[it * 256 + ptid];     // fetched by the helpers
+                  }
+                  build_pieces(np);
+                }
+                issue_x(ncc, half ^ 1);
+              }
+            } else if (g == 4) {
+              if (!tail) { issue_w(ncc, 0); issue_w(ncc, 1); }
+            } else if (g == 8) {
+              if (!tail) { issue_w(ncc, 2); issue_w(ncc, 3); }
             }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
@@ -231,6 +368,7 @@ void conv_pc_kernel(ConvHArgs a) {
       xwrite(0);
       lgkm0();
       bar();                                             // X1: first half published
+      if (more) { wait_vm<2 * W_ITERS>(); zero_fill(0); }        // (the next tile's first operands, while the helper reads)
       bar();                                             // X2: the helper has it in registers
       xwrite(1);
       lgkm0();
@@ -240,138 +378,21 @@ void conv_pc_kernel(ConvHArgs a) {
         ldw(wf[0], 0);
         ldx(xf[0], Abuf + x_frag, 0, 0);
       }
+      cur = np;
+      tile_of(pass + 2, np);
     }
     PC_ST_END(0);
     return;
   }
 
   // ============================================= HELPER WAVE =================================================
-  const int htid = tid - 256;                            // 0..255: the helper threads take the DMA duties of the
-                                                         // two-workgroup kernel's 256 threads one for one
+  // The fused epilogue of the PREVIOUS tile, one 32 x 32 accumulator block per chunk of the math waves' loop, in three
+  // parts behind the chunk's three step barriers; plus the next tile's input-mask bytes for the math waves' piece table.
   const int hw = wid - 4;
   __builtin_amdgcn_s_setprio(JG_PC_HPRIO);
   PC_ST_DECL;
-  const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + hw * 1024);                        // + buf*a_items*16 + it*4096
-  const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + hw * 1024);    // + slot*8192 + it*4096
   uint4 *Sp = Sbuf + hw * S_ITEMS;                       // this wave's staging: [4 items][64 lanes] + 64 mask dwords
   const unsigned ldsS = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((Sbuf - lds) + hw * S_ITEMS) * 16u);
-
-  auto resolve = [&](const Tile &tile, int local, int len, int &row, int &p) -> bool {
-    if constexpr (!FLAT) {
-      row = tile.rowblk;
-      p = tile.m0 + local;
-      return tile.valid && p >= 0 && p < len;
-    }
-    const int v = tile.T * HM + local;
-    if (v < 0 || !tile.valid) { row = 0; p = 0; return false; }
-    int g, u, f;
-    udivmod24(v, a.flat_wp, a.flat_inv_wp, g, u);
-    udivmod24(u, a.flat_p, a.flat_inv_p, f, p);
-    row = g * a.flat_frames + f;
-    return f < a.flat_frames && p < len && row < a.rows;
-  };
-  auto tile_of = [&](int pass, Tile &t) {
-    const int T = vb + pass * vgrid;
-    const int Tc = min(T, n_tiles - 1);
-    t.rowblk = Tc / a.tiles_m;
-    t.m0 = (Tc - t.rowblk * a.tiles_m) * HM;
-    t.valid = T < n_tiles;
-    t.T = Tc;
-  };
-  // per-thread activation piece coordinates (as in conv_f16x3_kernel)
-  unsigned a_pk[A_ITERS];
-#pragma unroll
-  for (int it = 0; it < A_ITERS; ++it) {
-    const int q = htid + it * HT;
-    const int ph = q / rows_a;          // >= 4: no piece
-    a_pk[it] = ((unsigned)(ph >> 2) << 20) | ((unsigned)(ph & 3) << 16) | (unsigned)(q - ph * rows_a);
-  }
-  unsigned w_voff[W_ITERS];
-#pragma unroll
-  for (int it = 0; it < W_ITERS; ++it) {
-    const int q = htid + it * HT;          // [plane][h][n]
-    w_voff[it] = (unsigned)((((q >> 8) * PK * PCC * 2 + ((q >> 7) & 1)) * HN + (q & (HN - 1))) * 16);
-  }
-  const uint8_t *bsrc = a.mask_in;
-  unsigned raw[A_ITERS];
-  unsigned x_voff[A_ITERS];
-  unsigned x_ok = 0;
-  auto piece_pos = [&](const Tile &tl, int it, int &pc, bool &inr) -> int {
-    const int a_u = (int)(a_pk[it] >> 20), a_r = (int)(a_pk[it] & 0xffff);
-    int rb, p;
-    inr = resolve(tl, a_r - a.pad_left, a.L_in, rb, p) && a_u < 1;
-    pc = min(max(p, 0), a.L_in - 1);
-    if constexpr (FLAT) rb = min(rb, a.rows - 1);
-    return rb;
-  };
-  auto load_bytes = [&](const Tile &tl) {
-    if (bsrc != nullptr) {
-#pragma unroll
-      for (int it = 0; it < A_ITERS; ++it) {
-        int pc; bool inr;
-        const int rb = piece_pos(tl, it, pc, inr);
-        raw[it] = bsrc[(size_t)rb * a.L_in + pc];
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < A_ITERS; ++it) raw[it] = 1;
-    }
-  };
-  // the same bytes for the NEXT tile, without a load the compiler would track (its vmcnt waits would drain the operand
-  // ring): LDS-DMA into the wave's staging area at step A of chunk 6 - in front of that step's operand DMAs, so the step-B
-  // wait covers them - and out of it at step B, before the next block's epilogue inputs are requested
-  auto request_bytes = [&](const Tile &tl) {
-    if (bsrc != nullptr) {
-#pragma unroll
-      for (int it = 0; it < A_ITERS; ++it) {
-        int pc; bool inr;
-        const int rb = piece_pos(tl, it, pc, inr);
-        glds_ubyte(bsrc, (unsigned)(rb * a.L_in + pc), ldsS + it * 256);
-      }
-    }
-  };
-  auto collect_bytes = [&]() {
-    if (bsrc != nullptr) {
-#pragma unroll
-      for (int it = 0; it < A_ITERS; ++it) raw[it] = reinterpret_cast<const unsigned *>(Sp)[it * 64 + lane];
-    }
-  };
-  auto build_pieces = [&](const Tile &tl) {      // consumes raw[] (fetched a chunk ago)
-    x_ok = 0;
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      int pc; bool inr;
-      const int rb = piece_pos(tl, it, pc, inr);
-      const unsigned ph = (a_pk[it] >> 16) & 3;
-      x_voff[it] = (unsigned)(((rb * PCC * 4 + (int)ph) * a.L_in + pc) * 16);
-      if (inr && raw[it] != 0) x_ok |= 1u << it;
-    }
-  };
-  const char *x_base = reinterpret_cast<const char *>(a.xh);
-  const unsigned x_cc_stride = 4u * (unsigned)a.L_in * 16u;   // bytes per chunk
-  const bool x_last_wave = __builtin_amdgcn_readfirstlane((int)((A_ITERS - 1) * HT + hw * 64 < 4 * rows_a)) != 0;
-  auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
-    const char *sb = reinterpret_cast<const char *>(a.wh) + ((size_t)(t * PCC * 2 + cc * 2) * HN) * 16;
-#pragma unroll
-    for (int it = 0; it < W_ITERS; ++it) glds16(sb, w_voff[it], ldsW + t * (W_ITEMS * 16) + it * (HT * 16));
-  };
-  auto issue_x = [&](int cc, int buf) {      // the tile's activation slice of chunk cc
-    const char *sb = x_base + (size_t)cc * x_cc_stride;
-    const unsigned dst = ldsA + buf * (a_items * 16);
-#pragma unroll
-    for (int it = 0; it < A_ITERS - 1; ++it) glds16_nt(sb, x_voff[it], dst + it * (HT * 16));
-    if (x_last_wave) {                        // wave-uniform: the counted waits must know how many DMAs are in flight
-      if ((a_pk[A_ITERS - 1] >> 20) < 1) glds16_nt(sb, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
-    }
-  };
-  auto zero_fill = [&](int buf) {
-    uint4 *A = Abuf + buf * a_items;
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it)
-      if ((a_pk[it] >> 20) < 1 && !((x_ok >> it) & 1u)) A[htid + it * HT] = make_uint4(0u, 0u, 0u, 0u);
-  };
-
-  // ---- epilogue pieces (expressions of conv_f16x3_kernel's compiled patterns, tanh-GELU) -----------------
   const int L_res = a.L_out;
   auto item4 = [&](int row, int mc, int nb, int j) -> unsigned {
     const int G = (nb >> 3) + 2 * j + h;                 // hi-plane item of group 2j + h (uint4 units); lo plane = + 2*L_out
@@ -386,7 +407,7 @@ void conv_pc_kernel(ConvHArgs a) {
     }
     return live;
   };
-  // request what block (tm, tn) of `tile` needs from memory: NL LDS-DMAs into the wave's staging area
+  // request what block (tm, tn) of `tile` needs from memory: LDS-DMAs into the wave's staging area
   auto epi_request = [&](const Tile &tile, int tm, int tn) {
     const int nb = (wn * 2 + tn) * 32;
     int orow, mc;
@@ -399,9 +420,7 @@ void conv_pc_kernel(ConvHArgs a) {
         glds16_nt(a.addh, (it4 + 2u * (unsigned)a.L_out) * 16u, ldsS + (2 * j + 1) * 1024);
       }
     }
-    // (no output mask: any readable byte - the value is ignored)
-    const void *mb = a.mask_out != nullptr ? static_cast<const void *>(a.mask_out) : static_cast<const void *>(a.wh);
-    glds_ubyte(mb, a.mask_out != nullptr ? (unsigned)(orow * a.L_out + mc) : 0u, ldsS + 4 * 1024);
+    if (a.mask_out != nullptr) glds_ubyte(a.mask_out, (unsigned)(orow * a.L_out + mc), ldsS + 4 * 1024);
   };
   struct Pre {
     uint2 sh[4], sl[4];
@@ -412,8 +431,8 @@ void conv_pc_kernel(ConvHArgs a) {
   // ... and take it out of the staging area (after the wait that covers those DMAs)
   auto epi_collect = [&](Pre &p, const Tile &tile, int tm) {
     p.live = out_pos(tile, tm, p.orow, p.mc);
-    const unsigned mbyte = reinterpret_cast<const unsigned *>(Sp + 4 * 64)[lane];
-    p.mk = (a.mask_out == nullptr || mbyte != 0u) ? 1.f : 0.f;
+    p.mk = 1.f;
+    if (a.mask_out != nullptr) p.mk = reinterpret_cast<const unsigned *>(Sp + 4 * 64)[lane] != 0u ? 1.f : 0.f;
     if constexpr (HAS_ADD) {
       // lane (i, h) staged the whole item of group 2j + h at its position; it needs channels 4h..4h+3 of groups 2j and 2j+1
       const uint2 *S2 = reinterpret_cast<const uint2 *>(Sp);
@@ -605,32 +624,23 @@ void conv_pc_kernel(ConvHArgs a) {
         }
   };
 
-  // ---- prologue: the pipeline of pass 0 ------------------------------------------------------------------------
-  Tile cur, np, et;                  // tile of this pass (operands) / of the next pass / whose accumulators this wave holds
+  Tile cur, np, et;                  // tile the math waves work on / the next one / the one whose accumulators this wave holds
   tile_of(0, cur);
   tile_of(1, np);
   et = cur;
-  load_bytes(cur);
-  build_pieces(cur);                 // the only exposed byte-load latency of the launch
-  issue_x(0, 0);
-#pragma unroll
-  for (int t = 0; t < 4; ++t) issue_w(0, t);
   Pre pre;
   pre.live = false; pre.mk = 0.f; pre.orow = 0; pre.mc = 0;
 #pragma unroll
   for (int g = 0; g < 4; ++g) pre.sh[g] = pre.sl[g] = make_uint2(0u, 0u);
+  unsigned char nb_raw[A_ITERS] = {1, 1, 1, 1, 1};
 
-  // Pass `my_pairs` is the drain: no operands, no barriers - only the last tile's epilogue, through the same code.
+  // Pass `my_pairs` is the drain: no barriers - only the last tile's epilogue, through the same code.
   for (int pass = 0; pass <= my_pairs; ++pass) {
     const bool drain = pass == my_pairs;
     const bool epi = pass > 0;                         // this wave holds a tile's accumulators
-    const bool last_pass = pass == my_pairs - 1;
     if (epi) {
-      // X1 / X2: first half of the finished tile's accumulators (the step-A wait and zero-fill of this pass's first
-      // chunk are done first, so that the math waves find barrier A right behind X2)
-      if (!drain) { wait_vm<2 * W_ITERS>(); zero_fill(0); lgkm0(); }
-      PC_ST(3);
-      bar();                                           // X1
+      PC_ST(4);
+      bar();                                           // X1: first half of the finished tile's accumulators
       xread(0);
       lgkm0();
       bar();                                           // X2
@@ -638,41 +648,23 @@ void conv_pc_kernel(ConvHArgs a) {
     }
 #pragma unroll
     for (int cc = 0; cc < PCC; ++cc) {
-      const int abuf = cc & 1;
       const bool last_chunk = cc == PCC - 1;
-      const bool tail = last_chunk && last_pass;       // nothing is issued behind this chunk
-      const int ncc = last_chunk ? 0 : cc + 1;
       const int tm = cc & 3, tn = cc >> 2;             // the accumulator block this chunk's steps carry
-      // ---- step A: taps 0, 1 ----
-      if (!drain) {
-        if (!(cc == 0 && epi)) { wait_vm<2 * W_ITERS>(); zero_fill(abuf); lgkm0(); }
-        PC_ST(0);
-        bar();                                         // A (after a pass: also X3 - the second half is in the slot)
+      // ---- step A ----
+      if (!drain || cc == 0) {
+        PC_ST(4);
+        bar();                                         // A (after a pass: the second half is in the slot; drain: X3)
         PC_ST(1);
-      } else if (cc == 0) {
-        PC_ST(0);
-        bar();                                         // X3
-        PC_ST(1);
-        wait_vm<0>();                                  // the first block's staged inputs
       }
-      if (cc == 0 && epi) xread(1);
       if (epi) {
-        // stores of the previous block (its registers are final since step B of the previous chunk)
-        if (cc > 0 && a.pool_out == nullptr) store_block(acc[(cc - 1) & 3][(cc - 1) >> 2], pre, (cc - 1) >> 2);
-        if (HAS_NMD && cc == 4) nmd_flush(et, 0);
-      }
-      if (epi) epi_collect(pre, et, tm);               // staged by the DMAs of the previous chunk's step B (covered by wait A)
-      PC_ST(4);
-      if (!drain) {
-        if (cc == PCC - 2 && !last_pass) { lgkm0(); request_bytes(np); }     // (the staging area was just read out)
-        issue_w(cc, 4);
-        if (!tail) {
-          if (last_chunk) build_pieces(np);
-          issue_x(ncc, abuf ^ 1);
+        if (cc == 0) {
+          xread(1);
+          wait_vm<0>();                                // block 0's inputs, requested at the end of the previous pass
+          PC_ST(0);
+          epi_collect(pre, et, 0);
+          lgkm0();
         }
-      }
-      PC_ST(3);
-      if (epi) {
+        if (!last_chunk) epi_request(et, (cc + 1) & 3, (cc + 1) >> 2);      // (the staging area has just been read out)
         if (cc == 0 || cc == 4) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) nmd_acc[r] = 0.f;
@@ -680,46 +672,45 @@ void conv_pc_kernel(ConvHArgs a) {
         if (tn == 0) mk_tm[tm] = pre.live ? pre.mk : 0.f;
         epi_half(acc[tm][tn], pre, tn, 0);
       }
-      PC_ST(4);
-      // ---- step B: taps 2, 3 ----
+      if (!drain && cc == 2 && bsrc != nullptr) {      // the next tile's input-mask bytes, for the math waves' piece table
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) {
+          int pc; bool inr;
+          const int rb = piece_pos(np, it, pc, inr);
+          nb_raw[it] = bsrc[(size_t)rb * a.L_in + pc];
+        }
+      }
+      // ---- step B ----
       if (!drain) {
-        if (tail) wait_vm<W_ITERS>();
-        else if (x_last_wave) wait_vm<W_ITERS + A_ITERS>();
-        else wait_vm<W_ITERS + A_ITERS - 1>();
-        PC_ST(0);
+        PC_ST(4);
         bar();
         PC_ST(1);
       }
-      // inputs of the next block: block cc + 1 of the tile in hand, or block 0 of the tile the math waves are finishing
-      // (pass 0 requests them too - for its own tile, unused - so that the counts below do not depend on the pass)
-      if (!drain && cc == PCC - 2 && !last_pass) { collect_bytes(); lgkm0(); }
-      if (!drain || !last_chunk) {
-        if (last_chunk) epi_request(cur, 0, 0);
-        else epi_request(et, (cc + 1) & 3, (cc + 1) >> 2);
-      }
-      if (!drain && !tail) { issue_w(ncc, 0); issue_w(ncc, 1); }
-      PC_ST(3);
       if (epi) epi_half(acc[tm][tn], pre, tn, 1);
-      PC_ST(4);
-      // ---- step C: tap 4 ----
+      if (!drain && cc == 4 && bsrc != nullptr) {
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) Bbuf[it * 256 + ptid] = nb_raw[it];
+      }
+      // ---- step C ----
       if (!drain) {
-        if (tail) wait_vm<0>();
-        else if (x_last_wave) wait_vm<2 * W_ITERS + A_ITERS + NL>();
-        else wait_vm<2 * W_ITERS + A_ITERS - 1 + NL>();
-        PC_ST(0);
+        PC_ST(4);
         bar();
         PC_ST(1);
-      } else {
-        wait_vm<0>();                                  // drain pass: the next block's staged inputs
       }
-      if (epi && last_chunk) {
+      if (epi) {
+        Pre nxt = pre;
+        if (!last_chunk) {
+          wait_vm<0>();                                // the next block's inputs (requested two steps ago; older stores are long done)
+          PC_ST(0);
+          epi_collect(nxt, et, (cc + 1) & 3);
+          lgkm0();
+        }
         if (a.pool_out == nullptr) store_block(acc[tm][tn], pre, tn);
-        if (HAS_NMD) nmd_flush(et, 1);
-        if (a.pool_out != nullptr) pool_reduce(et);
+        if (HAS_NMD && (cc == 3 || cc == 7)) nmd_flush(et, tn);
+        if (last_chunk && a.pool_out != nullptr) pool_reduce(et);
+        pre = nxt;
       }
-      PC_ST(4);
-      if (!drain && !tail) { issue_w(ncc, 2); issue_w(ncc, 3); }
-      PC_ST(3);
+      if (!drain && last_chunk) epi_request(cur, 0, 0);       // block 0 of the tile the math waves are finishing
     }
     if (drain) break;
     et = cur;
@@ -732,22 +723,22 @@ void conv_pc_kernel(ConvHArgs a) {
 
 int pc_lds_bytes(int dil) {
   const int rows_a = HM + (PK - 1) * dil;
-  return (2 * 4 * rows_a + PK * W_ITEMS + 4 * X_ITEMS + 4 * S_ITEMS) * 16 + JG_EPI_ROWS * 2 * HN * 4;
+  return (2 * 4 * rows_a + PK * W_ITEMS + 4 * X_ITEMS + 4 * S_ITEMS) * 16 + JG_EPI_ROWS * 2 * HN * 4 + A_ITERS * 256;
 }
 
-template <unsigned EP, bool FLAT>
+template <unsigned EP, bool FLAT, int DIL>
 int launch_pc(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   const int smem = pc_lds_bytes(a.dil);
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pc_kernel<EP, FLAT>),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pc_kernel<EP, FLAT, DIL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const int n_tiles = FLAT ? a.flat_tiles : a.rows * a.tiles_m;
   int grid = e->n_cu;                                   // one 8-wave workgroup per CU
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL((conv_pc_kernel<EP, FLAT>), dim3((unsigned)grid), dim3(PT), (size_t)smem, s, a);
+  hipLaunchKernelGGL((conv_pc_kernel<EP, FLAT, DIL>), dim3((unsigned)grid), dim3(PT), (size_t)smem, s, a);
   JG_HIP(hipGetLastError());
 #ifdef JG_STAMP
   {
@@ -757,7 +748,7 @@ int launch_pc(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(jg_pc_stamp_acc), z, sizeof(z)));
     const double tm = (double)hh[7], th = (double)hh[15];
     fprintf(stderr, "PCSTAMP ep=0x%x rows=%d grid=%d math: cyc/wave=%.0f mfma+lds=%.3f barrier=%.3f handoff=%.3f | helper: cyc/wave=%.0f "
-            "wait=%.3f barrier=%.3f handoff=%.3f dma_issue=%.3f epilogue=%.3f\n", EP, a.rows, grid, tm / (grid * 4.0), hh[0] / tm, hh[1] / tm, hh[2] / tm,
+            "wait=%.3f barrier=%.3f handoff=%.3f (unused=%.3f) epilogue=%.3f\n", EP, a.rows, grid, tm / (grid * 4.0), hh[0] / tm, hh[1] / tm, hh[2] / tm,
             th / (grid * 4.0), hh[8] / th, hh[9] / th, hh[10] / th, hh[11] / th, hh[12] / th);
   }
 #endif
@@ -768,6 +759,7 @@ int launch_pc(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
 
 // the stage patterns of the residual stacks (tanh-GELU): plain / + shortcut / stack end with NMD tap, norm and second GELU
 bool jg_conv_pc_supports(const ConvHArgs &a) {
+  if (a.dil != 3) return false;                  // the instantiated dilation (the residual stacks of the in-tree 128-channel models)
   if (a.k != PK || a.cc_in != PCC || a.cout != HN || a.cout_pad != HN || a.cw != HN || a.ch0 != 0 || a.ostride != 1 ||
       a.tap_lo != 0 || a.tap_hi != PK - 1 || a.lut != nullptr || a.ids != nullptr || a.act_kind != JG_ACT_GELU_TANH)
     return false;
@@ -785,7 +777,7 @@ bool jg_conv_pc_supports(const ConvHArgs &a) {
 
 int jg_conv_pc_launch(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   switch (a.ep) {
-#define JG_CASE(ep) case (ep): return a.flat ? launch_pc<(ep), true>(e, a, s) : launch_pc<(ep), false>(e, a, s);
+#define JG_CASE(ep) case (ep): return a.flat ? launch_pc<(ep), true, 3>(e, a, s) : launch_pc<(ep), false, 3>(e, a, s);
     JG_CASE(JG_EP_ACT1)
     JG_CASE(JG_EP_ADD | JG_EP_ACT1)
     JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)

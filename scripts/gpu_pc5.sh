@@ -1,0 +1,21 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "producer_consumer" 2>&1 | tail -4
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32"
+run() {  # label lib pc
+  JAEGER_HIP_LIB=$2 timeout 300 $B --conv-pc $3 > gpurun_out/pc5_$1.json 2> gpurun_out/pc5_$1.err
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/pc5_$1.json"))
+print("$1:", d["value"], "Mbp/s frac", d["roofline"]["frac"], "avg ms", d["roofline"]["avg_launch_ms"])
+PY
+}
+for r in 1 2; do
+  run classic_$r jaeger_amd/libjaeger_hip.so 0
+  run pc_$r jaeger_amd/libjaeger_hip.so 1
+  for v in $VARIANTS; do run ${v}_$r jaeger_amd/libjaeger_hip_$v.so 1; done
+done
+for v in $STAMPS; do
+JAEGER_HIP_LIB=jaeger_amd/libjaeger_hip_$v.so timeout 300 python bench.py --contigs 1500 --steps 1 --warmup 1 --no-cpu-baseline --no-exact-f32 --conv-pc 1 > gpurun_out/pc5_$v.json 2> gpurun_out/pc5_$v.err
+echo $v; grep PCSTAMP gpurun_out/pc5_$v.err | grep "rows=12288" | tail -3
+done
