@@ -51,7 +51,7 @@ constexpr int S_ITEMS = 4 * 64 + 16;  // 16-byte items of one helper's staging a
 #ifdef JG_STAMP
 static __device__ unsigned long long jg_pc_stamp_acc[16];
 #define PC_ST_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime(); const unsigned long long st_t0 = st_t
-#define PC_ST(idx) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[idx] += n_ - st_t; st_t = n_; } while (0)
+#define PC_ST(idx) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[idx] += n_ - st_t; st_t = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PC_ST_END(base) do { st_[7] = __builtin_amdgcn_s_memtime() - st_t0; if (lane == 0) { for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&jg_pc_stamp_acc[(base) + q_], st_[q_]); } } while (0)
 #else
 #define PC_ST_DECL
@@ -79,12 +79,38 @@ __device__ __forceinline__ void glds_ubyte(const void *sbase, unsigned voff, uns
                : "memory");
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// tanh-GELU of two values with the operation sequence of fast_gelu() (jg_conv_dev.h) - bit-identical results - on the
+// packed-f32 forms: five v_pk_* instructions and four transcendentals per pair instead of ten + four
+__device__ __forceinline__ f32x2 fast_gelu2(f32x2 v) {
+  const f32x2 c2 = {0.10294324f, 0.10294324f}, c1 = {-2.3022082f, -2.3022082f}, one = {1.0f, 1.0f};
+  const f32x2 m = c2 * v;
+  const f32x2 u = __builtin_elementwise_fma(-v, m, c1);
+  const f32x2 t = v * u;
+  f32x2 e;
+#ifdef JG_PC_NOTRANS           // timing experiment: no transcendental instructions (results are garbage)
+  e = t * c2;
+  const f32x2 d0 = one + e;
+  return v * (d0 * c1);
+#endif
+  e.x = __builtin_amdgcn_exp2f(t.x);
+  e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2 d = one + e;
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x);
+  r.y = __builtin_amdgcn_rcpf(d.y);
+  return v * r;
+}
+
 // DIL: the dilation as a compile-time constant - every LDS offset of the fragment reads and of the DMA destinations folds
-// into an instruction immediate (the math waves have no registers to spare for address arithmetic)
-template <unsigned EP, bool FLAT, int DIL>
+// into an instruction immediate.  F32OUT: the conv's output stays f32 (the last conv of a stack: masked max pool fused,
+// or an f32 reader behind it) - no F16S re-split.
+template <unsigned EP, bool FLAT, int DIL, bool F32OUT>
 __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_pc_kernel(ConvHArgs a) {
   constexpr bool HAS_ADD = (EP & JG_EP_ADD) != 0;
+  constexpr int NL = (HAS_ADD ? 4 : 0) + 1;            // DMAs of one block's epilogue inputs: shortcut items + mask byte
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,7 +118,6 @@ void conv_pc_kernel(ConvHArgs a) {
   const int w4 = wid & 3;                               // pair index: math wave w4 and helper wave w4 + 4 share a SIMD
   const int wm = w4 >> 1, wn = w4 & 1;                  // the pair's 128-position x 64-channel quarter of the tile
   const int i = lane & 31, h = lane >> 5;
-  const int ptid = tid & 255;                           // thread index inside the role (0..255)
   const int vgrid = (int)gridDim.x;
   int vb = (int)blockIdx.x;
   if ((vgrid & 7) == 0) vb = (vb & 7) * (vgrid >> 3) + (vb >> 3);     // XCD-aware tile order (see conv_f16x3_kernel)
@@ -104,7 +129,6 @@ void conv_pc_kernel(ConvHArgs a) {
   float *epiL = reinterpret_cast<float *>(Wbuf + PK * W_ITEMS);      // [JG_EPI_ROWS][2][HN]
   uint4 *Xbuf = Wbuf + PK * W_ITEMS + JG_EPI_ROWS * 2 * HN / 4;      // [4 pairs][X_ITEMS]
   uint4 *Sbuf = Xbuf + 4 * X_ITEMS;                                   // [4 helpers][S_ITEMS]
-  unsigned char *Bbuf = reinterpret_cast<unsigned char *>(Sbuf + 4 * S_ITEMS);   // [A_ITERS][256] input-mask bytes of the next tile
   for (int q = tid; q < a.n_epi_rows * 2 * HN; q += PT) epiL[q] = a.epi[q];   // visible after the first barrier
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
   const int n_tiles = FLAT ? a.flat_tiles : a.rows * a.tiles_m;
@@ -114,93 +138,11 @@ void conv_pc_kernel(ConvHArgs a) {
   uint4 *Xp = Xbuf + w4 * X_ITEMS + lane;                // this pair's transit slot, lane column
   f32x16 acc[4][2];                                      // [tm: position block][tn: channel block]; both roles
 
-  auto resolve = [&](const Tile &tile, int local, int len, int &row, int &p) -> bool {
-    if constexpr (!FLAT) {
-      row = tile.rowblk;
-      p = tile.m0 + local;
-      return tile.valid && p >= 0 && p < len;
-    }
-    const int v = tile.T * HM + local;
-    if (v < 0 || !tile.valid) { row = 0; p = 0; return false; }
-    int g, u, f;
-    udivmod24(v, a.flat_wp, a.flat_inv_wp, g, u);
-    udivmod24(u, a.flat_p, a.flat_inv_p, f, p);
-    row = g * a.flat_frames + f;
-    return f < a.flat_frames && p < len && row < a.rows;
-  };
-  auto tile_of = [&](int pass, Tile &t) {
-    const int T = vb + pass * vgrid;
-    const int Tc = min(T, n_tiles - 1);
-    t.rowblk = Tc / a.tiles_m;
-    t.m0 = (Tc - t.rowblk * a.tiles_m) * HM;
-    t.valid = T < n_tiles;
-    t.T = Tc;
-  };
-  // per-thread activation piece coordinates (as in conv_f16x3_kernel): piece q = ptid + it*256 -> (plane/half ph, row r);
-  // ph >= 4: no piece (only the last iteration can run past the slice).  Recomputed where needed: divisions by constants.
-  auto piece_ph = [&](int it) -> int { return (ptid + it * HT) / rows_a; };
-  auto piece_row = [&](int it) -> int { return (ptid + it * HT) % rows_a; };
-  const uint8_t *bsrc = a.mask_in;
-  auto piece_pos = [&](const Tile &tl, int it, int &pc, bool &inr) -> int {
-    int rb, p;
-    inr = resolve(tl, piece_row(it) - a.pad_left, a.L_in, rb, p) && piece_ph(it) < 4;
-    pc = min(max(p, 0), a.L_in - 1);
-    if constexpr (FLAT) rb = min(rb, a.rows - 1);
-    return rb;
-  };
-
   if (is_math) {
     // =========================================== MATH WAVE ===============================================
-    // MFMA stream + the operand ring of conv_f16x3_kernel (same slots, same issue points, same counted waits); no
-    // epilogue.  Nothing else this wave issues touches vector memory, so the counts are exact.
     lgkm0();                                             // the epilogue-table writes above
     __builtin_amdgcn_s_setprio(JG_PC_PRIO);
     PC_ST_DECL;
-    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);                       // + buf*a_items*16 + it*4096
-    const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + wid * 1024);   // + slot*8192 + it*4096
-    unsigned w_voff[W_ITERS];
-#pragma unroll
-    for (int it = 0; it < W_ITERS; ++it) {
-      const int q = ptid + it * HT;          // [plane][h][n]
-      w_voff[it] = (unsigned)((((q >> 8) * PK * PCC * 2 + ((q >> 7) & 1)) * HN + (q & (HN - 1))) * 16);
-    }
-    unsigned raw[A_ITERS];
-    unsigned x_voff[A_ITERS];
-    unsigned x_ok = 0;
-    auto build_pieces = [&](const Tile &tl) {      // consumes raw[]
-      x_ok = 0;
-#pragma unroll
-      for (int it = 0; it < A_ITERS; ++it) {
-        int pc; bool inr;
-        const int rb = piece_pos(tl, it, pc, inr);
-        const int ph = piece_ph(it) & 3;
-        x_voff[it] = (unsigned)(((rb * PCC * 4 + ph) * a.L_in + pc) * 16);
-        if (inr && raw[it] != 0) x_ok |= 1u << it;
-      }
-    };
-    const char *x_base = reinterpret_cast<const char *>(a.xh);
-    const unsigned x_cc_stride = 4u * (unsigned)a.L_in * 16u;   // bytes per chunk
-    const bool x_last_wave = __builtin_amdgcn_readfirstlane((int)((A_ITERS - 1) * HT + wid * 64 < 4 * rows_a)) != 0;
-    auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
-      const char *sb = reinterpret_cast<const char *>(a.wh) + ((size_t)(t * PCC * 2 + cc * 2) * HN) * 16;
-#pragma unroll
-      for (int it = 0; it < W_ITERS; ++it) glds16(sb, w_voff[it], ldsW + t * (W_ITEMS * 16) + it * (HT * 16));
-    };
-    auto issue_x = [&](int cc, int buf) {      // the tile's activation slice of chunk cc
-      const char *sb = x_base + (size_t)cc * x_cc_stride;
-      const unsigned dst = ldsA + buf * (a_items * 16);
-#pragma unroll
-      for (int it = 0; it < A_ITERS - 1; ++it) glds16_nt(sb, x_voff[it], dst + it * (HT * 16));
-      if (x_last_wave) {                        // wave-uniform: the counted waits must know how many DMAs are in flight
-        if (piece_ph(A_ITERS - 1) < 4) glds16_nt(sb, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
-      }
-    };
-    auto zero_fill = [&](int buf) {
-      uint4 *A = Abuf + buf * a_items;
-#pragma unroll
-      for (int it = 0; it < A_ITERS; ++it)
-        if (piece_ph(it) < 4 && !((x_ok >> it) & 1u)) A[ptid + it * HT] = make_uint4(0u, 0u, 0u, 0u);
-    };
     const uint4 *Wb = Wbuf + h * HN + wn * 64 + i;       // + t*W_ITEMS + plane*2*HN + tn*32
     const int x_frag = h * rows_a + wm * 128 + i;        // + plane*2*rows_a + tm*32 + t*dil
     constexpr int dil = DIL;
@@ -261,28 +203,6 @@ void conv_pc_kernel(ConvHArgs a) {
                                                           __float_as_uint(c[4 * r4 + 2]), __float_as_uint(c[4 * r4 + 3]));
           }
     };
-    // ---- prologue: the pipeline of pass 0 ----
-    Tile cur, np;
-    tile_of(0, cur);
-    tile_of(1, np);
-    if (bsrc != nullptr) {
-#pragma unroll
-      for (int it = 0; it < A_ITERS; ++it) {
-        int pc; bool inr;
-        const int rb = piece_pos(cur, it, pc, inr);
-        raw[it] = bsrc[(size_t)rb * a.L_in + pc];
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < A_ITERS; ++it) raw[it] = 1;
-    }
-    build_pieces(cur);                 // the only exposed byte-load latency of the launch
-    issue_x(0, 0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) issue_w(0, t);
-    wait_vm<2 * W_ITERS>();
-    zero_fill(0);
-    lgkm0();
     bar();                                               // step A of (pass 0, chunk 0)
     ldw(wf[0], 0);
     ldx(xf[0], Abuf + x_frag, 0, 0);
@@ -291,40 +211,21 @@ void conv_pc_kernel(ConvHArgs a) {
       for (int cp = 0; cp < PCC / 2; ++cp) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {           // chunk cc = 2*cp + half reads activation buffer `half`
-          const int cc = 2 * cp + half;
-          const bool last_chunk = half == 1 && cp == PCC / 2 - 1;
-          const bool tail = last_chunk && !more;          // nothing is issued behind this chunk
-          const int ncc = last_chunk ? 0 : cc + 1;
           const uint4 *A = Abuf + half * a_items + x_frag;
           const uint4 *An = Abuf + (half ^ 1) * a_items + x_frag;
 #pragma unroll
           for (int g = 0; g < 10; ++g) {                 // group g: tap g/2, position-block pair g%2
             const int t = g >> 1, tp = g & 1;
             const bool step_end = g == 3 || g == 7 || g == 9;
-            const bool pass_end = g == 9 && last_chunk;
-            if (step_end && !pass_end) {
-              // the next step's operands: counted wait, padding / mask zeros, publish.  Taken BEFORE this step's last
-              // group is issued - its fragments are in registers (lgkmcnt 0), so the slots may be refilled - and the
-              // first fragments of the next step are requested under those 12 MFMAs.
-              if (g == 3) {
-                if (tail) wait_vm<W_ITERS>();
-                else if (x_last_wave) wait_vm<W_ITERS + A_ITERS>();
-                else wait_vm<W_ITERS + A_ITERS - 1>();
-              } else if (g == 7) {
-                if (tail) wait_vm<0>();
-                else if (x_last_wave) wait_vm<2 * W_ITERS + A_ITERS>();
-                else wait_vm<2 * W_ITERS + A_ITERS - 1>();
-              } else {
-                wait_vm<2 * W_ITERS>();
-                zero_fill(half ^ 1);
-              }
-              lgkm0();
+            const bool pass_end = g == 9 && half == 1 && cp == PCC / 2 - 1;      // (cp is a run-time value)
+            if (step_end && JG_PC_LATE && !pass_end) {
+              lgkm0();                                   // this step's last fragments are in registers: the slots may be refilled
               PC_STM(0);
               bar();
               PC_STM(1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (!pass_end) {                             // fragments of the group after g
+            if (!(step_end && !JG_PC_LATE) && !pass_end) {       // fragments of the group after g
               if (g < 9) {
                 ldx(xf[(g + 1) & 1], A, (g + 1) >> 1, (g + 1) & 1);
                 if (tp == 1) ldw(wf[(half + t + 1) & 1], t + 1);
@@ -341,25 +242,18 @@ void conv_pc_kernel(ConvHArgs a) {
               mm(std::false_type{}, wf[(half + t) & 1], xf[g & 1], tp);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // keep the ring full: issued behind the step's first 12 MFMAs, so the issue cost runs under matrix-core time
-            if (g == 0) {
-              issue_w(cc, 4);
-              if (!tail) {
-                if (last_chunk) {
-                  if (bsrc != nullptr) {
-#pragma unroll
-                    for (int it = 0; it < A_ITERS; ++it) raw[it] = Bbuf[it * 256 + ptid];     // fetched by the helpers
-                  }
-                  build_pieces(np);
-                }
-                issue_x(ncc, half ^ 1);
+            if (step_end && !JG_PC_LATE && !pass_end) {
+              PC_STM(0);
+              bar();
+              PC_STM(1);
+              if (g < 9) {
+                ldx(xf[(g + 1) & 1], A, (g + 1) >> 1, (g + 1) & 1);
+                if (tp == 1) ldw(wf[(half + t + 1) & 1], t + 1);
+              } else {
+                ldx(xf[0], An, 0, 0);
+                ldw(wf[(half ^ 1) & 1], 0);
               }
-            } else if (g == 4) {
-              if (!tail) { issue_w(ncc, 0); issue_w(ncc, 1); }
-            } else if (g == 8) {
-              if (!tail) { issue_w(ncc, 2); issue_w(ncc, 3); }
             }
-            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
@@ -368,7 +262,6 @@ void conv_pc_kernel(ConvHArgs a) {
       xwrite(0);
       lgkm0();
       bar();                                             // X1: first half published
-      if (more) { wait_vm<2 * W_ITERS>(); zero_fill(0); }        // (the next tile's first operands, while the helper reads)
       bar();                                             // X2: the helper has it in registers
       xwrite(1);
       lgkm0();
@@ -378,61 +271,159 @@ void conv_pc_kernel(ConvHArgs a) {
         ldw(wf[0], 0);
         ldx(xf[0], Abuf + x_frag, 0, 0);
       }
-      cur = np;
-      tile_of(pass + 2, np);
     }
     PC_ST_END(0);
     return;
   }
 
   // ============================================= HELPER WAVE =================================================
-  // The fused epilogue of the PREVIOUS tile, one 32 x 32 accumulator block per chunk of the math waves' loop, in three
-  // parts behind the chunk's three step barriers; plus the next tile's input-mask bytes for the math waves' piece table.
+  const int htid = tid - 256;                            // 0..255: the helper threads take the DMA duties of the
+                                                         // two-workgroup kernel's 256 threads one for one
   const int hw = wid - 4;
   __builtin_amdgcn_s_setprio(JG_PC_HPRIO);
   PC_ST_DECL;
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + hw * 1024);                        // + buf*a_items*16 + it*4096
+  const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + hw * 1024);    // + slot*8192 + it*4096
   uint4 *Sp = Sbuf + hw * S_ITEMS;                       // this wave's staging: [4 items][64 lanes] + 64 mask dwords
   const unsigned ldsS = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((Sbuf - lds) + hw * S_ITEMS) * 16u);
-  const int L_res = a.L_out;
-  auto item4 = [&](int row, int mc, int nb, int j) -> unsigned {
-    const int G = (nb >> 3) + 2 * j + h;                 // hi-plane item of group 2j + h (uint4 units); lo plane = + 2*L_out
-    return (unsigned)(((row * (a.cout_pad >> 4) + (G >> 1)) * 4 + (G & 1)) * a.L_out + mc);
-  };
-  auto out_pos = [&](const Tile &tile, int tm, int &row, int &mc) -> bool {
-    int p;
-    const bool live = resolve(tile, (wm * 4 + tm) * 32 + i, L_res, row, p);
-    mc = live ? p : 0;
-    if constexpr (FLAT) {
-      if (!live) row = min(max(row, 0), a.rows - 1);
+
+  auto resolve = [&](const Tile &tile, int local, int len, int &row, int &p) -> bool {
+    if constexpr (!FLAT) {
+      row = tile.rowblk;
+      p = tile.m0 + local;
+      return tile.valid && p >= 0 && p < len;
     }
-    return live;
+    const int v = tile.T * HM + local;
+    if (v < 0 || !tile.valid) { row = 0; p = 0; return false; }
+    int g, u, f;
+    udivmod24(v, a.flat_wp, a.flat_inv_wp, g, u);
+    udivmod24(u, a.flat_p, a.flat_inv_p, f, p);
+    row = g * a.flat_frames + f;
+    return f < a.flat_frames && p < len && row < a.rows;
   };
-  // request what block (tm, tn) of `tile` needs from memory: LDS-DMAs into the wave's staging area
-  auto epi_request = [&](const Tile &tile, int tm, int tn) {
-    const int nb = (wn * 2 + tn) * 32;
-    int orow, mc;
-    out_pos(tile, tm, orow, mc);
+  auto tile_of = [&](int pass, Tile &t) {
+    const int T = vb + pass * vgrid;
+    const int Tc = min(T, n_tiles - 1);
+    t.rowblk = Tc / a.tiles_m;
+    t.m0 = (Tc - t.rowblk * a.tiles_m) * HM;
+    t.valid = T < n_tiles;
+    t.T = Tc;
+  };
+  // per-thread activation piece coordinates (as in conv_f16x3_kernel): piece q = htid + it*256 -> (plane/half ph, row r);
+  // ph >= 4: no piece (only the last iteration can run past the slice).  Recomputed where needed: divisions by constants.
+  auto piece_ph = [&](int it) -> int { return (htid + it * HT) / rows_a; };
+  auto piece_row = [&](int it) -> int { return (htid + it * HT) % rows_a; };
+  unsigned w_voff[W_ITERS];
+#pragma unroll
+  for (int it = 0; it < W_ITERS; ++it) {
+    const int q = htid + it * HT;          // [plane][h][n]
+    w_voff[it] = (unsigned)((((q >> 8) * PK * PCC * 2 + ((q >> 7) & 1)) * HN + (q & (HN - 1))) * 16);
+  }
+  const uint8_t *bsrc = a.mask_in;
+  unsigned raw[A_ITERS];
+  unsigned x_voff[A_ITERS];
+  unsigned x_ok = 0;
+  auto piece_pos = [&](const Tile &tl, int it, int &pc, bool &inr) -> int {
+    int rb, p;
+    inr = resolve(tl, piece_row(it) - a.pad_left, a.L_in, rb, p) && piece_ph(it) < 4;
+    pc = min(max(p, 0), a.L_in - 1);
+    if constexpr (FLAT) rb = min(rb, a.rows - 1);
+    return rb;
+  };
+  // the input-mask bytes of the NEXT tile's pieces, without a load the compiler would track (its vmcnt waits would drain
+  // the operand ring): LDS-DMA into the wave's staging area at step A of chunk 6 - in front of that step's operand DMAs,
+  // so the step-B wait covers them - and out of it at step B, before the next block's epilogue inputs are requested
+  auto request_bytes = [&](const Tile &tl) {
+    if (bsrc != nullptr) {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        int pc; bool inr;
+        const int rb = piece_pos(tl, it, pc, inr);
+        glds_ubyte(bsrc, (unsigned)(rb * a.L_in + pc), ldsS + it * 256);
+      }
+    }
+  };
+  auto collect_bytes = [&]() {
+    if (bsrc != nullptr) {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) raw[it] = reinterpret_cast<const unsigned *>(Sp)[it * 64 + lane];
+    }
+  };
+  auto build_pieces = [&](const Tile &tl) {      // consumes raw[]
+    x_ok = 0;
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      int pc; bool inr;
+      const int rb = piece_pos(tl, it, pc, inr);
+      const int ph = piece_ph(it) & 3;
+      x_voff[it] = (unsigned)(((rb * PCC * 4 + ph) * a.L_in + pc) * 16);
+      if (inr && raw[it] != 0) x_ok |= 1u << it;
+    }
+  };
+  const char *x_base = reinterpret_cast<const char *>(a.xh);
+  const unsigned x_cc_stride = 4u * (unsigned)a.L_in * 16u;   // bytes per chunk
+  const bool x_last_wave = __builtin_amdgcn_readfirstlane((int)((A_ITERS - 1) * HT + hw * 64 < 4 * rows_a)) != 0;
+  auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
+    const char *sb = reinterpret_cast<const char *>(a.wh) + ((size_t)(t * PCC * 2 + cc * 2) * HN) * 16;
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) glds16(sb, w_voff[it], ldsW + t * (W_ITEMS * 16) + it * (HT * 16));
+  };
+  auto issue_x = [&](int cc, int buf) {      // the tile's activation slice of chunk cc
+    const char *sb = x_base + (size_t)cc * x_cc_stride;
+    const unsigned dst = ldsA + buf * (a_items * 16);
+#pragma unroll
+    for (int it = 0; it < A_ITERS - 1; ++it) glds16_nt(sb, x_voff[it], dst + it * (HT * 16));
+    if (x_last_wave) {                        // wave-uniform: the counted waits must know how many DMAs are in flight
+      if (piece_ph(A_ITERS - 1) < 4) glds16_nt(sb, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
+    }
+  };
+  auto zero_fill = [&](int buf) {
+    uint4 *A = Abuf + buf * a_items;
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it)
+      if (piece_ph(it) < 4 && !((x_ok >> it) & 1u)) A[htid + it * HT] = make_uint4(0u, 0u, 0u, 0u);
+  };
+
+  // ---- epilogue (expressions of conv_f16x3_kernel's compiled patterns, tanh-GELU) ------------------------
+  // Per tile and position block tm this lane's output position is resolved ONCE: ob[tm] = item offset (16-byte units) of
+  // its hi-plane item of channel group 8*wn + h... (tn, j) and the lo plane are constant strides away; om[tm] = offset of
+  // its output-mask byte; bit tm of olive = the position exists.  Dead lanes point at position 0 of their row.
+  const unsigned L4 = 4u * (unsigned)a.L_out;
+  unsigned ob[4], om[4], olive = 0;
+  auto tile_positions = [&](const Tile &tile) {
+    olive = 0;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      int row, p;
+      bool live = resolve(tile, (wm * 4 + tm) * 32 + i, a.L_out, row, p);
+      const int mc = live ? p : 0;
+      if constexpr (FLAT) {
+        if (!live) row = min(max(row, 0), a.rows - 1);
+      }
+      ob[tm] = (unsigned)(((row * 8 + 4 * wn) * 4 + h) * a.L_out + mc);
+      om[tm] = (unsigned)(row * a.L_out + mc);
+      if (live) olive |= 1u << tm;
+    }
+  };
+  // request what block (tm, tn) needs from memory: NL LDS-DMAs into the wave's staging area
+  auto epi_request = [&](unsigned obase, unsigned omask, int tn) {
     if constexpr (HAS_ADD) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const unsigned it4 = item4(orow, mc, nb, j);
+        const unsigned it4 = obase + (unsigned)(2 * tn + j) * L4;
         glds16_nt(a.addh, it4 * 16u, ldsS + (2 * j) * 1024);
         glds16_nt(a.addh, (it4 + 2u * (unsigned)a.L_out) * 16u, ldsS + (2 * j + 1) * 1024);
       }
     }
-    if (a.mask_out != nullptr) glds_ubyte(a.mask_out, (unsigned)(orow * a.L_out + mc), ldsS + 4 * 1024);
+    // (no output mask: any readable byte - the value is ignored)
+    const void *mb = a.mask_out != nullptr ? static_cast<const void *>(a.mask_out) : static_cast<const void *>(a.wh);
+    glds_ubyte(mb, a.mask_out != nullptr ? omask : 0u, ldsS + 4 * 1024);
   };
-  struct Pre {
-    uint2 sh[4], sl[4];
-    float mk;
-    bool live;
-    int orow, mc;
-  };
-  // ... and take it out of the staging area (after the wait that covers those DMAs)
-  auto epi_collect = [&](Pre &p, const Tile &tile, int tm) {
-    p.live = out_pos(tile, tm, p.orow, p.mc);
-    p.mk = 1.f;
-    if (a.mask_out != nullptr) p.mk = reinterpret_cast<const unsigned *>(Sp + 4 * 64)[lane] != 0u ? 1.f : 0.f;
+  uint2 sh[4], sl[4];                // residual shortcut of the block in hand: this lane's 4 channels of groups 0..3, hi / lo
+  float mk = 0.f;                    // its output-mask value (1 / 0), 0 on dead positions
+  auto epi_collect = [&](int tm) {   // ... out of the staging area (after the wait that covers those DMAs)
+    const unsigned mbyte = reinterpret_cast<const unsigned *>(Sp + 4 * 64)[lane];
+    mk = (((olive >> tm) & 1u) != 0u && (a.mask_out == nullptr || mbyte != 0u)) ? 1.f : 0.f;
     if constexpr (HAS_ADD) {
       // lane (i, h) staged the whole item of group 2j + h at its position; it needs channels 4h..4h+3 of groups 2j and 2j+1
       const uint2 *S2 = reinterpret_cast<const uint2 *>(Sp);
@@ -440,59 +431,61 @@ void conv_pc_kernel(ConvHArgs a) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int gg = 0; gg < 2; ++gg) {
-          p.sh[2 * j + gg] = S2[((2 * j) * 64 + gg * 32 + i) * 2 + h];
-          p.sl[2 * j + gg] = S2[((2 * j + 1) * 64 + gg * 32 + i) * 2 + h];
+          sh[2 * j + gg] = S2[((2 * j) * 64 + gg * 32 + i) * 2 + h];
+          sl[2 * j + gg] = S2[((2 * j + 1) * 64 + gg * 32 + i) * 2 + h];
         }
-    } else {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) p.sh[g] = p.sl[g] = make_uint2(0u, 0u);
     }
   };
   float vmax = 0.f;                  // f16-range guard: running max |output| (drops NaN) and "an output is NaN"
   bool vnan = false;
-  float nmd_acc[16];
-  float mk_tm[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x2 nmd2[8];                     // NMD sums of the channel block in hand (pairs of channels)
+  uint4 outv[4];                     // converted outputs of the block in hand: [j][hi | lo] items, stored a step later
   auto swap32 = [](unsigned &lo_half_keeps, unsigned &hi_half_keeps) {
     const auto r = __builtin_amdgcn_permlane32_swap(lo_half_keeps, hi_half_keeps, false, false);
     lo_half_keeps = r[0];
     hi_half_keeps = r[1];
   };
-  // half j (channel groups 2j, 2j+1: registers 8j .. 8j+7) of one 32 x 32 block, in place; afterwards registers
-  // 8j..8j+3 hold the hi item and 8j+4..8j+7 the lo item of group 2j + h (F16S outputs)
-  auto epi_half = [&](f32x16 &x, const Pre &p, int tn, int j) {
+  // half j (channel groups 2j, 2j+1: accumulator registers 8j .. 8j+7) of one 32 x 32 block.  Stage-major over the four
+  // channel pairs, so that the independent chains interleave; F16S outputs go to outv[2j], outv[2j+1] (hi, lo item of group
+  // 2j + h), f32 outputs stay in the accumulator registers.
+  auto epi_half = [&](f32x16 &x, int tn, int j) {
 #ifdef JG_PC_NOEPI             // timing experiment: no epilogue arithmetic (results are garbage)
     return;
 #endif
     const int nb = (wn * 2 + tn) * 32;
-    auto st_affine = [&](int row) {
-      const float *pr = epiL + (row * 2) * HN + nb + 4 * h;
+    f32x2 v[4];
 #pragma unroll
-      for (int g = 2 * j; g < 2 * j + 2; ++g) {
-        const float4 sc = *reinterpret_cast<const float4 *>(pr + 8 * g);
-        const float4 of = *reinterpret_cast<const float4 *>(pr + HN + 8 * g);
-        x[4 * g + 0] = fmaf(x[4 * g + 0], sc.x, of.x);
-        x[4 * g + 1] = fmaf(x[4 * g + 1], sc.y, of.y);
-        x[4 * g + 2] = fmaf(x[4 * g + 2], sc.z, of.z);
-        x[4 * g + 3] = fmaf(x[4 * g + 3], sc.w, of.w);
-      }
+    for (int q = 0; q < 4; ++q) v[q] = f32x2{x[8 * j + 2 * q], x[8 * j + 2 * q + 1]};
+    auto st_affine = [&](int row) {
+      const float *pr = epiL + (row * 2) * HN + nb + 4 * h + 16 * j;
+#ifdef JG_PC_NOPARAM           // timing experiment: no LDS reads of the epilogue parameters (results are garbage)
+      const float4 sc0 = make_float4(1.f, 1.5f, 0.5f, 0.25f), sc1 = sc0, of0 = make_float4(0.5f, 0.25f, 0.125f, 1.f), of1 = of0;
+      (void)pr;
+#else
+      const float4 sc0 = *reinterpret_cast<const float4 *>(pr), sc1 = *reinterpret_cast<const float4 *>(pr + 8);
+      const float4 of0 = *reinterpret_cast<const float4 *>(pr + HN), of1 = *reinterpret_cast<const float4 *>(pr + HN + 8);
+#endif
+      v[0] = __builtin_elementwise_fma(v[0], f32x2{sc0.x, sc0.y}, f32x2{of0.x, of0.y});
+      v[1] = __builtin_elementwise_fma(v[1], f32x2{sc0.z, sc0.w}, f32x2{of0.z, of0.w});
+      v[2] = __builtin_elementwise_fma(v[2], f32x2{sc1.x, sc1.y}, f32x2{of1.x, of1.y});
+      v[3] = __builtin_elementwise_fma(v[3], f32x2{sc1.z, sc1.w}, f32x2{of1.z, of1.w});
     };
     auto st_add = [&]() {
 #pragma unroll
-      for (int g = 2 * j; g < 2 * j + 2; ++g) {
-        x[4 * g + 0] += mix_sum<0>(p.sh[g].x, p.sl[g].x);
-        x[4 * g + 1] += mix_sum<1>(p.sh[g].x, p.sl[g].x);
-        x[4 * g + 2] += mix_sum<0>(p.sh[g].y, p.sl[g].y);
-        x[4 * g + 3] += mix_sum<1>(p.sh[g].y, p.sl[g].y);
+      for (int gg = 0; gg < 2; ++gg) {
+        const int g = 2 * j + gg;
+        v[2 * gg] += f32x2{mix_sum<0>(sh[g].x, sl[g].x), mix_sum<1>(sh[g].x, sl[g].x)};
+        v[2 * gg + 1] += f32x2{mix_sum<0>(sh[g].y, sl[g].y), mix_sum<1>(sh[g].y, sl[g].y)};
       }
     };
     auto st_gelu = [&]() {
 #pragma unroll
-      for (int r = 8 * j; r < 8 * j + 8; ++r) x[r] = fast_gelu(x[r]);
+      for (int q = 0; q < 4; ++q) v[q] = fast_gelu2(v[q]);
     };
     auto st_nmd = [&]() {
-      const float mkl = p.live ? p.mk : 0.f;
+      const f32x2 mk2 = {mk, mk};
 #pragma unroll
-      for (int r = 8 * j; r < 8 * j + 8; ++r) nmd_acc[r] = fmaf(x[r], mkl, nmd_acc[r]);
+      for (int q = 0; q < 4; ++q) nmd2[4 * j + q] = __builtin_elementwise_fma(v[q], mk2, nmd2[4 * j + q]);
     };
     constexpr int N1 = (EP >> 1) & 3, N2 = (EP >> 6) & 3;
     static_assert(N1 != 2 && N2 != 2, "DyT patterns are not built into the producer / consumer kernel");
@@ -504,56 +497,59 @@ void conv_pc_kernel(ConvHArgs a) {
     if constexpr (EP & JG_EP_NMD2) st_nmd();
     if constexpr (N2 == 1) st_affine(N1 ? 2 : 1);
     if constexpr (EP & JG_EP_ACT2) st_gelu();
-    if (a.out_f16s) {
-      uint2 ph[2], pl[2];
+    if constexpr (F32OUT) {
 #pragma unroll
-      for (int gg = 0; gg < 2; ++gg) {
-        const int g = 2 * j + gg;
-        half4 hh4, ll4;
+      for (int q = 0; q < 4; ++q) { x[8 * j + 2 * q] = v[q].x; x[8 * j + 2 * q + 1] = v[q].y; }
+    } else {
+      unsigned hp[4], lp[4];             // packed hi / lo halves of the four pairs
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          hh4[q] = (_Float16)x[4 * g + q];
-          vmax = fmaxf(vmax, fabsf(x[4 * g + q]));
-        }
-        vnan = vnan || __builtin_isunordered(x[4 * g + 0], x[4 * g + 1]) || __builtin_isunordered(x[4 * g + 2], x[4 * g + 3]);
-        ph[gg] = *reinterpret_cast<uint2 *>(&hh4);
-        ll4[0] = (_Float16)mix_rem<0>(x[4 * g + 0], ph[gg].x);
-        ll4[1] = (_Float16)mix_rem<1>(x[4 * g + 1], ph[gg].x);
-        ll4[2] = (_Float16)mix_rem<0>(x[4 * g + 2], ph[gg].y);
-        ll4[3] = (_Float16)mix_rem<1>(x[4 * g + 3], ph[gg].y);
-        pl[gg] = *reinterpret_cast<uint2 *>(&ll4);
+      for (int q = 0; q < 4; ++q) {
+        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+        const half2_t hh = {(_Float16)v[q].x, (_Float16)v[q].y};
+        hp[q] = *reinterpret_cast<const unsigned *>(&hh);
+        const half2_t ll = {(_Float16)mix_rem<0>(v[q].x, hp[q]), (_Float16)mix_rem<1>(v[q].y, hp[q])};
+        lp[q] = *reinterpret_cast<const unsigned *>(&ll);
       }
-      unsigned h0 = ph[0].x, h1 = ph[0].y, h2 = ph[1].x, h3 = ph[1].y;
-      unsigned l0 = pl[0].x, l1 = pl[0].y, l2 = pl[1].x, l3 = pl[1].y;
-      swap32(h0, h2); swap32(h1, h3);      // -> whole item of group 2j+h
-      swap32(l0, l2); swap32(l1, l3);
-      x[8 * j + 0] = __uint_as_float(h0); x[8 * j + 1] = __uint_as_float(h1);
-      x[8 * j + 2] = __uint_as_float(h2); x[8 * j + 3] = __uint_as_float(h3);
-      x[8 * j + 4] = __uint_as_float(l0); x[8 * j + 5] = __uint_as_float(l1);
-      x[8 * j + 6] = __uint_as_float(l2); x[8 * j + 7] = __uint_as_float(l3);
+      vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0].x), fabsf(v[0].y))), fmaxf(fabsf(v[1].x), fabsf(v[1].y)));
+      vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[2].x), fabsf(v[2].y))), fmaxf(fabsf(v[3].x), fabsf(v[3].y)));
+      vnan = vnan || __builtin_isunordered(v[0].x, v[0].y) || __builtin_isunordered(v[1].x, v[1].y) ||
+             __builtin_isunordered(v[2].x, v[2].y) || __builtin_isunordered(v[3].x, v[3].y);
+      // pairs 0, 1 = group 2j (this lane's channels 4h..4h+3), pairs 2, 3 = group 2j+1: lane half h keeps group 2j+h whole
+      swap32(hp[0], hp[2]); swap32(hp[1], hp[3]);
+      swap32(lp[0], lp[2]); swap32(lp[1], lp[3]);
+      outv[2 * j] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+      outv[2 * j + 1] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
     }
   };
-  auto store_block = [&](const f32x16 &x, const Pre &p, int tn) {
-    const int nb = (wn * 2 + tn) * 32;
-    if (p.live) {
-      if (a.out_f16s) {
+  // stores of half j of a block in channel block tn whose position data is (obase, omask, live)
+  auto store_half = [&](const f32x16 &x, unsigned obase, unsigned omask, bool live, int tn, int j) {
+#ifdef JG_PC_NOSTORE           // timing experiment: outputs are not stored (results are garbage)
+    if (outv[2 * j].x == 0x12345678u && outv[2 * j + 1].y == 0x9abcdef0u) a.overflow[0] = 8;
+    return;
+#endif
+    if (live) {
+      if constexpr (!F32OUT) {
         uint4 *yh = reinterpret_cast<uint4 *>(a.y);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const unsigned it4 = item4(p.orow, p.mc, nb, j);
-          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-          const u32x4 vhi = {__float_as_uint(x[8 * j]), __float_as_uint(x[8 * j + 1]),
-                             __float_as_uint(x[8 * j + 2]), __float_as_uint(x[8 * j + 3])};
-          const u32x4 vlo = {__float_as_uint(x[8 * j + 4]), __float_as_uint(x[8 * j + 5]),
-                             __float_as_uint(x[8 * j + 6]), __float_as_uint(x[8 * j + 7])};
-          __builtin_nontemporal_store(vhi, reinterpret_cast<u32x4 *>(yh + it4));
-          __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)a.L_out));
-        }
-      } else {
-        float *yf = reinterpret_cast<float *>(a.y) + ((size_t)p.orow * a.L_out + p.mc) * a.cout + nb + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4 *>(yf + 8 * g) = make_float4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+#ifdef JG_PC_SAMESTORE          // timing experiment: every store of a wave lands in one 2 KB window of the output (results are garbage)
+        const unsigned it4 = (unsigned)(wid * 128 + lane);
+        (void)obase;
+#else
+        const unsigned it4 = obase + (unsigned)(2 * tn + j) * L4;
+#endif
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 vhi = {outv[2 * j].x, outv[2 * j].y, outv[2 * j].z, outv[2 * j].w};
+        const u32x4 vlo = {outv[2 * j + 1].x, outv[2 * j + 1].y, outv[2 * j + 1].z, outv[2 * j + 1].w};
+#ifdef JG_PC_PLAINSTORE
+        *reinterpret_cast<u32x4 *>(yh + it4) = vhi;
+        *reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)a.L_out) = vlo;
+#else
+        __builtin_nontemporal_store(vhi, reinterpret_cast<u32x4 *>(yh + it4));
+        __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)a.L_out));
+#endif
+      } else if (a.pool_out == nullptr) {
+        float *yf = reinterpret_cast<float *>(a.y) + (size_t)omask * a.cout + (wn * 2 + tn) * 32 + 4 * h + 16 * j;
+        *reinterpret_cast<float4 *>(yf) = make_float4(x[8 * j], x[8 * j + 1], x[8 * j + 2], x[8 * j + 3]);
+        *reinterpret_cast<float4 *>(yf + 8) = make_float4(x[8 * j + 4], x[8 * j + 5], x[8 * j + 6], x[8 * j + 7]);
       }
     }
   };
@@ -588,129 +584,189 @@ void conv_pc_kernel(ConvHArgs a) {
   };
   constexpr bool HAS_NMD = (EP & (JG_EP_NMD1 | JG_EP_NMD2)) != 0;
   auto nmd_flush = [&](const Tile &tile, int tn) {
-    const float v = lane_reduce(nmd_acc, [](float x, float y) { return x + y; });
+    float na[16];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { na[2 * q] = nmd2[q].x; na[2 * q + 1] = nmd2[q].y; }
+    const float v = lane_reduce(na, [](float x, float y) { return x + y; });
     int ch;
     const size_t slot = reduced_slot(tile, tn, ch);
     if (i < 16 && tile.valid) a.nmd_out[slot] = v;
   };
-  auto pool_reduce = [&](const Tile &tile) {
+  // fused masked global max pool (layers.py:496-538): running max of the channel block in hand over its position blocks
+  // (the block outputs are not stored), reduced over the lanes once per channel block like the NMD sums
+  float pool_acc[16];
+  auto pool_block = [&](const f32x16 &x) {
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      float pa[16];
+    for (int r = 0; r < 16; ++r) pool_acc[r] = mk != 0.f ? fmaxf(pool_acc[r], x[r]) : pool_acc[r];
+  };
+  auto pool_flush = [&](const Tile &tile, int tn) {
+    const float v = lane_reduce(pool_acc, [](float x, float y) { return fmaxf(x, y); });
+    int ch;
+    const size_t slot = reduced_slot(tile, tn, ch);
+    if (i < 16 && tile.valid) a.pool_out[slot] = v;
+  };
+  // accumulator hand-off, helper side.  The first half (blocks tm = 0, 1) is taken into registers between the X1 / X2
+  // barriers; the second half stays in the transit slot for the whole pass and is read block by block when its turn
+  // comes (tm = 2, 3 at chunks 2, 3, 6, 7): the helper never holds more than 80 accumulator registers.
+  f32x16 hacc[2][2];
+  f32x16 blk;
+  auto xread_block = [&](f32x16 &c, int tq, int tn) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pa[r] = -INFINITY;
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pa[r] = mk_tm[tm] != 0.f ? fmaxf(pa[r], acc[tm][tn][r]) : pa[r];
-      const float v = lane_reduce(pa, [](float x, float y) { return fmaxf(x, y); });
-      int ch;
-      const size_t slot = reduced_slot(tile, tn, ch);
-      if (i < 16 && tile.valid) a.pool_out[slot] = v;
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const uint4 v = Xp[((tq * 2 + tn) * 4 + r4) * 64];
+      c[4 * r4] = __uint_as_float(v.x); c[4 * r4 + 1] = __uint_as_float(v.y);
+      c[4 * r4 + 2] = __uint_as_float(v.z); c[4 * r4 + 3] = __uint_as_float(v.w);
     }
   };
-  // accumulator hand-off, helper side: registers of blocks tm = 2*half, 2*half + 1 out of the transit slot
-  auto xread = [&](int half) {
-#pragma unroll
-    for (int tq = 0; tq < 2; ++tq)
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const uint4 v = Xp[((tq * 2 + tn) * 4 + r4) * 64];
-          f32x16 &c = acc[half * 2 + tq][tn];
-          c[4 * r4] = __uint_as_float(v.x); c[4 * r4 + 1] = __uint_as_float(v.y);
-          c[4 * r4 + 2] = __uint_as_float(v.z); c[4 * r4 + 3] = __uint_as_float(v.w);
-        }
-  };
 
-  Tile cur, np, et;                  // tile the math waves work on / the next one / the one whose accumulators this wave holds
+  // ---- prologue: the pipeline of pass 0 ------------------------------------------------------------------------
+  Tile cur, np, et;                  // tile of this pass (operands) / of the next pass / whose accumulators this wave holds
   tile_of(0, cur);
   tile_of(1, np);
   et = cur;
-  Pre pre;
-  pre.live = false; pre.mk = 0.f; pre.orow = 0; pre.mc = 0;
+  if (bsrc != nullptr) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) pre.sh[g] = pre.sl[g] = make_uint2(0u, 0u);
-  unsigned char nb_raw[A_ITERS] = {1, 1, 1, 1, 1};
+    for (int it = 0; it < A_ITERS; ++it) {
+      int pc; bool inr;
+      const int rb = piece_pos(cur, it, pc, inr);
+      raw[it] = bsrc[(size_t)rb * a.L_in + pc];
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) raw[it] = 1;
+  }
+  build_pieces(cur);                 // the only exposed byte-load latency of the launch
+  issue_x(0, 0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) issue_w(0, t);
+  tile_positions(cur);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sh[g] = sl[g] = make_uint2(0u, 0u);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) outv[q] = make_uint4(0u, 0u, 0u, 0u);
 
-  // Pass `my_pairs` is the drain: no barriers - only the last tile's epilogue, through the same code.
+  // Pass `my_pairs` is the drain: no operands, no barriers - only the last tile's epilogue, through the same code.
   for (int pass = 0; pass <= my_pairs; ++pass) {
     const bool drain = pass == my_pairs;
     const bool epi = pass > 0;                         // this wave holds a tile's accumulators
+    const bool last_pass = pass == my_pairs - 1;
     if (epi) {
-      PC_ST(4);
-      bar();                                           // X1: first half of the finished tile's accumulators
-      xread(0);
+      // X1 / X2: first half of the finished tile's accumulators (the step-A wait and zero-fill of this pass's first
+      // chunk are done first, so that the math waves find barrier A right behind X2)
+      if (!drain) { wait_vm<2 * W_ITERS>(); zero_fill(0); lgkm0(); }
+      PC_ST(0);
+      bar();                                           // X1
+#pragma unroll
+      for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int tn2 = 0; tn2 < 2; ++tn2) xread_block(hacc[tq][tn2], tq, tn2);
       lgkm0();
       bar();                                           // X2
       PC_ST(2);
     }
 #pragma unroll
     for (int cc = 0; cc < PCC; ++cc) {
+      const int abuf = cc & 1;
       const bool last_chunk = cc == PCC - 1;
+      const bool tail = last_chunk && last_pass;       // nothing is issued behind this chunk
+      const int ncc = last_chunk ? 0 : cc + 1;
       const int tm = cc & 3, tn = cc >> 2;             // the accumulator block this chunk's steps carry
-      // ---- step A ----
-      if (!drain || cc == 0) {
-        PC_ST(4);
-        bar();                                         // A (after a pass: the second half is in the slot; drain: X3)
-        PC_ST(1);
-      }
-      if (epi) {
-        if (cc == 0) {
-          xread(1);
-          wait_vm<0>();                                // block 0's inputs, requested at the end of the previous pass
-          PC_ST(0);
-          epi_collect(pre, et, 0);
-          lgkm0();
-        }
-        if (!last_chunk) epi_request(et, (cc + 1) & 3, (cc + 1) >> 2);      // (the staging area has just been read out)
-        if (cc == 0 || cc == 4) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) nmd_acc[r] = 0.f;
-        }
-        if (tn == 0) mk_tm[tm] = pre.live ? pre.mk : 0.f;
-        epi_half(acc[tm][tn], pre, tn, 0);
-      }
-      if (!drain && cc == 2 && bsrc != nullptr) {      // the next tile's input-mask bytes, for the math waves' piece table
-#pragma unroll
-        for (int it = 0; it < A_ITERS; ++it) {
-          int pc; bool inr;
-          const int rb = piece_pos(np, it, pc, inr);
-          nb_raw[it] = bsrc[(size_t)rb * a.L_in + pc];
-        }
-      }
-      // ---- step B ----
+      // ---- step A: taps 0, 1 ----
       if (!drain) {
-        PC_ST(4);
+        if (!(cc == 0 && epi)) { wait_vm<2 * W_ITERS>(); zero_fill(abuf); lgkm0(); }
+        PC_ST(0);
+        bar();                                         // A (after a pass: also X3 - the second half is in the slot)
+        PC_ST(1);
+      } else if (cc == 0) {
+        PC_ST(0);
+        bar();                                         // X3
+        PC_ST(1);
+        wait_vm<0>();                                  // the first block's staged inputs
+      }
+      f32x16 &xb = tm < 2 ? hacc[tm & 1][tn] : blk;    // the block in hand (cc is a compile-time value)
+      if (epi) {
+        // second half of the previous block's stores (converted during the previous chunk's step B)
+        if (cc > 0) store_half((((cc - 1) & 3) < 2 ? hacc[(cc - 1) & 1][(cc - 1) >> 2] : blk), ob[(cc - 1) & 3], om[(cc - 1) & 3], ((olive >> ((cc - 1) & 3)) & 1u) != 0u, (cc - 1) >> 2, 1);
+        PC_ST(5);
+        if (tm >= 2) xread_block(blk, tm - 2, tn);      // (published by barrier A of this pass's first chunk)
+        if (HAS_NMD && cc == 4) nmd_flush(et, 0);
+        epi_collect(tm);                               // staged by the DMAs of the previous chunk's step B (covered by wait A)
+        lgkm0();
+      }
+      PC_ST(6);
+      if (!drain) {
+        if (cc == PCC - 2 && !last_pass) { lgkm0(); request_bytes(np); }     // (the staging area was just read out)
+        issue_w(cc, 4);
+        if (!tail) {
+          if (last_chunk) build_pieces(np);
+          issue_x(ncc, abuf ^ 1);
+        }
+      }
+      PC_ST(3);
+      if (epi) {
+        if (HAS_NMD && (cc == 0 || cc == 4)) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) nmd2[q] = f32x2{0.f, 0.f};
+        }
+        if (F32OUT && (cc == 0 || cc == 4)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pool_acc[r] = -INFINITY;
+        }
+        epi_half(xb, tn, 0);
+      }
+      PC_ST(4);
+      // ---- step B: taps 2, 3 ----
+      if (!drain) {
+        if (tail) wait_vm<W_ITERS>();
+        else if (x_last_wave) wait_vm<W_ITERS + A_ITERS>();
+        else wait_vm<W_ITERS + A_ITERS - 1>();
+        PC_ST(0);
         bar();
         PC_ST(1);
       }
-      if (epi) epi_half(acc[tm][tn], pre, tn, 1);
-      if (!drain && cc == 4 && bsrc != nullptr) {
-#pragma unroll
-        for (int it = 0; it < A_ITERS; ++it) Bbuf[it * 256 + ptid] = nb_raw[it];
+      const unsigned ob_c = ob[tm], om_c = om[tm];
+      const bool live_c = ((olive >> tm) & 1u) != 0u;  // (kept: the last chunk re-resolves the positions for the next tile below)
+      if (epi) store_half(xb, ob_c, om_c, live_c, tn, 0);     // (converted during step A; in front of this step's DMAs)
+      PC_ST(5);
+      if (!drain && cc == PCC - 2 && !last_pass) { collect_bytes(); lgkm0(); }
+      PC_ST(6);
+      // inputs of the next block: block cc + 1 of the tile in hand, or block 0 of the tile the math waves are finishing
+      // (pass 0 requests them too - for its own tile, unused - so that the counts below do not depend on the pass)
+      if (!drain || !last_chunk) {
+        if (last_chunk) {
+          tile_positions(cur);                          // (block 7's remaining stores use ob_c / om_c / live_c)
+          epi_request(ob[0], om[0], 0);
+        } else {
+          epi_request(ob[(cc + 1) & 3], om[(cc + 1) & 3], (cc + 1) >> 2);
+        }
       }
-      // ---- step C ----
+      PC_ST(5);
+      if (!drain && !tail) { issue_w(ncc, 0); issue_w(ncc, 1); }
+      PC_ST(3);
+      if (epi) {
+        epi_half(xb, tn, 1);
+        if (F32OUT && a.pool_out != nullptr) pool_block(xb);
+      }
+      PC_ST(4);
+      // ---- step C: tap 4 ----
       if (!drain) {
-        PC_ST(4);
+        if (tail) wait_vm<0>();
+        else if (x_last_wave) wait_vm<2 * W_ITERS + A_ITERS + NL>();
+        else wait_vm<2 * W_ITERS + A_ITERS - 1 + NL>();
+        PC_ST(0);
         bar();
         PC_ST(1);
+      } else {
+        wait_vm<0>();                                  // drain pass: the next block's staged inputs
       }
-      if (epi) {
-        Pre nxt = pre;
-        if (!last_chunk) {
-          wait_vm<0>();                                // the next block's inputs (requested two steps ago; older stores are long done)
-          PC_ST(0);
-          epi_collect(nxt, et, (cc + 1) & 3);
-          lgkm0();
-        }
-        if (a.pool_out == nullptr) store_block(acc[tm][tn], pre, tn);
-        if (HAS_NMD && (cc == 3 || cc == 7)) nmd_flush(et, tn);
-        if (last_chunk && a.pool_out != nullptr) pool_reduce(et);
-        pre = nxt;
+      if (epi && last_chunk) {
+        store_half(xb, ob_c, om_c, live_c, tn, 1);
+        if (HAS_NMD) nmd_flush(et, 1);
       }
-      if (!drain && last_chunk) epi_request(cur, 0, 0);       // block 0 of the tile the math waves are finishing
+      if (epi && F32OUT && (cc == 3 || cc == 7) && a.pool_out != nullptr) pool_flush(et, tn);
+      PC_ST(5);
+      if (!drain && !tail) { issue_w(ncc, 2); issue_w(ncc, 3); }
+      PC_ST(3);
     }
     if (drain) break;
     et = cur;
@@ -723,22 +779,22 @@ void conv_pc_kernel(ConvHArgs a) {
 
 int pc_lds_bytes(int dil) {
   const int rows_a = HM + (PK - 1) * dil;
-  return (2 * 4 * rows_a + PK * W_ITEMS + 4 * X_ITEMS + 4 * S_ITEMS) * 16 + JG_EPI_ROWS * 2 * HN * 4 + A_ITERS * 256;
+  return (2 * 4 * rows_a + PK * W_ITEMS + 4 * X_ITEMS + 4 * S_ITEMS) * 16 + JG_EPI_ROWS * 2 * HN * 4;
 }
 
-template <unsigned EP, bool FLAT, int DIL>
+template <unsigned EP, bool FLAT, int DIL, bool F32OUT>
 int launch_pc(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   const int smem = pc_lds_bytes(a.dil);
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pc_kernel<EP, FLAT, DIL>),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pc_kernel<EP, FLAT, DIL, F32OUT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const int n_tiles = FLAT ? a.flat_tiles : a.rows * a.tiles_m;
   int grid = e->n_cu;                                   // one 8-wave workgroup per CU
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL((conv_pc_kernel<EP, FLAT, DIL>), dim3((unsigned)grid), dim3(PT), (size_t)smem, s, a);
+  hipLaunchKernelGGL((conv_pc_kernel<EP, FLAT, DIL, F32OUT>), dim3((unsigned)grid), dim3(PT), (size_t)smem, s, a);
   JG_HIP(hipGetLastError());
 #ifdef JG_STAMP
   {
@@ -748,8 +804,8 @@ int launch_pc(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(jg_pc_stamp_acc), z, sizeof(z)));
     const double tm = (double)hh[7], th = (double)hh[15];
     fprintf(stderr, "PCSTAMP ep=0x%x rows=%d grid=%d math: cyc/wave=%.0f mfma+lds=%.3f barrier=%.3f handoff=%.3f | helper: cyc/wave=%.0f "
-            "wait=%.3f barrier=%.3f handoff=%.3f (unused=%.3f) epilogue=%.3f\n", EP, a.rows, grid, tm / (grid * 4.0), hh[0] / tm, hh[1] / tm, hh[2] / tm,
-            th / (grid * 4.0), hh[8] / th, hh[9] / th, hh[10] / th, hh[11] / th, hh[12] / th);
+            "wait=%.3f barrier=%.3f handoff=%.3f dma_issue=%.3f epi_math=%.3f stores+requests=%.3f lds_reads=%.3f\n", EP, a.rows, grid, tm / (grid * 4.0), hh[0] / tm, hh[1] / tm, hh[2] / tm,
+            th / (grid * 4.0), hh[8] / th, hh[9] / th, hh[10] / th, hh[11] / th, hh[12] / th, hh[13] / th, hh[14] / th);
   }
 #endif
   return JG_OK;
@@ -777,7 +833,10 @@ bool jg_conv_pc_supports(const ConvHArgs &a) {
 
 int jg_conv_pc_launch(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   switch (a.ep) {
-#define JG_CASE(ep) case (ep): return a.flat ? launch_pc<(ep), true, 3>(e, a, s) : launch_pc<(ep), false, 3>(e, a, s);
+#define JG_CASE(ep)                                                                                                   \
+  case (ep):                                                                                                          \
+    if (a.out_f16s) return a.flat ? launch_pc<(ep), true, 3, false>(e, a, s) : launch_pc<(ep), false, 3, false>(e, a, s); \
+    return a.flat ? launch_pc<(ep), true, 3, true>(e, a, s) : launch_pc<(ep), false, 3, true>(e, a, s);
     JG_CASE(JG_EP_ACT1)
     JG_CASE(JG_EP_ADD | JG_EP_ACT1)
     JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)
