@@ -110,7 +110,6 @@ template <unsigned EP, bool FLAT, int DIL, bool F32OUT>
 __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_pc_kernel(ConvHArgs a) {
   constexpr bool HAS_ADD = (EP & JG_EP_ADD) != 0;
-  constexpr int NL = (HAS_ADD ? 4 : 0) + 1;            // DMAs of one block's epilogue inputs: shortcut items + mask byte
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,6 +202,24 @@ void conv_pc_kernel(ConvHArgs a) {
                                                           __float_as_uint(c[4 * r4 + 2]), __float_as_uint(c[4 * r4 + 3]));
           }
     };
+    // The WEIGHT ring (one slot per tap, slices two steps ahead - conv_f16x3_kernel's schedule) is this wave's: 2 DMA
+    // pieces per slice, issued behind the first 12 MFMAs of a step so that the issue cost runs under matrix-core time,
+    // counted waits in front of each step barrier.  Nothing else this wave issues touches vector memory: the counts are exact.
+    const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + wid * 1024);   // + slot*8192 + it*4096
+    unsigned w_voff[W_ITERS];
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) {
+      const int q = tid + it * HT;          // [plane][h][n]
+      w_voff[it] = (unsigned)((((q >> 8) * PK * PCC * 2 + ((q >> 7) & 1)) * HN + (q & (HN - 1))) * 16);
+    }
+    auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
+      const char *sb = reinterpret_cast<const char *>(a.wh) + ((size_t)(t * PCC * 2 + cc * 2) * HN) * 16;
+#pragma unroll
+      for (int it = 0; it < W_ITERS; ++it) glds16(sb, w_voff[it], ldsW + t * (W_ITEMS * 16) + it * (HT * 16));
+    };
+#pragma unroll
+    for (int t = 0; t < 4; ++t) issue_w(0, t);
+    wait_vm<2 * W_ITERS>();
     bar();                                               // step A of (pass 0, chunk 0)
     ldw(wf[0], 0);
     ldx(xf[0], Abuf + x_frag, 0, 0);
@@ -213,12 +230,20 @@ void conv_pc_kernel(ConvHArgs a) {
         for (int half = 0; half < 2; ++half) {           // chunk cc = 2*cp + half reads activation buffer `half`
           const uint4 *A = Abuf + half * a_items + x_frag;
           const uint4 *An = Abuf + (half ^ 1) * a_items + x_frag;
+          const int cc = 2 * cp + half;
+          const bool last_chunk = half == 1 && cp == PCC / 2 - 1;
+          const bool tail = last_chunk && !more;          // no slice is issued behind this chunk
+          const int ncc = last_chunk ? 0 : cc + 1;
 #pragma unroll
           for (int g = 0; g < 10; ++g) {                 // group g: tap g/2, position-block pair g%2
             const int t = g >> 1, tp = g & 1;
             const bool step_end = g == 3 || g == 7 || g == 9;
             const bool pass_end = g == 9 && half == 1 && cp == PCC / 2 - 1;      // (cp is a run-time value)
             if (step_end && JG_PC_LATE && !pass_end) {
+              // the next step's weight slices have landed (everything but what was issued after them)
+              if (g == 3) wait_vm<W_ITERS>();
+              else if (g == 7) { if (tail) wait_vm<0>(); else wait_vm<2 * W_ITERS>(); }
+              else wait_vm<2 * W_ITERS>();
               lgkm0();                                   // this step's last fragments are in registers: the slots may be refilled
               PC_STM(0);
               bar();
@@ -242,7 +267,12 @@ void conv_pc_kernel(ConvHArgs a) {
               mm(std::false_type{}, wf[(half + t) & 1], xf[g & 1], tp);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (g == 0) issue_w(cc, 4);
+            else if (g == 4) { if (!tail) { issue_w(ncc, 0); issue_w(ncc, 1); } }
+            else if (g == 8) { if (!tail) { issue_w(ncc, 2); issue_w(ncc, 3); } }
+            __builtin_amdgcn_sched_barrier(0);
             if (step_end && !JG_PC_LATE && !pass_end) {
+              static_assert(JG_PC_LATE, "the weight ring's waits are written for the late-barrier schedule");
               PC_STM(0);
               bar();
               PC_STM(1);
@@ -264,6 +294,7 @@ void conv_pc_kernel(ConvHArgs a) {
       bar();                                             // X1: first half published
       bar();                                             // X2: the helper has it in registers
       xwrite(1);
+      if (more) wait_vm<2 * W_ITERS>();                  // the next tile's first two weight slices
       lgkm0();
       bar();                                             // step A of the next pass / X3 after the last one
       PC_ST(2);
@@ -283,7 +314,6 @@ void conv_pc_kernel(ConvHArgs a) {
   __builtin_amdgcn_s_setprio(JG_PC_HPRIO);
   PC_ST_DECL;
   const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + hw * 1024);                        // + buf*a_items*16 + it*4096
-  const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + hw * 1024);    // + slot*8192 + it*4096
   uint4 *Sp = Sbuf + hw * S_ITEMS;                       // this wave's staging: [4 items][64 lanes] + 64 mask dwords
   const unsigned ldsS = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((Sbuf - lds) + hw * S_ITEMS) * 16u);
 
@@ -313,12 +343,6 @@ void conv_pc_kernel(ConvHArgs a) {
   // ph >= 4: no piece (only the last iteration can run past the slice).  Recomputed where needed: divisions by constants.
   auto piece_ph = [&](int it) -> int { return (htid + it * HT) / rows_a; };
   auto piece_row = [&](int it) -> int { return (htid + it * HT) % rows_a; };
-  unsigned w_voff[W_ITERS];
-#pragma unroll
-  for (int it = 0; it < W_ITERS; ++it) {
-    const int q = htid + it * HT;          // [plane][h][n]
-    w_voff[it] = (unsigned)((((q >> 8) * PK * PCC * 2 + ((q >> 7) & 1)) * HN + (q & (HN - 1))) * 16);
-  }
   const uint8_t *bsrc = a.mask_in;
   unsigned raw[A_ITERS];
   unsigned x_voff[A_ITERS];
@@ -330,23 +354,19 @@ void conv_pc_kernel(ConvHArgs a) {
     if constexpr (FLAT) rb = min(rb, a.rows - 1);
     return rb;
   };
-  // the input-mask bytes of the NEXT tile's pieces, without a load the compiler would track (its vmcnt waits would drain
-  // the operand ring): LDS-DMA into the wave's staging area at step A of chunk 6 - in front of that step's operand DMAs,
-  // so the step-B wait covers them - and out of it at step B, before the next block's epilogue inputs are requested
-  auto request_bytes = [&](const Tile &tl) {
+  // the input-mask bytes of a tile's pieces (plain loads: this wave's vector-memory waits are all vmcnt(0), a wait the
+  // compiler adds for them cannot drain anything that matters)
+  auto load_bytes = [&](const Tile &tl) {
     if (bsrc != nullptr) {
 #pragma unroll
       for (int it = 0; it < A_ITERS; ++it) {
         int pc; bool inr;
         const int rb = piece_pos(tl, it, pc, inr);
-        glds_ubyte(bsrc, (unsigned)(rb * a.L_in + pc), ldsS + it * 256);
+        raw[it] = bsrc[(size_t)rb * a.L_in + pc];
       }
-    }
-  };
-  auto collect_bytes = [&]() {
-    if (bsrc != nullptr) {
+    } else {
 #pragma unroll
-      for (int it = 0; it < A_ITERS; ++it) raw[it] = reinterpret_cast<const unsigned *>(Sp)[it * 64 + lane];
+      for (int it = 0; it < A_ITERS; ++it) raw[it] = 1;
     }
   };
   auto build_pieces = [&](const Tile &tl) {      // consumes raw[]
@@ -363,11 +383,6 @@ void conv_pc_kernel(ConvHArgs a) {
   const char *x_base = reinterpret_cast<const char *>(a.xh);
   const unsigned x_cc_stride = 4u * (unsigned)a.L_in * 16u;   // bytes per chunk
   const bool x_last_wave = __builtin_amdgcn_readfirstlane((int)((A_ITERS - 1) * HT + hw * 64 < 4 * rows_a)) != 0;
-  auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
-    const char *sb = reinterpret_cast<const char *>(a.wh) + ((size_t)(t * PCC * 2 + cc * 2) * HN) * 16;
-#pragma unroll
-    for (int it = 0; it < W_ITERS; ++it) glds16(sb, w_voff[it], ldsW + t * (W_ITEMS * 16) + it * (HT * 16));
-  };
   auto issue_x = [&](int cc, int buf) {      // the tile's activation slice of chunk cc
     const char *sb = x_base + (size_t)cc * x_cc_stride;
     const unsigned dst = ldsA + buf * (a_items * 16);
@@ -624,21 +639,9 @@ void conv_pc_kernel(ConvHArgs a) {
   tile_of(0, cur);
   tile_of(1, np);
   et = cur;
-  if (bsrc != nullptr) {
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      int pc; bool inr;
-      const int rb = piece_pos(cur, it, pc, inr);
-      raw[it] = bsrc[(size_t)rb * a.L_in + pc];
-    }
-  } else {
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) raw[it] = 1;
-  }
+  load_bytes(cur);
   build_pieces(cur);                 // the only exposed byte-load latency of the launch
   issue_x(0, 0);
-#pragma unroll
-  for (int t = 0; t < 4; ++t) issue_w(0, t);
   tile_positions(cur);
 #pragma unroll
   for (int g = 0; g < 4; ++g) sh[g] = sl[g] = make_uint2(0u, 0u);
@@ -646,6 +649,8 @@ void conv_pc_kernel(ConvHArgs a) {
   for (int q = 0; q < 4; ++q) outv[q] = make_uint4(0u, 0u, 0u, 0u);
 
   // Pass `my_pairs` is the drain: no operands, no barriers - only the last tile's epilogue, through the same code.
+  // This wave's ring duty is the ACTIVATION slices (one per chunk, a whole chunk ahead): issued behind barrier A,
+  // landed (vmcnt 0: everything else in the queue is older) and zero-filled in front of the next barrier A.
   for (int pass = 0; pass <= my_pairs; ++pass) {
     const bool drain = pass == my_pairs;
     const bool epi = pass > 0;                         // this wave holds a tile's accumulators
@@ -653,7 +658,7 @@ void conv_pc_kernel(ConvHArgs a) {
     if (epi) {
       // X1 / X2: first half of the finished tile's accumulators (the step-A wait and zero-fill of this pass's first
       // chunk are done first, so that the math waves find barrier A right behind X2)
-      if (!drain) { wait_vm<2 * W_ITERS>(); zero_fill(0); lgkm0(); }
+      if (!drain) { wait_vm<0>(); zero_fill(0); lgkm0(); }
       PC_ST(0);
       bar();                                           // X1
 #pragma unroll
@@ -671,36 +676,44 @@ void conv_pc_kernel(ConvHArgs a) {
       const bool tail = last_chunk && last_pass;       // nothing is issued behind this chunk
       const int ncc = last_chunk ? 0 : cc + 1;
       const int tm = cc & 3, tn = cc >> 2;             // the accumulator block this chunk's steps carry
+      f32x16 &xb = tm < 2 ? hacc[tm & 1][tn] : blk;    // the block in hand (cc is a compile-time value)
       // ---- step A: taps 0, 1 ----
       if (!drain) {
-        if (!(cc == 0 && epi)) { wait_vm<2 * W_ITERS>(); zero_fill(abuf); lgkm0(); }
+        if (!(cc == 0 && epi)) { wait_vm<0>(); zero_fill(abuf); lgkm0(); }
         PC_ST(0);
         bar();                                         // A (after a pass: also X3 - the second half is in the slot)
         PC_ST(1);
-      } else if (cc == 0) {
-        PC_ST(0);
-        bar();                                         // X3
-        PC_ST(1);
-        wait_vm<0>();                                  // the first block's staged inputs
+      } else {
+        if (cc == 0) {
+          PC_ST(0);
+          bar();                                       // X3
+          PC_ST(1);
+        }
+        wait_vm<0>();                                  // drain pass: this block's staged inputs
       }
-      f32x16 &xb = tm < 2 ? hacc[tm & 1][tn] : blk;    // the block in hand (cc is a compile-time value)
+      const unsigned ob_c = ob[tm], om_c = om[tm];
+      const bool live_c = ((olive >> tm) & 1u) != 0u;  // (kept: the last chunk re-resolves the positions for the next tile)
       if (epi) {
         // second half of the previous block's stores (converted during the previous chunk's step B)
         if (cc > 0) store_half((((cc - 1) & 3) < 2 ? hacc[(cc - 1) & 1][(cc - 1) >> 2] : blk), ob[(cc - 1) & 3], om[(cc - 1) & 3], ((olive >> ((cc - 1) & 3)) & 1u) != 0u, (cc - 1) >> 2, 1);
+        if (HAS_NMD && cc == 4) nmd_flush(et, 0);
         PC_ST(5);
         if (tm >= 2) xread_block(blk, tm - 2, tn);      // (published by barrier A of this pass's first chunk)
-        if (HAS_NMD && cc == 4) nmd_flush(et, 0);
-        epi_collect(tm);                               // staged by the DMAs of the previous chunk's step B (covered by wait A)
+        epi_collect(tm);                               // staged a chunk ago (covered by the wait above)
         lgkm0();
+        PC_ST(6);
       }
-      PC_ST(6);
-      if (!drain) {
-        if (cc == PCC - 2 && !last_pass) { lgkm0(); request_bytes(np); }     // (the staging area was just read out)
-        issue_w(cc, 4);
-        if (!tail) {
-          if (last_chunk) build_pieces(np);
-          issue_x(ncc, abuf ^ 1);
-        }
+      // inputs of the next block: block cc + 1 of the tile in hand, or block 0 of the tile the math waves are finishing
+      if (epi && !last_chunk) epi_request(ob[(cc + 1) & 3], om[(cc + 1) & 3], (cc + 1) >> 2);
+      if (!drain && last_chunk) {
+        tile_positions(cur);                            // (block 7's remaining stores use ob_c / om_c / live_c)
+        epi_request(ob[0], om[0], 0);
+      }
+      PC_ST(5);
+      if (!drain && !tail) {
+        if (last_chunk) build_pieces(np);
+        issue_x(ncc, abuf ^ 1);
+        if (cc == PCC - 2 && !last_pass) load_bytes(np);          // consumed by build_pieces a chunk later
       }
       PC_ST(3);
       if (epi) {
@@ -717,32 +730,11 @@ void conv_pc_kernel(ConvHArgs a) {
       PC_ST(4);
       // ---- step B: taps 2, 3 ----
       if (!drain) {
-        if (tail) wait_vm<W_ITERS>();
-        else if (x_last_wave) wait_vm<W_ITERS + A_ITERS>();
-        else wait_vm<W_ITERS + A_ITERS - 1>();
-        PC_ST(0);
         bar();
         PC_ST(1);
       }
-      const unsigned ob_c = ob[tm], om_c = om[tm];
-      const bool live_c = ((olive >> tm) & 1u) != 0u;  // (kept: the last chunk re-resolves the positions for the next tile below)
-      if (epi) store_half(xb, ob_c, om_c, live_c, tn, 0);     // (converted during step A; in front of this step's DMAs)
+      if (epi) store_half(xb, ob_c, om_c, live_c, tn, 0);     // (converted during step A)
       PC_ST(5);
-      if (!drain && cc == PCC - 2 && !last_pass) { collect_bytes(); lgkm0(); }
-      PC_ST(6);
-      // inputs of the next block: block cc + 1 of the tile in hand, or block 0 of the tile the math waves are finishing
-      // (pass 0 requests them too - for its own tile, unused - so that the counts below do not depend on the pass)
-      if (!drain || !last_chunk) {
-        if (last_chunk) {
-          tile_positions(cur);                          // (block 7's remaining stores use ob_c / om_c / live_c)
-          epi_request(ob[0], om[0], 0);
-        } else {
-          epi_request(ob[(cc + 1) & 3], om[(cc + 1) & 3], (cc + 1) >> 2);
-        }
-      }
-      PC_ST(5);
-      if (!drain && !tail) { issue_w(ncc, 0); issue_w(ncc, 1); }
-      PC_ST(3);
       if (epi) {
         epi_half(xb, tn, 1);
         if (F32OUT && a.pool_out != nullptr) pool_block(xb);
@@ -750,14 +742,8 @@ void conv_pc_kernel(ConvHArgs a) {
       PC_ST(4);
       // ---- step C: tap 4 ----
       if (!drain) {
-        if (tail) wait_vm<0>();
-        else if (x_last_wave) wait_vm<2 * W_ITERS + A_ITERS + NL>();
-        else wait_vm<2 * W_ITERS + A_ITERS - 1 + NL>();
-        PC_ST(0);
         bar();
         PC_ST(1);
-      } else {
-        wait_vm<0>();                                  // drain pass: the next block's staged inputs
       }
       if (epi && last_chunk) {
         store_half(xb, ob_c, om_c, live_c, tn, 1);
@@ -765,8 +751,6 @@ void conv_pc_kernel(ConvHArgs a) {
       }
       if (epi && F32OUT && (cc == 3 || cc == 7) && a.pool_out != nullptr) pool_flush(et, tn);
       PC_ST(5);
-      if (!drain && !tail) { issue_w(ncc, 2); issue_w(ncc, 3); }
-      PC_ST(3);
     }
     if (drain) break;
     et = cur;
