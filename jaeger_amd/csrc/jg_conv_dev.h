@@ -24,6 +24,28 @@ __device__ __forceinline__ float fast_gelu(float v) {
   const float t = v * (-2.3022082f - 0.10294324f * v * v);   // -2u * log2(e)
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
+// tanh-GELU of two values with the operation sequence of fast_gelu() - bit-identical results - on the packed-f32 forms:
+// five v_pk_* instructions and four transcendentals per pair instead of ten + four
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fast_gelu2(f32x2 v) {
+  const f32x2 c2 = {0.10294324f, 0.10294324f}, c1 = {-2.3022082f, -2.3022082f}, one = {1.0f, 1.0f};
+  const f32x2 m = c2 * v;
+  const f32x2 u = __builtin_elementwise_fma(-v, m, c1);
+  const f32x2 t = v * u;
+  f32x2 e;
+#ifdef JG_PC_NOTRANS           // timing experiment: no transcendental instructions (results are garbage)
+  e = t * c2;
+  const f32x2 d0 = one + e;
+  return v * (d0 * c1);
+#endif
+  e.x = __builtin_amdgcn_exp2f(t.x);
+  e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2 d = one + e;
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x);
+  r.y = __builtin_amdgcn_rcpf(d.y);
+  return v * r;
+}
 // exact GELU 0.5 x (1 + erf(x / sqrt 2)): tf.nn.gelu's default, used by the legacy tower (nnlib/v1/layers.py:72-79)
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678f)); }
 __device__ __forceinline__ float fast_tanh(float v) {

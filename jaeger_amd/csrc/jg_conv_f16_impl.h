@@ -67,6 +67,9 @@ static __device__ unsigned long long jg_stamp_acc[8];
 #ifndef JG_LUT_WAVES
 #define JG_LUT_WAVES 8  // waves of a first-layer table workgroup: 8 = two per SIMD share one table half (4 tiles per pass)
 #endif
+#ifndef JG_FASTEP
+#define JG_FASTEP 1     // the hot tanh-GELU patterns run the packed-f32, store-as-you-go epilogue (0: the general one; A/B builds)
+#endif
 #ifndef JG_PAIRED
 #define JG_PAIRED 1     // k = 5: one barrier per two taps (+1.3 % measured A/B); 0 = one per tap
 #endif
@@ -555,6 +558,216 @@ void conv_f16x3_kernel(ConvHArgs a) {
     // ---- pass finished: fused epilogue straight from the accumulators ----------------------
     if (a.dbg & 1) {
       if (acc[0][0][0] + acc[1][TN - 1][3] + acc[TM - 1][TN - 1][7] + acc[TM - 1][0][9] == 12345.678f) a.overflow[0] = 2;
+    } else if constexpr (JG_FASTEP && TANH && !LUT && CW == 128 && EP != JG_EP_GENERIC && K == 5) {
+      // ---- the residual stacks' hot patterns (128 channels, tanh-GELU): the same expressions on packed-f32 forms ----
+      // Every instruction a wave issues besides its MFMAs costs the SIMD matrix-core time (about 6 cycles each, whichever
+      // of the two resident waves issues it - profiles/r3_pc_*), so this epilogue is written for instruction count:
+      // v_pk_* arithmetic on channel pairs (the operation sequence per element is unchanged: results are bit-identical),
+      // output positions resolved once per position block, every block converted and stored as soon as it is finished
+      // (no write-back into the accumulator tuple: no register moves), its inputs fetched two blocks ahead so that no
+      // load's wait meets a fresh store.
+      JG_PRIO_EPI();
+      constexpr bool HAS_ADD = (EP & JG_EP_ADD) != 0;
+      constexpr bool HAS_NMD = (EP & (JG_EP_NMD1 | JG_EP_NMD2)) != 0;
+      constexpr int N1 = (EP >> 1) & 3, N2 = (EP >> 6) & 3;
+      static_assert(N1 != 2 && N2 != 2, "the tanh-GELU builds carry no DyT stage");
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const Tile &tile = cur[0];
+      float vmax = 0.f;
+      bool vnan = false;
+      const unsigned L4 = 4u * (unsigned)a.L_out;
+      unsigned ob[4], om[4], olive = 0;          // per position block: hi-plane item base, mask-byte offset, "position exists"
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        int row, p;
+        const bool live = resolve(tile, (wm * 4 + tm) * 32 + i, a.L_out, row, p);
+        const int mc = live ? p : 0;
+        if constexpr (FLAT) {
+          if (!live) row = min(max(row, 0), a.rows - 1);
+        }
+        ob[tm] = (unsigned)(((row * 8 + 4 * wn) * 4 + h) * a.L_out + mc);
+        om[tm] = (unsigned)(row * a.L_out + mc);
+        if (live) olive |= 1u << tm;
+      }
+      struct In {                                  // what a block needs from memory
+        u32x4 sh0, sh1, sl0, sl1;                  // whole shortcut items of groups h and 2 + h, hi / lo plane (separate
+        unsigned char mkb;                         // fields, not arrays: register promotion wants static indices)
+      };
+      auto fetch = [&](In &q, int b) {
+        const int tm = b & 3, tn = b >> 2;
+        q.mkb = a.mask_out != nullptr ? a.mask_out[om[tm]] : (unsigned char)1;
+        if constexpr (HAS_ADD) {
+          if (!(a.dbg & 128)) {
+            const unsigned it0 = ob[tm] + (unsigned)(2 * tn) * L4, it1 = it0 + L4;
+            q.sh0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.addh + it0));
+            q.sl0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.addh + it0 + 2u * (unsigned)a.L_out));
+            q.sh1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.addh + it1));
+            q.sl1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.addh + it1 + 2u * (unsigned)a.L_out));
+          } else {
+            q.sh0 = q.sh1 = q.sl0 = q.sl1 = u32x4{0u, 0u, 0u, 0u};
+          }
+        }
+      };
+      auto swap32 = [](unsigned &lo_half_keeps, unsigned &hi_half_keeps) {
+        const auto r = __builtin_amdgcn_permlane32_swap(lo_half_keeps, hi_half_keeps, false, false);
+        lo_half_keeps = r[0];
+        hi_half_keeps = r[1];
+      };
+#define JG_DPP(v, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), (ctrl), 0xf, 0xf, false))
+      auto lane_reduce = [&](const float (&in)[16], auto op) -> float {      // (see the general epilogue below)
+        const bool b2 = (i & 4) != 0, b1 = (i & 2) != 0, b0 = (i & 1) != 0, b3 = (i & 8) != 0;
+        float s8[8], s4[4], s2[2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float keep = b2 ? in[8 + q] : in[q], send = b2 ? in[q] : in[8 + q];
+          s8[q] = op(keep, JG_DPP(send, 0x141));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float keep = b1 ? s8[4 + q] : s8[q], send = b1 ? s8[q] : s8[4 + q];
+          s4[q] = op(keep, JG_DPP(send, 0x4e));
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float keep = b0 ? s4[2 + q] : s4[q], send = b0 ? s4[q] : s4[2 + q];
+          s2[q] = op(keep, JG_DPP(send, 0xb1));
+        }
+        const float keep1 = b3 ? s2[1] : s2[0], send1 = b3 ? s2[0] : s2[1];
+        const float v = op(keep1, JG_DPP(send1, 0x128));
+        return op(v, __shfl_xor(v, 16, 32));
+      };
+#undef JG_DPP
+      auto reduced_slot = [&](int tn, int &ch) -> size_t {
+        const int r = 8 * (int)((i & 4) != 0) + 4 * (int)((i & 2) != 0) + 2 * (int)((i & 1) != 0) + (int)((i & 8) != 0);
+        ch = (wn * 2 + tn) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        return ((size_t)tile.T * STRIPS + wm) * a.cout + ch;
+      };
+      f32x2 nmd2[8];
+      float pool_acc[16];
+      In in0, in1;                                 // (two objects, not an array: the register promotion wants static indices)
+      fetch(in0, 0);
+      fetch(in1, 1);
+      auto do_block = [&](int b, In &q) {
+        const int tm = b & 3, tn = b >> 2;
+        f32x16 &x = acc[tm][tn];
+        const bool live = ((olive >> tm) & 1u) != 0u;
+        const float mk = (live && q.mkb != 0) ? 1.f : 0.f;
+        const int nb = (wn * 2 + tn) * 32;
+        if (tm == 0) {
+          if constexpr (HAS_NMD) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) nmd2[r] = f32x2{0.f, 0.f};
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pool_acc[r] = -INFINITY;
+        }
+        if (!(a.dbg & 32)) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {              // half j: channel groups 2j, 2j + 1 (accumulator registers 8j .. 8j + 7)
+            f32x2 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = f32x2{x[8 * j + 2 * r], x[8 * j + 2 * r + 1]};
+            auto st_affine = [&](int row) {
+              const float *pr = epiL + (row * 2) * HN + nb + 4 * h + 16 * j;
+              const float4 sc0 = *reinterpret_cast<const float4 *>(pr), sc1 = *reinterpret_cast<const float4 *>(pr + 8);
+              const float4 of0 = *reinterpret_cast<const float4 *>(pr + HN), of1 = *reinterpret_cast<const float4 *>(pr + HN + 8);
+              v[0] = __builtin_elementwise_fma(v[0], f32x2{sc0.x, sc0.y}, f32x2{of0.x, of0.y});
+              v[1] = __builtin_elementwise_fma(v[1], f32x2{sc0.z, sc0.w}, f32x2{of0.z, of0.w});
+              v[2] = __builtin_elementwise_fma(v[2], f32x2{sc1.x, sc1.y}, f32x2{of1.x, of1.y});
+              v[3] = __builtin_elementwise_fma(v[3], f32x2{sc1.z, sc1.w}, f32x2{of1.z, of1.w});
+            };
+            auto st_add = [&]() {
+              // lanes i and i + 32 loaded the whole items of groups 2j and 2j + 1: one permlane32 swap per dword pair gives
+              // every lane its own four channels of both groups
+              const u32x4 qh = j == 0 ? q.sh0 : q.sh1, ql = j == 0 ? q.sl0 : q.sl1;
+              unsigned hx = qh[0], hy = qh[1], hz = qh[2], hw_ = qh[3];
+              unsigned lx = ql[0], ly = ql[1], lz = ql[2], lw_ = ql[3];
+              swap32(hx, hz); swap32(hy, hw_);
+              swap32(lx, lz); swap32(ly, lw_);
+              v[0] += f32x2{mix_sum<0>(hx, lx), mix_sum<1>(hx, lx)};
+              v[1] += f32x2{mix_sum<0>(hy, ly), mix_sum<1>(hy, ly)};
+              v[2] += f32x2{mix_sum<0>(hz, lz), mix_sum<1>(hz, lz)};
+              v[3] += f32x2{mix_sum<0>(hw_, lw_), mix_sum<1>(hw_, lw_)};
+            };
+            auto st_gelu = [&]() {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fast_gelu2(v[r]);
+            };
+            auto st_nmd = [&]() {
+              const f32x2 mk2 = {mk, mk};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) nmd2[4 * j + r] = __builtin_elementwise_fma(v[r], mk2, nmd2[4 * j + r]);
+            };
+            st_affine(0);
+            if constexpr (EP & JG_EP_NMD1) st_nmd();
+            if constexpr (N1 == 1) st_affine(1);
+            if constexpr (HAS_ADD) st_add();
+            if constexpr (EP & JG_EP_ACT1) st_gelu();
+            if constexpr (EP & JG_EP_NMD2) st_nmd();
+            if constexpr (N2 == 1) st_affine(N1 ? 2 : 1);
+            if constexpr (EP & JG_EP_ACT2) st_gelu();
+            if (a.out_f16s) {
+              unsigned hp[4], lp[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+                const half2_t hh = {(_Float16)v[r].x, (_Float16)v[r].y};
+                hp[r] = *reinterpret_cast<const unsigned *>(&hh);
+                const half2_t ll = {(_Float16)mix_rem<0>(v[r].x, hp[r]), (_Float16)mix_rem<1>(v[r].y, hp[r])};
+                lp[r] = *reinterpret_cast<const unsigned *>(&ll);
+              }
+              vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0].x), fabsf(v[0].y))), fmaxf(fabsf(v[1].x), fabsf(v[1].y)));
+              vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[2].x), fabsf(v[2].y))), fmaxf(fabsf(v[3].x), fabsf(v[3].y)));
+              vnan = vnan || __builtin_isunordered(v[0].x, v[0].y) || __builtin_isunordered(v[1].x, v[1].y) ||
+                     __builtin_isunordered(v[2].x, v[2].y) || __builtin_isunordered(v[3].x, v[3].y);
+              swap32(hp[0], hp[2]); swap32(hp[1], hp[3]);      // -> whole item of group 2j + h
+              swap32(lp[0], lp[2]); swap32(lp[1], lp[3]);
+              if (live && !(a.dbg & 64)) {
+                uint4 *yh = reinterpret_cast<uint4 *>(a.y);
+                const unsigned it4 = ob[tm] + (unsigned)(2 * tn + j) * L4;
+                const u32x4 vhi = {hp[0], hp[1], hp[2], hp[3]}, vlo = {lp[0], lp[1], lp[2], lp[3]};
+                __builtin_nontemporal_store(vhi, reinterpret_cast<u32x4 *>(yh + it4));
+                __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)a.L_out));
+              }
+            } else if (a.pool_out != nullptr) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                pool_acc[8 * j + 2 * r] = mk != 0.f ? fmaxf(pool_acc[8 * j + 2 * r], v[r].x) : pool_acc[8 * j + 2 * r];
+                pool_acc[8 * j + 2 * r + 1] = mk != 0.f ? fmaxf(pool_acc[8 * j + 2 * r + 1], v[r].y) : pool_acc[8 * j + 2 * r + 1];
+              }
+            } else if (live && !(a.dbg & 64)) {
+              float *yf = reinterpret_cast<float *>(a.y) + (size_t)om[tm] * a.cout + nb + 4 * h + 16 * j;
+              *reinterpret_cast<float4 *>(yf) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+              *reinterpret_cast<float4 *>(yf + 8) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+            }
+          }
+        }
+        if (b + 2 < 8) fetch(q, b + 2);
+        if (tm == 3) {
+          if constexpr (HAS_NMD) {
+            float na[16];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { na[2 * r] = nmd2[r].x; na[2 * r + 1] = nmd2[r].y; }
+            const float rv = lane_reduce(na, [](float x_, float y_) { return x_ + y_; });
+            int ch;
+            const size_t slot = reduced_slot(tn, ch);
+            if (i < 16 && tile.valid) a.nmd_out[slot] = rv;
+          }
+          if (a.pool_out != nullptr) {
+            const float rv = lane_reduce(pool_acc, [](float x_, float y_) { return fmaxf(x_, y_); });
+            int ch;
+            const size_t slot = reduced_slot(tn, ch);
+            if (i < 16 && tile.valid) a.pool_out[slot] = rv;
+          }
+        }
+      };
+#pragma unroll
+      for (int bp = 0; bp < 4; ++bp) {
+        do_block(2 * bp, in0);
+        do_block(2 * bp + 1, in1);
+      }
+      if ((!(vmax <= 65000.0f) || vnan) && a.overflow != nullptr && a.dbg == 0) atomicOr(a.overflow, 1);
+      JG_PRIO_MAIN();
     } else {
       JG_PRIO_EPI();
       float vmax = 0.f;             // running max |output|: f16-range guard

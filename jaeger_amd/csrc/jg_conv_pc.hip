@@ -79,30 +79,6 @@ __device__ __forceinline__ void glds_ubyte(const void *sbase, unsigned voff, uns
                : "memory");
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// tanh-GELU of two values with the operation sequence of fast_gelu() (jg_conv_dev.h) - bit-identical results - on the
-// packed-f32 forms: five v_pk_* instructions and four transcendentals per pair instead of ten + four
-__device__ __forceinline__ f32x2 fast_gelu2(f32x2 v) {
-  const f32x2 c2 = {0.10294324f, 0.10294324f}, c1 = {-2.3022082f, -2.3022082f}, one = {1.0f, 1.0f};
-  const f32x2 m = c2 * v;
-  const f32x2 u = __builtin_elementwise_fma(-v, m, c1);
-  const f32x2 t = v * u;
-  f32x2 e;
-#ifdef JG_PC_NOTRANS           // timing experiment: no transcendental instructions (results are garbage)
-  e = t * c2;
-  const f32x2 d0 = one + e;
-  return v * (d0 * c1);
-#endif
-  e.x = __builtin_amdgcn_exp2f(t.x);
-  e.y = __builtin_amdgcn_exp2f(t.y);
-  const f32x2 d = one + e;
-  f32x2 r;
-  r.x = __builtin_amdgcn_rcpf(d.x);
-  r.y = __builtin_amdgcn_rcpf(d.y);
-  return v * r;
-}
-
 // DIL: the dilation as a compile-time constant - every LDS offset of the fragment reads and of the DMA destinations folds
 // into an instruction immediate.  F32OUT: the conv's output stays f32 (the last conv of a stack: masked max pool fused,
 // or an f32 reader behind it) - no F16S re-split.

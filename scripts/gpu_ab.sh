@@ -1,13 +1,18 @@
-# A/B of builds in the same session (same box, interleaved): bash scripts/gpu_ab.sh libA.so libB.so ...  (names under jaeger_amd/)
-# first the parity tests on every non-default build, then 3 interleaved bench rounds
-for lib in "$@"; do
-  [ $lib = libjaeger_hip.so ] && continue
-  echo "== parity with $lib"
-  JAEGER_HIP_LIB=$GRAFT_REPO_ROOT/jaeger_amd/$lib python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -1
-done
-for rep in 1 2 3; do
-  for lib in "$@"; do
-    echo -n "$lib: "
-    JAEGER_HIP_LIB=$GRAFT_REPO_ROOT/jaeger_amd/$lib python bench.py --no-cpu-baseline --contigs 3000 --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['avg_launch_ms'])"
+#!/bin/bash
+# interleaved A/B of bench.py over library builds on one box: RUNS="label:lib:pc ..." (lib = suffix of libjaeger_hip<suffix>.so)
+mkdir -p gpurun_out
+B="python bench.py --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline --no-exact-f32 ${BENCH_ARGS}"
+for r in 1 2 ${EXTRA_ROUNDS}; do
+  for spec in $RUNS; do
+    IFS=: read label lib pc <<< "$spec"
+    JAEGER_HIP_LIB=jaeger_amd/libjaeger_hip${lib}.so timeout 300 $B --conv-pc $pc > gpurun_out/ab_${label}_$r.json 2> gpurun_out/ab_${label}_$r.err
+    python - <<PY
+import json
+try:
+    d=json.load(open("gpurun_out/ab_${label}_$r.json"))
+    print("${label} run $r:", d["value"], "Mbp/s frac", d["roofline"]["frac"], "avg ms", d["roofline"]["avg_launch_ms"])
+except Exception as e:
+    print("${label} run $r: FAILED", e); print(open("gpurun_out/ab_${label}_$r.err").read()[-800:])
+PY
   done
 done
