@@ -68,7 +68,7 @@ static __device__ unsigned long long jg_stamp_acc[8];
 #define JG_LUT_WAVES 8  // waves of a first-layer table workgroup: 8 = two per SIMD share one table half (4 tiles per pass)
 #endif
 #ifndef JG_FASTEP
-#define JG_FASTEP 1     // the hot tanh-GELU patterns run the packed-f32, store-as-you-go epilogue (0: the general one; A/B builds)
+#define JG_FASTEP 0     // 1: the hot tanh-GELU patterns run the packed-f32, store-as-you-go epilogue (bit-identical; measured 2 % slower - the epilogue is bound by store-issue stalls, not by its instruction count: DESIGN 3.1)
 #endif
 #ifndef JG_PAIRED
 #define JG_PAIRED 1     // k = 5: one barrier per two taps (+1.3 % measured A/B); 0 = one per tap

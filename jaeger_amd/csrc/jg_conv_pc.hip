@@ -44,6 +44,9 @@ constexpr int S_ITEMS = 4 * 64 + 16;  // 16-byte items of one helper's staging a
 #ifndef JG_PC_PRIO
 #define JG_PC_PRIO 3                  // s_setprio of the math waves
 #endif
+#ifndef JG_PC_RINGFENCE
+#define JG_PC_RINGFENCE 1             // scheduling fences around the ring's DMA pieces inside a group's MFMAs
+#endif
 #ifndef JG_PC_HPRIO
 #define JG_PC_HPRIO 0                 // s_setprio of the helper waves
 #endif
@@ -80,8 +83,9 @@ __device__ __forceinline__ void glds_ubyte(const void *sbase, unsigned voff, uns
 }
 
 // DIL: the dilation as a compile-time constant - every LDS offset of the fragment reads and of the DMA destinations folds
-// into an instruction immediate.  F32OUT: the conv's output stays f32 (the last conv of a stack: masked max pool fused,
-// or an f32 reader behind it) - no F16S re-split.
+// into an instruction immediate (the math waves have no registers to spare for address arithmetic)
+// F32OUT: the conv's output stays f32 (the last conv of a stack: masked max pool fused, or an f32 reader behind it) - no
+// F16S re-split.
 template <unsigned EP, bool FLAT, int DIL, bool F32OUT>
 __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_pc_kernel(ConvHArgs a) {
@@ -93,6 +97,7 @@ void conv_pc_kernel(ConvHArgs a) {
   const int w4 = wid & 3;                               // pair index: math wave w4 and helper wave w4 + 4 share a SIMD
   const int wm = w4 >> 1, wn = w4 & 1;                  // the pair's 128-position x 64-channel quarter of the tile
   const int i = lane & 31, h = lane >> 5;
+  const int ptid = tid & 255;                           // thread index inside the role (0..255)
   const int vgrid = (int)gridDim.x;
   int vb = (int)blockIdx.x;
   if ((vgrid & 7) == 0) vb = (vb & 7) * (vgrid >> 3) + (vb >> 3);     // XCD-aware tile order (see conv_f16x3_kernel)
@@ -104,6 +109,7 @@ void conv_pc_kernel(ConvHArgs a) {
   float *epiL = reinterpret_cast<float *>(Wbuf + PK * W_ITEMS);      // [JG_EPI_ROWS][2][HN]
   uint4 *Xbuf = Wbuf + PK * W_ITEMS + JG_EPI_ROWS * 2 * HN / 4;      // [4 pairs][X_ITEMS]
   uint4 *Sbuf = Xbuf + 4 * X_ITEMS;                                   // [4 helpers][S_ITEMS]
+  unsigned char *Bbuf = reinterpret_cast<unsigned char *>(Sbuf + 4 * S_ITEMS);   // [A_ITERS][256] input-mask bytes of the next tile
   for (int q = tid; q < a.n_epi_rows * 2 * HN; q += PT) epiL[q] = a.epi[q];   // visible after the first barrier
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
   const int n_tiles = FLAT ? a.flat_tiles : a.rows * a.tiles_m;
@@ -112,186 +118,6 @@ void conv_pc_kernel(ConvHArgs a) {
   if (my_pairs == 0) return;
   uint4 *Xp = Xbuf + w4 * X_ITEMS + lane;                // this pair's transit slot, lane column
   f32x16 acc[4][2];                                      // [tm: position block][tn: channel block]; both roles
-
-  if (is_math) {
-    // =========================================== MATH WAVE ===============================================
-    lgkm0();                                             // the epilogue-table writes above
-    __builtin_amdgcn_s_setprio(JG_PC_PRIO);
-    PC_ST_DECL;
-    const uint4 *Wb = Wbuf + h * HN + wn * 64 + i;       // + t*W_ITEMS + plane*2*HN + tn*32
-    const int x_frag = h * rows_a + wm * 128 + i;        // + plane*2*rows_a + tm*32 + t*dil
-    constexpr int dil = DIL;
-    struct XF { uint4 h[2], l[2]; };
-    struct WF { uint4 h[2], l[2]; };
-    XF xf[2];
-    WF wf[2];
-    auto ldx = [&](XF &f, const uint4 *A, int t, int tp) {
-#pragma unroll
-      for (int tq = 0; tq < 2; ++tq) {
-        f.h[tq] = A[(tp * 2 + tq) * 32 + t * dil];
-        f.l[tq] = A[2 * rows_a + (tp * 2 + tq) * 32 + t * dil];
-      }
-    };
-    auto ldw = [&](WF &f, int t) {
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        f.h[tn] = Wb[t * W_ITEMS + tn * 32];
-        f.l[tn] = Wb[t * W_ITEMS + 2 * HN + tn * 32];
-      }
-    };
-    // 12 MFMAs: two position blocks x two channel blocks x (hi.lo, lo.hi, hi.hi), in the order of conv_f16x3_kernel;
-    // ZERO: the block's first product of the tile starts from C = 0 (no accumulator clearing between tiles)
-    auto mm = [&](auto zero_c, const WF &w, const XF &x, int tp) {
-      constexpr bool ZERO = decltype(zero_c)::value;
-#ifdef JG_PC_NOMFMA            // timing experiment: fragments are still read, the matrix cores stay idle (results are garbage)
-      acc[tp * 2][0][0] += __uint_as_float(w.h[0].x ^ w.l[1].y ^ x.h[0].z ^ x.l[1].w ^ w.h[1].x ^ w.l[0].y ^ x.h[1].z ^ x.l[0].w);
-      return;
-#endif
-#pragma unroll
-      for (int tq = 0; tq < 2; ++tq)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          f32x16 &c = acc[tp * 2 + tq][tn];
-          const half8 wh = *reinterpret_cast<const half8 *>(&w.h[tn]), wl = *reinterpret_cast<const half8 *>(&w.l[tn]);
-          const half8 xh = *reinterpret_cast<const half8 *>(&x.h[tq]), xl = *reinterpret_cast<const half8 *>(&x.l[tq]);
-          if constexpr (ZERO) {
-            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, z, 0, 0, 0);
-          } else {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, c, 0, 0, 0);
-          }
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, c, 0, 0, 0);
-        }
-    };
-    // accumulator hand-off: blocks tm = 2*half, 2*half + 1 -> the pair's transit slot (register r of lane l lands where
-    // the helper's register r of lane l reads it back)
-    auto xwrite = [&](int half) {
-#pragma unroll
-      for (int tq = 0; tq < 2; ++tq)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x16 &c = acc[half * 2 + tq][tn];
-            Xp[((tq * 2 + tn) * 4 + r4) * 64] = make_uint4(__float_as_uint(c[4 * r4]), __float_as_uint(c[4 * r4 + 1]),
-                                                          __float_as_uint(c[4 * r4 + 2]), __float_as_uint(c[4 * r4 + 3]));
-          }
-    };
-    // The WEIGHT ring (one slot per tap, slices two steps ahead - conv_f16x3_kernel's schedule) is this wave's: 2 DMA
-    // pieces per slice, issued behind the first 12 MFMAs of a step so that the issue cost runs under matrix-core time,
-    // counted waits in front of each step barrier.  Nothing else this wave issues touches vector memory: the counts are exact.
-    const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + wid * 1024);   // + slot*8192 + it*4096
-    unsigned w_voff[W_ITERS];
-#pragma unroll
-    for (int it = 0; it < W_ITERS; ++it) {
-      const int q = tid + it * HT;          // [plane][h][n]
-      w_voff[it] = (unsigned)((((q >> 8) * PK * PCC * 2 + ((q >> 7) & 1)) * HN + (q & (HN - 1))) * 16);
-    }
-    auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
-      const char *sb = reinterpret_cast<const char *>(a.wh) + ((size_t)(t * PCC * 2 + cc * 2) * HN) * 16;
-#pragma unroll
-      for (int it = 0; it < W_ITERS; ++it) glds16(sb, w_voff[it], ldsW + t * (W_ITEMS * 16) + it * (HT * 16));
-    };
-#pragma unroll
-    for (int t = 0; t < 4; ++t) issue_w(0, t);
-    wait_vm<2 * W_ITERS>();
-    bar();                                               // step A of (pass 0, chunk 0)
-    ldw(wf[0], 0);
-    ldx(xf[0], Abuf + x_frag, 0, 0);
-    for (int pass = 0; pass < my_pairs; ++pass) {
-      const bool more = pass + 1 < my_pairs;
-      for (int cp = 0; cp < PCC / 2; ++cp) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {           // chunk cc = 2*cp + half reads activation buffer `half`
-          const uint4 *A = Abuf + half * a_items + x_frag;
-          const uint4 *An = Abuf + (half ^ 1) * a_items + x_frag;
-          const int cc = 2 * cp + half;
-          const bool last_chunk = half == 1 && cp == PCC / 2 - 1;
-          const bool tail = last_chunk && !more;          // no slice is issued behind this chunk
-          const int ncc = last_chunk ? 0 : cc + 1;
-#pragma unroll
-          for (int g = 0; g < 10; ++g) {                 // group g: tap g/2, position-block pair g%2
-            const int t = g >> 1, tp = g & 1;
-            const bool step_end = g == 3 || g == 7 || g == 9;
-            const bool pass_end = g == 9 && half == 1 && cp == PCC / 2 - 1;      // (cp is a run-time value)
-            if (step_end && JG_PC_LATE && !pass_end) {
-              // the next step's weight slices have landed (everything but what was issued after them)
-              if (g == 3) wait_vm<W_ITERS>();
-              else if (g == 7) { if (tail) wait_vm<0>(); else wait_vm<2 * W_ITERS>(); }
-              else wait_vm<2 * W_ITERS>();
-              lgkm0();                                   // this step's last fragments are in registers: the slots may be refilled
-              PC_STM(0);
-              bar();
-              PC_STM(1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(step_end && !JG_PC_LATE) && !pass_end) {       // fragments of the group after g
-              if (g < 9) {
-                ldx(xf[(g + 1) & 1], A, (g + 1) >> 1, (g + 1) & 1);
-                if (tp == 1) ldw(wf[(half + t + 1) & 1], t + 1);
-              } else {
-                ldx(xf[0], An, 0, 0);
-                ldw(wf[(half ^ 1) & 1], 0);
-              }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (half == 0 && g < 2) {
-              if (cp == 0) mm(std::true_type{}, wf[(half + t) & 1], xf[g & 1], tp);
-              else mm(std::false_type{}, wf[(half + t) & 1], xf[g & 1], tp);
-            } else {
-              mm(std::false_type{}, wf[(half + t) & 1], xf[g & 1], tp);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (g == 0) issue_w(cc, 4);
-            else if (g == 4) { if (!tail) { issue_w(ncc, 0); issue_w(ncc, 1); } }
-            else if (g == 8) { if (!tail) { issue_w(ncc, 2); issue_w(ncc, 3); } }
-            __builtin_amdgcn_sched_barrier(0);
-            if (step_end && !JG_PC_LATE && !pass_end) {
-              static_assert(JG_PC_LATE, "the weight ring's waits are written for the late-barrier schedule");
-              PC_STM(0);
-              bar();
-              PC_STM(1);
-              if (g < 9) {
-                ldx(xf[(g + 1) & 1], A, (g + 1) >> 1, (g + 1) & 1);
-                if (tp == 1) ldw(wf[(half + t + 1) & 1], t + 1);
-              } else {
-                ldx(xf[0], An, 0, 0);
-                ldw(wf[(half ^ 1) & 1], 0);
-              }
-            }
-          }
-        }
-      }
-      // ---- tile finished: hand the accumulators to the helper ----
-      PC_ST(0);
-      xwrite(0);
-      lgkm0();
-      bar();                                             // X1: first half published
-      bar();                                             // X2: the helper has it in registers
-      xwrite(1);
-      if (more) wait_vm<2 * W_ITERS>();                  // the next tile's first two weight slices
-      lgkm0();
-      bar();                                             // step A of the next pass / X3 after the last one
-      PC_ST(2);
-      if (more) {
-        ldw(wf[0], 0);
-        ldx(xf[0], Abuf + x_frag, 0, 0);
-      }
-    }
-    PC_ST_END(0);
-    return;
-  }
-
-  // ============================================= HELPER WAVE =================================================
-  const int htid = tid - 256;                            // 0..255: the helper threads take the DMA duties of the
-                                                         // two-workgroup kernel's 256 threads one for one
-  const int hw = wid - 4;
-  __builtin_amdgcn_s_setprio(JG_PC_HPRIO);
-  PC_ST_DECL;
-  const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + hw * 1024);                        // + buf*a_items*16 + it*4096
-  uint4 *Sp = Sbuf + hw * S_ITEMS;                       // this wave's staging: [4 items][64 lanes] + 64 mask dwords
-  const unsigned ldsS = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((Sbuf - lds) + hw * S_ITEMS) * 16u);
 
   auto resolve = [&](const Tile &tile, int local, int len, int &row, int &p) -> bool {
     if constexpr (!FLAT) {
@@ -315,14 +141,11 @@ void conv_pc_kernel(ConvHArgs a) {
     t.valid = T < n_tiles;
     t.T = Tc;
   };
-  // per-thread activation piece coordinates (as in conv_f16x3_kernel): piece q = htid + it*256 -> (plane/half ph, row r);
+  // per-thread activation piece coordinates (as in conv_f16x3_kernel): piece q = ptid + it*256 -> (plane/half ph, row r);
   // ph >= 4: no piece (only the last iteration can run past the slice).  Recomputed where needed: divisions by constants.
-  auto piece_ph = [&](int it) -> int { return (htid + it * HT) / rows_a; };
-  auto piece_row = [&](int it) -> int { return (htid + it * HT) % rows_a; };
+  auto piece_ph = [&](int it) -> int { return (ptid + it * HT) / rows_a; };
+  auto piece_row = [&](int it) -> int { return (ptid + it * HT) % rows_a; };
   const uint8_t *bsrc = a.mask_in;
-  unsigned raw[A_ITERS];
-  unsigned x_voff[A_ITERS];
-  unsigned x_ok = 0;
   auto piece_pos = [&](const Tile &tl, int it, int &pc, bool &inr) -> int {
     int rb, p;
     inr = resolve(tl, piece_row(it) - a.pad_left, a.L_in, rb, p) && piece_ph(it) < 4;
@@ -330,50 +153,280 @@ void conv_pc_kernel(ConvHArgs a) {
     if constexpr (FLAT) rb = min(rb, a.rows - 1);
     return rb;
   };
-  // the input-mask bytes of a tile's pieces (plain loads: this wave's vector-memory waits are all vmcnt(0), a wait the
-  // compiler adds for them cannot drain anything that matters)
-  auto load_bytes = [&](const Tile &tl) {
-    if (bsrc != nullptr) {
+
+  if (is_math) {
+    // =========================================== MATH WAVE ===============================================
+    // MFMA stream + the operand ring of conv_f16x3_kernel (same slots, same issue points, same counted waits); no
+    // epilogue.  Nothing else this wave issues touches vector memory, so the counts are exact.
+    lgkm0();                                             // the epilogue-table writes above
+    __builtin_amdgcn_s_setprio(JG_PC_PRIO);
+    PC_ST_DECL;
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);                       // + buf*a_items*16 + it*4096
+    const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + 2 * a_items * 16 + wid * 1024);   // + slot*8192 + it*4096
+    unsigned w_voff[W_ITERS];
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) {
+      const int q = ptid + it * HT;          // [plane][h][n]
+      w_voff[it] = (unsigned)((((q >> 8) * PK * PCC * 2 + ((q >> 7) & 1)) * HN + (q & (HN - 1))) * 16);
+    }
+    unsigned raw[A_ITERS];
+    unsigned x_voff[A_ITERS];
+    unsigned x_ok = 0;
+    auto build_pieces = [&](const Tile &tl) {      // consumes raw[]
+      x_ok = 0;
 #pragma unroll
       for (int it = 0; it < A_ITERS; ++it) {
         int pc; bool inr;
         const int rb = piece_pos(tl, it, pc, inr);
+        const int ph = piece_ph(it) & 3;
+        x_voff[it] = (unsigned)(((rb * PCC * 4 + ph) * a.L_in + pc) * 16);
+        if (inr && raw[it] != 0) x_ok |= 1u << it;
+      }
+    };
+    const char *x_base = reinterpret_cast<const char *>(a.xh);
+    const unsigned x_cc_stride = 4u * (unsigned)a.L_in * 16u;   // bytes per chunk
+    const bool x_last_wave = __builtin_amdgcn_readfirstlane((int)((A_ITERS - 1) * HT + wid * 64 < 4 * rows_a)) != 0;
+    auto issue_w = [&](int cc, int t) {        // weight slice (cc, t) -> ring slot t
+      const char *sb = reinterpret_cast<const char *>(a.wh) + ((size_t)(t * PCC * 2 + cc * 2) * HN) * 16;
+#pragma unroll
+      for (int it = 0; it < W_ITERS; ++it) glds16(sb, w_voff[it], ldsW + t * (W_ITEMS * 16) + it * (HT * 16));
+    };
+    auto issue_x = [&](int cc, int buf) {      // the tile's activation slice of chunk cc
+      const char *sb = x_base + (size_t)cc * x_cc_stride;
+      const unsigned dst = ldsA + buf * (a_items * 16);
+#pragma unroll
+      for (int it = 0; it < A_ITERS - 1; ++it) glds16_nt(sb, x_voff[it], dst + it * (HT * 16));
+      if (x_last_wave) {                        // wave-uniform: the counted waits must know how many DMAs are in flight
+        if (piece_ph(A_ITERS - 1) < 4) glds16_nt(sb, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
+      }
+    };
+    auto zero_fill = [&](int buf) {
+      uint4 *A = Abuf + buf * a_items;
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it)
+        if (piece_ph(it) < 4 && !((x_ok >> it) & 1u)) A[ptid + it * HT] = make_uint4(0u, 0u, 0u, 0u);
+    };
+    const uint4 *Wb = Wbuf + h * HN + wn * 64 + i;       // + t*W_ITEMS + plane*2*HN + tn*32
+    const int x_frag = h * rows_a + wm * 128 + i;        // + plane*2*rows_a + tm*32 + t*dil
+    constexpr int dil = DIL;
+    struct XF { uint4 h[2], l[2]; };
+    struct WF { uint4 h[2], l[2]; };
+    XF xf[2];
+    WF wf[2];
+    auto ldx = [&](XF &f, const uint4 *A, int t, int tp) {
+#pragma unroll
+      for (int tq = 0; tq < 2; ++tq) {
+        f.h[tq] = A[(tp * 2 + tq) * 32 + t * dil];
+        f.l[tq] = A[2 * rows_a + (tp * 2 + tq) * 32 + t * dil];
+      }
+    };
+    auto ldw = [&](WF &f, int t) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        f.h[tn] = Wb[t * W_ITEMS + tn * 32];
+        f.l[tn] = Wb[t * W_ITEMS + 2 * HN + tn * 32];
+      }
+    };
+    // 12 MFMAs: two position blocks x two channel blocks x (hi.lo, lo.hi, hi.hi), in the order of conv_f16x3_kernel;
+    // ZERO: the block's first product of the tile starts from C = 0 (no accumulator clearing between tiles)
+    auto mm = [&](auto zero_c, const WF &w, const XF &x, int tp, auto &&between) {
+      constexpr bool ZERO = decltype(zero_c)::value;
+#ifdef JG_PC_NOMFMA            // timing experiment: fragments are still read, the matrix cores stay idle (results are garbage)
+      acc[tp * 2][0][0] += __uint_as_float(w.h[0].x ^ w.l[1].y ^ x.h[0].z ^ x.l[1].w ^ w.h[1].x ^ w.l[0].y ^ x.h[1].z ^ x.l[0].w);
+      for (int k = 0; k < 4; ++k) between(k);
+      return;
+#endif
+#pragma unroll
+      for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          f32x16 &c = acc[tp * 2 + tq][tn];
+          const half8 wh = *reinterpret_cast<const half8 *>(&w.h[tn]), wl = *reinterpret_cast<const half8 *>(&w.l[tn]);
+          const half8 xh = *reinterpret_cast<const half8 *>(&x.h[tq]), xl = *reinterpret_cast<const half8 *>(&x.l[tq]);
+          if constexpr (ZERO) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, z, 0, 0, 0);
+          } else {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, c, 0, 0, 0);
+          between(tq * 2 + tn);
+        }
+    };
+    // accumulator hand-off: blocks tm = 2*half, 2*half + 1 -> the pair's transit slot (register r of lane l lands where
+    // the helper's register r of lane l reads it back)
+    auto xwrite = [&](int half) {
+#pragma unroll
+      for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x16 &c = acc[half * 2 + tq][tn];
+            Xp[((tq * 2 + tn) * 4 + r4) * 64] = make_uint4(__float_as_uint(c[4 * r4]), __float_as_uint(c[4 * r4 + 1]),
+                                                          __float_as_uint(c[4 * r4 + 2]), __float_as_uint(c[4 * r4 + 3]));
+          }
+    };
+    // ---- prologue: the pipeline of pass 0 ----
+    Tile cur, np;
+    tile_of(0, cur);
+    tile_of(1, np);
+    if (bsrc != nullptr) {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        int pc; bool inr;
+        const int rb = piece_pos(cur, it, pc, inr);
         raw[it] = bsrc[(size_t)rb * a.L_in + pc];
       }
     } else {
 #pragma unroll
       for (int it = 0; it < A_ITERS; ++it) raw[it] = 1;
     }
-  };
-  auto build_pieces = [&](const Tile &tl) {      // consumes raw[]
-    x_ok = 0;
+    build_pieces(cur);                 // the only exposed byte-load latency of the launch
+    issue_x(0, 0);
 #pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      int pc; bool inr;
-      const int rb = piece_pos(tl, it, pc, inr);
-      const int ph = piece_ph(it) & 3;
-      x_voff[it] = (unsigned)(((rb * PCC * 4 + ph) * a.L_in + pc) * 16);
-      if (inr && raw[it] != 0) x_ok |= 1u << it;
+    for (int t = 0; t < 4; ++t) issue_w(0, t);
+    wait_vm<2 * W_ITERS>();
+    zero_fill(0);
+    lgkm0();
+    bar();                                               // step A of (pass 0, chunk 0)
+    ldw(wf[0], 0);
+    ldx(xf[0], Abuf + x_frag, 0, 0);
+    for (int pass = 0; pass < my_pairs; ++pass) {
+      const bool more = pass + 1 < my_pairs;
+      for (int cp = 0; cp < PCC / 2; ++cp) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {           // chunk cc = 2*cp + half reads activation buffer `half`
+          const int cc = 2 * cp + half;
+          const bool last_chunk = half == 1 && cp == PCC / 2 - 1;
+          const bool tail = last_chunk && !more;          // nothing is issued behind this chunk
+          const int ncc = last_chunk ? 0 : cc + 1;
+          const uint4 *A = Abuf + half * a_items + x_frag;
+          const uint4 *An = Abuf + (half ^ 1) * a_items + x_frag;
+#pragma unroll
+          for (int g = 0; g < 10; ++g) {                 // group g: tap g/2, position-block pair g%2
+            const int t = g >> 1, tp = g & 1;
+            const bool step_end = g == 3 || g == 7 || g == 9;
+            const bool pass_end = g == 9 && last_chunk;
+            if (step_end && !pass_end) {
+              // the next step's operands: counted wait, padding / mask zeros, publish.  Taken BEFORE this step's last
+              // group is issued - its fragments are in registers (lgkmcnt 0), so the slots may be refilled - and the
+              // first fragments of the next step are requested under those 12 MFMAs.
+              if (g == 3) {
+                if (tail) wait_vm<W_ITERS>();
+                else if (x_last_wave) wait_vm<W_ITERS + A_ITERS>();
+                else wait_vm<W_ITERS + A_ITERS - 1>();
+              } else if (g == 7) {
+                if (tail) wait_vm<0>();
+                else if (x_last_wave) wait_vm<2 * W_ITERS + A_ITERS>();
+                else wait_vm<2 * W_ITERS + A_ITERS - 1>();
+              } else {
+                wait_vm<2 * W_ITERS>();
+                zero_fill(half ^ 1);
+              }
+              lgkm0();
+              PC_STM(0);
+              bar();
+              PC_STM(1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!pass_end) {                             // fragments of the group after g
+              if (g < 9) {
+                ldx(xf[(g + 1) & 1], A, (g + 1) >> 1, (g + 1) & 1);
+                if (tp == 1) ldw(wf[(half + t + 1) & 1], t + 1);
+              } else {
+                ldx(xf[0], An, 0, 0);
+                ldw(wf[(half ^ 1) & 1], 0);
+              }
+            }
+            // (no fence here: the fragment reads above are independent of this group's MFMAs - the group barriers below
+            // deal them out one per MFMA, so that their issue runs in the matrix cores' shadow instead of in front of it)
+            // the ring's DMA pieces of this step ride in the same shadow, one or two behind each accumulator block's three MFMAs
+            auto ring = [&](int k) {
+              if (g != 0 && g != 4 && g != 8) return;
+#if JG_PC_RINGFENCE
+              __builtin_amdgcn_sched_barrier(0);
+#endif
+              if (g == 0) {
+                const char *sbw = reinterpret_cast<const char *>(a.wh) + ((size_t)(4 * PCC * 2 + cc * 2) * HN) * 16;
+                if (k == 0) glds16(sbw, w_voff[0], ldsW + 4 * (W_ITEMS * 16));
+                if (k == 1) glds16(sbw, w_voff[1], ldsW + 4 * (W_ITEMS * 16) + HT * 16);
+                if (!tail) {
+                  if (k == 0 && last_chunk) {
+                    if (bsrc != nullptr) {
+#pragma unroll
+                      for (int it = 0; it < A_ITERS; ++it) raw[it] = Bbuf[it * 256 + ptid];     // fetched by the helpers
+                    }
+                    build_pieces(np);
+                  }
+                  const char *sbx = x_base + (size_t)ncc * x_cc_stride;
+                  const unsigned dst = ldsA + (half ^ 1) * (a_items * 16);
+                  if (k == 1) glds16_nt(sbx, x_voff[0], dst);
+                  if (k == 2) { glds16_nt(sbx, x_voff[1], dst + HT * 16); glds16_nt(sbx, x_voff[2], dst + 2 * (HT * 16)); }
+                  if (k == 3) {
+                    glds16_nt(sbx, x_voff[3], dst + 3 * (HT * 16));
+                    if (x_last_wave) {
+                      if (piece_ph(A_ITERS - 1) < 4) glds16_nt(sbx, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
+                    }
+                  }
+                }
+              } else if (!tail) {
+                const int t0 = g == 4 ? 0 : 2;           // slices (ncc, t0), (ncc, t0 + 1): one piece per slot
+                const int tt = t0 + (k >> 1);
+                const char *sbw = reinterpret_cast<const char *>(a.wh) + ((size_t)(tt * PCC * 2 + ncc * 2) * HN) * 16;
+                glds16(sbw, w_voff[k & 1], ldsW + tt * (W_ITEMS * 16) + (k & 1) * (HT * 16));
+              }
+#if JG_PC_RINGFENCE
+              __builtin_amdgcn_sched_barrier(0);
+#endif
+            };
+            if (half == 0 && g < 2) {
+              if (cp == 0) mm(std::true_type{}, wf[(half + t) & 1], xf[g & 1], tp, ring);
+              else mm(std::false_type{}, wf[(half + t) & 1], xf[g & 1], tp, ring);
+            } else {
+              mm(std::false_type{}, wf[(half + t) & 1], xf[g & 1], tp, ring);
+            }
+            if (g != 0 && g != 4 && g != 8) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      // ---- tile finished: hand the accumulators to the helper ----
+      PC_ST(0);
+      xwrite(0);
+      lgkm0();
+      bar();                                             // X1: first half published
+      if (more) { wait_vm<2 * W_ITERS>(); zero_fill(0); }        // (the next tile's first operands, while the helper reads)
+      bar();                                             // X2: the helper has it in registers
+      xwrite(1);
+      lgkm0();
+      bar();                                             // step A of the next pass / X3 after the last one
+      PC_ST(2);
+      if (more) {
+        ldw(wf[0], 0);
+        ldx(xf[0], Abuf + x_frag, 0, 0);
+      }
+      cur = np;
+      tile_of(pass + 2, np);
     }
-  };
-  const char *x_base = reinterpret_cast<const char *>(a.xh);
-  const unsigned x_cc_stride = 4u * (unsigned)a.L_in * 16u;   // bytes per chunk
-  const bool x_last_wave = __builtin_amdgcn_readfirstlane((int)((A_ITERS - 1) * HT + hw * 64 < 4 * rows_a)) != 0;
-  auto issue_x = [&](int cc, int buf) {      // the tile's activation slice of chunk cc
-    const char *sb = x_base + (size_t)cc * x_cc_stride;
-    const unsigned dst = ldsA + buf * (a_items * 16);
-#pragma unroll
-    for (int it = 0; it < A_ITERS - 1; ++it) glds16_nt(sb, x_voff[it], dst + it * (HT * 16));
-    if (x_last_wave) {                        // wave-uniform: the counted waits must know how many DMAs are in flight
-      if (piece_ph(A_ITERS - 1) < 4) glds16_nt(sb, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
-    }
-  };
-  auto zero_fill = [&](int buf) {
-    uint4 *A = Abuf + buf * a_items;
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it)
-      if (piece_ph(it) < 4 && !((x_ok >> it) & 1u)) A[htid + it * HT] = make_uint4(0u, 0u, 0u, 0u);
-  };
+    PC_ST_END(0);
+    return;
+  }
+
+  // ============================================= HELPER WAVE =================================================
+  const int hw = wid - 4;
+  __builtin_amdgcn_s_setprio(JG_PC_HPRIO);
+  PC_ST_DECL;
+  uint4 *Sp = Sbuf + hw * S_ITEMS;                       // this wave's staging: [4 items][64 lanes] + 64 mask dwords
+  const unsigned ldsS = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((Sbuf - lds) + hw * S_ITEMS) * 16u);
+  unsigned char nb_raw[A_ITERS] = {1, 1, 1, 1, 1};
 
   // ---- epilogue (expressions of conv_f16x3_kernel's compiled patterns, tanh-GELU) ------------------------
   // Per tile and position block tm this lane's output position is resolved ONCE: ob[tm] = item offset (16-byte units) of
@@ -610,33 +663,25 @@ void conv_pc_kernel(ConvHArgs a) {
     }
   };
 
-  // ---- prologue: the pipeline of pass 0 ------------------------------------------------------------------------
-  Tile cur, np, et;                  // tile of this pass (operands) / of the next pass / whose accumulators this wave holds
+  Tile cur, np, et;                  // tile the math waves work on / the next one / the one whose accumulators this wave holds
   tile_of(0, cur);
   tile_of(1, np);
   et = cur;
-  load_bytes(cur);
-  build_pieces(cur);                 // the only exposed byte-load latency of the launch
-  issue_x(0, 0);
   tile_positions(cur);
 #pragma unroll
   for (int g = 0; g < 4; ++g) sh[g] = sl[g] = make_uint2(0u, 0u);
 #pragma unroll
   for (int q = 0; q < 4; ++q) outv[q] = make_uint4(0u, 0u, 0u, 0u);
 
-  // Pass `my_pairs` is the drain: no operands, no barriers - only the last tile's epilogue, through the same code.
-  // This wave's ring duty is the ACTIVATION slices (one per chunk, a whole chunk ahead): issued behind barrier A,
-  // landed (vmcnt 0: everything else in the queue is older) and zero-filled in front of the next barrier A.
+  // Pass `my_pairs` is the drain: no barriers - only the last tile's epilogue, through the same code.  The helper owns no
+  // part of the operand ring: besides the epilogue it fetches the next tile's input-mask bytes for the math waves' piece
+  // table (plain loads - nothing here counts vmcnt) and joins the step barriers.
   for (int pass = 0; pass <= my_pairs; ++pass) {
     const bool drain = pass == my_pairs;
     const bool epi = pass > 0;                         // this wave holds a tile's accumulators
-    const bool last_pass = pass == my_pairs - 1;
     if (epi) {
-      // X1 / X2: first half of the finished tile's accumulators (the step-A wait and zero-fill of this pass's first
-      // chunk are done first, so that the math waves find barrier A right behind X2)
-      if (!drain) { wait_vm<0>(); zero_fill(0); lgkm0(); }
-      PC_ST(0);
-      bar();                                           // X1
+      PC_ST(4);
+      bar();                                           // X1: first half of the finished tile's accumulators
 #pragma unroll
       for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
@@ -647,52 +692,29 @@ void conv_pc_kernel(ConvHArgs a) {
     }
 #pragma unroll
     for (int cc = 0; cc < PCC; ++cc) {
-      const int abuf = cc & 1;
       const bool last_chunk = cc == PCC - 1;
-      const bool tail = last_chunk && last_pass;       // nothing is issued behind this chunk
-      const int ncc = last_chunk ? 0 : cc + 1;
       const int tm = cc & 3, tn = cc >> 2;             // the accumulator block this chunk's steps carry
       f32x16 &xb = tm < 2 ? hacc[tm & 1][tn] : blk;    // the block in hand (cc is a compile-time value)
-      // ---- step A: taps 0, 1 ----
-      if (!drain) {
-        if (!(cc == 0 && epi)) { wait_vm<0>(); zero_fill(abuf); lgkm0(); }
-        PC_ST(0);
-        bar();                                         // A (after a pass: also X3 - the second half is in the slot)
+      // ---- step A ----
+      if (!drain || cc == 0) {
+        PC_ST(4);
+        bar();                                         // A (after a pass: the second half is in the slot; drain: X3)
         PC_ST(1);
-      } else {
-        if (cc == 0) {
-          PC_ST(0);
-          bar();                                       // X3
-          PC_ST(1);
-        }
-        wait_vm<0>();                                  // drain pass: this block's staged inputs
       }
       const unsigned ob_c = ob[tm], om_c = om[tm];
       const bool live_c = ((olive >> tm) & 1u) != 0u;  // (kept: the last chunk re-resolves the positions for the next tile)
       if (epi) {
-        // second half of the previous block's stores (converted during the previous chunk's step B)
+        wait_vm<0>();                                  // this block's inputs (requested a chunk ago; the stores in the queue are older still)
+        PC_ST(0);
+        // second half of the previous block's stores (converted during the previous chunk's step B; F32OUT blocks read `blk`
+        // before it is refilled below)
         if (cc > 0) store_half((((cc - 1) & 3) < 2 ? hacc[(cc - 1) & 1][(cc - 1) >> 2] : blk), ob[(cc - 1) & 3], om[(cc - 1) & 3], ((olive >> ((cc - 1) & 3)) & 1u) != 0u, (cc - 1) >> 2, 1);
         if (HAS_NMD && cc == 4) nmd_flush(et, 0);
         PC_ST(5);
         if (tm >= 2) xread_block(blk, tm - 2, tn);      // (published by barrier A of this pass's first chunk)
-        epi_collect(tm);                               // staged a chunk ago (covered by the wait above)
+        epi_collect(tm);
         lgkm0();
         PC_ST(6);
-      }
-      // inputs of the next block: block cc + 1 of the tile in hand, or block 0 of the tile the math waves are finishing
-      if (epi && !last_chunk) epi_request(ob[(cc + 1) & 3], om[(cc + 1) & 3], (cc + 1) >> 2);
-      if (!drain && last_chunk) {
-        tile_positions(cur);                            // (block 7's remaining stores use ob_c / om_c / live_c)
-        epi_request(ob[0], om[0], 0);
-      }
-      PC_ST(5);
-      if (!drain && !tail) {
-        if (last_chunk) build_pieces(np);
-        issue_x(ncc, abuf ^ 1);
-        if (cc == PCC - 2 && !last_pass) load_bytes(np);          // consumed by build_pieces a chunk later
-      }
-      PC_ST(3);
-      if (epi) {
         if (HAS_NMD && (cc == 0 || cc == 4)) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) nmd2[q] = f32x2{0.f, 0.f};
@@ -703,20 +725,39 @@ void conv_pc_kernel(ConvHArgs a) {
         }
         epi_half(xb, tn, 0);
       }
+      if (!drain && cc == 2 && bsrc != nullptr) {      // the next tile's input-mask bytes, for the math waves' piece table
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) {
+          int pc; bool inr;
+          const int rb = piece_pos(np, it, pc, inr);
+          nb_raw[it] = bsrc[(size_t)rb * a.L_in + pc];
+        }
+      }
       PC_ST(4);
-      // ---- step B: taps 2, 3 ----
+      // ---- step B ----
       if (!drain) {
         bar();
         PC_ST(1);
       }
       if (epi) store_half(xb, ob_c, om_c, live_c, tn, 0);     // (converted during step A)
+      // inputs of the next block: block cc + 1 of the tile in hand, or block 0 of the tile the math waves are finishing
+      // (the staging area was read out at step A)
+      if (epi && !last_chunk) epi_request(ob[(cc + 1) & 3], om[(cc + 1) & 3], (cc + 1) >> 2);
+      if (!drain && last_chunk) {
+        tile_positions(cur);                            // (block 7's remaining stores use ob_c / om_c / live_c)
+        epi_request(ob[0], om[0], 0);
+      }
       PC_ST(5);
       if (epi) {
         epi_half(xb, tn, 1);
         if (F32OUT && a.pool_out != nullptr) pool_block(xb);
       }
+      if (!drain && cc == 4 && bsrc != nullptr) {
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) Bbuf[it * 256 + ptid] = nb_raw[it];
+      }
       PC_ST(4);
-      // ---- step C: tap 4 ----
+      // ---- step C ----
       if (!drain) {
         bar();
         PC_ST(1);
@@ -739,7 +780,7 @@ void conv_pc_kernel(ConvHArgs a) {
 
 int pc_lds_bytes(int dil) {
   const int rows_a = HM + (PK - 1) * dil;
-  return (2 * 4 * rows_a + PK * W_ITEMS + 4 * X_ITEMS + 4 * S_ITEMS) * 16 + JG_EPI_ROWS * 2 * HN * 4;
+  return (2 * 4 * rows_a + PK * W_ITEMS + 4 * X_ITEMS + 4 * S_ITEMS) * 16 + JG_EPI_ROWS * 2 * HN * 4 + A_ITERS * 256;
 }
 
 template <unsigned EP, bool FLAT, int DIL, bool F32OUT>
