@@ -127,6 +127,8 @@ def cpu_baseline(cfg, weights, bases, offsets, fsize, flops_per_window: float, t
             run(8)                                               # warm-up (thread pools, oneDNN primitives)
             n_w, dt = run(96)
             want = int(max(96, min(n_w / dt * target_s, 20000)))
+            if threads == all_cores:                         # at least 2 000 windows on the full-quota leg
+                want = max(want, 2000)
             if want > 96 * 1.5:
                 n_w, dt = run(want)
             legs.append({"threads": threads, "value": round(n_w * fsize / dt / 1e6, 5), "windows": n_w,
@@ -163,6 +165,99 @@ def visible_gpus() -> int:
         return n
     dri = Path("/dev/dri")
     return len(list(dri.glob("renderD*"))) if dri.is_dir() else 0
+
+
+def kernel_hash() -> str:
+    """Fingerprint of the conv-kernel sources: the PMC summaries under profiles/ record it, and a bench line only
+    quotes counters that were collected on the build it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    src = ROOT / "jaeger_amd" / "csrc"
+    for name in ("jg_common.h", "jg_conv_dev.h", "jg_conv_f16.hip", "jg_conv_f16_impl.h", "jg_conv_pc.hip", "jg_small.h",
+                 "jg_small.hip"):
+        h.update((src / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def e2e_leg(cfg, weights, wl, lengths, bases, fsize):
+    """FASTA on tmpfs -> ``jaeger_amd.predict.run_core`` in-process (defaults: DUST on, host pipeline on) -> TSV:
+    the end-to-end figure SURVEY 8(d) asks for next to the resident-input metric (commands/predict.py:488-860).
+    The FASTA and the model directory are written before the clock starts."""
+    import re
+    import shutil
+    import tempfile
+
+    import yaml
+
+    from jaeger_amd.predict import run_core
+    from jaeger_amd.weights import save_npz
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = Path(tempfile.mkdtemp(prefix="jaeger_bench_e2e_", dir=base))
+    try:
+        fa = tmp / "bench.fasta"
+        with open(fa, "wb") as fh:
+            off = 0
+            for i, n in enumerate(lengths.tolist()):
+                fh.write(b">contig_%d len=%d\n" % (i, n))
+                seq = bases[off:off + n].tobytes()
+                off += n
+                fh.write(b"\n".join(seq[j:j + 80] for j in range(0, n, 80)) + b"\n")
+        mdir = tmp / "model_root" / "model"
+        mdir.mkdir(parents=True)
+        name = "bench_model"
+        shutil.copyfile(ROOT / "tests" / "golden" / f"{wl['model']}_project.yaml", mdir / f"{name}_project.yaml")
+        (mdir / f"{name}_classes.yaml").write_text(yaml.safe_dump({"classes": cfg["class_label_map"]}))
+        save_npz(mdir / f"{name}.weights.npz", weights)
+        out = tmp / "out"
+        t0 = time.perf_counter()
+        n_rows = run_core(input=str(fa), output=str(out), model_path=str(tmp / "model_root"), fsize=fsize, stride=fsize,
+                          overwrite=True, dustmask=True, verbose=0, batch=96, rc=0.1, pc=3)
+        dt = time.perf_counter() - t0
+        stages = {}
+        for log in out.rglob("*_jaeger.log"):
+            text = log.read_text()
+            for key, pat in (("model_setup_s", r"model set-up ([0-9.]+) s"), ("forward_s", r"classified in ([0-9.]+) s"),
+                             ("terminal_repeats_s", r"contigs in ([0-9.]+) s"), ("dust_s", r"soft-masked in ([0-9.]+) s")):
+                m = re.search(pat, text)
+                if m:
+                    stages[key] = float(m.group(1))
+        tsv = next(out.rglob("bench.tsv"), None)
+        return {"mbps": round(bases.size / dt / 1e6, 2), "seconds": round(dt, 3), "bp": int(bases.size), "tsv_rows": int(n_rows or 0),
+                "tsv_bytes": tsv.stat().st_size if tsv else 0, "stages": stages,
+                "what": "FASTA (tmpfs) -> ingest -> DUST on the GPU -> window table -> encode + forward (host buffers over "
+                        "PCIe) -> terminal-repeat scan -> per-contig aggregation -> TSV, in-process run_core with its "
+                        "defaults; writing the FASTA / model directory is outside the clock"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_fields(name: str, mode: str, fsize: int, chunk: int, avg_launch_ms: float):
+    """HBM traffic and matrix-core utilisation of the dominant kernel from the committed rocprofv3 --pmc summaries
+    (profiles/pmc_traffic.json, profiles/mfma_util.json) - attached only when they were collected on THIS kernel build."""
+    out = {"traffic": None, "hbm_gbs": None, "mfma_busy_frac": None, "eff_clock_ghz": None, "pmc_kernel_hash": None,
+           "pmc_stale": None}
+    try:
+        tr = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        mu = json.loads((ROOT / "profiles" / "mfma_util.json").read_text())
+    except (OSError, ValueError):
+        return out
+    here = kernel_hash()
+    key = {"default": "conv_f16x3_kernel", "baseline500": "small_net_kernel"}.get(name)
+    if key is None or mode != "f16x3" or chunk != 0:
+        return out
+    t, m = tr.get(key, {}), mu.get(key, {})
+    if t.get("fsize", fsize) != fsize:
+        return out
+    out["pmc_kernel_hash"] = tr.get("kernel_hash")
+    out["pmc_stale"] = tr.get("kernel_hash") != here or mu.get("kernel_hash") != here
+    if out["pmc_stale"]:
+        return out
+    out["traffic"] = t.get("traffic_bytes_per_launch")
+    if out["traffic"] and avg_launch_ms > 0:
+        out["hbm_gbs"] = round(out["traffic"] / (avg_launch_ms * 1e-3) / 1e9, 1)
+    out["mfma_busy_frac"] = m.get("mfma_busy_frac")
+    out["eff_clock_ghz"] = m.get("eff_clock_ghz")
+    return out
 
 
 def spawn_ranks(n: int, oversubscribe: bool = False, timeout_s: float = 1800.0) -> int:
@@ -238,6 +333,7 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the short exact-f32 side measurement")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end FASTA -> TSV leg")
     ap.add_argument("--no-profile", action="store_true",
                     help="experiments only: no HIP events around the conv launches (roofline fields read 0)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -401,19 +497,12 @@ def main():
         # roofline: algorithmic (f32-equivalent) conv FLOP/s against the matrix-core peak the kernel can reach:
         # exact-f32 MFMA, or the f16 MFMA peak / 3 for the split-f16 scheme
         peak = F32_MFMA_PEAK_TFLOPS if mode == "f32" else F16_MFMA_PEAK_TFLOPS / 3.0
-        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (it cannot be read from
-        # inside the process); the committed summary applies to the default configuration only
-        traffic = None
-        try:
-            pmc_all = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-            pmc = pmc_all["conv_f16x3_kernel"]
-            if args.config == "default" and mode == pmc["precision"] and fsize == pmc["fsize"] \
-                    and args.chunk in (0, pmc["chunk"]):
-                traffic = pmc["traffic_bytes_per_launch"]
-            if args.config == "baseline500" and mode == "f16x3" and args.chunk == 0 and args.fsize is None:
-                traffic = pmc_all["small_net_kernel"]["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM traffic and matrix-core utilisation of the dominant kernel come from separate rocprofv3 --pmc passes
+        # (counters cannot be read from inside the process): scripts/gpu_r3_profiles.sh -> profiles/*.json, keyed by
+        # the kernel-source hash so that a stale summary is never quoted
+        pmc = pmc_fields(args.config if args.fsize is None else "", mode, fsize, args.chunk,
+                         dom["ms"] / max(dom["launches"], 1))
+        traffic = pmc["traffic"]
         all_s = prof["conv_ms"] / 1e3
         line = {
             "metric": f"Mbp/s classified ({fsize}bp frags)", "value": round(value, 3), "unit": "Mbp/s",
@@ -432,6 +521,9 @@ def main():
                                   "per window) are computed but not copied out in the timed region"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1),
                          "unit": "TFLOP/s", "frac": round(ach / peak, 4) if peak else 0.0, "traffic": traffic,
+                         "hbm_gbs": pmc["hbm_gbs"], "mfma_busy_frac": pmc["mfma_busy_frac"],
+                         "eff_clock_ghz": pmc["eff_clock_ghz"], "kernel_hash": kernel_hash(),
+                         "pmc_kernel_hash": pmc["pmc_kernel_hash"], "pmc_stale": pmc["pmc_stale"],
                          "kernel": dom_name,
                          "launches": int(dom["launches"]),
                          "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
@@ -458,6 +550,11 @@ def main():
             torch.cuda.synchronize()
             line["exact_f32_mbps"] = round(float(win_len[:n_s].sum()) / (time.perf_counter() - t1) / 1e6, 2)
             eng.model.set_precision("f16x3")
+        if world == 1 and not args.no_e2e and args.timed_dbg is None:
+            try:
+                line["e2e"] = e2e_leg(cfg, weights, wl, lengths, bases, fsize)
+            except SystemExit as e:               # run_core exits on its own errors: report, do not lose the bench line
+                line["e2e"] = {"error": f"run_core exited with {e.code}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, weights, bases, offsets, fsize, eng.model.flops_per_window(l_pad))
         else:

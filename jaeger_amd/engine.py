@@ -281,9 +281,13 @@ class JaegerHipEngine:
     """Drop-in for ``InferModel`` (nnlib/inference.py:300-483) on one MI355X.
 
     ``path_dict`` keys as produced by ``AvailableModels`` (utils/misc.py:346-392):
-    ``classes`` (yaml), ``project`` (yaml), ``weights`` (Keras-3 ``.weights.h5``) or ``weights_npz`` (canonical
-    names); ``graph`` (the SavedModel directory) is NOT read: the layer plan comes from ``project.yaml``, the
-    weights from the weights file, and a model entry without one is an error.
+    ``classes`` (yaml), ``project`` (yaml), ``graph`` (the SavedModel directory the reference executes,
+    nnlib/inference.py:307-325), ``weights`` (Keras-3 ``.weights.h5``) or ``weights_npz`` (canonical names).  The layer
+    plan comes from ``project.yaml``; the weights come from the graph's own variable bundle when there is one
+    (``<name>_graph/variables``, mapped by object-graph order and variable names - ``weights.load_savedmodel_bundle``),
+    else from the weights file.  When the graph also holds ``saved_model.pb`` its census (Conv2D count, dilations,
+    batch-norm epsilons, GELU form, variable shapes) is compared with the plan first and a disagreement refuses the
+    model: an engine that silently computed something else than the graph the reference runs is worse than none.
     Alternatively pass ``model_cfg`` + ``weights`` (canonical-name dict) directly.
     """
 
@@ -305,6 +309,14 @@ class JaegerHipEngine:
             model_cfg = cfg.get("model")
             if weights is None:
                 from .weights import load_weights
+                graph = path_dict.get("graph")
+                if graph is not None and (Path(graph) / "saved_model.pb").exists() \
+                        and (Path(graph) / "variables" / "variables.index").exists():
+                    from .verify import verify_model
+                    findings = verify_model(graph, build_plan(model_cfg))
+                    if findings:
+                        raise ValueError(f"{graph}: the SavedModel the reference would execute disagrees with the layer plan "
+                                         f"compiled from {project}:\n  " + "\n  ".join(findings))
                 weights = load_weights(path_dict, build_plan(model_cfg))
         if model_cfg is None or weights is None:
             raise ValueError("JaegerHipEngine: provide path_dict or model_cfg + weights")

@@ -75,6 +75,25 @@ def load_legacy_h5(path) -> dict[str, np.ndarray]:
     return {n: out[n] for n in want}
 
 
+def load_legacy_bundle(graph_dir) -> dict[str, np.ndarray]:
+    """The legacy tower's weights out of a SavedModel's ``variables/`` bundle (``<name>_graph/``, the artefact
+    ``nnlib/inference.py:307-325`` executes): owner groups in object-graph order and variable attribute names
+    (:func:`jaeger_amd.weights.assign_groups`) against the tower's layers in graph order."""
+    from pathlib import Path as _P
+
+    from .savedmodel_lite import bundle_layer_groups
+    from .weights import assign_groups
+    order: list[tuple[str, list[str]]] = [("aa", ["embeddings"])]
+    for conv, bn, _, _, _, _ in tower_layers():
+        order.append((conv, ["kernel", "bias"]))
+        order.append((bn, ["gamma", "beta", "moving_mean", "moving_variance"]))
+    for name in ("augdense-1", "augdense-2", "outdense"):
+        order.append((name, ["kernel", "bias"]))
+    vdir = _P(graph_dir) / "variables"
+    got = assign_groups(bundle_layer_groups(vdir), order, weight_shapes(), str(vdir))
+    return {n: got[n] for n in weight_shapes()}
+
+
 def random_weights(seed: int = 1) -> dict[str, np.ndarray]:
     rng = np.random.Generator(np.random.PCG64(seed))
     out = {}
@@ -157,7 +176,8 @@ class LegacyHipEngine:
                  precision: str | None = None):
         from .engine import HipDevice, HipModel, codon_lut
         if not isinstance(weights, dict):
-            weights = load_legacy_h5(weights)
+            # a SavedModel directory (``<name>_graph/`` - what the reference executes) or the Keras-2.5 H5 beside it
+            weights = load_legacy_bundle(weights) if Path(weights).is_dir() else load_legacy_h5(weights)
         self.program = compile_legacy(weights)
         self.device = HipDevice(device_id)
         # split-f16 by default like the modern models (f32-accurate; measured 186 Mbp/s of 2000-bp windows

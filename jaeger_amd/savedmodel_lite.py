@@ -142,6 +142,131 @@ def read_bundle(variables_dir) -> dict[str, np.ndarray]:
     return out
 
 
+# ---- writing a tensor bundle (tests, and exporting canonical weights in the reference's own container) ---------------
+def _crc32c_table():
+    tbl = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        tbl.append(c)
+    return tbl
+
+
+_CRC_TABLE = _crc32c_table()
+
+
+def crc32c(data: bytes, crc: int = 0) -> int:
+    """CRC-32C (Castagnoli), the checksum of SSTable blocks and of BundleEntryProto.crc32c."""
+    crc ^= 0xFFFFFFFF
+    for b in data:
+        crc = _CRC_TABLE[(crc ^ b) & 0xFF] ^ (crc >> 8)
+    return crc ^ 0xFFFFFFFF
+
+
+def _masked_crc(data: bytes) -> int:
+    c = crc32c(data)
+    return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _enc_varint(v: int) -> bytes:
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _pb_field(field: int, wt: int, payload) -> bytes:
+    key = _enc_varint((field << 3) | wt)
+    if wt == 0:
+        return key + _enc_varint(payload)
+    if wt == 5:
+        return key + struct.pack("<I", payload)
+    return key + _enc_varint(len(payload)) + payload
+
+
+def write_bundle(variables_dir, tensors: dict[str, np.ndarray]) -> None:
+    """``variables.index`` (SSTable: one data block per <= 4 KB of entries, an index block, the 48-byte footer, every block
+    followed by its type byte and masked CRC-32C) + ``variables.data-00000-of-00001`` holding ``tensors`` by checkpoint
+    key - the container ``tf.train.Checkpoint`` / ``tf.saved_model.save`` write (tensor_bundle.proto, table_format)."""
+    d = Path(variables_dir)
+    d.mkdir(parents=True, exist_ok=True)
+    rev = {np.dtype(v): k for k, v in _DTYPES.items()}
+    data = bytearray()
+    entries: list[tuple[bytes, bytes]] = [(b"", _pb_field(1, 0, 1) + _pb_field(3, 2, _pb_field(1, 0, 1)))]   # BundleHeaderProto{num_shards 1, version{producer 1}}
+    for key in sorted(tensors):
+        arr = np.ascontiguousarray(tensors[key])
+        raw = arr.tobytes()
+        shape = b"".join(_pb_field(2, 2, _pb_field(1, 0, int(n))) for n in arr.shape)
+        entry = (_pb_field(1, 0, rev[arr.dtype]) + _pb_field(2, 2, shape) + _pb_field(4, 0, len(data))
+                 + _pb_field(5, 0, len(raw)) + _pb_field(6, 5, _masked_crc(raw)))
+        entries.append((key.encode(), entry))
+        data += raw
+    (d / "variables.data-00000-of-00001").write_bytes(bytes(data))
+
+    def block(items: list[tuple[bytes, bytes]]) -> bytes:       # no prefix compression: every entry is a restart point
+        body, restarts = bytearray(), []
+        for k, v in items:
+            restarts.append(len(body))
+            body += _enc_varint(0) + _enc_varint(len(k)) + _enc_varint(len(v)) + k + v
+        for r in restarts:
+            body += struct.pack("<I", r)
+        body += struct.pack("<I", len(restarts))
+        return bytes(body)
+
+    out = bytearray()
+    index_items = []
+
+    def emit(raw_block: bytes) -> tuple[int, int]:
+        off = len(out)
+        out.extend(raw_block)
+        out.extend(b"\x00" + struct.pack("<I", _masked_crc(raw_block + b"\x00")))
+        return off, len(raw_block)
+
+    chunk, size = [], 0
+    for kv in entries:
+        chunk.append(kv)
+        size += len(kv[0]) + len(kv[1])
+        if size >= 4096:
+            off, ln = emit(block(chunk))
+            index_items.append((chunk[-1][0], _enc_varint(off) + _enc_varint(ln)))
+            chunk, size = [], 0
+    if chunk:
+        off, ln = emit(block(chunk))
+        index_items.append((chunk[-1][0], _enc_varint(off) + _enc_varint(ln)))
+    meta_off, meta_len = emit(block([]))
+    idx_off, idx_len = emit(block(index_items))
+    footer = _enc_varint(meta_off) + _enc_varint(meta_len) + _enc_varint(idx_off) + _enc_varint(idx_len)
+    footer += b"\x00" * (40 - len(footer)) + bytes.fromhex("57fb808b247547db")
+    out.extend(footer)
+    (d / "variables.index").write_bytes(bytes(out))
+
+
+def bundle_layer_groups(variables_dir) -> list[tuple[tuple[str, ...], dict[str, np.ndarray]]]:
+    """The float variables of a bundle grouped by the object that owns them, in creation order: checkpoint keys are
+    ``<object path>/<attribute>/.ATTRIBUTES/VARIABLE_VALUE`` where a Keras-3 model's object path is
+    ``_operations/<n>[/<sub-layer attribute>...]`` (or ``layers/<n>/...``) with ``n`` = position in the model's operation
+    list, i.e. graph order; the attribute (``_kernel``, ``bias``, ``gamma``, ``moving_mean``, ``_embeddings`` ...) names
+    the variable - leading underscores dropped.  Optimizer slots and non-float entries are skipped."""
+    import re
+    bundle = read_bundle(variables_dir)
+    groups: dict[tuple[str, ...], dict[str, np.ndarray]] = {}
+    for key, arr in bundle.items():
+        if not key.endswith("/.ATTRIBUTES/VARIABLE_VALUE") or arr.dtype != np.float32:
+            continue
+        parts = key[:-len("/.ATTRIBUTES/VARIABLE_VALUE")].split("/")
+        if len(parts) < 2 or parts[0] in ("optimizer", "_optimizer") or ".OPTIMIZER_SLOT" in key:
+            continue
+        groups.setdefault(tuple(parts[:-1]), {})[parts[-1].lstrip("_")] = arr
+
+    def nat(path):
+        return [tuple((1, int(t), "") if t.isdigit() else (0, 0, t) for t in re.split(r"(\d+)", c) if t != "") for c in path]
+    return [(k, groups[k]) for k in sorted(groups, key=nat)]
+
+
 # ---- saved_model.pb ------------------------------------------------------------------------------------------------
 class Node:
     """One NodeDef of a FunctionDef: ``name``, ``op``, ``inputs`` (strings) and raw ``attr`` (name -> AttrValue bytes)."""

@@ -152,10 +152,94 @@ def load_keras3_h5(path, plan: ModelPlan) -> dict[str, np.ndarray]:
     return out
 
 
+def assign_groups(groups: list[tuple[tuple[str, ...], dict[str, np.ndarray]]], order: list[tuple[str, list[str]]],
+                  shapes: dict[str, tuple], source: str) -> dict[str, np.ndarray]:
+    """Owner groups in creation order (``savedmodel_lite.bundle_layer_groups``) -> canonical names.  Nothing is guessed:
+    a residual block's sub-layers are found by their attribute names under the block's own path (blocks paired in
+    order), every other weighted layer takes the NEXT unused group, whose variable names and shapes must be exactly
+    the layer's - the first disagreement is an error that names both sides."""
+    block_paths = []
+    for path, _ in groups:
+        if path[-1] in _BLOCK_SUBLAYERS and path[:-1] not in block_paths:
+            block_paths.append(path[:-1])
+    by_path = dict(groups)
+    loose = [path for path, _ in groups if not (path[-1] in _BLOCK_SUBLAYERS and path[:-1] in block_paths)]
+    plan_blocks: list[str] = []
+    for prefix, _ in order:
+        head, _, sub = prefix.rpartition("/")
+        if sub in _BLOCK_SUBLAYERS and head not in plan_blocks:
+            plan_blocks.append(head)
+    if len(plan_blocks) != len(block_paths):
+        raise ValueError(f"{source}: {len(block_paths)} residual blocks in the bundle, the plan has {len(plan_blocks)}")
+    if len(groups) != len(order):
+        raise ValueError(f"{source}: {len(groups)} weighted layers in the bundle, the plan has {len(order)}")
+    out: dict[str, np.ndarray] = {}
+    nxt = 0
+    for prefix, leaves in order:
+        head, _, sub = prefix.rpartition("/")
+        if sub in _BLOCK_SUBLAYERS and head in plan_blocks:
+            path = block_paths[plan_blocks.index(head)] + (sub,)
+            if path not in by_path:
+                raise ValueError(f"{source}: residual block {'/'.join(path[:-1])} has no sub-layer {sub!r} (plan layer {prefix})")
+        else:
+            if nxt >= len(loose):
+                raise ValueError(f"{source}: no variables left for plan layer {prefix}")
+            path = loose[nxt]
+            nxt += 1
+        have = by_path[path]
+        if sorted(have) != sorted(leaves):
+            raise ValueError(f"{source}: {'/'.join(path)} holds {sorted(have)}, plan layer {prefix} needs {sorted(leaves)}")
+        for leaf in leaves:
+            want = tuple(shapes[f"{prefix}/{leaf}"])
+            if tuple(have[leaf].shape) != want:
+                raise ValueError(f"{source}: {'/'.join(path)}/{leaf} has shape {tuple(have[leaf].shape)}, "
+                                 f"plan layer {prefix} needs {want}")
+            out[f"{prefix}/{leaf}"] = np.asarray(have[leaf], np.float32)
+    return out
+
+
+def load_savedmodel_bundle(graph_dir, plan: ModelPlan) -> dict[str, np.ndarray]:
+    """Weights out of ``<name>_graph/variables`` - the artefact the reference executes (nnlib/inference.py:307-325) -
+    by object-graph order and variable attribute names (:func:`assign_groups`), no shape heuristics."""
+    from .savedmodel_lite import bundle_layer_groups
+    vdir = Path(graph_dir) / "variables"
+    return assign_groups(bundle_layer_groups(vdir), _layer_order(plan), weight_shapes(plan), str(vdir))
+
+
+def bundle_checkpoint_keys(plan: ModelPlan) -> dict[str, str]:
+    """Canonical name -> the checkpoint key a Keras-3 export of this plan's model carries: ``_operations/<n>/...`` with n
+    counting the model's operations in graph order (weighted or not - here only the weighted ones are known, so they are
+    numbered densely from 1), ``_kernel`` / ``_embeddings`` for the kernels, the attribute name otherwise.  Used to
+    write bundles in the reference's container (tests; exporting stand-in weights)."""
+    keys = {}
+    n = 0
+    last_block = None
+    for prefix, leaves in _layer_order(plan):
+        head, _, sub = prefix.rpartition("/")
+        if sub in _BLOCK_SUBLAYERS:
+            if head != last_block:
+                n += 1
+                last_block = head
+            base = f"_operations/{n}/{sub}"
+        else:
+            n += 1
+            last_block = None
+            base = f"_operations/{n}"
+        for leaf in leaves:
+            attr = "_" + leaf if leaf in ("kernel", "embeddings") else leaf
+            keys[f"{prefix}/{leaf}"] = f"{base}/{attr}/.ATTRIBUTES/VARIABLE_VALUE"
+    return keys
+
+
 def load_weights(path_dict: dict, plan: ModelPlan) -> dict[str, np.ndarray]:
+    """Weights of a model entry (AvailableModels keys, utils/misc.py:346-392).  The SavedModel's own variable bundle
+    (``graph``) comes first - it is what the reference runs; then the canonical ``.npz``, then a Keras-3 ``.weights.h5``."""
+    graph = path_dict.get("graph")
+    if graph is not None and (Path(graph) / "variables" / "variables.index").exists():
+        return load_savedmodel_bundle(graph, plan)
     w = path_dict.get("weights") or path_dict.get("weights_npz")     # AvailableModels keys (predict.py)
     if w is None:
-        raise FileNotFoundError("model entry has no weights file (*.weights.h5 or canonical *.npz)")
+        raise FileNotFoundError("model entry has no weights (a <name>_graph/variables bundle, *.weights.h5 or canonical *.npz)")
     w = Path(w)
     if w.suffix == ".npz":
         return load_npz(w)

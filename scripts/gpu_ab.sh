@@ -1,7 +1,7 @@
 #!/bin/bash
 # interleaved A/B of bench.py over library builds on one box: RUNS="label:lib:pc ..." (lib = suffix of libjaeger_hip<suffix>.so)
 mkdir -p gpurun_out
-B="python bench.py --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline --no-exact-f32 ${BENCH_ARGS}"
+B="python bench.py --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline --no-exact-f32 --no-e2e ${BENCH_ARGS}"
 for r in 1 2 ${EXTRA_ROUNDS}; do
   for spec in $RUNS; do
     IFS=: read label lib pc <<< "$spec"

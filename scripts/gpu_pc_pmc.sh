@@ -15,7 +15,7 @@ for pc in 0 1; do
   i=0
   for grp in "$G1" "$G2" "$G3"; do
     i=$((i+1))
-    timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pc${pc}_g$i -- python3 $R/bench.py --contigs 1500 --steps 1 --warmup 1 --no-cpu-baseline --no-exact-f32 --conv-pc $pc > $O/pc${pc}_g$i.json 2> $O/pc${pc}_g$i.err
+    timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pc${pc}_g$i -- python3 $R/bench.py --contigs 1500 --steps 1 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-e2e --conv-pc $pc > $O/pc${pc}_g$i.json 2> $O/pc${pc}_g$i.err
   done
 done
 python3 - <<PY

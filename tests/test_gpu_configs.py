@@ -84,7 +84,7 @@ def test_config3_shard_125k_fragments(brain):
     assert stats["groups"] >= 11 and stats["peak_device_bases"] < 40 << 20
     for k in ("prediction", "reliability", "counts"):
         np.testing.assert_array_equal(got[k], again[k])
-    sample = np.sort(np.random.Generator(np.random.PCG64(3)).choice(n_frag, 512, replace=False))
+    sample = np.sort(np.random.Generator(np.random.PCG64(3)).choice(n_frag, 2048, replace=False))   # (>= 2 000)
     _oracle_check(cfg, weights, bases, starts, table.length, fsize, got, sample)
 
 
@@ -150,13 +150,13 @@ def test_config5_shard_mixed_lengths_streamed(brain):
         np.testing.assert_array_equal(got[k], again[k])
     # sampled oracle parity across the run: windows of short, medium and megabase contigs, first / last windows
     srng = np.random.Generator(np.random.PCG64(5))
-    sample = set(srng.choice(n_win, 480, replace=False).tolist())
+    sample = set(srng.choice(n_win, 2000, replace=False).tolist())
     big = int(np.argmax(lengths))
     w_big = np.nonzero(table.contig == big)[0]
     sample.update([0, n_win - 1, int(w_big[0]), int(w_big[-1]), int(w_big[len(w_big) // 2])])
     sample.update(np.nonzero(table.is_last == 1)[0][:16].tolist())
     sample = np.sort(np.fromiter(sample, np.int64))
-    assert len(sample) >= 500
+    assert len(sample) >= 2000
     _oracle_check(cfg, weights, bases, starts, table.length, fsize, got, sample)
 
 

@@ -116,11 +116,25 @@ def _forward_case(name, fsize, n_win, seed, n_frac, chunk=0, short=False, precis
         np.testing.assert_array_equal(got[k], got2[k])
     print(name, fsize, mode, {k: f"{v:.2e}" for k, v in errs.items()})
     for k, v in errs.items():
-        # the 1e-4 gate is on the logits; wide-range side outputs scale with their magnitude
-        tol = TOL if k in ("prediction", "reliability") else TOL * max(1.0, float(np.abs(ref[k]).max()) / 8)
-        assert v <= tol, (k, v, tol)
+        if k in ("prediction", "reliability"):
+            assert v <= TOL, (k, v)                # the north-star gate: 1e-4 absolute on the logits
+        else:
+            check_side_output(k, got[k], ref[k])
     ref_counts = np.array([oenc.window_counts(w) for w in windows], np.int32)
     np.testing.assert_array_equal(got["counts"], ref_counts)
+
+
+def check_side_output(name, got, ref):
+    """Side outputs (``embedding`` = pooled activations, ``nmd`` = masked channel means): 1e-4 absolute wherever
+    |ref| <= 8, and 1.25e-5 relative (= 1e-4 / 8) on the larger elements - element by element, printed per test."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    small = np.abs(ref) <= 8.0
+    abs_err = float(np.abs(got - ref)[small].max()) if small.any() else 0.0
+    rel_err = float((np.abs(got - ref)[~small] / np.abs(ref)[~small]).max()) if (~small).any() else 0.0
+    print(f"  {name}: max abs err {abs_err:.2e} on {int(small.sum())} elements with |ref| <= 8 (bound {TOL:.0e}); "
+          f"max rel err {rel_err:.2e} on {int((~small).sum())} larger ones (bound {TOL / 8:.2e}; max |ref| {np.abs(ref).max():.1f})")
+    assert abs_err <= TOL, (name, abs_err)
+    assert rel_err <= TOL / 8, (name, rel_err)
 
 
 PRECISIONS = ["f32", "f16x3"]
@@ -577,8 +591,11 @@ def test_forward_variant_layernorm():
     ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
     ref = ofwd.forward(cfg, weights, ids)
     for k, r in ref.items():
-        tol = TOL if k in ("prediction", "reliability") else TOL * max(1.0, float(np.abs(r).max()) / 8)
-        assert got[k].shape == r.shape and float(np.abs(got[k] - r).max()) <= tol, (k, float(np.abs(got[k] - r).max()))
+        assert got[k].shape == r.shape
+        if k in ("prediction", "reliability"):
+            assert float(np.abs(got[k] - r).max()) <= TOL, (k, float(np.abs(got[k] - r).max()))
+        else:
+            check_side_output(k, got[k], r)
 
 
 @pytest.mark.parametrize("signals", [None, ["energy", "margin", "max_prob"]])
@@ -683,8 +700,10 @@ def test_forward_return_nmd_norm_and_blocks():
         ids = oenc.encode_windows([seq[s:s + fsize].tobytes() for s in starts], fsize, pad_to=frame_length(fsize))
         ref = ofwd.forward(cfg, weights, ids)
         for k, r in ref.items():
-            tol = TOL if k in ("prediction", "reliability") else TOL * max(1.0, float(np.abs(r).max()) / 8)
-            assert float(np.abs(got[k] - r).max()) <= tol, (fsize, k)
+            if k in ("prediction", "reliability"):
+                assert float(np.abs(got[k] - r).max()) <= TOL, (fsize, k)
+            else:
+                check_side_output(k, got[k], r)
 
 
 @pytest.mark.parametrize("embedding_size", [64, 0])
@@ -715,3 +734,39 @@ def test_forward_onehot_translated_input(embedding_size):
     for k, r in ref.items():
         assert float(np.abs(got[k] - r).max()) <= TOL, k
         np.testing.assert_array_equal(via_api[k], got[k])
+
+
+def test_engine_takes_its_weights_from_the_graph_bundle(tmp_path):
+    """``JaegerHipEngine(path_dict)`` with a ``graph`` entry reads ``<name>_graph/variables`` (Keras-3 checkpoint keys,
+    written here with the repo's own SSTable writer) in preference to the weights file beside it - the artefact the
+    reference executes (nnlib/inference.py:307-325) - and computes exactly what the canonical weights compute."""
+    import yaml
+    from jaeger_amd import savedmodel_lite as S
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import bundle_checkpoint_keys, random_weights, save_npz
+    from oracle import encoder as oenc
+    cfg = load_model_cfg("baseline500")
+    plan = build_plan(cfg)
+    w = random_weights(plan, seed=38341)
+    keys = bundle_checkpoint_keys(plan)
+    mdir = tmp_path / "model"
+    mdir.mkdir()
+    S.write_bundle(mdir / "m_graph" / "variables", {keys[k]: v for k, v in w.items()})
+    (mdir / "m_project.yaml").write_text(yaml.safe_dump({"model": cfg}))
+    (mdir / "m_classes.yaml").write_text(yaml.safe_dump({"classes": cfg["class_label_map"]}))
+    save_npz(mdir / "m.weights.npz", random_weights(plan, seed=1))          # a DIFFERENT weights file: must not be used
+    rng = np.random.Generator(np.random.PCG64(3))
+    fsize, n_win = 500, 20
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.01)
+    ids = oenc.encode_windows([seq[i * fsize:(i + 1) * fsize].tobytes() for i in range(n_win)], fsize,
+                              pad_to=frame_length(fsize))
+    a = JaegerHipEngine({"graph": mdir / "m_graph", "project": mdir / "m_project.yaml", "classes": mdir / "m_classes.yaml",
+                         "weights_npz": mdir / "m.weights.npz"}, device_id=0)
+    got = a.model.forward(ids)
+    a.close()
+    b = JaegerHipEngine(model_cfg=cfg, weights=w, device_id=0)
+    ref = b.model.forward(ids)
+    b.close()
+    for k in ref:
+        np.testing.assert_array_equal(got[k], ref[k])

@@ -134,3 +134,77 @@ def test_verify_model_accepts_the_matching_plan_and_flags_others():
     text = " ".join(findings)
     assert "variable shapes differ" in text and "GELU form" in text and "epsilons differ" in text
     assert "no mask comparison ops" in text
+
+
+def test_legacy_bundle_loader_equals_the_h5_loader():
+    """Weights straight out of ``<name>_graph/variables`` (Keras-3 ``_operations/<n>/<attribute>`` keys, mapped by
+    object-graph order and variable names) are the ``WRes_1024.h5`` values tensor for tensor, bit for bit."""
+    from jaeger_amd import legacy
+    wb = legacy.load_legacy_bundle(GRAPH)
+    wh = legacy.load_legacy_h5(GRAPH.parents[2] / "models" / "default" / "WRes_1024.h5"
+                               if (GRAPH.parents[2] / "models" / "default" / "WRes_1024.h5").exists()
+                               else next(GRAPH.parents[2].rglob("WRes_1024.h5")))
+    assert list(wb) == list(wh) and len(wb) == 79
+    for k in wb:
+        np.testing.assert_array_equal(wb[k], wh[k])
+
+
+@pytest.mark.parametrize("name", ["baseline500", "brain", "pyramid", "zeus"])
+def test_hand_built_keras3_bundle_round_trips_through_the_loader(tmp_path, name):
+    """A variable bundle written with the repo's own SSTable writer under the Keras-3 key scheme
+    (``_operations/<n>[/convK|bnK]/_kernel|bias|gamma|...``) loads back to the canonical weights by order and names -
+    including through ``load_weights`` / the engine's path_dict route, which prefers the graph's bundle to a weights file."""
+    from conftest import load_model_cfg
+    from jaeger_amd import savedmodel_lite as S
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import (bundle_checkpoint_keys, load_savedmodel_bundle, load_weights, random_weights,
+                                    save_npz)
+    plan = build_plan(load_model_cfg(name))
+    w = random_weights(plan, seed=11)
+    keys = bundle_checkpoint_keys(plan)
+    assert set(keys) == set(w)
+    graph = tmp_path / f"{name}_graph"
+    tensors = {keys[k]: v for k, v in w.items()}
+    tensors["_CHECKPOINTABLE_OBJECT_GRAPH_SIZE"] = np.array([len(tensors)], np.int64)      # a non-float entry is skipped
+    S.write_bundle(graph / "variables", tensors)
+    assert S.crc32c(b"123456789") == 0xE3069283
+    back = load_savedmodel_bundle(graph, plan)
+    assert set(back) == set(w)
+    for k in w:
+        np.testing.assert_array_equal(back[k], w[k])
+    # the model-entry route: the bundle wins over a (here: different) weights file
+    other = tmp_path / "other.weights.npz"
+    save_npz(other, random_weights(plan, seed=12))
+    got = load_weights({"graph": graph, "weights_npz": other}, plan)
+    for k in w:
+        np.testing.assert_array_equal(got[k], w[k])
+
+
+def test_bundle_loader_refuses_instead_of_guessing(tmp_path):
+    """A bundle whose layers do not line up with the plan - a missing layer, swapped variable names, a wrong shape - is
+    an error that names both sides, never a best-effort assignment."""
+    from conftest import load_model_cfg
+    from jaeger_amd import savedmodel_lite as S
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import bundle_checkpoint_keys, load_savedmodel_bundle, random_weights
+    plan = build_plan(load_model_cfg("baseline500"))
+    w = random_weights(plan, seed=11)
+    keys = bundle_checkpoint_keys(plan)
+    base = {keys[k]: v for k, v in w.items()}
+
+    def write(tensors, sub):
+        S.write_bundle(tmp_path / sub / "variables", tensors)
+        return tmp_path / sub
+
+    first_bias = next(k for k in sorted(base) if k.endswith("/bias/.ATTRIBUTES/VARIABLE_VALUE"))
+    missing = {k: v for k, v in base.items() if k != first_bias}
+    with pytest.raises(ValueError, match="holds|weighted layers"):
+        load_savedmodel_bundle(write(missing, "a"), plan)
+    renamed = {k.replace("/gamma/", "/scale/"): v for k, v in base.items()}
+    with pytest.raises(ValueError, match="holds"):
+        load_savedmodel_bundle(write(renamed, "b"), plan)
+    kern = next(k for k in sorted(base) if k.endswith("/_kernel/.ATTRIBUTES/VARIABLE_VALUE") and base[k].ndim == 3)
+    reshaped = dict(base)
+    reshaped[kern] = np.zeros(base[kern].shape[:-1] + (base[kern].shape[-1] + 1,), np.float32)
+    with pytest.raises(ValueError, match="shape"):
+        load_savedmodel_bundle(write(reshaped, "c"), plan)
