@@ -21,6 +21,24 @@ for cfg in default baseline500; do
     timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_${cfg}_g$i -- python3 $R/bench.py --config $cfg --contigs $n --steps 1 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-e2e > /dev/null 2> $O/pmc_${cfg}_g$i.err
   done
 done
+# the producer / consumer kernel (JG_OPT_CONV_PC = 1) through the same SQ / GRBM passes, an interleaved A/B against the
+# two-workgroup kernel on this box, and the per-role cycle stamps of its experiment build (if that library was shipped)
+i=4
+for grp in "$G_SQ" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_default_g$i -- python3 $R/bench.py --contigs 1500 --steps 1 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-e2e --conv-pc 1 > /dev/null 2> $O/pmc_default_g$i.err
+done
+( cd $R
+  for r in 1 2 3; do for pc in 0 1; do
+    timeout 300 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-e2e --conv-pc $pc > $O/ab_pc${pc}_$r.json 2>/dev/null
+    python3 -c "import json; d=json.load(open('$O/ab_pc${pc}_$r.json')); print('conv_pc=$pc round $r:', d['value'], 'Mbp/s  k5 frac', d['roofline']['frac'], ' avg launch ms', d['roofline']['avg_launch_ms'])"
+  done; done > $O/pc_ab.txt
+  cat $O/pc_ab.txt
+  if [ -f jaeger_amd/libjaeger_hip_stamp.so ]; then
+    JAEGER_HIP_LIB=jaeger_amd/libjaeger_hip_stamp.so timeout 300 python3 bench.py --contigs 1500 --steps 1 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-e2e --conv-pc 1 > /dev/null 2> $O/pc_stamp.err
+    grep PCSTAMP $O/pc_stamp.err | grep "rows=12288" | sort | uniq -c | sort -rn | head -0
+    grep PCSTAMP $O/pc_stamp.err | grep "rows=12288" | tail -6 > $O/pc_stamps.txt; cat $O/pc_stamps.txt
+  fi )
 HASH=$(cd $R && python3 -c "import bench; print(bench.kernel_hash())")
 python3 - <<PY
 import csv, glob, collections, json
@@ -32,7 +50,7 @@ def kname(name):
     return None
 raw = {}
 for cfg in ("default", "baseline500"):
-    for g in (1, 2, 3, 4):
+    for g in (1, 2, 3, 4, 5, 6):
         d = "%s/pmc_%s_g%d" % (O, cfg, g)
         cc = sorted(glob.glob(d + "/*/*counter_collection.csv")); kt = sorted(glob.glob(d + "/*/*kernel_trace.csv"))
         if not cc: continue
