@@ -720,7 +720,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
     // size, layers.py:1787) ride the 5-tap kernel: weights in the middle taps, the matrix-core work of the others skipped
     hp.as_k5 = op.k >= 1 && op.k <= 4 && op.in_buf != JG_BUF_IDS;       // (2- and 4-tap convs the same way)
     const int kk = hp.as_k5 ? 5 : op.k, kdil = (hp.as_k5 && op.k == 1) ? 1 : op.dilation;
-    if (op.stride != 1 && !(op.stride == 2 && kk == 5 && op.in_buf != JG_BUF_IDS)) { fail("strided conv"); continue; }
+    if (op.stride != 1 && !(op.stride == 2 && (kk == 5 || kk == 7 || kk == 9) && op.in_buf != JG_BUF_IDS)) { fail("strided conv"); continue; }
     // (a first conv on ids runs as the table variant whatever its tap count, when the table fits LDS)
     static const bool no_lut = jg_exp_env("JG_NO_LUT") != nullptr;
     const bool lut_ok = !no_lut && op.in_buf == JG_BUF_IDS && (op.in_mask == JG_BUF_IDS || op.in_mask < 0) && op.cout <= 128 &&
@@ -732,9 +732,8 @@ static int prepare_f16(jg_model *m, const float *weights) {
       fail("conv width is not 32, 64, 80..128 or a multiple of 128 channels");
       continue;
     }
-    // only the k = 5 kernels are built with run-time output geometry (other widths than 128, stride 2); a first conv of
-    // up to 128 channels runs as the table variant, which has it too (checked below: no table -> 128 channels only)
-    if (op.in_buf != JG_BUF_IDS && kk != 5 && op.cout != 128) { fail("conv width is not 128 channels (k = 7 / 9)"); continue; }
+    // (the k = 5, 7 and 9 kernels are all built with run-time output geometry - other widths than 128, stride 2; a first
+    // conv of up to 128 channels runs as the table variant, which has it too: no table -> 128 channels only, below)
     if (op.in_buf == JG_BUF_IDS && op.cout > 128) { fail("first conv wider than 128 channels"); continue; }
     if (op.in_buf != JG_BUF_IDS && op.cin % 16 != 0) { fail("conv input width is not a multiple of 16"); continue; }
     bool conv_ok = true;

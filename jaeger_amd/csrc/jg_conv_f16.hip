@@ -11,6 +11,12 @@ int jg_conv_f16_part_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_n64(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_n32(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_g128(jg_engine *e, const ConvHArgs &a, hipStream_t s);
+int jg_conv_f16_part_x8(jg_engine *e, const ConvHArgs &a, hipStream_t s);     // k = 7: 64 / 32-channel tiles, general tile
+int jg_conv_f16_part_x9(jg_engine *e, const ConvHArgs &a, hipStream_t s);
+int jg_conv_f16_part_x10(jg_engine *e, const ConvHArgs &a, hipStream_t s);
+int jg_conv_f16_part_x11(jg_engine *e, const ConvHArgs &a, hipStream_t s);    // k = 9
+int jg_conv_f16_part_x12(jg_engine *e, const ConvHArgs &a, hipStream_t s);
+int jg_conv_f16_part_x13(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 bool jg_conv_pc_supports(const ConvHArgs &a);                                  // jg_conv_pc.hip
 int jg_conv_pc_launch(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 
@@ -127,12 +133,15 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   const_cast<ConvHArgs &>(a).dbg = jg_dbg_env();
   JG_REQUIRE(!a.lut_one_half, JG_ERR_INVALID, "conv_f16x3: lut_one_half without a table");
   if (a.cw != HN) {
-    JG_REQUIRE(a.k == 5, JG_ERR_UNSUPPORTED, "conv_f16x3: narrow convs are only built for k = 5");
-    return a.cw == 64 ? jg_conv_f16_part_n64(e, a, s) : jg_conv_f16_part_n32(e, a, s);
+    if (a.k == 5) return a.cw == 64 ? jg_conv_f16_part_n64(e, a, s) : jg_conv_f16_part_n32(e, a, s);
+    JG_REQUIRE(!a.flat, JG_ERR_UNSUPPORTED, "conv_f16x3: window-packed tiling is only built for k = 5");
+    if (a.k == 7) return a.cw == 64 ? jg_conv_f16_part_x8(e, a, s) : jg_conv_f16_part_x9(e, a, s);
+    return a.cw == 64 ? jg_conv_f16_part_x11(e, a, s) : jg_conv_f16_part_x12(e, a, s);
   }
   if (a.cout != HN || a.ostride != 1 || a.tap_lo != 0 || a.tap_hi != a.k - 1) {     // (ch0 != 0 implies cout > 128)
-    JG_REQUIRE(a.k == 5, JG_ERR_UNSUPPORTED, "conv_f16x3: cout=%d out-stride %d is only built for k = 5", a.cout, a.ostride);
-    return jg_conv_f16_part_g128(e, a, s);
+    if (a.k == 5) return jg_conv_f16_part_g128(e, a, s);
+    JG_REQUIRE(!a.flat, JG_ERR_UNSUPPORTED, "conv_f16x3: window-packed tiling is only built for k = 5");
+    return a.k == 7 ? jg_conv_f16_part_x10(e, a, s) : jg_conv_f16_part_x13(e, a, s);
   }
   // the residual stacks' 128 -> 128 five-tap convs: producer / consumer kernel (math waves + DMA / epilogue helper waves);
   // JG_OPT_CONV_PC = 0 keeps them on the two-workgroup kernel below (same results bit for bit)

@@ -1300,4 +1300,33 @@ int jg_conv_f16_part_g128(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   jg_set_error("conv_f16x3: stage pattern 0x%x has no compiled narrow-conv epilogue", a.ep);
   return JG_ERR_UNSUPPORTED;
 }
+#elif JG_CONV_PART >= 8 && JG_CONV_PART <= 13  // run-time output geometry, k = 7 and 9, row-tiled: 64 / 32-channel tiles and the
+                                               // general 128-wide tile (other widths, more than 128 channels, stride 2)
+#define JG_X_CW (((JG_CONV_PART - 8) % 3) == 0 ? 64 : ((JG_CONV_PART - 8) % 3) == 1 ? 32 : 129)
+#define JG_X_K ((JG_CONV_PART - 8) / 3 == 0 ? 7 : 9)
+#define JG_X_NAME2(p) jg_conv_f16_part_x##p
+#define JG_X_NAME(p) JG_X_NAME2(p)
+int JG_X_NAME(JG_CONV_PART)(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  switch (a.ep) {
+#define JG_CASE(ep) case (ep): return launch_ke<JG_X_K, (ep), false, JG_X_CW>(e, a, s);
+    JG_CASE(0u)
+    JG_CASE(JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_AFF | JG_EP_ACT1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2)
+    JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1)
+    JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ACT1)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1)
+    JG_CASE(JG_EP_NMD1)
+    JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
+    JG_CASE(JG_EP_NORM1_DYT)
+    JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
+#undef JG_CASE
+    default: break;
+  }
+  jg_set_error("conv_f16x3: stage pattern 0x%x has no compiled k = 7 / 9 run-time-geometry epilogue", a.ep);
+  return JG_ERR_UNSUPPORTED;
+}
 #endif

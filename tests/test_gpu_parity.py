@@ -173,6 +173,51 @@ def test_forward_pyramid_resnet(precision):
                   placement={"convs": 36, "convs_f16x3": 36, "layout_conversions": 0, "small_fused": False})
 
 
+@pytest.mark.parametrize("ksize", [7, 9])
+def test_forward_pyramid_resnet_with_seven_and_nine_tap_blocks(ksize):
+    """The pyramid ResNet with 7- / 9-tap residual blocks: convs of 32 / 64 / 256 channels and stride-2 convs with 7 or 9 taps
+    run on the split-f16 kernels' run-time-geometry instantiations for those tap counts (round 3; before, k = 7 / 9 was
+    built for exactly 128 channels at stride 1 and everything else fell to the exact-f32 kernel with layout conversions
+    either side)."""
+    import copy
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("pyramid"))
+    n_blocks = 0
+    for layer in cfg["representation_learner"]["hidden_layers"]:
+        if layer["name"] == "residual_block":
+            layer["config"]["kernel_size"] = ksize
+            layer["config"]["dilation_rate"] = min(int(layer["config"].get("dilation_rate", 1)), 64 // (ksize - 1))
+            n_blocks += 1
+    assert n_blocks >= 8
+    weights = ofwd.random_weights(cfg, seed=38341)
+    for key in weights:
+        if key.startswith("rep/") and key.endswith("/kernel"):
+            weights[key] = weights[key] * np.float32(0.7)
+    rng = np.random.Generator(np.random.PCG64(31 + ksize))
+    fsize, n_win = 2000, 6
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.01)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    lens[1::3] = rng.integers(fsize // 2, fsize, lens[1::3].size)
+    ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, precision="f16x3")
+    pl = eng.model.placement()
+    print(eng.model.describe())
+    assert pl["convs_f16x3"] == pl["convs"] and pl["layout_conversions"] == 0, (pl, eng.model.describe())
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    again = eng.predict_windows(seq, starts, lens, fsize)
+    assert eng.model.precision == "f16x3"
+    eng.close()
+    for k in ("prediction", "reliability"):
+        np.testing.assert_array_equal(got[k], again[k])
+        err = float(np.abs(got[k] - ref[k]).max())
+        print(ksize, k, f"{err:.2e}", float(np.abs(ref[k]).max()))
+        assert err <= TOL, (k, err)
+
+
 def test_forward_pyramid_resnet_short_windows_chunked():
     _forward_case("pyramid", 2000, 9, 22, n_frac=0.03, short=True, chunk=4, precision="f16x3", gain=0.85)
     _forward_case("pyramid", 900, 5, 23, n_frac=0.0, precision="f16x3", gain=0.85)
