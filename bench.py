@@ -285,20 +285,21 @@ def spawn_ranks(n: int, oversubscribe: bool = False, timeout_s: float = 1800.0) 
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=err,
                                       start_new_session=True))
     deadline = time.monotonic() + timeout_s
-    out, timed_out = b"", False
-    try:
-        out = procs[0].communicate(timeout=max(1.0, deadline - time.monotonic()))[0]
-        for p in procs[1:]:
-            p.wait(timeout=max(1.0, deadline - time.monotonic()))
-    except subprocess.TimeoutExpired:
-        timed_out = True
-    # a rank that died leaves the others in a collective: give them a moment, then end every group we started
-    for p in procs:
-        if p.poll() is None:
-            try:
-                p.wait(timeout=0.0 if timed_out else 20.0)
-            except subprocess.TimeoutExpired:
-                timed_out = True
+    timed_out, failed_at = False, None
+    out_chunks: list[bytes] = []
+    import threading
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()                                        # rank 0's one JSON line (drained so that the pipe never fills)
+    while any(p.poll() is None for p in procs):
+        now = time.monotonic()
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = now                               # a rank died: the others sit in a collective - a short grace, then end them
+        if now > deadline:
+            timed_out = True
+            break
+        if failed_at is not None and now > failed_at + 15.0:
+            break
+        time.sleep(0.2)
     for p in procs:
         if p.poll() is None:
             try:
@@ -306,6 +307,8 @@ def spawn_ranks(n: int, oversubscribe: bool = False, timeout_s: float = 1800.0) 
             except ProcessLookupError:
                 pass
             p.wait()
+    reader.join(timeout=10.0)
+    out = b"".join(out_chunks)
     rcs = [p.returncode for p in procs]
     for r, (rc, err) in enumerate(zip(rcs, errs)):
         err.seek(0)
@@ -347,7 +350,7 @@ def main():
     ap.add_argument("--dump-gather", default=None,
                     help="tests only: rank 0 writes the gathered (or, with one rank, its own) logits of the last step to "
                          "this .npy file")
-    ap.add_argument("--conv-pc", type=int, choices=[0, 1], default=0,
+    ap.add_argument("--conv-pc", type=int, choices=[0, 1, 2], default=0,
                     help="A/B switch: 128-channel five-tap convs on the producer / consumer kernel (1, the default) or "
                          "on the two-workgroup kernel (0); same results bit for bit")
     ap.add_argument("--timed-dbg", type=int, default=None,
@@ -400,7 +403,7 @@ def main():
     eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=local_rank, chunk=args.chunk,
                           precision=args.precision)
     mode = eng.model.precision
-    eng.device.set_conv_pc(bool(args.conv_pc))
+    eng.device.set_conv_pc(args.conv_pc)
     if args.timed_dbg is not None and "_exp" not in _lib.lib_path().name:
         print("bench.py: --timed-dbg needs the experiment build (make -C jaeger_amd/csrc exp; "
               "JAEGER_HIP_LIB=jaeger_amd/libjaeger_hip_exp.so)", file=sys.stderr)

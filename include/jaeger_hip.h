@@ -127,8 +127,9 @@ int jg_engine_sync(jg_engine *e);
  * previous group is encoded and classified; the device never holds more than two spans of bases.  This is the
  * "host-DRAM -> HBM streamed" ingest of BASELINE.json configs[4]; the reference streams Python strings through
  * tf.data instead (commands/predict.py:186-245).
- * JG_OPT_CONV_PC (default 0 while the kernel is being tuned): the 128 -> 128 channel five-tap convs of the residual stacks (layers.py:1882-1915) run on
- * the producer / consumer kernel (jg_conv_pc.hip); 0 = on the two-workgroup kernel.  Same results bit for bit - the
+ * JG_OPT_CONV_PC (default 0): which kernel runs the 128 -> 128 channel five-tap convs of the residual stacks
+ * (layers.py:1882-1915): 0 = the two-workgroup kernel, 1 = the producer / consumer kernel (jg_conv_pc.hip), 2 = the
+ * two-workgroup kernel with the producer / consumer experiment's pipelined main loop.  Same results bit for bit - the
  * switch exists for A/B timing and for the test that asserts exactly that. */
 enum { JG_OPT_STREAM_BYTES = 1, JG_OPT_CONV_PC = 2 };
 int jg_engine_set_option(jg_engine *e, int key, int64_t value);

@@ -88,7 +88,7 @@ extern "C" int jg_engine_set_option(jg_engine *e, int key, int64_t value) {
       e->stream_bytes = value;
       return JG_OK;
     case JG_OPT_CONV_PC:
-      JG_REQUIRE(value == 0 || value == 1, JG_ERR_INVALID, "jg_engine_set_option: JG_OPT_CONV_PC takes 0 or 1, got %lld", (long long)value);
+      JG_REQUIRE(value >= 0 && value <= 2, JG_ERR_INVALID, "jg_engine_set_option: JG_OPT_CONV_PC takes 0, 1 or 2, got %lld", (long long)value);
       e->conv_pc = (int)value;
       return JG_OK;
     default:

@@ -146,7 +146,7 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   // the residual stacks' 128 -> 128 five-tap convs: producer / consumer kernel (math waves + DMA / epilogue helper waves);
   // JG_OPT_CONV_PC = 0 keeps them on the two-workgroup kernel below (same results bit for bit)
   static const bool no_pc = jg_exp_env("JG_NO_PC") != nullptr;
-  if (e->conv_pc && !no_pc && a.dbg == 0 && jg_conv_pc_supports(a)) return jg_conv_pc_launch(e, a, s);
+  if (e->conv_pc == 1 && !no_pc && a.dbg == 0 && jg_conv_pc_supports(a)) return jg_conv_pc_launch(e, a, s);
   if (a.flat) {
     JG_REQUIRE(a.k == 5 && a.ostride == 1, JG_ERR_UNSUPPORTED, "conv_f16x3: window-packed tiling is only built for k = 5, stride 1");
     return jg_conv_f16_part_flat(e, a, s);

@@ -37,6 +37,7 @@
 // (JG_CONV_PART, see the bottom of this file).
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "jg_common.h"
 
@@ -90,7 +91,11 @@ static __device__ unsigned long long jg_stamp_acc[8];
 // 4 x 1, 64 positions x 64 / 32 channels each, run-time geometry too - the weight slices and the epilogue table keep
 // their 128-wide (zero-padded) layout, only the matrix-core work and the outputs shrink.
 // TANH: compiled for the tanh-GELU alone (the residual stacks' hot patterns: half the code, inside the instruction cache).
-template <int K, unsigned EP, bool LUT = false, bool FLAT = false, int CW = 128, bool TANH = false>
+// PIPE (k = 5, 128 channels, dilation 3, an even number of input chunks): the main loop of the producer / consumer
+// experiment's math wave (jg_conv_pc.hip) in this kernel - MFMA fragments of the next 12-MFMA group are requested while the
+// current group is issued, dealt out one LDS read per MFMA; a step's barrier is taken before the step's last group
+// is issued; the ring's DMA pieces ride behind single accumulator blocks; the tile's first products start from C = 0.
+template <int K, unsigned EP, bool LUT = false, bool FLAT = false, int CW = 128, bool TANH = false, bool PIPE = false>
 // K = 5 fits two workgroups per CU in LDS (<= 80 KB each): hold the register file to 256 per
 // lane so that both are really resident (without the bound hipcc takes ~340 and the second
 // workgroup of a CU only starts when the first has finished).
@@ -356,7 +361,141 @@ void conv_f16x3_kernel(ConvHArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if constexpr (!LUT) for (int cc = 0; cc < a.cc_in; ++cc) {
+    if constexpr (PIPE) {
+      static_assert(K == 5 && !LUT && CW == 128, "the pipelined main loop is built for the 128-channel five-tap convs");
+      constexpr int DIL = 3;                       // (launch_ke checks a.dil)
+      struct XF { uint4 h[2], l[2]; };
+      struct WF { uint4 h[2], l[2]; };
+      XF xf[2];
+      WF wf[2];
+      const uint4 *Wb = Wbuf + w_frag;
+      auto ldx = [&](XF &f, const uint4 *A, int t, int tp) {
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq) {
+          f.h[tq] = A[(tp * 2 + tq) * 32 + t * DIL];
+          f.l[tq] = A[2 * rows_a + (tp * 2 + tq) * 32 + t * DIL];
+        }
+      };
+      auto ldw = [&](WF &f, int t) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          f.h[tn] = Wb[t * W_ITEMS + tn * 32];
+          f.l[tn] = Wb[t * W_ITEMS + 2 * HN + tn * 32];
+        }
+      };
+      auto mm = [&](auto zero_c, const WF &w, const XF &x, int tp, auto &&between) {
+        constexpr bool ZERO = decltype(zero_c)::value;
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            f32x16 &c = acc[tp * 2 + tq][tn];
+            const half8 wh = *reinterpret_cast<const half8 *>(&w.h[tn]), wl = *reinterpret_cast<const half8 *>(&w.l[tn]);
+            const half8 xh = *reinterpret_cast<const half8 *>(&x.h[tq]), xl = *reinterpret_cast<const half8 *>(&x.l[tq]);
+            if constexpr (ZERO) {
+              const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, z, 0, 0, 0);
+            } else {
+              c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, c, 0, 0, 0);
+            }
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, c, 0, 0, 0);
+            between(tq * 2 + tn);
+          }
+      };
+      const bool last_pass_ = pass == my_pairs - 1;
+      // step A of the pass's first chunk: its operands were requested by the prologue / the previous pass
+      wait_vm<2 * W_ITERS>();
+      zero_fill(0);
+      __syncthreads();
+      ldw(wf[0], 0);
+      ldx(xf[0], Abuf + x_frag, 0, 0);
+      for (int cp = 0; cp < a.cc_in / 2; ++cp) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int cc = 2 * cp + half;
+          const bool last_chunk = cc == a.cc_in - 1;
+          const bool tail = last_chunk && last_pass_;
+          const int ncc = last_chunk ? 0 : cc + 1;
+          const uint4 *A = Abuf + half * a_items + x_frag;
+          const uint4 *An = Abuf + (half ^ 1) * a_items + x_frag;
+#pragma unroll
+          for (int g = 0; g < 10; ++g) {
+            const int t = g >> 1, tp = g & 1;
+            const bool step_end = g == 3 || g == 7 || g == 9;
+            const bool pass_end = g == 9 && last_chunk;
+            if (step_end && !pass_end) {
+              if (g == 3) {
+                if (tail) wait_vm<W_ITERS>();
+                else if (x_last_wave) wait_vm<W_ITERS + A_ITERS>();
+                else wait_vm<W_ITERS + A_ITERS - 1>();
+              } else if (g == 7) {
+                if (tail) wait_vm<0>();
+                else if (x_last_wave) wait_vm<2 * W_ITERS + A_ITERS>();
+                else wait_vm<2 * W_ITERS + A_ITERS - 1>();
+              } else {
+                wait_vm<2 * W_ITERS>();
+                zero_fill(half ^ 1);
+              }
+              __syncthreads();       // (lgkmcnt 0: this step's last fragments are in registers, the slots may be refilled)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!pass_end) {
+              if (g < 9) {
+                ldx(xf[(g + 1) & 1], A, (g + 1) >> 1, (g + 1) & 1);
+                if (tp == 1) ldw(wf[(half + t + 1) & 1], t + 1);
+              } else {
+                ldx(xf[0], An, 0, 0);
+                ldw(wf[(half ^ 1) & 1], 0);
+              }
+            }
+            auto ring = [&](int k) {
+              if (g != 0 && g != 4 && g != 8) return;
+              __builtin_amdgcn_sched_barrier(0);
+              if (g == 0) {
+                const char *sbw = reinterpret_cast<const char *>(a.wh) + ((size_t)(4 * a.cc_in * 2 + cc * 2) * HN) * 16;
+                if (k == 0) glds16(sbw, w_voff[0], ldsW + 4 * (W_ITEMS * 16));
+                if (k == 1) glds16(sbw, w_voff[1], ldsW + 4 * (W_ITEMS * 16) + HT * 16);
+                if (!tail) {
+                  if (k == 0 && last_chunk) build_pieces(np);
+                  const char *sbx = x_base + (size_t)ncc * x_cc_stride;
+                  const unsigned dst = ldsA + (half ^ 1) * (a_items * 16);
+                  if (k == 1) glds16_nt(sbx, x_voff[0], dst);
+                  if (k == 2) { glds16_nt(sbx, x_voff[1], dst + HT * 16); glds16_nt(sbx, x_voff[2], dst + 2 * (HT * 16)); }
+                  if (k == 3) {
+                    glds16_nt(sbx, x_voff[3], dst + 3 * (HT * 16));
+                    if (x_last_wave) {
+                      if ((a_pk[A_ITERS - 1] >> 20) < NT) glds16_nt(sbx, x_voff[A_ITERS - 1], dst + (A_ITERS - 1) * (HT * 16));
+                    }
+                  }
+                }
+              } else if (!tail) {
+                const int tt = (g == 4 ? 0 : 2) + (k >> 1);
+                const char *sbw = reinterpret_cast<const char *>(a.wh) + ((size_t)(tt * a.cc_in * 2 + ncc * 2) * HN) * 16;
+                glds16(sbw, w_voff[k & 1], ldsW + tt * (W_ITEMS * 16) + (k & 1) * (HT * 16));
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            };
+            if (half == 0 && g < 2) {
+              if (cp == 0) mm(std::true_type{}, wf[(half + t) & 1], xf[g & 1], tp, ring);
+              else mm(std::false_type{}, wf[(half + t) & 1], xf[g & 1], tp, ring);
+            } else {
+              mm(std::false_type{}, wf[(half + t) & 1], xf[g & 1], tp, ring);
+            }
+            if (g != 0 && g != 4 && g != 8) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      xc += a.cc_in;
+    }
+    if constexpr (!LUT && !PIPE) for (int cc = 0; cc < a.cc_in; ++cc) {
       const int abuf = xc & 1;
       const bool last_chunk = cc == a.cc_in - 1;
       const bool tail = last_chunk && pass == my_pairs - 1;     // nothing is issued behind this chunk
@@ -1087,7 +1226,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
       if ((!(vmax <= 65000.0f) || vnan) && a.overflow != nullptr && a.dbg == 0) atomicOr(a.overflow, 1);
       JG_PRIO_MAIN();
     }
-    zero_acc();
+    if constexpr (!PIPE) zero_acc();          // (the pipelined loop starts every tile's accumulators from C = 0)
 #pragma unroll
     for (int u = 0; u < NT; ++u) cur[u] = np[u];
     tiles_of(pass + 2, np);
@@ -1100,12 +1239,12 @@ void conv_f16x3_kernel(ConvHArgs a) {
   JG_ST_END;
 }
 
-template <int K, unsigned EP, bool FLAT = false, int CW = 128, bool TANH = false>
+template <int K, unsigned EP, bool FLAT = false, int CW = 128, bool TANH = false, bool PIPE = false>
 int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   const int smem = jg_conv_f16_lds_bytes(K, a.dil);
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<K, EP, false, FLAT, CW, TANH>),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16x3_kernel<K, EP, false, FLAT, CW, TANH, PIPE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -1118,7 +1257,7 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   int grid = ((smem <= 80 * 1024 && !one_wg) ? 2 : 1) * e->n_cu;
   if (grid > n_pairs) grid = n_pairs;
   ConvHArgs b = a;
-  hipLaunchKernelGGL((conv_f16x3_kernel<K, EP, false, FLAT, CW, TANH>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, b);
+  hipLaunchKernelGGL((conv_f16x3_kernel<K, EP, false, FLAT, CW, TANH, PIPE>), dim3((unsigned)grid), dim3(HT), (size_t)smem, s, b);
   JG_HIP(hipGetLastError());
 #ifdef JG_STAMP
   {
@@ -1132,6 +1271,18 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   }
 #endif
   return JG_OK;
+}
+
+// the residual stacks' hot tanh-GELU patterns (k = 5, 128 channels): the pipelined main loop when the engine asks for it
+// (JG_OPT_CONV_PC = 2) and the geometry is the one it is built for
+template <int K, unsigned EP, bool FLAT>
+int launch_hot(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
+  if constexpr (K == 5) {
+    if (e->conv_pc == 2 && a.dil == 3 && a.cc_in % 2 == 0 && a.dbg == 0) return launch_ke<5, EP, FLAT, 128, true, true>(e, a, s);
+    return launch_ke<5, EP, FLAT, 128, true>(e, a, s);
+  } else {
+    return launch_ke<K, EP, FLAT>(e, a, s);
+  }
 }
 
 #if JG_CONV_PART == 4
@@ -1186,18 +1337,18 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     case 0u: return launch_ke<K, 0u>(e, a, s);           /* plain affine: a LayerNorm follows */      \
     case (JG_EP_NMD1): return launch_ke<K, (JG_EP_NMD1)>(e, a, s);                                   \
     case (JG_EP_ACT1):                                   /* the residual stacks' three hot patterns: tanh-GELU build */ \
-      if (K == 5 && a.act_kind == JG_ACT_GELU_TANH) return launch_ke<K, (JG_EP_ACT1), false, 128, true>(e, a, s); \
+      if (K == 5 && a.act_kind == JG_ACT_GELU_TANH) return launch_hot<K, (JG_EP_ACT1), false>(e, a, s); \
       return launch_ke<K, (JG_EP_ACT1)>(e, a, s);                                                     \
     case (JG_EP_NORM1_AFF | JG_EP_ACT1): return launch_ke<K, (JG_EP_NORM1_AFF | JG_EP_ACT1)>(e, a, s); \
     case (JG_EP_NORM1_DYT | JG_EP_ACT1): return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ACT1)>(e, a, s); \
     case (JG_EP_ADD | JG_EP_ACT1):                                                                   \
-      if (K == 5 && a.act_kind == JG_ACT_GELU_TANH) return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1), false, 128, true>(e, a, s); \
+      if (K == 5 && a.act_kind == JG_ACT_GELU_TANH) return launch_hot<K, (JG_EP_ADD | JG_EP_ACT1), false>(e, a, s); \
       return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1)>(e, a, s);                                         \
     case (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1):                                                 \
       return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1)>(e, a, s);                      \
     case (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2):                       \
       if (K == 5 && a.act_kind == JG_ACT_GELU_TANH)                                                  \
-        return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2), false, 128, true>(e, a, s); \
+        return launch_hot<K, (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2), false>(e, a, s); \
       return launch_ke<K, (JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2)>(e, a, s); \
     case (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2):     \
       return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_DYT | JG_EP_ACT2)>(e, a, s); \
@@ -1241,7 +1392,7 @@ int jg_conv_f16_part_flat(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
 #define JG_CASE(ep) case (ep): return launch_ke<5, (ep), true>(e, a, s);
 #define JG_CASE_HOT(ep)     /* the residual stacks' hot patterns: a tanh-GELU build beside the general one */ \
   case (ep):                                                                                                  \
-    return a.act_kind == JG_ACT_GELU_TANH ? launch_ke<5, (ep), true, 128, true>(e, a, s) : launch_ke<5, (ep), true>(e, a, s);
+    return a.act_kind == JG_ACT_GELU_TANH ? launch_hot<5, (ep), true>(e, a, s) : launch_ke<5, (ep), true>(e, a, s);
     JG_CASE_HOT(JG_EP_ACT1)
     JG_CASE(JG_EP_NORM1_AFF | JG_EP_ACT1)
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ACT1)

@@ -84,7 +84,7 @@ class HipDevice:
     def set_conv_pc(self, on: bool):
         """128 -> 128 five-tap convs on the producer / consumer kernel (default) or on the two-workgroup kernel
         (JG_OPT_CONV_PC); the two give the same results bit for bit."""
-        L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_CONV_PC, 1 if on else 0), "jg_engine_set_option")
+        L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_CONV_PC, int(on)), "jg_engine_set_option")
 
     def stream_stats(self) -> dict:
         """Streaming statistics of the last ``jg_predict_windows`` call on this engine."""

@@ -11,6 +11,7 @@ Also the N-rank launch of ``bench.py --gpus N`` (two ranks sharing the one GPU o
 import json
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -187,10 +188,12 @@ def test_bench_failing_rank_is_reported_and_times_out(tmp_path):
     import os
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--oversubscribe", "--contigs", "50", "--steps", "1",
            "--warmup", "0", "--no-cpu-baseline", "--no-exact-f32", "--rank-timeout", "240"]
+    t0 = time.time()
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, JAEGER_BENCH_FAIL_RANK="1"))
     assert res.returncode != 0
     assert "rank 1" in res.stderr and "JAEGER_BENCH_FAIL_RANK" in res.stderr, res.stderr[-2000:]
+    assert time.time() - t0 < 200, "the surviving rank was not ended after the grace period"
 
 
 def test_bench_gpus_flag_spawns_ranks():

@@ -458,16 +458,17 @@ def test_producer_consumer_conv_matches_two_workgroup_kernel(name, fsize, n_win,
     windows = [seq[i * fsize:i * fsize + n].tobytes() for i, n in enumerate(lens)]
     ids = oenc.encode_windows(windows, fsize, pad_to=frame_length(fsize))
     eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, precision="f16x3")
-    eng.device.set_conv_pc(False)
+    eng.device.set_conv_pc(0)
     classic = eng.model.forward(ids)
-    eng.device.set_conv_pc(True)
-    bad = 0
-    for rep in range(12):
-        got = eng.model.forward(ids, chunk=(0, 7, 64)[rep % 3])
-        bad += any(not np.array_equal(classic[k], got[k]) for k in classic)
+    for mode in (1, 2):                              # 1: producer / consumer kernel; 2: two-workgroup kernel, pipelined main loop
+        eng.device.set_conv_pc(mode)
+        bad = 0
+        for rep in range(12):
+            got = eng.model.forward(ids, chunk=(0, 7, 64)[rep % 3])
+            bad += any(not np.array_equal(classic[k], got[k]) for k in classic)
+        assert bad == 0, f"JG_OPT_CONV_PC={mode}: {bad}/12 runs differ from the two-workgroup kernel"
     assert eng.model.precision == "f16x3"           # the range guard did not trip
     eng.close()
-    assert bad == 0, f"{bad}/12 runs differ from the two-workgroup kernel"
     if n_win <= 48:
         ref = ofwd.forward(cfg, weights, ids)
         for k in ("prediction", "reliability"):
