@@ -644,6 +644,44 @@ def test_forward_variant_layernorm():
             check_side_output(k, got[k], r)
 
 
+def test_f16_range_guard_in_the_layout_conversion_of_a_mixed_program():
+    """A mixed program hands f32 tensors (here: LayerNorm outputs) to split-f16 convs through ``f32_to_f16s_kernel``.  A
+    value beyond the f16 range would become hi = +Inf, lo = -Inf there and a NaN in the next conv, which a running max
+    does not see: the conversion raises the overflow flag itself, the chunk reruns on the exact-f32 kernels and the
+    logits come out finite and equal to the oracle's relative to their size (ADVICE, round 2)."""
+    import copy
+
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("brain"))
+    layers = cfg["representation_learner"]["hidden_layers"]
+    n_std = 0
+    for layer in layers:
+        if layer["name"] == "masked_batchnorm" and n_std < 1:
+            layer["name"] = "masked_layernorm"              # the norm behind the first conv: LayerNorm -> GELU -> F16S conversion
+            layer["config"] = {}
+            n_std += 1
+    weights = ofwd.random_weights(cfg, seed=31)
+    ln = [k for k in weights if k.endswith("/gamma") and weights[k].shape == (128,)][0]
+    weights[ln] = weights[ln] * np.float32(3.0e5)           # LayerNorm outputs ~1e5..1e6: fine in f32, not in f16
+    rng = np.random.Generator(np.random.PCG64(33))
+    fsize, n_win = 1500, 5
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.01)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0)
+    assert eng.model.precision == "f16x3" and eng.model.placement()["layout_conversions"] >= 1
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    assert eng.model.precision == "f32"                     # the conversion's guard tripped
+    eng.close()
+    ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    assert np.isfinite(got["prediction"]).all() and np.isfinite(got["reliability"]).all()
+    scale = max(1.0, float(np.abs(ref["prediction"]).max()))
+    assert float(np.abs(got["prediction"] - ref["prediction"]).max()) <= 1e-4 * scale
+
+
 @pytest.mark.parametrize("signals", [None, ["energy", "margin", "max_prob"]])
 def test_forward_variant_reliability_signals(signals):
     """reliability_model.mode = nmd_plus_signals (OODSignalLayer, layers.py:1598-1667; builder.py:618-667): the
