@@ -838,7 +838,12 @@ static int prepare_f16(jg_model *m, const float *weights) {
           case JG_ST_ACT:
             h.kind = JG_HST_ACT;
             break;
-          case JG_ST_NMD: h.kind = JG_HST_NMD; hp.nmd_slot = st.arg; break;
+          case JG_ST_NMD:
+            h.kind = JG_HST_NMD;
+            if (hp.nmd_slot < 0) hp.nmd_slot = st.arg;
+            else if (hp.nmd_slot2 < 0) hp.nmd_slot2 = st.arg;
+            else cfail("more than two NMD taps in one conv");
+            break;
           case JG_ST_MASKMUL: h.kind = JG_HST_MASKMUL; break;
           default: cfail("epilogue stage not supported by the split-f16 kernel"); break;
         }
@@ -884,6 +889,17 @@ static int prepare_f16(jg_model *m, const float *weights) {
             hp.act_kind != JG_ACT_GELU_TANH)
           ok = false;               // the DyT patterns are compiled for the tanh-GELU only
         hp.ep = ok ? ep : JG_EP_GENERIC;
+        hp.ep_rt = 0;
+        // a canonical stage list without an instantiation of its own (incl. two NMD taps in one conv): the run-time-flag
+        // epilogue - tanh-GELU stage lists only (it carries every stage kind at once; the erf / ReLU forms beside them spill)
+        const bool narrow_geo = op.in_buf != JG_BUF_IDS && (op.cout != 128 || op.stride != 1 || hp.as_k5);
+        if (ok && hp.act_kind == JG_ACT_GELU_TANH && !(ep & JG_EP_ADD && op.in_buf == JG_BUF_IDS) &&
+            (!jg_conv_f16_has_pattern(ep, op.in_buf == JG_BUF_IDS) || (narrow_geo && !jg_conv_f16_has_narrow_pattern(ep)) ||
+             ((ep & JG_EP_NMD1) && (ep & JG_EP_NMD2)))) {
+          hp.ep_rt = ep;
+          hp.ep = JG_EP_RUNTIME;
+        }
+        if (hp.ep != JG_EP_RUNTIME && hp.nmd_slot2 >= 0) ok = false, hp.ep = JG_EP_GENERIC;   // two taps need the second accumulator
         // Only compiled stage patterns run on the split-f16 path: the interpreted epilogue was measured
         // 12x slower than the compiled ones (and 3x slower than the exact-f32 kernels), so anything else
         // stays on the exact-f32 path.
@@ -892,7 +908,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
         }
         if (conv_ok && op.in_buf != JG_BUF_IDS && (op.cout != 128 || op.stride != 1 || hp.as_k5) && !jg_conv_f16_has_narrow_pattern(hp.ep))
           cfail("the stage list of a conv of other than 128 channels / stride 1 is not one of the patterns compiled for it");
-        if (conv_ok && op.stride == 2 && (hp.ep & (JG_EP_ADD | JG_EP_NMD1 | JG_EP_NMD2)))
+        if (conv_ok && op.stride == 2 && ((hp.ep == JG_EP_RUNTIME ? hp.ep_rt : hp.ep) & (JG_EP_ADD | JG_EP_NMD1 | JG_EP_NMD2)))
           cfail("strided conv with a shortcut or an NMD tap in its epilogue");
       }
       if (conv_ok) {
@@ -1427,6 +1443,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
             }
           }
           if (hp.nmd_slot >= 0) m->part_rows[hp.nmd_slot] = strips_per_win;
+          if (hp.nmd_slot2 >= 0) m->part_rows[hp.nmd_slot2] = strips_per_win;
           if (hp.pool_op >= 0) m->pool_rows = strips_per_win;
           a.out_f16s = hp.out_f16s ? 1 : 0;
           a.act_kind = hp.act_kind;
@@ -1439,6 +1456,8 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           for (int q = 0; q < hp.n_hst; ++q) a.hst[q] = hp.hst[q];
           if (hp.add_slot >= 0) a.addh = reinterpret_cast<const uint4 *>(m->act[hp.add_slot]);
           if (hp.nmd_slot >= 0) a.nmd_out = m->nmd_part[hp.nmd_slot];
+          if (hp.nmd_slot2 >= 0) a.nmd_out2 = m->nmd_part[hp.nmd_slot2];
+          a.ep_rt = hp.ep_rt;
           if (hp.pool_op >= 0) {
             const int64_t need = (int64_t)a.rows * a.tiles_m * strips * op.cout;
             if (need > m->pool_part_cap) {

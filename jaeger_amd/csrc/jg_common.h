@@ -80,6 +80,8 @@ struct ConvArgs {
 #define JG_EP_NORM2_DYT 0x080u
 #define JG_EP_ACT2 0x100u
 #define JG_EP_GENERIC 0xffffu
+#define JG_EP_RUNTIME 0xfffeu  /* the same canonical stage order with the optional stages behind wave-uniform run-time flags
+                                  (ConvHArgs.ep_rt): every canonical stage list without an instantiation of its own */
 #define JG_EPI_ROWS 4   /* parameter rows (affine / dyt stages) of a split-f16 epilogue */
 enum { JG_HST_AFFINE = 1, JG_HST_DYT = 2, JG_HST_ADD = 3, JG_HST_ACT = 4, JG_HST_NMD = 5, JG_HST_MASKMUL = 6 };
 struct HStageArg {
@@ -100,6 +102,8 @@ struct ConvHArgs {
   void *y;                 // F16S [rows][cout_pad/16][4][L_out] items, or f32 (rows, L_out, cout)
   const uint4 *addh;       // residual shortcut in F16S (same geometry as y) or null
   float *nmd_out;          // NMD partial sums [rows][tiles_m * 2][cout] (one row per wave strip) or null
+  float *nmd_out2;         // ... of a second NMD tap in the same conv (JG_EP_RUNTIME only: a tap before norm1 AND one behind act1)
+  unsigned ep_rt;          // JG_EP_RUNTIME: the JG_EP_* bits of the stage list
   float *pool_out;         // fused masked max-pool partials, same geometry; when set the output is not stored
   int *overflow;           // set to 1 when an output leaves the f16 range
   int rows, L_in, L_out;
@@ -194,7 +198,8 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   float *d_epi_lut = nullptr;
   int n_hst = 0, n_epi_rows = 0;
   HStageArg hst[JG_MAX_STAGES] = {};
-  int add_slot = -1, nmd_slot = -1;
+  int add_slot = -1, nmd_slot = -1, nmd_slot2 = -1;     // (nmd_slot2: the second NMD tap of one conv)
+  unsigned ep_rt = 0;       // stage bits when ep == JG_EP_RUNTIME
   int pool_op = -1;         // index of the OP_POOL (masked max) fused into this conv's epilogue, or -1
   int act_kind = JG_ACT_GELU_TANH;   // activation of the op's ACT stages (the compiled patterns allow one kind per op)
   bool pool_f16s = false;   // (MAXPOOL1D ops) input and output are F16S tensors

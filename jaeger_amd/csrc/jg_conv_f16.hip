@@ -52,7 +52,7 @@ int jg_conv_f16_tile_m(void) { return HM; }
 bool jg_conv_f16_has_pattern(unsigned ep, bool first_layer) {
   const unsigned lut[] = {0u, JG_EP_NMD1, JG_EP_ACT1, JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ACT1,
                           JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1,
-                          JG_EP_ACT1 | JG_EP_NORM2_AFF};
+                          JG_EP_ACT1 | JG_EP_NORM2_AFF, JG_EP_RUNTIME};
   const unsigned all[] = {0u, JG_EP_NMD1, JG_EP_ACT1, JG_EP_NORM1_AFF | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ACT1,
                           JG_EP_ADD | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1,
                           JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2,
@@ -64,7 +64,7 @@ bool jg_conv_f16_has_pattern(unsigned ep, bool first_layer) {
                           JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1,
                           JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2,
                           JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2,
-                          JG_EP_NORM1_DYT};
+                          JG_EP_NORM1_DYT, JG_EP_RUNTIME};
   if (first_layer) {
     for (unsigned p : lut) if (p == ep) return true;
     return false;      // (a first layer the table variant cannot take also needs one of `all`: same subset)
@@ -82,7 +82,7 @@ bool jg_conv_f16_has_flat_pattern(unsigned ep) {
                            JG_EP_ACT1 | JG_EP_NORM2_AFF, JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2,
                            JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_AFF | JG_EP_ACT2,
                            JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_DYT | JG_EP_ACT2,
-                           JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2};
+                           JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2, JG_EP_RUNTIME};
   for (unsigned p : flat) if (p == ep) return true;
   return false;
 }
@@ -95,7 +95,8 @@ bool jg_conv_f16_has_narrow_pattern(unsigned ep) {
                           JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ADD | JG_EP_ACT1,
                           JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2 | JG_EP_NORM2_AFF | JG_EP_ACT2,
                           JG_EP_NORM1_DYT | JG_EP_ACT1, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1, JG_EP_NMD1,
-                          JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2, JG_EP_NORM1_DYT, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2};
+                          JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2, JG_EP_NORM1_DYT, JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2,
+                          JG_EP_RUNTIME};
   for (unsigned p : nar) if (p == ep) return true;
   return false;
 }

@@ -912,6 +912,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
       float vmax = 0.f;             // running max |output|: f16-range guard
       bool vnan = false;            // ... and "an output is NaN"
       float nmd_acc[16];            // per-lane NMD sums of the current channel block
+      float nmd_acc2[16];           // ... of a second tap in the same conv (JG_EP_RUNTIME)
       // what a block needs from memory, fetched one block ahead so the loads of block b+1
       // fly under the arithmetic of block b
       struct Pre {
@@ -1022,7 +1023,9 @@ void conv_f16x3_kernel(ConvHArgs a) {
         auto st_gelu = [&]() {
           // DyT patterns (two tanh norms + two activations at a stack end) are compiled for the tanh-GELU only: with
           // the erf / ReLU alternatives beside it the stack-end pattern spilled 576 bytes per lane and ran 10x slower
-          constexpr bool TANH_ONLY = TANH || (EP != JG_EP_GENERIC && ((((EP >> 1) & 3) == 2) || (((EP >> 6) & 3) == 2)));
+          // (the run-time-flag epilogue carries every stage kind at once: tanh-GELU only as well - the planner sees to it)
+          constexpr bool TANH_ONLY = TANH || EP == JG_EP_RUNTIME ||
+                                     (EP != JG_EP_GENERIC && ((((EP >> 1) & 3) == 2) || (((EP >> 6) & 3) == 2)));
           if (TANH_ONLY || a.act_kind == JG_ACT_GELU_TANH) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = fast_gelu(x[r]);
@@ -1034,10 +1037,17 @@ void conv_f16x3_kernel(ConvHArgs a) {
             for (int r = 0; r < 16; ++r) x[r] = fmaxf(x[r], 0.0f);
           }
         };
-        auto st_nmd = [&]() {
+        auto st_nmd = [&](int which = 0) {
           // masked channel sums: accumulated per lane over the wave's four position blocks of this
           // channel block, reduced across lanes once (nmd_flush) - one partial row per 128 positions
           const float mkl = live ? mk : 0.f;
+          if constexpr (EP == JG_EP_RUNTIME) {
+            if (which) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) nmd_acc2[r] = fmaf(x[r], mkl, nmd_acc2[r]);
+              return;
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) nmd_acc[r] = fmaf(x[r], mkl, nmd_acc[r]);
         };
@@ -1062,6 +1072,22 @@ void conv_f16x3_kernel(ConvHArgs a) {
               default: break;
             }
           }
+        } else if constexpr (EP == JG_EP_RUNTIME) {
+          // the canonical order affine [nmd] [norm1] [add] [gelu] [nmd] [norm2] [gelu] with every optional stage behind a
+          // wave-uniform flag: one instantiation for all the canonical stage lists that have none of their own (a few
+          // scalar branches per block; before, such convs fell to the exact-f32 kernel, 4 x slower)
+          const unsigned e_ = a.ep_rt;
+          const int n1 = (int)((e_ >> 1) & 3u), n2 = (int)((e_ >> 6) & 3u);
+          st_affine(0);
+          if (e_ & JG_EP_NMD1) st_nmd(0);
+          if (n1 == 1) st_affine(1);
+          else if (n1 == 2) st_dyt(1, a.alpha1, a.dytmask1);
+          if (e_ & JG_EP_ADD) st_add();
+          if (e_ & JG_EP_ACT1) st_gelu();
+          if (e_ & JG_EP_NMD2) st_nmd((e_ & JG_EP_NMD1) ? 1 : 0);
+          if (n2 == 1) st_affine(n1 ? 2 : 1);
+          else if (n2 == 2) st_dyt(n1 ? 2 : 1, a.alpha2, a.dytmask2);
+          if (e_ & JG_EP_ACT2) st_gelu();
         } else if (!(a.dbg & 32)) {
           // compiled pattern: affine [nmd] [norm1] [add] [gelu] [nmd] [norm2] [gelu], straight line
           constexpr int N1 = (EP >> 1) & 3, N2 = (EP >> 6) & 3;
@@ -1182,14 +1208,26 @@ void conv_f16x3_kernel(ConvHArgs a) {
         const size_t slot = reduced_slot(tile, tn, ch);
         if (i < 16 && tile.valid && ch < a.cout) a.nmd_out[slot] = v;
       };
-      const bool has_nmd = EP == JG_EP_GENERIC ? a.nmd_out != nullptr : (EP & (JG_EP_NMD1 | JG_EP_NMD2)) != 0;
+      const bool has_nmd = (EP == JG_EP_GENERIC || EP == JG_EP_RUNTIME) ? a.nmd_out != nullptr : (EP & (JG_EP_NMD1 | JG_EP_NMD2)) != 0;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) nmd_acc[r] = 0.f;
+        if constexpr (EP == JG_EP_RUNTIME) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) nmd_acc2[r] = 0.f;
+        }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) epi_block(acc[tm][tn], cur[0], tm, tn);
         if (has_nmd) nmd_flush(cur[0], tn);
+        if constexpr (EP == JG_EP_RUNTIME) {
+          if (a.nmd_out2 != nullptr) {
+            const float v2 = lane_reduce(nmd_acc2, [](float x, float y) { return x + y; });
+            int ch2;
+            const size_t slot2 = reduced_slot(cur[0], tn, ch2);
+            if (i < 16 && cur[0].valid && ch2 < a.cout) a.nmd_out2[slot2] = v2;
+          }
+        }
       }
       if (a.pool_out != nullptr) {
         // fused masked global max pool (layers.py:496-538): the block outputs are not stored at all; each
@@ -1321,6 +1359,7 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
                            : launch_lut_e<(JG_EP_NMD1 | JG_EP_NORM1_AFF | JG_EP_ACT1), 129>(e, a, s);
     JG_CASE(JG_EP_NMD1 | JG_EP_NORM1_DYT | JG_EP_ACT1)
     JG_CASE(JG_EP_ACT1 | JG_EP_NORM2_AFF)
+    JG_CASE(JG_EP_RUNTIME)
 #undef JG_CASE
     default: break;
   }
@@ -1372,6 +1411,7 @@ int launch_lut(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     case (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2):                                    \
       return launch_ke<K, (JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)>(e, a, s);         \
     case (JG_EP_NORM1_DYT): return launch_ke<K, (JG_EP_NORM1_DYT)>(e, a, s);                         \
+    case (JG_EP_RUNTIME): return launch_ke<K, (JG_EP_RUNTIME)>(e, a, s);                             \
     default: break;                                                                                  \
   }                                                                                                  \
   jg_set_error("conv_f16x3: stage pattern 0x%x has no compiled epilogue", a.ep);                     \
@@ -1406,6 +1446,7 @@ int jg_conv_f16_part_flat(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NORM2_DYT | JG_EP_ACT2)
     JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
+    JG_CASE(JG_EP_RUNTIME)
 #undef JG_CASE
 #undef JG_CASE_HOT
     default: break;
@@ -1445,6 +1486,7 @@ int jg_conv_f16_part_g128(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
     JG_CASE(JG_EP_NORM1_DYT)
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
+    JG_CASE(JG_EP_RUNTIME)
 #undef JG_CASE
     default: break;
   }
@@ -1474,6 +1516,7 @@ int JG_X_NAME(JG_CONV_PART)(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_CASE(JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
     JG_CASE(JG_EP_NORM1_DYT)
     JG_CASE(JG_EP_NORM1_DYT | JG_EP_ADD | JG_EP_ACT1 | JG_EP_NMD2)
+    JG_CASE(JG_EP_RUNTIME)
 #undef JG_CASE
     default: break;
   }
