@@ -103,17 +103,6 @@ __device__ __forceinline__ float mix_rem(float v, unsigned hi2) {
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// tanh-GELU of two values: the polynomial and the final product as packed f32 instructions (v_pk_mul / v_pk_fma:
-// two elements per issue slot - a lone wave per SIMD issues one vector instruction per 4 cycles, so instruction
-// count is what the epilogue costs), exp2 / rcp per element
-__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 v) {
-  const f32x2 c0 = {-2.3022082f, -2.3022082f}, c1 = {-0.10294324f, -0.10294324f}, one = {1.0f, 1.0f};
-  const f32x2 t = v * (c0 + c1 * (v * v));
-  f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-  e = e + one;
-  const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
-  return v * r;
-}
 
 // One layer's epilogue over the five accumulator blocks of a row.  Lane (n, h) holds position 32 b + n and channels
 // 8 g + 4 h + i in register 4 g + i of block b.  Compiled per pattern (the activation is always the tanh-GELU):
@@ -126,83 +115,247 @@ __device__ __forceinline__ f32x2 gelu_tanh2(f32x2 v) {
 #define JG_SDBG(bit) false
 #endif
 
-template <bool LAST, bool P2, bool ADD, bool SAVE, bool TAP>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], const float *epi, M192 mout, char *act,
-                                         int n, int h, float &vmax, float (&pool)[16], int pool_kind, int dbg,
-                                         float (&tapv)[16]) {
-  (void)dbg;
-  // the lane's 16 channels' parameters, read once per layer (broadcast LDS reads; a read per block and channel
-  // group left the wave waiting on LDS latency twenty times a layer)
-  f32x4 s1[4], t1[4], s2[4], t2[4];
+// the lane's 16 channels' parameters of a layer, read once per layer (broadcast LDS reads; a read per block and channel
+// group left the wave waiting on LDS latency twenty times a layer)
+template <bool P2>
+struct EpiParams {
+  f32x4 s1[4], t1[4], s2[P2 ? 4 : 1], t2[P2 ? 4 : 1];
+  __device__ __forceinline__ void load(const float *epi, int h) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    s1[g] = *reinterpret_cast<const f32x4 *>(epi + 0 * C + g * 8 + h * 4);
-    t1[g] = *reinterpret_cast<const f32x4 *>(epi + 1 * C + g * 8 + h * 4);
-    if constexpr (P2) {
-      s2[g] = *reinterpret_cast<const f32x4 *>(epi + 2 * C + g * 8 + h * 4);
-      t2[g] = *reinterpret_cast<const f32x4 *>(epi + 3 * C + g * 8 + h * 4);
+    for (int g = 0; g < 4; ++g) {
+      s1[g] = *reinterpret_cast<const f32x4 *>(epi + 0 * C + g * 8 + h * 4);
+      t1[g] = *reinterpret_cast<const f32x4 *>(epi + 1 * C + g * 8 + h * 4);
+      if constexpr (P2) {
+        s2[g] = *reinterpret_cast<const f32x4 *>(epi + 2 * C + g * 8 + h * 4);
+        t2[g] = *reinterpret_cast<const f32x4 *>(epi + 3 * C + g * 8 + h * 4);
+      }
     }
   }
+};
+
+// A stage boundary: nothing is scheduled across it.  The epilogue below is written stage by stage - the same
+// instruction for the eight channel pairs of a block, then the next instruction for all of them - because a lone wave per
+// SIMD pays a full issue slot (4 cycles) for every s_nop, and the compiler separates a packed-f32 or transcendental
+// instruction from a consumer right behind it by one (scripts/ubench/valu_rates.hip); left to its own scheduling it
+// walks the pairs one after the other under this kernel's register pressure, a nop behind every instruction.
+#define JG_STAGE() __builtin_amdgcn_sched_barrier(0)
+
+// tanh-GELU of the eight channel pairs of a block, stage by stage (the arithmetic of gelu_tanh2)
+__device__ __forceinline__ void gelu_stages(f32x2 (&x)[8]) {
+  const f32x2 c0 = {-2.3022082f, -2.3022082f}, c1 = {-0.10294324f, -0.10294324f}, one = {1.0f, 1.0f};
+  f32x2 t[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) t[p] = x[p] * x[p];
+  JG_STAGE();
+#pragma unroll
+  for (int p = 0; p < 8; ++p) t[p] = c0 + c1 * t[p];
+  JG_STAGE();
+#pragma unroll
+  for (int p = 0; p < 8; ++p) t[p] = x[p] * t[p];
+  JG_STAGE();
+#pragma unroll
+  for (int p = 0; p < 8; ++p) t[p] = f32x2{__builtin_amdgcn_exp2f(t[p][0]), __builtin_amdgcn_exp2f(t[p][1])};
+  JG_STAGE();
+#pragma unroll
+  for (int p = 0; p < 8; ++p) t[p] = t[p] + one;
+  JG_STAGE();
+#pragma unroll
+  for (int p = 0; p < 8; ++p) t[p] = f32x2{__builtin_amdgcn_rcpf(t[p][0]), __builtin_amdgcn_rcpf(t[p][1])};
+  JG_STAGE();
+#pragma unroll
+  for (int p = 0; p < 8; ++p) x[p] = x[p] * t[p];
+  JG_STAGE();
+}
+
+// epilogue of ONE 32-position block in two steps.  epi_math: accumulators c (+ shortcut block scb) -> the layer's output
+// values v (packed-f32 arithmetic and transcendentals);  epi_out: v -> masked hi / lo halves into the row image, or the
+// pool / tap sums - plain vector instructions only, cut into chunks of 4-8: those issue for free beside a running MFMA
+// (scripts/ubench/valu_rates.hip: five per MFMA; packed-f32 instructions wait for the MFMA to finish)
+template <bool P2, bool ADD, bool SAVE>
+__device__ __forceinline__ void epi_math(const f32x16 &c, f32x16 &scb, const EpiParams<P2> &q, int dbg, float (&v)[16]) {
+  (void)dbg;
+  f32x2 x[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int g = p >> 1, i = (p & 1) * 2;
+    x[p] = f32x2{c[2 * p], c[2 * p + 1]} * f32x2{q.s1[g][i], q.s1[g][i + 1]} + f32x2{q.t1[g][i], q.t1[g][i + 1]};
+  }
+  JG_STAGE();
+  if constexpr (ADD) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) x[p] = x[p] + f32x2{scb[2 * p], scb[2 * p + 1]};
+    JG_STAGE();
+  }
+  if (!JG_SDBG(4)) gelu_stages(x);
+  if constexpr (P2) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int g = p >> 1, i = (p & 1) * 2;
+      x[p] = x[p] * f32x2{q.s2[g][i], q.s2[g][i + 1]} + f32x2{q.t2[g][i], q.t2[g][i + 1]};
+    }
+    JG_STAGE();
+    if (!JG_SDBG(4)) gelu_stages(x);
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    v[2 * p] = x[p][0];
+    v[2 * p + 1] = x[p][1];
+  }
+  if constexpr (SAVE) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scb[r] = v[r];
+    JG_STAGE();
+  }
+}
+
+// the output step of a block in chunks.  Row-image layers: per channel group g the chunks  A: range guard + hi halves,
+// B: the four remainders, C: lo halves + mask + the two stores;  tap layers add  T: masked tap sums;  the last layer has
+// the pool sums only (P).
+template <bool LAST, bool TAP>
+constexpr int out_chunks() { return LAST ? (TAP ? 8 : 4) : (TAP ? 16 : 12); }
+struct OutRegs {
+  unsigned h01, h23;
+  float r0, r1, r2, r3;
+};
+template <bool LAST, bool TAP, bool PMAX>
+__device__ __forceinline__ void epi_out_chunk(const int k, const float (&v)[16], OutRegs (&o)[4], const int b, const bool keep,
+                                              char *act, int n, int h, float &vmax, float (&pool)[16], float (&tapv)[16],
+                                              int dbg) {
+  (void)dbg;
+  constexpr int PER = LAST ? (TAP ? 2 : 1) : (TAP ? 4 : 3);
+  const int g = k / PER, kind = k % PER;            // kind: row image 0 A, 1 B, 2 C, 3 T;  last layer 0 P, 1 T
+  const float *x = &v[g * 4];
+  if (kind == (LAST ? 1 : 3)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tapv[g * 4 + r] += keep ? x[r] : 0.0f;
+    return;
+  }
+  if constexpr (LAST) {
+    if constexpr (!PMAX) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pool[g * 4 + r] += keep ? x[r] : 0.0f;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pool[g * 4 + r] = fmaxf(pool[g * 4 + r], keep ? x[r] : -1.0e9f);
+    }
+  } else {
+    // x = hi + lo: hi = f16(x) by packed converts, lo = f16(x - hi) with the remainder from v_fma_mix_f32 (reads the
+    // f16 half straight out of the packed register); the range guard watches the unmasked values (one v_max3 per two
+    // elements); the mask is applied to the packed halves
+    if (kind == 0) {
+      vmax = fmaxf(fmaxf(vmax, fabsf(x[0])), fabsf(x[1]));
+      vmax = fmaxf(fmaxf(vmax, fabsf(x[2])), fabsf(x[3]));
+      o[g].h01 = pk_f16(x[0], x[1]);
+      o[g].h23 = pk_f16(x[2], x[3]);
+    } else if (kind == 1) {
+      o[g].r0 = mix_rem<0>(x[0], o[g].h01);
+      o[g].r1 = mix_rem<1>(x[1], o[g].h01);
+      o[g].r2 = mix_rem<0>(x[2], o[g].h23);
+      o[g].r3 = mix_rem<1>(x[3], o[g].h23);
+    } else {
+      const unsigned km = keep ? 0xffffffffu : 0u;
+      const unsigned l01 = pk_f16(o[g].r0, o[g].r1) & km, l23 = pk_f16(o[g].r2, o[g].r3) & km;
+      char *p = act + (1 + b * 32 + n) * ROWB + (g * 8 + h * 4) * 2;
+      if (!JG_SDBG(8)) {
+        *reinterpret_cast<uint2 *>(p) = make_uint2(o[g].h01 & km, o[g].h23 & km);
+        *reinterpret_cast<uint2 *>(p + 64) = make_uint2(l01, l23);
+      }
+    }
+  }
+}
+
+// The first layer's epilogue over the five accumulator blocks of a row (its accumulators come out of the table phase).
+template <bool LAST, bool P2, bool ADD, bool SAVE, bool TAP, bool PMAX>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], const float *epi, M192 mout, char *act,
+                                         int n, int h, float &vmax, float (&pool)[16], int dbg, float (&tapv)[16]) {
+  EpiParams<P2> q;
+  q.load(epi, h);
   JG_FENCE();
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const bool keep = (mout.w[b >> 1] >> ((b & 1) * 32 + n)) & 1ull;
-    const unsigned km = keep ? 0xffffffffu : 0u;
     float v[16];
+    OutRegs o[4];
+    epi_math<P2, ADD, SAVE>(acc[b], sc[b], q, dbg, v);
+    const bool keep = (mout.w[b >> 1] >> ((b & 1) * 32 + n)) & 1ull;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-      for (int i = 0; i < 4; i += 2) {
-        const int r = g * 4 + i;
-        f32x2 x = f32x2{acc[b][r], acc[b][r + 1]} * f32x2{s1[g][i], s1[g][i + 1]} + f32x2{t1[g][i], t1[g][i + 1]};
-        if constexpr (ADD) x = x + f32x2{sc[b][r], sc[b][r + 1]};
-        if (!JG_SDBG(4)) x = gelu_tanh2(x);
-        if constexpr (P2) {
-          x = x * f32x2{s2[g][i], s2[g][i + 1]} + f32x2{t2[g][i], t2[g][i + 1]};
-          if (!JG_SDBG(4)) x = gelu_tanh2(x);
-        }
-        v[r] = x[0];
-        v[r + 1] = x[1];
-      }
-    }
-    if constexpr (SAVE) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc[b][r] = v[r];
-    }
-    if constexpr (TAP) {            // NMD tap behind the layer's last stage: masked channel sums of its output
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tapv[r] += keep ? v[r] : 0.0f;
-    }
-    if constexpr (LAST) {
-      if (pool_kind == JG_POOL_AVG) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pool[r] += keep ? v[r] : 0.0f;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pool[r] = fmaxf(pool[r], keep ? v[r] : -1.0e9f);
-      }
-    } else {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        // x = hi + lo: hi = f16(x) by packed converts, lo = f16(x - hi) with the remainder from v_fma_mix_f32 (reads
-        // the f16 half straight out of the packed register)
-        // (the range guard watches the unmasked values: one v_max3 per two elements; the mask is applied to the packed
-        // halves - four v_and per four elements and plane instead of a select per element)
-        const float *x = &v[g * 4];
-        vmax = fmaxf(fmaxf(vmax, fabsf(x[0])), fabsf(x[1]));
-        vmax = fmaxf(fmaxf(vmax, fabsf(x[2])), fabsf(x[3]));
-        unsigned h01 = pk_f16(x[0], x[1]), h23 = pk_f16(x[2], x[3]);
-        unsigned l01 = pk_f16(mix_rem<0>(x[0], h01), mix_rem<1>(x[1], h01));
-        unsigned l23 = pk_f16(mix_rem<0>(x[2], h23), mix_rem<1>(x[3], h23));
-        h01 &= km; h23 &= km; l01 &= km; l23 &= km;
-        char *p = act + (1 + b * 32 + n) * ROWB + (g * 8 + h * 4) * 2;
-        if (!JG_SDBG(8)) {
-          *reinterpret_cast<uint2 *>(p) = make_uint2(h01, h23);
-          *reinterpret_cast<uint2 *>(p + 64) = make_uint2(l01, l23);
-        }
-      }
-    }
+    for (int k = 0; k < out_chunks<LAST, TAP>(); ++k)
+      epi_out_chunk<LAST, TAP, PMAX>(k, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
     JG_FENCE();      // one block at a time: hoisted loads of later blocks would spill
+  }
+}
+
+// One k = 3 layer of a row, software-pipelined over its five position blocks: the 18 MFMAs of block b + 1 are issued
+// one by one BETWEEN the chunks of block b's output step (plain vector instructions: they issue while the matrix pipe
+// works), block b + 1's arithmetic follows once its accumulators are complete.  Only block 0's MFMAs stand alone.  The
+// in-place update of the row image stays safe: block b + 2's fragments (rows 32 b + 63 .. 32 b + 96) are read - in
+// program order, i.e. in LDS order - before block b + 1's output step stores rows 32 b + 32 .. 32 b + 63, and block
+// b's stores (rows 32 b .. 32 b + 31) come behind block b + 1's own reads, issued a step earlier.
+__device__ __forceinline__ void read_frags(half8 (&fr)[12], const char *fp, const int b) {
+#pragma unroll
+  for (int q = 0; q < 12; ++q)
+    fr[q] = *reinterpret_cast<const half8 *>(fp + (b * 32 + (q >> 2)) * ROWB + ((q >> 1) & 1) * 32 + (q & 1) * 64);
+}
+// MFMA i of a block's 18: tap i / 6, channel chunk (i / 3) % 2, product i % 3 (hi.hi, hi.lo, lo.hi)
+__device__ __forceinline__ void mfma_one(const int i, f32x16 &c, const half8 (&w)[3][2][2], const half8 (&fr)[12], int dbg) {
+  (void)dbg;
+  const int t = i / 6, cc = (i / 3) % 2, k = i % 3;
+  const half8 xh = fr[(t * 2 + cc) * 2], xl = fr[(t * 2 + cc) * 2 + 1];
+  if (JG_SDBG(2)) {
+    if (k == 0) c[0] += (float)xh[0] + (float)xl[1];
+    return;
+  }
+  if (k == 0) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t][cc][0], xh, c, 0, 0, 0);
+  else if (k == 1) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t][cc][0], xl, c, 0, 0, 0);
+  else c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t][cc][1], xh, c, 0, 0, 0);
+}
+template <bool LAST, bool P2, bool ADD, bool SAVE, bool TAP, bool PMAX>
+__device__ __forceinline__ void conv_layer(half8 (&w)[3][2][2], const half8 *wn, f32x16 (&sc)[NB], const float *epi, M192 mout,
+                                           char *act, int n, int h, float &vmax, float (&pool)[16], int dbg,
+                                           float (&tapv)[16]) {
+  constexpr int K = out_chunks<LAST, TAP>();
+  EpiParams<P2> q;
+  q.load(epi, h);
+  const char *fp = act + n * ROWB + h * 16;
+  half8 fr[12];
+  read_frags(fr, fp, 0);
+  f32x16 cc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 18; ++i) mfma_one(i, cc, w, fr, dbg);
+  read_frags(fr, fp, 1);
+  JG_STAGE();
+  float v[16];
+  epi_math<P2, ADD, SAVE>(cc, sc[0], q, dbg, v);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    OutRegs o[4];
+    const bool keep = (mout.w[b >> 1] >> ((b & 1) * 32 + n)) & 1ull;
+    if (b + 1 < NB) {
+      // block b + 1's MFMAs (its fragments were requested a block ago), a chunk of block b's output step behind each
+      const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      cc = z;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) {
+        mfma_one(i, cc, w, fr, dbg);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if (k * 18 / K == i) epi_out_chunk<LAST, TAP, PMAX>(k, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
+        JG_STAGE();
+      }
+      if (b + 2 < NB) read_frags(fr, fp, b + 2);        // rows 32 b + 63 ..: in front of block b + 1's stores
+      JG_STAGE();
+      epi_math<P2, ADD, SAVE>(cc, sc[b + 1], q, dbg, v);
+    } else {
+      // the next layer's weight fragments, behind this layer's last MFMA: they land under the last block's output step
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) w[t][c2][p] = wn[((t * 2 + c2) * 2 + p) << 6];
+#pragma unroll
+      for (int k = 0; k < K; ++k) epi_out_chunk<LAST, TAP, PMAX>(k, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
+      JG_STAGE();
+    }
   }
 }
 
@@ -225,11 +378,31 @@ static __device__ unsigned long long jg_small_stamp[8];
     float tapv[16];                                                                                           \
     if (TAPS && tap) {                                                                                        \
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) tapv[i_] = 0.0f;                                      \
-      epilogue<LASTV, P2V, ADDV, SAVEV, true>(acc, sc, ep, mo, act, n, h, vmax, pool, a.pool_kind, dbg, tapv); \
+      epilogue<LASTV, P2V, ADDV, SAVEV, true, false>(acc, sc, ep, mo, act, n, h, vmax, pool, dbg, tapv);      \
       row_reduce_store(tapv, true, prow + tap * PARTW, m_count(mo), n, h, lane);                              \
     } else {                                                                                                  \
-      epilogue<LASTV, P2V, ADDV, SAVEV, false>(acc, sc, ep, mo, act, n, h, vmax, pool, a.pool_kind, dbg, tapv); \
+      epilogue<LASTV, P2V, ADDV, SAVEV, false, false>(acc, sc, ep, mo, act, n, h, vmax, pool, dbg, tapv);     \
     }                                                                                                         \
+  } while (0)
+
+// (the pool kind of the last layer is a template parameter: a run-time branch in the block would end the scheduling
+// region that interleaves its MFMAs and vector instructions)
+#define JG_LAYER_CALL2(LASTV, P2V, ADDV, SAVEV, PMAXV)                                                        \
+  do {                                                                                                        \
+    float tapv[16];                                                                                           \
+    if (TAPS && tap) {                                                                                        \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) tapv[i_] = 0.0f;                                      \
+      conv_layer<LASTV, P2V, ADDV, SAVEV, true, PMAXV>(w, wn, sc, ep, mo, act, n, h, vmax, pool, dbg, tapv);  \
+      row_reduce_store(tapv, true, prow + tap * PARTW, m_count(mo), n, h, lane);                              \
+    } else {                                                                                                  \
+      conv_layer<LASTV, P2V, ADDV, SAVEV, false, PMAXV>(w, wn, sc, ep, mo, act, n, h, vmax, pool, dbg, tapv); \
+    }                                                                                                         \
+  } while (0)
+#define JG_LAYER_CALL(P2V, ADDV, SAVEV) JG_LAYER_CALL2(false, P2V, ADDV, SAVEV, false)
+#define JG_LAYER_CALL_LAST(P2V, ADDV)                              \
+  do {                                                             \
+    if (a.pool_kind == JG_POOL_AVG) JG_LAYER_CALL2(true, P2V, ADDV, false, false); \
+    else JG_LAYER_CALL2(true, P2V, ADDV, false, true);             \
   } while (0)
 
 // Reduce a lane's 16 channel values over the 32 lanes that share h and store the row's 32 channel totals + the mask
@@ -394,49 +567,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- k = 3 convolutions on the matrix cores -----------------------------------------------------------
 #pragma unroll 1
     for (int j = 0; j < NC; ++j) {
-      // fragments of block b + 1 are read (12 x 16 B per lane) while block b's 18 MFMAs run: the twelve reads of a
-      // block issued right in front of their MFMAs left the matrix pipe waiting on LDS latency (118 cycles per MFMA)
-      half8 fr[2][12];
-      const char *fp = act + n * ROWB + h * 16;
-#pragma unroll
-      for (int q = 0; q < 12; ++q)
-        fr[0][q] = *reinterpret_cast<const half8 *>(fp + (q >> 2) * ROWB + ((q >> 1) & 1) * 32 + (q & 1) * 64);
-      JG_FENCE();
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if (b + 1 < NB) {
-#pragma unroll
-          for (int q = 0; q < 12; ++q)
-            fr[(b + 1) & 1][q] = *reinterpret_cast<const half8 *>(fp + ((b + 1) * 32 + (q >> 2)) * ROWB +
-                                                                  ((q >> 1) & 1) * 32 + (q & 1) * 64);
-        }
-        f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int cc = 0; cc < 2; ++cc) {
-            const half8 xh = fr[b & 1][(t * 2 + cc) * 2], xl = fr[b & 1][(t * 2 + cc) * 2 + 1];
-            if (JG_SDBG(2)) {
-              c[0] += (float)xh[0] + (float)xl[1];
-              continue;
-            }
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t][cc][0], xh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t][cc][0], xl, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t][cc][1], xh, c, 0, 0, 0);
-          }
-        acc[b] = c;
-        JG_FENCE();
-      }
-      JG_SST(3);
-      {                                     // next layer's weights (layer 0 of the next row after the last one)
-        const half8 *wn = wsrc + ((j + 1 == NC ? 0 : j + 1) * 12 << 6);
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) w[t][cc][p] = wn[((t * 2 + cc) * 2 + p) << 6];
-      }
+      // next layer's weights (layer 0 of the next row after the last one): requested by conv_layer behind its last MFMA
+      const half8 *wn = wsrc + ((j + 1 == NC ? 0 : j + 1) * 12 << 6);
       if (a.use_mask) mo = m_and(m_or(m_or(m_shl(mo, 1), mo), m_shr(mo, 1)), valid0);
       const float *ep = epi + (j + 1) * 4 * C;
       {
@@ -448,18 +580,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         const int code = (j == NC - 1 ? 8 : 0) | (p2 ? 4 : 0) | (add ? 2 : 0) | (save ? 1 : 0);
         switch (code) {               // wave-uniform: one compiled epilogue per (last, second norm, add, save)
-          case 0: JG_EPI_CALL(false, false, false, false); break;
-          case 1: JG_EPI_CALL(false, false, false, true); break;
-          case 2: JG_EPI_CALL(false, false, true, false); break;
-          case 3: JG_EPI_CALL(false, false, true, true); break;
-          case 4: JG_EPI_CALL(false, true, false, false); break;
-          case 5: JG_EPI_CALL(false, true, false, true); break;
-          case 6: JG_EPI_CALL(false, true, true, false); break;
-          case 7: JG_EPI_CALL(false, true, true, true); break;
-          case 8: case 9: JG_EPI_CALL(true, false, false, false); break;
-          case 10: case 11: JG_EPI_CALL(true, false, true, false); break;
-          case 12: case 13: JG_EPI_CALL(true, true, false, false); break;
-          default: JG_EPI_CALL(true, true, true, false); break;
+          case 0: JG_LAYER_CALL(false, false, false); break;
+          case 1: JG_LAYER_CALL(false, false, true); break;
+          case 2: JG_LAYER_CALL(false, true, false); break;
+          case 3: JG_LAYER_CALL(false, true, true); break;
+          case 4: JG_LAYER_CALL(true, false, false); break;
+          case 5: JG_LAYER_CALL(true, false, true); break;
+          case 6: JG_LAYER_CALL(true, true, false); break;
+          case 7: JG_LAYER_CALL(true, true, true); break;
+          case 8: case 9: JG_LAYER_CALL_LAST(false, false); break;
+          case 10: case 11: JG_LAYER_CALL_LAST(false, true); break;
+          case 12: case 13: JG_LAYER_CALL_LAST(true, false); break;
+          default: JG_LAYER_CALL_LAST(true, true); break;
         }
       }
       JG_SST(4);

@@ -91,6 +91,32 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, float *sink, i
     } else if constexpr (V == 19) {  // 4 x (1 MFMA + 3 v_pk_fma_f32)
       asm volatile(R4("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_pk_fma_f32 %3, %3, %3, %3\n v_pk_fma_f32 %4, %4, %4, %4\n v_pk_fma_f32 %5, %5, %5, %5\n")
                    : "+v"(c) : "v"(wa), "v"(wb), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6));
+    } else if constexpr (V == 20) {  // is an s_nop a full issue slot for a lone wave?
+      asm volatile(R16("v_fma_f32 %0, %0, %0, %0\n s_nop 0\n") : "+v"(a0));
+    } else if constexpr (V == 21) {  // scalar instructions between vector instructions
+      asm volatile(R16("v_fma_f32 %0, %0, %0, %0\n s_add_u32 s20, s20, 1\n") : "+v"(a0) : : "s20");
+    } else if constexpr (V == 22) {  // dependent packed chain with the hazard nop the compiler inserts
+      asm volatile(R16("v_pk_mul_f32 %0, %0, %1\n s_nop 0\n") : "+v"(p0) : "v"(p1));
+    } else if constexpr (V == 23) {  // two interleaved packed chains (no nop needed)
+      asm volatile(R16("v_pk_mul_f32 %0, %0, %2\n v_pk_mul_f32 %1, %1, %2\n") : "+v"(p0), "+v"(p3) : "v"(p1));
+    } else if constexpr (V == 24) {  // 4 x (1 MFMA + cvt_pk, fma_mix, fma_mix: the store path's instructions)
+      asm volatile(R4("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_cvt_pk_f16_f32 %7, %3, %4\n v_fma_mix_f32 %5, %7, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n"
+                      "v_fma_mix_f32 %6, %7, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n")
+                   : "+v"(c) : "v"(wa), "v"(wb), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(u0));
+    } else if constexpr (V == 25) {  // 4 x (1 MFMA + 5 plain)
+      asm volatile(R4("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_fma_f32 %3, %3, %3, %3\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n")
+                   : "+v"(c) : "v"(wa), "v"(wb), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6));
+    } else if constexpr (V == 26) {  // 4 x (1 MFMA + 7 plain)
+      asm volatile(R4("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_fma_f32 %3, %3, %3, %3\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n v_fma_f32 %8, %8, %8, %8\n v_fma_f32 %9, %9, %9, %9\n")
+                   : "+v"(c) : "v"(wa), "v"(wb), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6));
+    } else if constexpr (V == 27) {  // 2 independent MFMA chains with 3 plain behind each MFMA
+      asm volatile(R4("v_mfma_f32_32x32x16_f16 %0, %2, %3, %0\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n"
+                      "v_mfma_f32_32x32x16_f16 %1, %2, %3, %1\n v_fma_f32 %7, %7, %7, %7\n v_fma_f32 %8, %8, %8, %8\n v_fma_f32 %9, %9, %9, %9\n")
+                   : "+v"(c), "+v"(c2) : "v"(wa), "v"(wb), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6));
+    } else if constexpr (V == 28) {  // 4 x (MFMA 16x16x32: 16 cycles + 2 plain)
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      asm volatile(R4("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n v_fma_f32 %3, %3, %3, %3\n v_fma_f32 %4, %4, %4, %4\n")
+                   : "+v"(*reinterpret_cast<f32x4 *>(&c)) : "v"(wa), "v"(wb), "v"(a0), "v"(a1));
     } else if constexpr (V == 15) {  // exp -> dependent add -> dependent rcp chain (the GELU tail), one element
       asm volatile(R8("v_exp_f32 %0, %0\n v_add_f32 %0, 1.0, %0\n v_rcp_f32 %0, %0\n v_mul_f32 %0, %0, %1\n") : "+v"(a0) : "v"(a1));
     }
@@ -141,5 +167,14 @@ int main() {
   RUN(17, 4, "4 x (1 MFMA + 2 v_exp_f32 + 2 v_rcp_f32)");
   RUN(18, 4, "4 x (1 MFMA + 3 v_fma_f32)");
   RUN(19, 4, "4 x (1 MFMA + 3 v_pk_fma_f32)");
+  RUN(20, 32, "(v_fma_f32 + s_nop 0) x16");
+  RUN(21, 32, "(v_fma_f32 + s_add_u32) x16");
+  RUN(22, 32, "(v_pk_mul_f32 dependent + s_nop 0) x16");
+  RUN(23, 32, "two interleaved dependent v_pk_mul_f32 chains x16");
+  RUN(24, 4, "4 x (1 MFMA + cvt_pk + 2 fma_mix)");
+  RUN(25, 4, "4 x (1 MFMA + 5 v_fma_f32)");
+  RUN(26, 4, "4 x (1 MFMA + 7 v_fma_f32)");
+  RUN(27, 8, "2 MFMA chains x4, 3 v_fma_f32 behind each MFMA");
+  RUN(28, 4, "4 x (1 MFMA 16x16x32 + 2 v_fma_f32)");
   return 0;
 }
