@@ -264,32 +264,6 @@ __device__ __forceinline__ void epi_out_chunk(const int k, const float (&v)[16],
   }
 }
 
-// The first layer's epilogue over the five accumulator blocks of a row (its accumulators come out of the table phase).
-template <bool LAST, bool P2, bool ADD, bool SAVE, bool TAP, bool PMAX>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], const float *epi, M192 mout, char *act,
-                                         int n, int h, float &vmax, float (&pool)[16], int dbg, float (&tapv)[16]) {
-  EpiParams<P2> q;
-  q.load(epi, h);
-  JG_FENCE();
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    float v[16];
-    OutRegs o[4];
-    epi_math<P2, ADD, SAVE>(acc[b], sc[b], q, dbg, v);
-    const bool keep = (mout.w[b >> 1] >> ((b & 1) * 32 + n)) & 1ull;
-#pragma unroll
-    for (int k = 0; k < out_chunks<LAST, TAP>(); ++k)
-      epi_out_chunk<LAST, TAP, PMAX>(k, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
-    JG_FENCE();      // one block at a time: hoisted loads of later blocks would spill
-  }
-}
-
-// One k = 3 layer of a row, software-pipelined over its five position blocks: the 18 MFMAs of block b + 1 are issued
-// one by one BETWEEN the chunks of block b's output step (plain vector instructions: they issue while the matrix pipe
-// works), block b + 1's arithmetic follows once its accumulators are complete.  Only block 0's MFMAs stand alone.  The
-// in-place update of the row image stays safe: block b + 2's fragments (rows 32 b + 63 .. 32 b + 96) are read - in
-// program order, i.e. in LDS order - before block b + 1's output step stores rows 32 b + 32 .. 32 b + 63, and block
-// b's stores (rows 32 b .. 32 b + 31) come behind block b + 1's own reads, issued a step earlier.
 __device__ __forceinline__ void read_frags(half8 (&fr)[12], const char *fp, const int b) {
 #pragma unroll
   for (int q = 0; q < 12; ++q)
@@ -308,50 +282,100 @@ __device__ __forceinline__ void mfma_one(const int i, f32x16 &c, const half8 (&w
   else if (k == 1) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t][cc][0], xl, c, 0, 0, 0);
   else c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t][cc][1], xh, c, 0, 0, 0);
 }
+// the 18 MFMAs of a block into cc (fragments fr), one per slot, with the chunks of block b's output step dealt out
+// behind them
+template <bool LAST, bool TAP, bool PMAX>
+__device__ __forceinline__ void mfma_slots(f32x16 &cc, const half8 (&w)[3][2][2], const half8 (&fr)[12], const float (&v)[16],
+                                           OutRegs (&o)[4], const int b, const bool keep, char *act, int n, int h,
+                                           float &vmax, float (&pool)[16], float (&tapv)[16], int dbg) {
+  constexpr int K = out_chunks<LAST, TAP>();
+  const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  cc = z;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    mfma_one(i, cc, w, fr, dbg);
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (k * 18 / K == i) epi_out_chunk<LAST, TAP, PMAX>(k, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
+    JG_STAGE();
+  }
+}
+__device__ __forceinline__ void load_weights(half8 (&w)[3][2][2], const half8 *wn) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) w[t][c2][p] = wn[((t * 2 + c2) * 2 + p) << 6];
+}
+
+// The first layer's epilogue over the five accumulator blocks of a row (its accumulators come out of the table phase).
+// The MFMAs of the first k = 3 layer's block 0 run between the chunks of the last block's output step (rows -1 .. 32 of
+// the image are complete by then): on return cc holds that block's accumulators.
+template <bool SAVE, bool TAP>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], const float *epi, M192 mout, char *act,
+                                         int n, int h, float &vmax, float (&pool)[16], int dbg, float (&tapv)[16],
+                                         const half8 (&w)[3][2][2], f32x16 &cc) {
+  constexpr int K = out_chunks<false, TAP>();
+  half8 fr[12];
+  EpiParams<false> q;
+  q.load(epi, h);
+  const char *fp = act + n * ROWB + h * 16;
+  JG_FENCE();
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float v[16];
+    OutRegs o[4];
+    if (b == NB - 1) read_frags(fr, fp, 0);
+    epi_math<false, false, SAVE>(acc[b], sc[b], q, dbg, v);
+    const bool keep = (mout.w[b >> 1] >> ((b & 1) * 32 + n)) & 1ull;
+    if (b < NB - 1) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) epi_out_chunk<false, TAP, false>(k, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
+    } else {
+      mfma_slots<false, TAP, false>(cc, w, fr, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
+    }
+    JG_FENCE();      // one block at a time: hoisted loads of later blocks would spill
+  }
+}
+
+// One k = 3 layer of a row, software-pipelined over its five position blocks: the 18 MFMAs of block b + 1 are issued
+// one by one BETWEEN the chunks of block b's output step (plain vector instructions: they issue while the matrix pipe
+// works), block b + 1's arithmetic follows once its accumulators are complete; the slots of the last block's output step
+// take the NEXT layer's block 0 (cc on entry: block 0's accumulators; the same for the next layer on return).  The in-place update of the row image stays safe: block b + 2's fragments (rows 32 b + 63 ..
+// 32 b + 96) are read - in program order, i.e. in LDS order - before block b + 1's output step stores rows 32 b + 32 ..
+// 32 b + 63, block b's stores (rows 32 b .. 32 b + 31) come behind block b + 1's own reads, issued a step earlier, and
+// the next layer's blocks 0 and 1 read rows -1 .. 64, final since this layer's third output step.
 template <bool LAST, bool P2, bool ADD, bool SAVE, bool TAP, bool PMAX>
-__device__ __forceinline__ void conv_layer(half8 (&w)[3][2][2], const half8 *wn, f32x16 (&sc)[NB], const float *epi, M192 mout,
-                                           char *act, int n, int h, float &vmax, float (&pool)[16], int dbg,
-                                           float (&tapv)[16]) {
+__device__ __forceinline__ void conv_layer(half8 (&w)[3][2][2], const half8 *wn, f32x16 &cc, f32x16 (&sc)[NB],
+                                           const float *epi, M192 mout, char *act, int n, int h, float &vmax,
+                                           float (&pool)[16], int dbg, float (&tapv)[16]) {
   constexpr int K = out_chunks<LAST, TAP>();
   EpiParams<P2> q;
   q.load(epi, h);
   const char *fp = act + n * ROWB + h * 16;
-  half8 fr[12];
-  read_frags(fr, fp, 0);
-  f32x16 cc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int i = 0; i < 18; ++i) mfma_one(i, cc, w, fr, dbg);
-  read_frags(fr, fp, 1);
-  JG_STAGE();
   float v[16];
+  half8 fr[12];
+  read_frags(fr, fp, 1);
   epi_math<P2, ADD, SAVE>(cc, sc[0], q, dbg, v);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     OutRegs o[4];
     const bool keep = (mout.w[b >> 1] >> ((b & 1) * 32 + n)) & 1ull;
     if (b + 1 < NB) {
-      // block b + 1's MFMAs (its fragments were requested a block ago), a chunk of block b's output step behind each
-      const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      cc = z;
-#pragma unroll
-      for (int i = 0; i < 18; ++i) {
-        mfma_one(i, cc, w, fr, dbg);
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-          if (k * 18 / K == i) epi_out_chunk<LAST, TAP, PMAX>(k, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
-        JG_STAGE();
+      mfma_slots<LAST, TAP, PMAX>(cc, w, fr, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
+      if (b + 2 < NB) {
+        read_frags(fr, fp, b + 2);                      // rows 32 b + 63 ..: in front of block b + 1's stores
+      } else {
+        load_weights(w, wn);                            // behind this layer's last MFMA: the next layer's weights
+        if constexpr (!LAST) read_frags(fr, fp, 0);     // and its block 0
       }
-      if (b + 2 < NB) read_frags(fr, fp, b + 2);        // rows 32 b + 63 ..: in front of block b + 1's stores
       JG_STAGE();
       epi_math<P2, ADD, SAVE>(cc, sc[b + 1], q, dbg, v);
+    } else if constexpr (!LAST) {
+      mfma_slots<LAST, TAP, PMAX>(cc, w, fr, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
+      JG_STAGE();
     } else {
-      // the next layer's weight fragments, behind this layer's last MFMA: they land under the last block's output step
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-          for (int p = 0; p < 2; ++p) w[t][c2][p] = wn[((t * 2 + c2) * 2 + p) << 6];
 #pragma unroll
       for (int k = 0; k < K; ++k) epi_out_chunk<LAST, TAP, PMAX>(k, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
       JG_STAGE();
@@ -373,15 +397,15 @@ static __device__ unsigned long long jg_small_stamp[8];
 
 // (a run-time tap flag inside the block loop cost 8 % of the kernel - the sixteen tap registers stayed allocated in
 // every variant - so the tap is a template parameter like the other stage flags)
-#define JG_EPI_CALL(LASTV, P2V, ADDV, SAVEV)                                                                  \
+#define JG_EPI_CALL(SAVEV)                                                                                     \
   do {                                                                                                        \
     float tapv[16];                                                                                           \
     if (TAPS && tap) {                                                                                        \
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) tapv[i_] = 0.0f;                                      \
-      epilogue<LASTV, P2V, ADDV, SAVEV, true, false>(acc, sc, ep, mo, act, n, h, vmax, pool, dbg, tapv);      \
+      epilogue<SAVEV, true>(acc, sc, ep, mo, act, n, h, vmax, pool, dbg, tapv, w, cc);                    \
       row_reduce_store(tapv, true, prow + tap * PARTW, m_count(mo), n, h, lane);                              \
     } else {                                                                                                  \
-      epilogue<LASTV, P2V, ADDV, SAVEV, false, false>(acc, sc, ep, mo, act, n, h, vmax, pool, dbg, tapv);     \
+      epilogue<SAVEV, false>(acc, sc, ep, mo, act, n, h, vmax, pool, dbg, tapv, w, cc);                   \
     }                                                                                                         \
   } while (0)
 
@@ -392,10 +416,10 @@ static __device__ unsigned long long jg_small_stamp[8];
     float tapv[16];                                                                                           \
     if (TAPS && tap) {                                                                                        \
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) tapv[i_] = 0.0f;                                      \
-      conv_layer<LASTV, P2V, ADDV, SAVEV, true, PMAXV>(w, wn, sc, ep, mo, act, n, h, vmax, pool, dbg, tapv);  \
+      conv_layer<LASTV, P2V, ADDV, SAVEV, true, PMAXV>(w, wn, cc, sc, ep, mo, act, n, h, vmax, pool, dbg, tapv); \
       row_reduce_store(tapv, true, prow + tap * PARTW, m_count(mo), n, h, lane);                              \
     } else {                                                                                                  \
-      conv_layer<LASTV, P2V, ADDV, SAVEV, false, PMAXV>(w, wn, sc, ep, mo, act, n, h, vmax, pool, dbg, tapv); \
+      conv_layer<LASTV, P2V, ADDV, SAVEV, false, PMAXV>(w, wn, cc, sc, ep, mo, act, n, h, vmax, pool, dbg, tapv); \
     }                                                                                                         \
   } while (0)
 #define JG_LAYER_CALL(P2V, ADDV, SAVEV) JG_LAYER_CALL2(false, P2V, ADDV, SAVEV, false)
@@ -556,12 +580,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     mo = m_and(mo, valid0);
     float pool[16];                 // (initialised right in front of the last layer: live there only)
+    f32x16 cc;                      // accumulators of block 0 of the upcoming k = 3 layer
     float *prow = a.part + row * (long)a.n_slots * PARTW;
     {
       const float *ep = epi;
       const int tap = TAPS ? a.layer[0].tap : 0;
-      if (a.layer[0].save) JG_EPI_CALL(false, false, false, true);
-      else JG_EPI_CALL(false, false, false, false);
+      if (a.layer[0].save) JG_EPI_CALL(true);
+      else JG_EPI_CALL(false);
     }
     JG_SST(2);
     // ---- k = 3 convolutions on the matrix cores -----------------------------------------------------------
