@@ -117,6 +117,27 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, float *sink, i
       typedef float f32x4 __attribute__((ext_vector_type(4)));
       asm volatile(R4("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n v_fma_f32 %3, %3, %3, %3\n v_fma_f32 %4, %4, %4, %4\n")
                    : "+v"(*reinterpret_cast<f32x4 *>(&c)) : "v"(wa), "v"(wb), "v"(a0), "v"(a1));
+    } else if constexpr (V == 29) {  // 4 x (1 MFMA + 2 transcendentals + 4 plain)
+      asm volatile(R4("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_fma_f32 %3, %3, %3, %3\n v_exp_f32 %7, %7\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_rcp_f32 %8, %8\n v_fma_f32 %6, %6, %6, %6\n")
+                   : "+v"(c) : "v"(wa), "v"(wb), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6));
+    } else if constexpr (V == 30) {  // 4 x (1 MFMA + 1 transcendental + 5 plain)
+      asm volatile(R4("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_fma_f32 %3, %3, %3, %3\n v_exp_f32 %7, %7\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %8, %8, %8, %8\n v_fma_f32 %6, %6, %6, %6\n")
+                   : "+v"(c) : "v"(wa), "v"(wb), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6));
+    } else if constexpr (V == 31) {  // 4 x (1 MFMA + 2 transcendentals + 2 plain)
+      asm volatile(R4("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_fma_f32 %3, %3, %3, %3\n v_exp_f32 %7, %7\n v_fma_f32 %4, %4, %4, %4\n v_rcp_f32 %8, %8\n")
+                   : "+v"(c) : "v"(wa), "v"(wb), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6));
+    } else if constexpr (V == 32) {  // 4 x (1 MFMA + 2 transcendentals)
+      asm volatile(R4("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_exp_f32 %7, %7\n v_rcp_f32 %8, %8\n")
+                   : "+v"(c) : "v"(wa), "v"(wb), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6));
+    } else if constexpr (V == 33) {  // 4 x (1 MFMA + 3 transcendentals + 3 plain)
+      asm volatile(R4("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_exp_f32 %7, %7\n v_fma_f32 %3, %3, %3, %3\n v_exp_f32 %9, %9\n v_fma_f32 %4, %4, %4, %4\n v_rcp_f32 %8, %8\n v_fma_f32 %5, %5, %5, %5\n")
+                   : "+v"(c) : "v"(wa), "v"(wb), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6));
+    } else if constexpr (V == 34) {  // 4 x (1 MFMA + 4 transcendentals + 4 plain)
+      asm volatile(R4("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_exp_f32 %7, %7\n v_fma_f32 %3, %3, %3, %3\n v_exp_f32 %9, %9\n v_fma_f32 %4, %4, %4, %4\n v_rcp_f32 %8, %8\n v_fma_f32 %5, %5, %5, %5\n v_rcp_f32 %6, %6\n v_fma_f32 %3, %3, %3, %3\n")
+                   : "+v"(c) : "v"(wa), "v"(wb), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6));
+    } else if constexpr (V == 35) {  // 4 transcendentals + 4 plain, no MFMA
+      asm volatile(R4("v_exp_f32 %7, %7\n v_fma_f32 %3, %3, %3, %3\n v_exp_f32 %9, %9\n v_fma_f32 %4, %4, %4, %4\n v_rcp_f32 %8, %8\n v_fma_f32 %5, %5, %5, %5\n v_rcp_f32 %6, %6\n v_fma_f32 %3, %3, %3, %3\n")
+                   : "+v"(c) : "v"(wa), "v"(wb), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6));
     } else if constexpr (V == 15) {  // exp -> dependent add -> dependent rcp chain (the GELU tail), one element
       asm volatile(R8("v_exp_f32 %0, %0\n v_add_f32 %0, 1.0, %0\n v_rcp_f32 %0, %0\n v_mul_f32 %0, %0, %1\n") : "+v"(a0) : "v"(a1));
     }
@@ -167,8 +188,14 @@ int main() {
   RUN(17, 4, "4 x (1 MFMA + 2 v_exp_f32 + 2 v_rcp_f32)");
   RUN(18, 4, "4 x (1 MFMA + 3 v_fma_f32)");
   RUN(19, 4, "4 x (1 MFMA + 3 v_pk_fma_f32)");
+  RUN(29, 4, "4 x (1 MFMA + 2 trans + 4 v_fma_f32)");
+  RUN(30, 4, "4 x (1 MFMA + 1 trans + 5 v_fma_f32)");
+  RUN(31, 4, "4 x (1 MFMA + 2 trans + 2 v_fma_f32)");
+  RUN(32, 4, "4 x (1 MFMA + 2 trans)");
+  RUN(33, 4, "4 x (1 MFMA + 3 trans + 3 v_fma_f32)");
+  RUN(34, 4, "4 x (1 MFMA + 4 trans + 4 v_fma_f32)");
+  RUN(35, 4, "4 x (4 trans + 4 v_fma_f32), no MFMA");
   RUN(20, 32, "(v_fma_f32 + s_nop 0) x16");
-  RUN(21, 32, "(v_fma_f32 + s_add_u32) x16");
   RUN(22, 32, "(v_pk_mul_f32 dependent + s_nop 0) x16");
   RUN(23, 32, "two interleaved dependent v_pk_mul_f32 chains x16");
   RUN(24, 4, "4 x (1 MFMA + cvt_pk + 2 fma_mix)");
