@@ -350,9 +350,6 @@ def main():
     ap.add_argument("--dump-gather", default=None,
                     help="tests only: rank 0 writes the gathered (or, with one rank, its own) logits of the last step to "
                          "this .npy file")
-    ap.add_argument("--small-generic", action="store_true",
-                    help="A/B only: the fused small-window kernel in its generic form (layer program read at run time) instead "
-                         "of the form compiled for the configuration's program (JG_OPT_SMALL_GENERIC)")
     ap.add_argument("--conv-pc", type=int, choices=[0, 1, 2], default=0,
                     help="A/B switch: 128-channel five-tap convs on the producer / consumer kernel (1, the default) or "
                          "on the two-workgroup kernel (0); same results bit for bit")
@@ -407,8 +404,6 @@ def main():
                           precision=args.precision)
     mode = eng.model.precision
     eng.device.set_conv_pc(args.conv_pc)
-    if args.small_generic:
-        eng.device.set_small_generic(True)
     if args.timed_dbg is not None and "_exp" not in _lib.lib_path().name:
         print("bench.py: --timed-dbg needs the experiment build (make -C jaeger_amd/csrc exp; "
               "JAEGER_HIP_LIB=jaeger_amd/libjaeger_hip_exp.so)", file=sys.stderr)

@@ -91,9 +91,6 @@ extern "C" int jg_engine_set_option(jg_engine *e, int key, int64_t value) {
       JG_REQUIRE(value >= 0 && value <= 2, JG_ERR_INVALID, "jg_engine_set_option: JG_OPT_CONV_PC takes 0, 1 or 2, got %lld", (long long)value);
       e->conv_pc = (int)value;
       return JG_OK;
-    case JG_OPT_SMALL_GENERIC:
-      e->small_generic = value != 0;
-      return JG_OK;
     default:
       jg_set_error("jg_engine_set_option: unknown key %d", key);
       return JG_ERR_INVALID;

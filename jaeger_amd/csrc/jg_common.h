@@ -164,7 +164,6 @@ struct jg_engine {
   int64_t cls_launches[4] = {};
   int n_cu = 256;
   int conv_pc = 0;                // JG_OPT_CONV_PC: producer / consumer kernel for the 128-channel five-tap convs
-  bool small_generic = false;     // JG_OPT_SMALL_GENERIC: never take a program-specialised small-window kernel
   // streamed ingest of host-resident bases (jg_predict_windows): spans above `stream_bytes` go through two pinned
   // staging buffers and two device buffers on a copy stream, record group by record group
   int64_t stream_bytes = (int64_t)1 << 30;

@@ -247,9 +247,6 @@ __device__ __forceinline__ void epi_out_chunk(const int k, const float (&v)[16],
       vmax = fmaxf(fmaxf(vmax, fabsf(x[2])), fabsf(x[3]));
       o[g].h01 = pk_f16(x[0], x[1]);
       o[g].h23 = pk_f16(x[2], x[3]);
-      // (pins the guard's running maximum to this point: in the straight-line code of a compile-time program the
-      // compiler otherwise sinks every v_max3 of a row to the row's end and keeps - spills - the values until then)
-      asm volatile("" : "+v"(vmax));
     } else if (kind == 1) {
       o[g].r0 = mix_rem<0>(x[0], o[g].h01);
       o[g].r1 = mix_rem<1>(x[1], o[g].h01);
@@ -441,7 +438,7 @@ __device__ __forceinline__ void conv_layer(half8 (&w)[3][2][2], const half8 *wn,
 #define JG_LAYER_CALL(P2V, ADDV, SAVEV) JG_LAYER_CALL2(false, P2V, ADDV, SAVEV, false)
 #define JG_LAYER_CALL_LAST(P2V, ADDV)                              \
   do {                                                             \
-    if (pool_avg) JG_LAYER_CALL2(true, P2V, ADDV, false, false);  \
+    if (a.pool_kind == JG_POOL_AVG) JG_LAYER_CALL2(true, P2V, ADDV, false, false); \
     else JG_LAYER_CALL2(true, P2V, ADDV, false, true);             \
   } while (0)
 
@@ -481,19 +478,17 @@ __device__ __forceinline__ void row_reduce_store(const float (&p)[16], const boo
   if (lane == 0) dst[C] = (float)count;
 }
 
+// Round-3 experiments that did NOT pay and are not in this file (git history has them):
+//   * the layer program as a compile-time constant (layer loop unrolled, every layer's variant chosen at compile time,
+//     nothing carried around a loop through the 16-way switch): bit-identical, 3 990 vs 3 990 Mbp/s interleaved;
+//   * the first layer's table reads dealt out between the stages of the previous block's arithmetic (one block of sums
+//     alive, LDS latency under vector work): bit-identical, 1.5 - 3 % slower - the compiler keeps every tap's rows in
+//     flight whatever the source order, the wave then runs into the 16-deep LDS queue, and pinning the sums step by
+//     step costs as much as it hides.
 // TAPS = false: the model has no NMD taps - the tap paths (24 more inlined epilogues, 17 more registers) are compiled out
-// PROG != 0: the layer program is a compile-time constant (program_code() of the two small-window configurations the
-// reference ships, nn_config_500bp_baseline and nn_config_500bp_nmd_merge): the layer loop is unrolled and every layer's
-// variant chosen at compile time, so that no value is carried around a loop through a 16-way switch - in the generic
-// kernel (PROG == 0, any program the matcher accepts) the register allocator copies the 80 shortcut registers in and
-// out of their homes and the freshly loaded weight fragments into theirs at every layer, waiting for the loads it was
-// supposed to leave in flight: 1.1 k of 12 k cycles per layer (cycle stamps).
-constexpr unsigned long long JG_SMALL_PROG_BASELINE = 0x0400000500030002ull;   // save | - | add save | - | add norm2
-constexpr unsigned long long JG_SMALL_PROG_NMDMERGE = 0x040000150003000aull;   // the same with taps behind layers 0 and 4
-template <bool TAPS, unsigned long long PROG>
+template <bool TAPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void small_net_kernel(JgSmallArgs a) {
-  constexpr bool STATIC = PROG != 0;
-  const int NC = STATIC ? (int)(PROG >> 56) : a.n_conv, K0 = a.k0;
+  const int NC = a.n_conv, K0 = a.k0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, h = lane >> 5;
@@ -528,23 +523,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int p = 0; p < 2; ++p) w[t][c][p] = wsrc[((t * 2 + c) * 2 + p) << 6];
   __syncthreads();
 
-  // the layers' stage flags packed into one scalar, a byte per layer (add | save << 1 | second norm << 2 | tap << 3):
-  // read from the kernel arguments once - a scalar load per layer and row (an indexed read of a.layer[j]) left the lone
-  // wave waiting on its latency at every layer
-  unsigned long long lcode = PROG & 0x00ffffffffffffffull;
-  if constexpr (!STATIC) {
-    for (int q = 0; q <= NC; ++q)
-      lcode |= (unsigned long long)((a.layer[q].add ? 1 : 0) | (a.layer[q].save ? 2 : 0) | (a.layer[q].aff2 ? 4 : 0) |
-                                    ((TAPS ? a.layer[q].tap : 0) << 3))
-               << (8 * q);
-    lcode = __builtin_amdgcn_readfirstlane((unsigned)lcode) |
-            ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(lcode >> 32)) << 32);
-  }
-  const bool pool_avg = a.pool_kind == JG_POOL_AVG, use_mask = a.use_mask != 0;
-  const long n_rows = a.rows;
-  const uint8_t *ids_g = a.ids;
-  float *part_g = a.part;
-  const int n_slots = a.n_slots, vocab = a.vocab;
   const int L = a.L, L0 = a.L0, pad0 = a.pad0;
   const int dbg = a.dbg;
   (void)dbg;
@@ -559,10 +537,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int q = j * 64 + lane;
-      idn[j] = (row0 < n_rows && q < L) ? (int)ids_g[row0 * L + q] : 0;
+      idn[j] = (row0 < a.rows && q < L) ? (int)a.ids[row0 * L + q] : 0;
     }
   }
-  for (long row = (long)blockIdx.x * 4 + wave; row < n_rows; row += (long)gridDim.x * 4) {
+  for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += (long)gridDim.x * 4) {
     // ---- ids of the row -> LDS, input mask by ballot --------------------------------------------------
     M192 m;
     const long nrow = row + (long)gridDim.x * 4;
@@ -570,9 +548,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int j = 0; j < 3; ++j) {
       const int q = j * 64 + lane;
       const int id = idn[j];
-      idn[j] = (nrow < n_rows && q < L) ? (int)ids_g[nrow * L + q] : 0;
-      m.w[j] = __ballot(use_mask ? id != 0 : q < L);
-      idbuf[IDM + q] = q < L ? (unsigned char)id : (unsigned char)vocab;
+      idn[j] = (nrow < a.rows && q < L) ? (int)a.ids[nrow * L + q] : 0;
+      m.w[j] = __ballot(a.use_mask ? id != 0 : q < L);
+      idbuf[IDM + q] = q < L ? (unsigned char)id : (unsigned char)a.vocab;
     }
     m = m_and(m, valid_in);
     JG_SST(0);
@@ -615,7 +593,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     JG_SST(1);
     // output mask of the first conv ("any" rule over its k0 taps), positions [0, L0)
     M192 mo = m;
-    if (use_mask) {
+    if (a.use_mask) {
       mo = M192{{0, 0, 0}};
 #pragma unroll
       for (int t = 0; t < K0; ++t) mo = m_or(mo, t >= pad0 ? m_shr(m, t - pad0) : m_shl(m, pad0 - t));
@@ -623,59 +601,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     mo = m_and(mo, valid0);
     float pool[16];                 // (initialised right in front of the last layer: live there only)
     f32x16 cc;                      // accumulators of block 0 of the upcoming k = 3 layer
-    float *prow = part_g + row * (long)n_slots * PARTW;
+    float *prow = a.part + row * (long)a.n_slots * PARTW;
     {
       const float *ep = epi;
-      const int tap = TAPS ? (int)(lcode >> 3) & 31 : 0;
-      if constexpr (STATIC) {
-        JG_EPI_CALL(((PROG & 2) != 0));
-      } else {
-        if (lcode & 2) JG_EPI_CALL(true);
-        else JG_EPI_CALL(false);
-      }
+      const int tap = TAPS ? a.layer[0].tap : 0;
+      if (a.layer[0].save) JG_EPI_CALL(true);
+      else JG_EPI_CALL(false);
     }
     JG_SST(2);
     // ---- k = 3 convolutions on the matrix cores -----------------------------------------------------------
-#define JG_LAYER_PRE                                                                                           \
-    /* next layer's weights (layer 0 of the next row after the last one): requested by conv_layer behind its last MFMA */ \
-    /* (the two offsets pass through an empty asm: with a compile-time program they are constants, and the    \
-       loads behind them - 48 weight and up to 64 parameter registers per layer - would be hoisted out of the   \
-       row loop as loop invariants, all layers' at once) */                                                     \
-    int wo_ = (j + 1 == NC ? 0 : j + 1) * 12 << 6, eo_ = (j + 1) * 4 * C;                                      \
-    asm volatile("" : "+s"(wo_), "+s"(eo_));                                                                   \
-    const half8 *wn = wsrc + wo_;                                                                              \
-    if (use_mask) mo = m_and(m_or(m_or(m_shl(mo, 1), mo), m_shr(mo, 1)), valid0);                              \
-    const float *ep = epi + eo_;                                                                               \
-    if (j == NC - 1) {                                                                                         \
-      _Pragma("unroll") for (int i = 0; i < 16; ++i) pool[i] = pool_avg ? 0.0f : -1.0e9f;                      \
-    }
-// layer J of a compile-time program: the variant is a constant expression
-#define JG_LAYER_STATIC(J)                                                                                     \
-  if constexpr ((J) < (int)(PROG >> 56)) {                                                                     \
-    constexpr int j = (J);                                                                                     \
-    constexpr unsigned lc = (unsigned)(PROG >> (8 * (j + 1))) & 0xffu;                                         \
-    constexpr bool addc = lc & 1, savec = lc & 2, p2c = lc & 4, lastc = j == (int)(PROG >> 56) - 1;            \
-    const int tap = TAPS ? (int)(lc >> 3) : 0;                                                                 \
-    JG_LAYER_PRE                                                                                               \
-    if constexpr (lastc) {                                                                                     \
-      JG_LAYER_CALL_LAST(p2c, addc);                                                                           \
-    } else {                                                                                                   \
-      JG_LAYER_CALL(p2c, addc, savec);                                                                         \
-    }                                                                                                          \
-    JG_SST(10);                                                                                                \
-  }
-    if constexpr (STATIC) {
-      JG_LAYER_STATIC(0)
-      JG_LAYER_STATIC(1)
-      JG_LAYER_STATIC(2)
-      JG_LAYER_STATIC(3)
-    } else {
 #pragma unroll 1
-      for (int j = 0; j < NC; ++j) {
-        JG_LAYER_PRE
-        const unsigned lc = (unsigned)(lcode >> (8 * (j + 1))) & 0xffu;
-        const int add = lc & 1, save = lc & 2, p2 = lc & 4;
-        const int tap = TAPS ? (int)(lc >> 3) : 0;
+    for (int j = 0; j < NC; ++j) {
+      // next layer's weights (layer 0 of the next row after the last one): requested by conv_layer behind its last MFMA
+      const half8 *wn = wsrc + ((j + 1 == NC ? 0 : j + 1) * 12 << 6);
+      if (a.use_mask) mo = m_and(m_or(m_or(m_shl(mo, 1), mo), m_shr(mo, 1)), valid0);
+      const float *ep = epi + (j + 1) * 4 * C;
+      {
+        const int add = a.layer[j + 1].add, save = a.layer[j + 1].save, p2 = a.layer[j + 1].aff2;
+        const int tap = TAPS ? a.layer[j + 1].tap : 0;
+        if (j == NC - 1) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) pool[i] = a.pool_kind == JG_POOL_AVG ? 0.0f : -1.0e9f;
+        }
         const int code = (j == NC - 1 ? 8 : 0) | (p2 ? 4 : 0) | (add ? 2 : 0) | (save ? 1 : 0);
         switch (code) {               // wave-uniform: one compiled epilogue per (last, second norm, add, save)
           case 0: JG_LAYER_CALL(false, false, false); break;
@@ -691,13 +638,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           case 12: case 13: JG_LAYER_CALL_LAST(true, false); break;
           default: JG_LAYER_CALL_LAST(true, true); break;
         }
-        JG_SST(10);
       }
+      JG_SST(10);
     }
-#undef JG_LAYER_PRE
-#undef JG_LAYER_STATIC
     // ---- pooled channel sums / maxima of the row -----------------------------------------------------------
-    row_reduce_store(pool, pool_avg, prow, m_count(mo), n, h, lane);
+    row_reduce_store(pool, a.pool_kind == JG_POOL_AVG, prow, m_count(mo), n, h, lane);
     JG_SST(5);
   }
   JG_SST_END;
@@ -724,40 +669,18 @@ __global__ void small_pool_final_kernel(const float *part, int frames, int n_slo
   out[(long)w * out_ld + c] = r;
 }
 
-// the layer program as one word: a byte of stage flags per layer (add | save << 1 | second norm << 2 | tap << 3), the
-// number of k = 3 convs in the top byte
-unsigned long long program_code(const JgSmallArgs &a) {
-  unsigned long long c = (unsigned long long)a.n_conv << 56;
-  for (int q = 0; q <= a.n_conv; ++q)
-    c |= (unsigned long long)((a.layer[q].add ? 1 : 0) | (a.layer[q].save ? 2 : 0) | (a.layer[q].aff2 ? 4 : 0) |
-                              (a.layer[q].tap << 3))
-         << (8 * q);
-  return c;
-}
-
 int launch(jg_engine *e, const JgSmallArgs &a, int smem, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_net_kernel<false, 0>),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_net_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_net_kernel<true, 0>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_net_kernel<false, JG_SMALL_PROG_BASELINE>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_net_kernel<true, JG_SMALL_PROG_NMDMERGE>),
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_net_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const int grid = (int)std::min<long>(e->n_cu, (a.rows + 3) / 4);
-  const unsigned long long prog = e->small_generic ? 0ull : program_code(a);
-  if (prog == JG_SMALL_PROG_BASELINE && a.n_slots == 1)
-    hipLaunchKernelGGL((small_net_kernel<false, JG_SMALL_PROG_BASELINE>), dim3((unsigned)grid), dim3(256), (size_t)smem, s, a);
-  else if (prog == JG_SMALL_PROG_NMDMERGE && a.n_slots == 3)
-    hipLaunchKernelGGL((small_net_kernel<true, JG_SMALL_PROG_NMDMERGE>), dim3((unsigned)grid), dim3(256), (size_t)smem, s, a);
-  else if (a.n_slots > 1)
-    hipLaunchKernelGGL((small_net_kernel<true, 0>), dim3((unsigned)grid), dim3(256), (size_t)smem, s, a);
-  else
-    hipLaunchKernelGGL((small_net_kernel<false, 0>), dim3((unsigned)grid), dim3(256), (size_t)smem, s, a);
+  if (a.n_slots > 1) hipLaunchKernelGGL(small_net_kernel<true>, dim3((unsigned)grid), dim3(256), (size_t)smem, s, a);
+  else hipLaunchKernelGGL(small_net_kernel<false>, dim3((unsigned)grid), dim3(256), (size_t)smem, s, a);
   JG_HIP(hipGetLastError());
 #ifdef JG_EXPERIMENT
   if (a.dbg & 16) {
@@ -766,9 +689,9 @@ int launch(jg_engine *e, const JgSmallArgs &a, int smem, hipStream_t s) {
     JG_HIP(hipMemcpyFromSymbol(hst, HIP_SYMBOL(jg_small_stamp), sizeof(hst)));
     JG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(jg_small_stamp), z, sizeof(z)));
     const double w = (double)a.rows;
-    fprintf(stderr, "SMALL PROGRAM 0x%llx k0 %d pool %d mask %d slots %d\n", program_code(a), a.k0, a.pool_kind, a.use_mask, a.n_slots);
     fprintf(stderr, "SMALL STAMP rows=%ld cycles/row: ids %.0f table %.0f epi0 %.0f slots %.0f math %.0f pool %.0f frag1 %.0f last-out %.0f dispatch %.0f params %.0f\n",
-            a.rows, hst[0] / w, hst[1] / w, hst[2] / w, hst[3] / w, hst[4] / w, hst[5] / w, hst[6] / w, hst[7] / w, hst[8] / w, hst[9] / w);
+            a.rows, hst[0] / w, hst[1] / w, hst[2] / w, hst[3] / w, hst[4] / w, hst[5] / w, hst[6] / w, hst[7] / w,
+            (hst[8] + hst[10]) / w, hst[9] / w);
   }
 #endif
   return JG_OK;

@@ -86,11 +86,6 @@ class HipDevice:
         (JG_OPT_CONV_PC); the two give the same results bit for bit."""
         L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_CONV_PC, int(on)), "jg_engine_set_option")
 
-    def set_small_generic(self, on: bool):
-        """Fused small-window kernel: always the generic form, never a program-specialised one (JG_OPT_SMALL_GENERIC);
-        same results bit for bit."""
-        L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_SMALL_GENERIC, int(bool(on))), "jg_engine_set_option")
-
     def stream_stats(self) -> dict:
         """Streaming statistics of the last ``jg_predict_windows`` call on this engine."""
         g = lambda k: int(self.lib.jg_engine_get_stat(self.handle, k))  # noqa: E731

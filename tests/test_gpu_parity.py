@@ -475,42 +475,6 @@ def test_producer_consumer_conv_matches_two_workgroup_kernel(name, fsize, n_win,
             assert np.abs(classic[k] - ref[k]).max() <= TOL, k
 
 
-@pytest.mark.parametrize("name", ["baseline500", "nmdmerge500"])
-def test_small_window_program_kernels_match_the_generic_kernel(name):
-    """The fused small-window kernel is compiled three times: generic (layer program read at run time) and with the
-    programs of the reference's two 500-bp configurations as compile-time constants (jg_small.hip: JG_SMALL_PROG_*).
-    Same arithmetic in the same order: every output bit-identical with JG_OPT_SMALL_GENERIC on, for full, ragged and
-    N-masked windows - and repeatable."""
-    from jaeger_amd.engine import JaegerHipEngine, frame_length
-    from oracle import encoder as oenc
-    from oracle import forward as ofwd
-    cfg = load_model_cfg(name)
-    weights = ofwd.random_weights(cfg, seed=38341)
-    fsize, n_win = 500, 700
-    rng = np.random.Generator(np.random.PCG64(4242))
-    seq = _random_dna(rng, fsize * n_win, n_frac=0.02)
-    lens = np.full(n_win, fsize, np.int32)
-    lens[1::3] = rng.integers(fsize // 2, fsize, lens[1::3].size)
-    windows = [seq[i * fsize:i * fsize + n].tobytes() for i, n in enumerate(lens)]
-    ids = oenc.encode_windows(windows, fsize, pad_to=frame_length(fsize))
-    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, precision="f16x3")
-    assert eng.model.placement()["small_fused"]
-    eng.device.set_small_generic(True)
-    generic = eng.model.forward(ids)
-    eng.device.set_small_generic(False)
-    bad = 0
-    for rep in range(8):
-        got = eng.model.forward(ids, chunk=(0, 96, 300)[rep % 3])
-        bad += any(not np.array_equal(generic[k], got[k]) for k in generic)
-    assert bad == 0, f"{bad}/8 runs of the program-specialised kernel differ from the generic kernel"
-    assert eng.model.precision == "f16x3"           # the range guard did not trip
-    eng.close()
-    ref = ofwd.forward(cfg, weights, ids[:48])
-    for k in ("prediction", "reliability"):
-        if k in ref and k in generic:
-            assert np.abs(generic[k][:48] - ref[k]).max() <= TOL, k
-
-
 def test_forward_variant_without_inner_nmd_taps():
     """A 128-channel model whose residual stacks are followed by BN + GELU without an NMD tap
     (stage list conv2: BIAS+BN+ADD+ACT+BN+ACT) must stay on the split-f16 path (compiled pattern) and
