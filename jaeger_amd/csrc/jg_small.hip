@@ -485,6 +485,11 @@ __device__ __forceinline__ void row_reduce_store(const float (&p)[16], const boo
 //     alive, LDS latency under vector work): bit-identical, 1.5 - 3 % slower - the compiler keeps every tap's rows in
 //     flight whatever the source order, the wave then runs into the 16-deep LDS queue, and pinning the sums step by
 //     step costs as much as it hides.
+//   * a two-block-deep pipeline with the block's 32 transcendentals in the MFMA slots as well (exp2 in slot p, + 1 in
+//     slot p + 5, 1 / x in slot p + 10; two accumulator sets across the layer boundary): bit-identical, 5.5 % slower
+//     (3 800 vs 4 023 Mbp/s) - 41 spilled registers, and the tap variant crashes the compiler's AGPR-copy rewrite pass;
+//     it would need the 32 affine parameter registers back first (scale folded into the weights, shift into the
+//     MFMA's C operand).
 // TAPS = false: the model has no NMD taps - the tap paths (24 more inlined epilogues, 17 more registers) are compiled out
 template <bool TAPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void small_net_kernel(JgSmallArgs a) {
