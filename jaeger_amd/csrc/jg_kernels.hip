@@ -20,21 +20,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
+// (tanh-GELU, tanh and sigmoid through v_exp_f32 / v_rcp_f32 - the formulas of the split-f16 kernels, jg_conv_dev.h -
+// instead of libm's tanhf / expf: 8 instead of ~40 instructions per element; the exact-f32 conv's epilogue was a third
+// of its tile time.  Saturates correctly: 2^t -> 0 or inf gives x or -0.)
 __device__ __forceinline__ float jg_apply_act(float v, int act) {
   switch (act) {
     case JG_ACT_GELU_TANH: {
-      // tf.nn.gelu(approximate=True): 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))
-      const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-      return 0.5f * v * (1.0f + tanhf(u));
+      // tf.nn.gelu(approximate=True): 0.5x(1+tanh(u)) = x / (1 + e^(-2u)), u = sqrt(2/pi)(x+0.044715x^3)
+      const float t = v * (-2.3022082f - 0.10294324f * v * v);   // -2u * log2(e)
+      return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
     }
     case JG_ACT_GELU_ERF:
       return 0.5f * v * erfcf(-v * 0.70710678118654752f);
     case JG_ACT_RELU:
       return fmaxf(v, 0.0f);
     case JG_ACT_TANH:
-      return tanhf(v);
+      return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853901f * v));
     case JG_ACT_SIGMOID:
-      return 1.0f / (1.0f + expf(-v));
+      return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950f * v));
     default:
       return v;
   }
@@ -102,6 +105,7 @@ __device__ __forceinline__ float4 jg_apply_stages(float4 v, const StageArg *st, 
   }
   return v;
 }
+
 
 // ---------------------------------------------------------------------------
 // encoder
@@ -419,11 +423,17 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
   }
 }
 
-// positions per workgroup tile of the exact-f32 conv: 128, or 64 when that wastes clearly less of the
-// last tile (e.g. the legacy tower's 166-codon frames: 3 x 64 = 192 instead of 2 x 128 = 256)
+// positions per workgroup tile of the exact-f32 conv: 64.  (Rounds 1 - 2 took 128 unless that wasted a tenth of the
+// last tile.  Round 3, bench.py --precision f32 on the brain stack, interleaved on one box: 64-position tiles
+// 22.5 Mbp/s against 18.9 - a 40 KB tile lets FOUR workgroups share a CU instead of two, and what the kernel lacked was
+// other workgroups' MFMAs under a workgroup's staging, barriers and epilogue (matrix cores 55 % busy, waves parked 29 %
+// of their life at barriers).  Measured beside it: the weight quads two steps ahead and the activation fragments one
+// step ahead instead of fetched for the step itself: 18.6; the epilogue's stage parameters preloaded into registers:
+// 18.4 with 64-position tiles - 158 registers, two waves per SIMD again; exp2 / rcp activations instead of libm's:
+// + 5 %, kept.)
 int jg_conv_tile_m(int l_out) {
-  const int t128 = (l_out + 127) / 128 * 128, t64 = (l_out + 63) / 64 * 64;
-  return (t64 * 10 <= t128 * 9) ? 64 : 128;
+  (void)l_out;
+  return 64;
 }
 
 // LDS bytes of a BM-position tile: `cch` channels of the staged input rows, or the accumulator exchange of the epilogue
