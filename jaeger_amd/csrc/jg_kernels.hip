@@ -271,7 +271,8 @@ int jg_launch_mask(const uint8_t *in, int rows, int L_in, int L_out, int k, int 
 // The contraction runs in groups of 8 input channels = four 32x32x2 MFMA steps: lane half h
 // takes channels 8q+4h..8q+4h+3 of its row with ONE ds_read_b128 and the matching weights
 // with ONE 16-byte load from the re-packed blob [tap][cin/8][cout_pad][8] (L2-resident),
-// fetched one group ahead of its use.
+// fetched two groups ahead of its use (with 64-position tiles a group is eight MFMAs = 512 cycles, less than an L2
+// round trip: + 1.5 % over one group ahead; the A fragment is read from LDS one group ahead).
 // Accumulators go through LDS once so the epilogue runs on float4 channel
 // quads with fully coalesced stores.
 template <int WM, int WN, int TM, int TN>
@@ -337,22 +338,45 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
   // ---- MFMA main loop over (tap, 8-channel group of this pass) ---------------------------------------------------
   const int gpass = cw >> 3, g0 = c0 >> 3;
   const int steps = a.k * gpass;
-  float4 bnext[TN];
+  // operands in flight: the weight quads of steps s + 1 and s + 2 (L2 round trips of several hundred ns against a step
+  // of sixteen MFMAs = 1 024 cycles), the activation fragments of step s + 1 (LDS)
+  const auto w_at = [&](int tt, int gg, int tn) { return wq[(size_t)(tt * groups + g0 + gg) * w_group + (size_t)tn * 64]; };
+  const float *abase = smem + ((wm * (TM * 32) + i) * a.stride) * ldr + 4 * h;
+  const auto a_at = [&](int tt, int gg, int tm) {
+    return *reinterpret_cast<const float4 *>(abase + (tt * a.dil + tm * 32 * a.stride) * ldr + gg * 8);
+  };
+  float4 b0[TN], b1[TN], a0[TM];
+  int tb = 0, gb = 0, ta = 0, ga = 0;
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) bnext[tn] = wq[(size_t)g0 * w_group + (size_t)tn * 64];
-  int t = 0, g = 0;
+  for (int tn = 0; tn < TN; ++tn) b0[tn] = w_at(0, 0, tn);
+  if (++gb == gpass) { gb = 0; ++tb; }
+  if (steps > 1) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b1[tn] = w_at(tb, gb, tn);
+    if (++gb == gpass) { gb = 0; ++tb; }
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) a0[tm] = a_at(0, 0, tm);
+  if (++ga == gpass) { ga = 0; ++ta; }
   for (int sidx = 0; sidx < steps; ++sidx) {
     float4 bv[TN], av[TM];
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) bv[tn] = bnext[tn];
-    if (sidx + 1 < steps) {
-      const int gn = g + 1 == gpass ? 0 : g + 1, tnx = g + 1 == gpass ? t + 1 : t;
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) bnext[tn] = wq[(size_t)(tnx * groups + g0 + gn) * w_group + (size_t)tn * 64];
+    for (int tn = 0; tn < TN; ++tn) {
+      bv[tn] = b0[tn];
+      b0[tn] = b1[tn];
     }
-    const float *arow = smem + ((wm * (TM * 32) + i) * a.stride + t * a.dil) * ldr + g * 8 + 4 * h;
+    if (sidx + 2 < steps) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) av[tm] = *reinterpret_cast<const float4 *>(arow + (tm * 32 * a.stride) * ldr);
+      for (int tn = 0; tn < TN; ++tn) b1[tn] = w_at(tb, gb, tn);
+      if (++gb == gpass) { gb = 0; ++tb; }
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) av[tm] = a0[tm];
+    if (sidx + 1 < steps) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) a0[tm] = a_at(ta, ga, tm);
+      if (++ga == gpass) { ga = 0; ++ta; }
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -362,7 +386,6 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].z, bv[tn].z, acc[tm][tn], 0, 0, 0);
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].w, bv[tn].w, acc[tm][tn], 0, 0, 0);
       }
-    if (++g == gpass) { g = 0; ++t; }
   }
   }
   __syncthreads();  // every wave is done reading the input rows
@@ -428,9 +451,11 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
 // 22.5 Mbp/s against 18.9 - a 40 KB tile lets FOUR workgroups share a CU instead of two, and what the kernel lacked was
 // other workgroups' MFMAs under a workgroup's staging, barriers and epilogue (matrix cores 55 % busy, waves parked 29 %
 // of their life at barriers).  Measured beside it: the weight quads two steps ahead and the activation fragments one
-// step ahead instead of fetched for the step itself: 18.6; the epilogue's stage parameters preloaded into registers:
-// 18.4 with 64-position tiles - 158 registers, two waves per SIMD again; exp2 / rcp activations instead of libm's:
-// + 5 %, kept.)
+// step ahead: 18.6 with 128-position tiles, + 1.5 % with 64 (kept); the epilogue's stage parameters preloaded into
+// registers: 18.4 with 64-position tiles - 158 registers, two waves per SIMD again; the epilogue straight from the
+// accumulators, stage by stage (a lane = one channel x 16 positions, no LDS round trip, parameters as scalars):
+// bit-compatible results, 21.5 vs 22.7 - 119 registers, three workgroups per CU; exp2 / rcp activations instead of
+// libm's: + 5 %, kept.)
 int jg_conv_tile_m(int l_out) {
   (void)l_out;
   return 64;
