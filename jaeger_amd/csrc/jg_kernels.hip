@@ -455,7 +455,8 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
 // registers: 18.4 with 64-position tiles - 158 registers, two waves per SIMD again; the epilogue straight from the
 // accumulators, stage by stage (a lane = one channel x 16 positions, no LDS round trip, parameters as scalars):
 // bit-compatible results, 21.5 vs 22.7 - 119 registers, three workgroups per CU; exp2 / rcp activations instead of
-// libm's: + 5 %, kept.)
+// libm's: + 5 %, kept; the input channels in two passes + the accumulator exchange one wave row at a time (21 KB of LDS)
+// with 80 registers per lane = SIX workgroups per CU: 22.85 vs 22.58 - beyond four the overlap is bought, dropped.)
 int jg_conv_tile_m(int l_out) {
   (void)l_out;
   return 64;
