@@ -490,9 +490,6 @@ __device__ __forceinline__ void row_reduce_store(const float (&p)[16], const boo
 //     (3 800 vs 4 023 Mbp/s) - 41 spilled registers, and the tap variant crashes the compiler's AGPR-copy rewrite pass;
 //     it would need the 32 affine parameter registers back first (scale folded into the weights, shift into the
 //     MFMA's C operand).
-//   * the mask as a rewrite of masked rows behind a branch instead of four v_and per channel group, and the range guard
-//     as NaN propagation into the pool instead of a v_max3 per two stored elements (560 vector instructions a row
-//     less, bit-identical): 3 960 vs 3 983 Mbp/s - they sat in MFMA slots that were free anyway.
 // TAPS = false: the model has no NMD taps - the tap paths (24 more inlined epilogues, 17 more registers) are compiled out
 template <bool TAPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void small_net_kernel(JgSmallArgs a) {
