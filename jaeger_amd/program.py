@@ -15,7 +15,7 @@ Pure host logic (numpy + ctypes structs): unit-tested on CPU.
 
 from __future__ import annotations
 
-from dataclasses import dataclass
+from dataclasses import dataclass, replace
 
 import numpy as np
 
@@ -255,6 +255,23 @@ class _Compiler:
         self.emb_off = self.blob.add(table)
         buf, mask = L.JG_BUF_IDS, L.JG_BUF_IDS      # Embedding(mask_zero=True), builder.py:858-867
         i = 0
+        if not layers or not isinstance(layers[0], Conv):
+            # A norm / activation / nmd / residual block - or the pool itself - directly on the Embedding output (the
+            # reference's own Embedding -> MaskedBatchNorm -> masked max pool case, tests/unit/test_masked_pooling.py:
+            # 186-209): the table rows pass through a one-tap identity conv that does NOT multiply by the mask, so that
+            # masked positions keep Embedding row 0 exactly as in the Keras graph, and the Embedding's mask (ids != 0)
+            # becomes a mask slot of its own; the layers that follow fuse into that conv's epilogue.
+            e = plan.embedding_dim
+            ident = Conv("embedding/identity", 1, e, e, 1, "same", 1, False, None, False, "any")
+            self.w = dict(self.w)
+            self.w["embedding/identity/kernel"] = np.eye(e, dtype=np.float32)[None]
+            om = self._conv_mask(replace(ident, use_masking=True), mask)
+            stages, pending = [], []
+            i, om2 = self._fuse_tail(layers, 0, stages, om, e, pending)
+            out = self.bufs.take()
+            self._emit_conv(ident, buf, L.JG_BUF_NONE, stages, om, out)
+            self._flush_nmd(pending, out)
+            buf, mask = out, om2
         while i < len(layers):
             layer = layers[i]
             pending: list = []

@@ -250,3 +250,32 @@ def test_onehot_translated_input_compiles_to_the_same_gather(embedding_size):
         bad = _onehot_variant(64)
         bad["string_processor"]["seq_onehot"] = False
         build_plan(bad)
+
+
+def test_layers_directly_on_the_embedding_get_an_identity_conv():
+    """Embedding -> MaskedBatchNorm -> masked max pool (the reference's tests/unit/test_masked_pooling.py:186-209 model)
+    and Embedding -> nmd: a one-tap identity conv that does not mask its input carries the table rows, the Embedding's
+    mask becomes a slot of its own, the norm / NMD tap fuse into the conv's epilogue."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).parent))
+    from kat_models import nmd_vs_bn_case, padded_pooling_case
+    from jaeger_amd import _lib as L
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.program import compile_plan
+    cfg, w, _, _ = padded_pooling_case()
+    prog = compile_plan(build_plan(cfg), w)
+    kinds = [op.kind for op in prog.ops]
+    assert kinds == [L.OP_MASK, L.OP_CONV, L.OP_POOL, L.OP_DENSE]
+    mask, conv, pool = prog.ops[0], prog.ops[1], prog.ops[2]
+    assert mask.in_mask == L.JG_BUF_IDS and mask.k == 1 and conv.in_buf == L.JG_BUF_IDS and conv.in_mask == L.JG_BUF_NONE
+    assert conv.k == 1 and conv.cin == conv.cout == 8 and conv.out_mask == mask.out_mask == pool.in_mask
+    assert [conv.stages[j].kind for j in range(conv.n_stages)] == [L.ST_BN]
+    kern = prog.blob[conv.w_off:conv.w_off + 8 * 32].reshape(8, 32)
+    np.testing.assert_array_equal(kern[:, :8], np.eye(8, dtype=np.float32))
+    (cfg_a, w_a), (cfg_b, w_b), _ = nmd_vs_bn_case()
+    for c, ww in ((cfg_a, w_a), (cfg_b, w_b)):
+        prog = compile_plan(build_plan(c), ww)
+        conv = next(op for op in prog.ops if op.kind == L.OP_CONV)
+        assert [conv.stages[j].kind for j in range(conv.n_stages)] == [L.ST_NMD, L.ST_BN]
+        assert prog.nmd_dim == 8
