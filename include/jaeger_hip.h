@@ -121,10 +121,12 @@ const char *jg_last_error(void);
 int jg_engine_create(int device_id, jg_engine **out);
 int jg_engine_destroy(jg_engine *e);
 int jg_engine_sync(jg_engine *e);
-/* Engine options.  JG_OPT_STREAM_BYTES: host-resident base buffers larger than this (default 1 GiB) are
+/* Engine options.  JG_OPT_STREAM_BYTES: host-resident base buffers larger than this (default 32 MiB) are
  * streamed by jg_predict_windows - the start-sorted window list is cut into groups whose base span fits the
- * budget, each span goes host -> pinned staging buffer -> device buffer on a copy stream (two of each) while the
- * previous group is encoded and classified; the device never holds more than two spans of bases.  This is the
+ * budget (and that hold a whole number of forward passes), each span goes host -> pinned staging buffer -> device
+ * buffer on a copy stream (two of each) while the previous group is encoded and classified, outputs come back through
+ * pinned staging, and no step of the loop synchronises the compute stream; the device never holds more than two
+ * spans of bases.  This is the
  * "host-DRAM -> HBM streamed" ingest of BASELINE.json configs[4]; the reference streams Python strings through
  * tf.data instead (commands/predict.py:186-245).
  * JG_OPT_CONV_PC (default 0): which kernel runs the 128 -> 128 channel five-tap convs of the residual stacks
@@ -134,8 +136,12 @@ int jg_engine_sync(jg_engine *e);
 enum { JG_OPT_STREAM_BYTES = 1, JG_OPT_CONV_PC = 2 };
 int jg_engine_set_option(jg_engine *e, int key, int64_t value);
 /* statistics of the engine's last jg_predict_windows call: number of streamed groups (0 = not streamed), bytes sent
- * through the staging buffers, peak bytes of bases resident on the device */
-enum { JG_STAT_STREAM_GROUPS = 1, JG_STAT_STREAM_BYTES = 2, JG_STAT_PEAK_DEVICE_BASES = 3, JG_STAT_DUST_MASKED = 4 };
+ * through the staging buffers, peak bytes of bases resident on the device.  JG_STAT_WINDOWS_DONE may be read from
+ * ANOTHER thread while a jg_predict_windows call with host outputs is running: the output rows (and counts) of windows
+ * [0, value) are final and may be consumed - the reference only sees its results when InferModel.predict returns
+ * (nnlib/inference.py:341-373); here per-contig aggregation runs beside the forward of later windows. */
+enum { JG_STAT_STREAM_GROUPS = 1, JG_STAT_STREAM_BYTES = 2, JG_STAT_PEAK_DEVICE_BASES = 3, JG_STAT_DUST_MASKED = 4,
+       JG_STAT_WINDOWS_DONE = 5 };
 int64_t jg_engine_get_stat(const jg_engine *e, int key);
 /* DUST inside the fused path (replaces the per-contig pydustmasker call of seqops/io.py:104-108 without a host pass):
  * attach the record table (n_records + 1 offsets into the HOST base buffer the following jg_predict_windows /
@@ -247,6 +253,19 @@ int jg_fasta_parse(const uint8_t *text, int64_t n, int64_t max_records, uint8_t 
  *                  torchrun rank 0 indexes, every rank parses only the byte ranges of the contigs it owns. */
 int jg_fasta_index(const uint8_t *text, int64_t n, int64_t max_records, int64_t *rec_off, int64_t *seq_len,
                    uint8_t *names, int64_t *name_off, int64_t *n_records);
+
+/* jg_fasta_scan / jg_fasta_fill : the same ingest on every core the process may use (n_threads <= 0: affinity mask,
+ *                  cgroup CPU quota, divided by LOCAL_WORLD_SIZE).  scan cuts the image into one slice per thread,
+ *                  finds the records and counts their bases, and returns the exact sizes the caller allocates; fill
+ *                  copies bases / names to their final places in parallel and optionally returns the header-line byte
+ *                  offsets jg_fasta_index gives (rec_off, n_records + 1 entries).  `text` must stay valid (and may be a
+ *                  read-only mapping) until jg_fasta_scan_free.  Identical output to jg_fasta_parse. */
+typedef struct jg_fasta_scan_t jg_fasta_scan_t;
+int jg_fasta_scan(const uint8_t *text, int64_t n, int32_t n_threads, jg_fasta_scan_t **out, int64_t *n_records,
+                  int64_t *n_bases, int64_t *name_bytes);
+int jg_fasta_fill(const jg_fasta_scan_t *scan, uint8_t *bases, int64_t *offsets, uint8_t *names, int64_t *name_off,
+                  int64_t *rec_off);
+void jg_fasta_scan_free(jg_fasta_scan_t *scan);
 
 /* ---- DUST soft-masking (host only; replaces pydustmasker.DustMasker(seq, window_size=64,
  * score_threshold=20).mask() of seqops/io.py:104-108) -------------------------------------------

@@ -64,6 +64,9 @@ extern "C" int jg_engine_destroy(jg_engine *e) {
     if (e->pin[i]) (void)hipHostFree(e->pin[i]);
     if (e->dbase[i]) (void)hipFree(e->dbase[i]);
     if (e->h2d_done[i]) (void)hipEventDestroy(e->h2d_done[i]);
+    if (e->enc_done[i]) (void)hipEventDestroy(e->enc_done[i]);
+    if (e->grp_done[i]) (void)hipEventDestroy(e->grp_done[i]);
+    if (e->pin_io[i]) (void)hipHostFree(e->pin_io[i]);
   }
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->d_rec_off) (void)hipFree(e->d_rec_off);
@@ -103,6 +106,7 @@ extern "C" int64_t jg_engine_get_stat(const jg_engine *e, int key) {
     case JG_STAT_STREAM_GROUPS: return e->streamed_groups;
     case JG_STAT_STREAM_BYTES: return e->streamed_bytes;
     case JG_STAT_PEAK_DEVICE_BASES: return e->peak_dev_bases;
+    case JG_STAT_WINDOWS_DONE: return e->windows_done.load(std::memory_order_acquire);
     case JG_STAT_DUST_MASKED: {          // bases the device DUST lower-cased since the records were attached (syncs)
       if (e->d_dust_cnt == nullptr) return 0;
       unsigned long long h = 0;
@@ -1648,12 +1652,10 @@ static int copy_out(jg_model *m, int slot, int width, float *dst, int64_t row0, 
   return JG_OK;
 }
 
-static int forward_device_ids(jg_model *m, const uint8_t *d_ids, int64_t n_win, int l,
-                              float *prediction, float *reliability, float *embedding, float *nmd,
-                              int out_loc, int chunk, hipStream_t s) {
-  // windows per launch group: amortises launch + pipeline fill.  2 048 windows of 498 codons per frame (+0.7 % over
-  // 1 024; 3.1 GB per activation slot), proportionally more for shorter frames (same positions: +6 % at 500 bp),
-  // and the 32-bit DMA offset cap below for longer ones
+// windows per launch group: amortises launch + pipeline fill.  2 048 windows of 498 codons per frame (+0.7 % over
+// 1 024; 3.1 GB per activation slot), proportionally more for shorter frames (same positions: +6 % at 500 bp),
+// and the 32-bit DMA offset cap below for longer ones
+static int effective_chunk(const jg_model *m, int chunk, int l, int64_t n_win) {
   if (chunk <= 0) chunk = (int)std::min<int64_t>(65536, std::max<int64_t>(1024, (int64_t)2048 * 498 / std::max(l, 1) / 256 * 256));
   // split-f16 DMA offsets are 32-bit: keep one activation tensor (6 frames x l x 512 B) < 3.5 GB
   if (m->precision == 1) {
@@ -1661,21 +1663,36 @@ static int forward_device_ids(jg_model *m, const uint8_t *d_ids, int64_t n_win, 
     if (chunk > cap) chunk = (int)std::max<int64_t>(cap, 1);
   }
   if (chunk > n_win) chunk = (int)std::max<int64_t>(n_win, 1);
+  return chunk;
+}
+
+// enqueue only: the chunk loop of one id tensor (workspace already sized for `chunk`); no range-guard readback
+static int forward_chunks(jg_model *m, const uint8_t *d_ids, int64_t n_win, int l, float *prediction,
+                          float *reliability, float *embedding, float *nmd, int out_loc, int chunk, hipStream_t s) {
+  const int w_pred = jg_model_vec_width(m, 0), w_rel = jg_model_vec_width(m, 1);
+  const int w_emb = jg_model_vec_width(m, 2), w_nmd = jg_model_vec_width(m, 3);
+  for (int64_t w0 = 0; w0 < n_win; w0 += chunk) {
+    const int nw = (int)std::min<int64_t>(chunk, n_win - w0);
+    int rc = run_chunk(m, d_ids + w0 * 6 * (int64_t)l, nw, l, s);
+    if (rc != JG_OK) return rc;
+    if ((rc = copy_out(m, 2, w_pred, prediction, w0, nw, out_loc, s)) != JG_OK) return rc;
+    if ((rc = copy_out(m, 3, w_rel, reliability, w0, nw, out_loc, s)) != JG_OK) return rc;
+    if ((rc = copy_out(m, 0, w_emb, embedding, w0, nw, out_loc, s)) != JG_OK) return rc;
+    if ((rc = copy_out(m, 1, w_nmd, nmd, w0, nw, out_loc, s)) != JG_OK) return rc;
+  }
+  return JG_OK;
+}
+
+static int forward_device_ids(jg_model *m, const uint8_t *d_ids, int64_t n_win, int l,
+                              float *prediction, float *reliability, float *embedding, float *nmd,
+                              int out_loc, int chunk, hipStream_t s) {
+  chunk = effective_chunk(m, chunk, l, n_win);
   JG_REQUIRE((int64_t)chunk * 6 <= 0x7fffffff / 8, JG_ERR_INVALID, "chunk too large");
   int rc = ensure_workspace(m, chunk, l);
   if (rc != JG_OK) return rc;
-  const int w_pred = jg_model_vec_width(m, 0), w_rel = jg_model_vec_width(m, 1);
-  const int w_emb = jg_model_vec_width(m, 2), w_nmd = jg_model_vec_width(m, 3);
   for (int attempt = 0; attempt < 2; ++attempt) {
-    for (int64_t w0 = 0; w0 < n_win; w0 += chunk) {
-      const int nw = (int)std::min<int64_t>(chunk, n_win - w0);
-      rc = run_chunk(m, d_ids + w0 * 6 * (int64_t)l, nw, l, s);
-      if (rc != JG_OK) return rc;
-      if ((rc = copy_out(m, 2, w_pred, prediction, w0, nw, out_loc, s)) != JG_OK) return rc;
-      if ((rc = copy_out(m, 3, w_rel, reliability, w0, nw, out_loc, s)) != JG_OK) return rc;
-      if ((rc = copy_out(m, 0, w_emb, embedding, w0, nw, out_loc, s)) != JG_OK) return rc;
-      if ((rc = copy_out(m, 1, w_nmd, nmd, w0, nw, out_loc, s)) != JG_OK) return rc;
-    }
+    if ((rc = forward_chunks(m, d_ids, n_win, l, prediction, reliability, embedding, nmd, out_loc, chunk, s)) != JG_OK)
+      return rc;
     if (m->precision != 1) break;
     // split-f16 range guard: an activation beyond the f16 range poisons the fast path;
     // fall back to the exact-f32 kernels for this and every later call of the model.
@@ -1840,13 +1857,24 @@ extern "C" int jg_encode(jg_engine *e, const uint8_t *bases, int64_t n_bases, in
 
 // ---- streamed ingest -------------------------------------------------------------------------
 // Host-resident bases larger than the engine's stream budget never exist on the device as a whole: the
-// (start-sorted) window list is cut into groups whose base span fits the budget; a group's span is copied
-// into one of two pinned staging buffers and sent to one of two device buffers on the copy stream while the
-// previous group is being encoded and classified on the compute stream.
-static int stream_setup(jg_engine *e, int64_t span_cap) {
+// (start-sorted) window list is cut into groups whose base span fits the budget and whose window count is a whole
+// number of forward passes.  The groups run as a two-deep pipeline that never drains the compute stream:
+//   helper thread   span of group g+1: host -> pinned staging -> device buffer (g+1)%2 on the copy stream
+//   compute stream  group g: window table (pinned) -> [DUST] -> encode -> forward passes -> outputs D2H into pinned
+//                   staging g%2 -> event
+//   calling thread  after ENQUEUEING group g it waits for group g-1's event, copies that group's rows from the pinned
+//                   staging into the caller's arrays and publishes the progress (JG_STAT_WINDOWS_DONE): the rows of
+//                   windows below that mark are final while the call is still running.
+// Nothing in the loop synchronises the whole stream; buffers are recycled on events (device span: the encode that
+// read it; pinned span: its H2D copy; pinned outputs: the calling thread's own copy-out).
+static int stream_setup(jg_engine *e, int64_t span_cap, int64_t io_cap) {
   if (e->copy_stream == nullptr) JG_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
     if (e->h2d_done[i] == nullptr) JG_HIP(hipEventCreateWithFlags(&e->h2d_done[i], hipEventDisableTiming));
+    if (e->enc_done[i] == nullptr) JG_HIP(hipEventCreateWithFlags(&e->enc_done[i], hipEventDisableTiming));
+    if (e->grp_done[i] == nullptr)
+      JG_HIP(hipEventCreateWithFlags(&e->grp_done[i], hipEventDisableTiming | hipEventBlockingSync));
+  }
   if (span_cap > e->pin_cap) {
     for (int i = 0; i < 2; ++i) {
       if (e->pin[i]) JG_HIP(hipHostFree(e->pin[i]));
@@ -1863,6 +1891,14 @@ static int stream_setup(jg_engine *e, int64_t span_cap) {
     }
     e->dbase_cap = span_cap;
   }
+  if (io_cap > e->pin_io_cap) {
+    for (int i = 0; i < 2; ++i) {
+      if (e->pin_io[i]) JG_HIP(hipHostFree(e->pin_io[i]));
+      e->pin_io[i] = nullptr;
+      JG_HIP(hipHostMalloc(&e->pin_io[i], (size_t)io_cap, hipHostMallocDefault));
+    }
+    e->pin_io_cap = io_cap;
+  }
   return JG_OK;
 }
 
@@ -1871,6 +1907,30 @@ struct StreamGroup {
   int64_t b0, b1;      // base span [b0, b1) they touch
 };
 
+// Groups of a start-sorted window list: base span <= budget; a group that holds at least one whole forward pass is cut
+// back to a multiple of `chunk` windows, so that only a call's last pass is ragged.
+static void stream_groups(const int64_t *win_start, const int32_t *win_len, int64_t n_win, int64_t budget, int64_t chunk,
+                          std::vector<StreamGroup> &groups) {
+  int64_t i = 0;
+  while (i < n_win) {
+    StreamGroup g{i, i, win_start[i], win_start[i] + win_len[i]};
+    int64_t j = i + 1;
+    for (; j < n_win; ++j) {
+      const int64_t b1 = std::max(g.b1, win_start[j] + win_len[j]);
+      if (b1 - g.b0 > budget) break;
+      g.b1 = b1;
+    }
+    if (j < n_win && j - i >= chunk && (j - i) % chunk != 0) {
+      j = i + (j - i) / chunk * chunk;
+      g.b1 = g.b0;
+      for (int64_t q = i; q < j; ++q) g.b1 = std::max(g.b1, win_start[q] + win_len[q]);
+    }
+    g.w1 = j;
+    groups.push_back(g);
+    i = j;
+  }
+}
+
 static int predict_streamed(jg_model *m, const uint8_t *bases, int64_t n_bases, const int64_t *win_start,
                             const int32_t *win_len, int64_t n_win, int32_t fsize, const uint8_t *lut65,
                             int32_t flags, int32_t l_pad, float *prediction, float *reliability,
@@ -1878,26 +1938,14 @@ static int predict_streamed(jg_model *m, const uint8_t *bases, int64_t n_bases, 
                             hipStream_t s) {
   jg_engine *e = m->e;
   const int64_t budget = e->stream_bytes;
+  const int fchunk = effective_chunk(m, chunk, l_pad, n_win);
+  JG_REQUIRE((int64_t)fchunk * 6 <= 0x7fffffff / 8, JG_ERR_INVALID, "chunk too large");
   std::vector<StreamGroup> groups;
+  stream_groups(win_start, win_len, n_win, budget, fchunk, groups);
   int64_t span_cap = 0, win_cap = 0;
-  {
-    StreamGroup g{0, 0, win_start[0], win_start[0]};
-    for (int64_t i = 0; i < n_win; ++i) {
-      const int64_t b1 = std::max(g.b1, win_start[i] + win_len[i]);
-      if (i > g.w0 && b1 - g.b0 > budget) {
-        g.w1 = i;
-        groups.push_back(g);
-        g = StreamGroup{i, i, win_start[i], win_start[i] + win_len[i]};
-      } else {
-        g.b1 = b1;
-      }
-    }
-    g.w1 = n_win;
-    groups.push_back(g);
-    for (const StreamGroup &q : groups) {
-      span_cap = std::max(span_cap, q.b1 - q.b0);
-      win_cap = std::max(win_cap, q.w1 - q.w0);
-    }
+  for (const StreamGroup &q : groups) {
+    span_cap = std::max(span_cap, q.b1 - q.b0);
+    win_cap = std::max(win_cap, q.w1 - q.w0);
   }
   // with records attached (jg_engine_set_dust) every span is staged with 64 bases of context either side and
   // soft-masked on the device before it is encoded: an interval that touches a window starts or ends < 64 bases outside it
@@ -1909,81 +1957,155 @@ static int predict_streamed(jg_model *m, const uint8_t *bases, int64_t n_bases, 
     flags |= 1;
   }
   span_cap = (span_cap + 2 * ctx + 4095) / 4096 * 4096;
-  int rc = stream_setup(e, std::max<int64_t>(span_cap, 4096));
+  // pinned staging per parity: [window starts i64][window lengths i32][outputs f32 ...][counts i32 x 4][range-guard flag]
+  const bool host_out = out_loc == JG_PTR_HOST;
+  const int w_pred = jg_model_vec_width(m, 0), w_rel = jg_model_vec_width(m, 1);
+  const int w_emb = jg_model_vec_width(m, 2), w_nmd = jg_model_vec_width(m, 3);
+  float *user[4] = {prediction, reliability, embedding, nmd};
+  const int width[4] = {w_pred, w_rel, w_emb, w_nmd};
+  int64_t off_out[4] = {0, 0, 0, 0};
+  int64_t io = (win_cap * 12 + 63) / 64 * 64;
+  for (int k = 0; k < 4; ++k) {
+    off_out[k] = io;
+    if (host_out && user[k] != nullptr && width[k] > 0) io += (win_cap * width[k] * 4 + 63) / 64 * 64;
+  }
+  const int64_t off_counts = io;
+  if (host_out && counts != nullptr) io += win_cap * 16;
+  const int64_t off_flag = io;
+  io += 64;
+  int rc = stream_setup(e, std::max<int64_t>(span_cap, 4096), (io + 4095) / 4096 * 4096);
   if (rc != JG_OK) return rc;
   if ((rc = grow(&m->d_ids, &m->d_ids_cap, win_cap * 6 * (int64_t)l_pad)) != JG_OK) return rc;
   if ((rc = grow(&m->d_win, &m->d_win_cap, win_cap * 12)) != JG_OK) return rc;
-  if (counts != nullptr && out_loc == JG_PTR_HOST)
+  if (counts != nullptr && host_out)
     if ((rc = grow(&m->d_counts, &m->d_counts_cap, win_cap * 16)) != JG_OK) return rc;
+  if ((rc = ensure_workspace(m, fchunk, l_pad)) != JG_OK) return rc;
   JG_HIP(hipMemcpyAsync(m->d_lut, lut65, 65, hipMemcpyHostToDevice, s));
-  std::vector<int64_t> rebased((size_t)win_cap);
+  JG_HIP(hipStreamSynchronize(s));               // (lut65 is the caller's pageable memory; nothing else waits in the loop)
   e->streamed_groups = (int64_t)groups.size();
   e->streamed_bytes = 0;
   e->peak_dev_bases = 2 * e->dbase_cap;
-  auto stage = [&](size_t gi) -> int {      // host span -> pinned -> device buffer gi % 2 (copy stream)
+
+  bool span_used[2] = {false, false};            // parity b's device span / pinned span have been used in this pipeline run
+  auto stage = [&](size_t gi) -> int {           // host span -> pinned -> device buffer gi % 2 (copy stream)
     const StreamGroup &g = groups[gi];
     const int b = (int)(gi & 1);
-    // both buffers of parity b are free: group gi - 2 (their last user) was synchronised at the end of its turn
     JG_HIP(hipSetDevice(e->dev));
     const int64_t h0 = std::max<int64_t>(0, g.b0 - ctx), h1 = std::min(n_bases, g.b1 + ctx);
+    if (span_used[b]) JG_HIP(hipEventSynchronize(e->h2d_done[b]));                 // the pinned span's last copy has left it
     memcpy(e->pin[b], bases + h0, (size_t)(h1 - h0));
+    if (span_used[b]) JG_HIP(hipStreamWaitEvent(e->copy_stream, e->enc_done[b], 0));   // the device span's last reader is done
     JG_HIP(hipMemcpyAsync(e->dbase[b], e->pin[b], (size_t)(h1 - h0), hipMemcpyHostToDevice, e->copy_stream));
     JG_HIP(hipEventRecord(e->h2d_done[b], e->copy_stream));
+    span_used[b] = true;
     e->streamed_bytes += g.b1 - g.b0;
     return JG_OK;
   };
-  if ((rc = stage(0)) != JG_OK) return rc;
-  const int w_pred = jg_model_vec_width(m, 0), w_rel = jg_model_vec_width(m, 1);
-  const int w_emb = jg_model_vec_width(m, 2), w_nmd = jg_model_vec_width(m, 3);
-  for (size_t gi = 0; gi < groups.size(); ++gi) {
+  auto enqueue = [&](size_t gi) -> int {         // everything group gi needs of the compute stream
     const StreamGroup &g = groups[gi];
     const int b = (int)(gi & 1);
     const int64_t nw = g.w1 - g.w0;
-    // the next group's span is staged by a helper thread while this group is encoded and classified
-    int stage_rc = JG_OK;
-    std::string stage_err;
-    std::thread stager;
-    if (gi + 1 < groups.size())
-      stager = std::thread([&, gi]() {
-        stage_rc = stage(gi + 1);
-        if (stage_rc != JG_OK) stage_err = jg_last_error();
-      });
-    struct Joiner {
-      std::thread &t;
-      ~Joiner() { if (t.joinable()) t.join(); }
-    } joiner{stager};
+    char *io_b = static_cast<char *>(e->pin_io[b]);
+    int64_t *p_start = reinterpret_cast<int64_t *>(io_b);
+    int32_t *p_len = reinterpret_cast<int32_t *>(io_b + win_cap * 8);
     const int64_t h0 = std::max<int64_t>(0, g.b0 - ctx), h1 = std::min(n_bases, g.b1 + ctx);     // the staged span
-    for (int64_t i = 0; i < nw; ++i) rebased[(size_t)i] = win_start[g.w0 + i] - h0;
+    for (int64_t i = 0; i < nw; ++i) p_start[i] = win_start[g.w0 + i] - h0;
+    memcpy(p_len, win_len + g.w0, (size_t)nw * 4);
     char *dw = static_cast<char *>(m->d_win);
-    JG_HIP(hipMemcpyAsync(dw, rebased.data(), (size_t)nw * 8, hipMemcpyHostToDevice, s));
-    JG_HIP(hipMemcpyAsync(dw + win_cap * 8, win_len + g.w0, (size_t)nw * 4, hipMemcpyHostToDevice, s));
-    JG_HIP(hipStreamSynchronize(s));          // `rebased` is reused by the next group (pageable source)
+    JG_HIP(hipMemcpyAsync(dw, io_b, (size_t)(win_cap * 8 + nw * 4), hipMemcpyHostToDevice, s));
     JG_HIP(hipStreamWaitEvent(s, e->h2d_done[b], 0));
     if (dust) {
-      rc = jg_launch_dust(static_cast<uint8_t *>(e->dbase[b]), h0, h1 - h0, e->d_rec_off, e->n_rec, e->dust_window,
-                          e->dust_threshold, g.b0, g.b1, e->d_dust_cnt, s);
-      if (rc != JG_OK) return rc;
+      const int drc = jg_launch_dust(static_cast<uint8_t *>(e->dbase[b]), h0, h1 - h0, e->d_rec_off, e->n_rec, e->dust_window,
+                                     e->dust_threshold, g.b0, g.b1, e->d_dust_cnt, s);
+      if (drc != JG_OK) return drc;
     }
-    int32_t *d_counts = counts == nullptr ? nullptr : (out_loc == JG_PTR_HOST ? m->d_counts : counts + g.w0 * 4);
-    rc = jg_launch_encode(static_cast<const uint8_t *>(e->dbase[b]), reinterpret_cast<const int64_t *>(dw),
-                          reinterpret_cast<const int32_t *>(dw + win_cap * 8), nw, fsize, m->d_lut, flags, l_pad,
-                          m->d_ids, d_counts, s);
-    if (rc != JG_OK) return rc;
-    rc = forward_device_ids(m, m->d_ids, nw, l_pad, prediction ? prediction + g.w0 * w_pred : nullptr,
-                            reliability ? reliability + g.w0 * w_rel : nullptr,
-                            embedding ? embedding + g.w0 * w_emb : nullptr, nmd ? nmd + g.w0 * w_nmd : nullptr,
-                            out_loc, chunk, s);
-    if (rc != JG_OK) return rc;
-    if (counts != nullptr && out_loc == JG_PTR_HOST)
-      JG_HIP(hipMemcpyAsync(counts + g.w0 * 4, d_counts, (size_t)nw * 16, hipMemcpyDeviceToHost, s));
+    int32_t *d_counts = counts == nullptr ? nullptr : (host_out ? m->d_counts : counts + g.w0 * 4);
+    int erc = jg_launch_encode(static_cast<const uint8_t *>(e->dbase[b]), reinterpret_cast<const int64_t *>(dw),
+                               reinterpret_cast<const int32_t *>(dw + win_cap * 8), nw, fsize, m->d_lut, flags, l_pad,
+                               m->d_ids, d_counts, s);
+    if (erc != JG_OK) return erc;
+    JG_HIP(hipEventRecord(e->enc_done[b], s));
+    float *dst[4];
+    for (int k = 0; k < 4; ++k)
+      dst[k] = user[k] == nullptr ? nullptr
+                                  : (host_out ? reinterpret_cast<float *>(io_b + off_out[k]) : user[k] + g.w0 * width[k]);
+    erc = forward_chunks(m, m->d_ids, nw, l_pad, dst[0], dst[1], dst[2], dst[3], out_loc, fchunk, s);
+    if (erc != JG_OK) return erc;
+    if (counts != nullptr && host_out)
+      JG_HIP(hipMemcpyAsync(io_b + off_counts, d_counts, (size_t)nw * 16, hipMemcpyDeviceToHost, s));
+    if (m->precision == 1)
+      JG_HIP(hipMemcpyAsync(io_b + off_flag, m->d_overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+    JG_HIP(hipEventRecord(e->grp_done[b], s));
+    return JG_OK;
+  };
+  // wait for group gi, hand its rows to the caller, publish the progress; *overflow: the f16 range guard tripped in it
+  auto finalize = [&](size_t gi, bool *overflow) -> int {
+    const StreamGroup &g = groups[gi];
+    const int b = (int)(gi & 1);
+    const int64_t nw = g.w1 - g.w0;
+    JG_HIP(hipEventSynchronize(e->grp_done[b]));
+    const char *io_b = static_cast<const char *>(e->pin_io[b]);
+    if (m->precision == 1 && *reinterpret_cast<const int *>(io_b + off_flag) != 0) {
+      *overflow = true;
+      return JG_OK;
+    }
+    if (host_out) {
+      for (int k = 0; k < 4; ++k)
+        if (user[k] != nullptr && width[k] > 0)
+          memcpy(user[k] + g.w0 * width[k], io_b + off_out[k], (size_t)nw * width[k] * 4);
+      if (counts != nullptr) memcpy(counts + g.w0 * 4, io_b + off_counts, (size_t)nw * 16);
+    }
+    e->windows_done.store(g.w1, std::memory_order_release);
+    return JG_OK;
+  };
+
+  size_t first = 0;
+  while (first < groups.size()) {
+    span_used[0] = span_used[1] = false;
+    if ((rc = stage(first)) != JG_OK) return rc;
+    bool overflow = false;
+    size_t redo = groups.size();
+    for (size_t gi = first; gi < groups.size() && !overflow; ++gi) {
+      // the next group's span is staged by a helper thread while this group is enqueued and the previous one handed over
+      int stage_rc = JG_OK;
+      std::string stage_err;
+      std::thread stager;
+      if (gi + 1 < groups.size())
+        stager = std::thread([&, gi]() {
+          stage_rc = stage(gi + 1);
+          if (stage_rc != JG_OK) stage_err = jg_last_error();
+        });
+      struct Joiner {
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+      } joiner{stager};
+      if ((rc = enqueue(gi)) != JG_OK) return rc;
+      if (gi > first) {
+        if ((rc = finalize(gi - 1, &overflow)) != JG_OK) return rc;
+        if (overflow) redo = gi - 1;
+      }
+      if (stager.joinable()) stager.join();
+      if (stage_rc != JG_OK) {
+        jg_set_error("%s", stage_err.c_str());
+        return stage_rc;
+      }
+    }
+    if (!overflow) {
+      if ((rc = finalize(groups.size() - 1, &overflow)) != JG_OK) return rc;
+      if (overflow) redo = groups.size() - 1;
+    }
+    if (!overflow) break;
+    // split-f16 range guard: an activation beyond the f16 range poisons the fast path - drain the pipeline, fall back to the
+    // exact-f32 kernels for the group that tripped it, for every later group and for every later call of the model
     JG_HIP(hipStreamSynchronize(s));
-    if (stager.joinable()) stager.join();
-    if (stage_rc != JG_OK) {
-      jg_set_error("%s", stage_err.c_str());
-      return stage_rc;
-    }
+    JG_HIP(hipStreamSynchronize(e->copy_stream));
+    JG_HIP(hipMemsetAsync(m->d_overflow, 0, sizeof(int), s));
+    m->precision = 0;
+    m->f16_reason = "an activation left the f16 range at run time";
+    if ((rc = ensure_workspace(m, fchunk, l_pad)) != JG_OK) return rc;
+    first = redo;
   }
-  (void)n_bases;
+  JG_HIP(hipStreamSynchronize(s));
   return JG_OK;
 }
 
@@ -2003,6 +2125,7 @@ extern "C" int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_b
   e->streamed_groups = 0;
   e->streamed_bytes = 0;
   e->peak_dev_bases = bases_loc == JG_PTR_HOST ? n_bases : 0;
+  e->windows_done.store(0, std::memory_order_release);
   if (bases_loc == JG_PTR_HOST && win_loc == JG_PTR_HOST && n_bases > e->stream_bytes) {
     // streamed ingest needs a start-sorted window list (the fragmenter's FASTA order is) inside the buffer
     bool sorted = true;
@@ -2047,5 +2170,6 @@ extern "C" int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_b
   }
   if (!to_free.empty() || out_loc == JG_PTR_HOST) (void)hipStreamSynchronize(s);
   for (void *p : to_free) (void)hipFree(p);
+  if (rc == JG_OK && out_loc == JG_PTR_HOST) e->windows_done.store(n_win, std::memory_order_release);
   return rc;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -166,12 +167,17 @@ struct jg_engine {
   int conv_pc = 0;                // JG_OPT_CONV_PC: producer / consumer kernel for the 128-channel five-tap convs
   // streamed ingest of host-resident bases (jg_predict_windows): spans above `stream_bytes` go through two pinned
   // staging buffers and two device buffers on a copy stream, record group by record group
-  int64_t stream_bytes = (int64_t)1 << 30;
+  int64_t stream_bytes = (int64_t)32 << 20;
   hipStream_t copy_stream = nullptr;
   void *pin[2] = {nullptr, nullptr};
   void *dbase[2] = {nullptr, nullptr};
   int64_t pin_cap = 0, dbase_cap = 0;
   hipEvent_t h2d_done[2] = {nullptr, nullptr};
+  hipEvent_t enc_done[2] = {nullptr, nullptr};    // group g's encode has read device span g % 2
+  hipEvent_t grp_done[2] = {nullptr, nullptr};    // group g's outputs are in pinned staging g % 2
+  void *pin_io[2] = {nullptr, nullptr};           // pinned window tables / outputs / counts of the two groups in flight
+  int64_t pin_io_cap = 0;
+  std::atomic<int64_t> windows_done{0};           // JG_STAT_WINDOWS_DONE: rows [0, windows_done) of the running call are final
   int64_t streamed_groups = 0, streamed_bytes = 0, peak_dev_bases = 0;   // statistics of the last call (jg_engine_get_stat)
   // DUST on the device (jg_engine_set_dust): record offsets of the host base buffer the next jg_predict_windows /
   // jg_encode calls are given; the uploaded bases are soft-masked before they are encoded
@@ -254,6 +260,9 @@ struct jg_model {
   int part_rows[JG_MAX_BUFS] = {};  // split-f16 path: partial rows per window the last conv wrote to each NMD slot
   int pool_rows = 0;                // same for the fused max pool
 };
+
+// cores this process may use: affinity mask, cgroup CPU quota, divided by LOCAL_WORLD_SIZE (jg_dust.hip)
+int jg_usable_cores();
 
 // ---- kernel launchers (defined in jg_kernels.hip) ---------------------------
 int jg_launch_conv(jg_engine *e, const ConvArgs &a, hipStream_t s);

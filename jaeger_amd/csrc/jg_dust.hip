@@ -148,7 +148,7 @@ struct Dust {
 // cores this process may actually use: the affinity mask, cut down to the cgroup CPU quota (cgroup v2 cpu.max, v1
 // cpu.cfs_quota_us / cpu.cfs_period_us) - a container can see 256 cores and own 16; threads beyond the quota only
 // preempt each other.  Under torchrun every rank masks its own contigs, so the quota is also shared by the ranks.
-static int usable_cores() {
+int jg_usable_cores() {
   int n = 0;
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
@@ -179,7 +179,7 @@ extern "C" int jg_dust_mask(uint8_t *bases, const int64_t *offsets, int64_t n_re
   for (int64_t r = 0; r < n_records; ++r)
     JG_REQUIRE(offsets[r + 1] >= offsets[r] && offsets[r + 1] - offsets[r] < (int64_t)2000000000,
                JG_ERR_INVALID, "jg_dust_mask: record %lld length out of range", (long long)r);
-  int nt = n_threads > 0 ? n_threads : usable_cores();
+  int nt = n_threads > 0 ? n_threads : jg_usable_cores();
   nt = std::max(1, std::min(nt, 256));
   if ((int64_t)nt > n_records) nt = (int)std::max<int64_t>(1, n_records);
   std::vector<int64_t> masked((size_t)nt, 0);

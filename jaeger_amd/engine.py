@@ -86,6 +86,11 @@ class HipDevice:
         (JG_OPT_CONV_PC); the two give the same results bit for bit."""
         L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_CONV_PC, int(on)), "jg_engine_set_option")
 
+    def windows_done(self) -> int:
+        """Progress of the ``predict_windows`` call running on this engine in ANOTHER thread (JG_STAT_WINDOWS_DONE): the
+        output rows and counts of windows [0, value) are final."""
+        return int(self.lib.jg_engine_get_stat(self.handle, L.JG_STAT_WINDOWS_DONE))
+
     def stream_stats(self) -> dict:
         """Streaming statistics of the last ``jg_predict_windows`` call on this engine."""
         g = lambda k: int(self.lib.jg_engine_get_stat(self.handle, k))  # noqa: E731
@@ -243,12 +248,14 @@ class HipModel:
 
     def predict_windows(self, bases, n_bases: int, win_start, win_len, n_win: int, fsize: int, lut,
                         flags: int = 0, l_pad: int | None = None, chunk: int = 0, device_inputs=False,
-                        want=("prediction", "reliability", "embedding", "nmd"), counts=True):
+                        want=("prediction", "reliability", "embedding", "nmd"), counts=True, out: dict | None = None):
         """``jg_predict_windows``.  With ``device_inputs`` the base / window buffers
-        are raw device pointers (ints); outputs always land in host arrays."""
+        are raw device pointers (ints); outputs always land in host arrays - the caller's (``out``, from
+        :meth:`host_outputs`: another thread may then read finished rows while the call runs) or fresh ones."""
         l_pad = frame_length(fsize) if l_pad is None else int(l_pad)
-        o = self._host_outputs(n_win, want)
-        cnt = np.zeros((n_win, 4), np.int32) if counts else None
+        res = out if out is not None else self.host_outputs(n_win, want, counts)
+        o = {k: res.get(k) for k in ("prediction", "reliability", "embedding", "nmd")}
+        cnt = res.get("counts")
         loc = L.JG_PTR_DEVICE if device_inputs else L.JG_PTR_HOST
         lut = np.ascontiguousarray(lut, np.uint8)
         L.check(self.lib.jg_predict_windows(
@@ -256,11 +263,14 @@ class HipModel:
             int(fsize), _ptr(lut), int(flags), l_pad, _ptr(o["prediction"]), _ptr(o["reliability"]),
             _ptr(o["embedding"]), _ptr(o["nmd"]), _ptr(cnt), L.JG_PTR_HOST, int(chunk), None),
             "jg_predict_windows")
-        res = {k: v for k, v in o.items() if v is not None}
-        if cnt is not None:
-            res["counts"] = cnt
         return res
 
+    def host_outputs(self, n_win: int, want=("prediction", "reliability", "embedding", "nmd"), counts=True) -> dict:
+        """Host arrays :meth:`predict_windows` fills: the model's outputs named in ``want`` (+ ``counts`` (n, 4) int32)."""
+        res = {k: v for k, v in self._host_outputs(n_win, want).items() if v is not None}
+        if counts:
+            res["counts"] = np.zeros((n_win, 4), np.int32)
+        return res
 
     def predict_windows_raw(self, bases_ptr: int, n_bases: int, win_start_ptr: int, win_len_ptr: int,
                             n_win: int, fsize: int, lut, flags: int, l_pad: int, out_ptrs: dict,
@@ -383,23 +393,24 @@ class JaegerHipEngine:
     def predict_windows(self, bases: np.ndarray, win_start: np.ndarray, win_len: np.ndarray, fsize: int,
                         l_pad: int | None = None, pre_cased: bool = False,
                         want=("prediction", "reliability", "embedding", "nmd"),
-                        dust_records: np.ndarray | None = None) -> dict[str, np.ndarray]:
+                        dust_records: np.ndarray | None = None, out: dict | None = None) -> dict[str, np.ndarray]:
         """Encode + forward for windows given as (start, length) into ``bases``.  ``want`` limits the
         outputs copied back (the embedding and NMD vectors are 2.6 KB per window).  ``dust_records``: the record
         offsets of ``bases`` (n + 1 entries) - the uploaded copy is then DUST soft-masked on the GPU before it is
         encoded (what ``fragment_generator`` does per contig with pydustmasker, io.py:104-108); ``bases`` itself is
-        left as it is."""
+        left as it is.  ``out``: preallocated arrays from ``model.host_outputs`` - rows below ``device.windows_done()`` may
+        be read by another thread while the call runs."""
         bases = np.ascontiguousarray(bases, np.uint8)
         ws = np.ascontiguousarray(win_start, np.int64)
         wl = np.ascontiguousarray(win_len, np.int32)
         flags = self.encode_flags | (1 if pre_cased else 0)
         if dust_records is None:
             return self.model.predict_windows(bases, bases.size, ws, wl, ws.size, fsize, self.lut, flags,
-                                              l_pad, self.chunk, want=want)
+                                              l_pad, self.chunk, want=want, out=out)
         self.device.attach_records(dust_records)
         try:
             return self.model.predict_windows(bases, bases.size, ws, wl, ws.size, fsize, self.lut, flags,
-                                              l_pad, self.chunk, want=want)
+                                              l_pad, self.chunk, want=want, out=out)
         finally:
             self.dust_masked_total += max(0, self.device.dust_masked())
             self.device.attach_records(None)

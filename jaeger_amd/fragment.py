@@ -57,33 +57,40 @@ class FastaBatch:
         return self.bases[self.offsets[i]:self.offsets[i + 1]].tobytes()
 
 
-def load_fasta(path) -> FastaBatch:
-    """Native one-pass ingest (``jg_fasta_parse``); same record rules as :func:`read_fasta`."""
+def _decode_names(names_buf: np.ndarray, name_off: np.ndarray) -> list[str]:
+    raw, no = names_buf.tobytes(), name_off.tolist()
+    return [raw[no[i]:no[i + 1]].decode() for i in range(len(no) - 1)]
+
+
+def _scan_fill(text: np.ndarray, threads: int = 0, want_bases: bool = True, want_rec_off: bool = False):
+    """``jg_fasta_scan`` + ``jg_fasta_fill`` over a file image: (names, bases or None, offsets, rec_off or None)."""
     import ctypes as C
 
     from . import _lib as L
     lib = L.load()
-    if str(path).endswith(".gz"):
-        with gzip.open(path, "rb") as fh:
-            text = np.frombuffer(fh.read(), np.uint8)
-    else:
-        text = np.fromfile(path, np.uint8)
-    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    n_rec, name_bytes = C.c_int64(), C.c_int64()
-    L.check(lib.jg_fasta_count(ptr(text), text.size, C.byref(n_rec), C.byref(name_bytes)), "jg_fasta_count")
-    if not text.flags.writeable:
-        text = text.copy()
-    offsets = np.zeros(n_rec.value + 1, np.int64)
-    names_buf = np.zeros(max(name_bytes.value, 1), np.uint8)
-    name_off = np.zeros(n_rec.value + 1, np.int64)
-    got, nb = C.c_int64(), C.c_int64()
-    # in place: the base buffer is the file image itself, compacted
-    L.check(lib.jg_fasta_parse(ptr(text), text.size, n_rec.value, ptr(text), ptr(offsets), ptr(names_buf),
-                               ptr(name_off), C.byref(got), C.byref(nb)), "jg_fasta_parse")
-    raw = names_buf.tobytes()
-    no = name_off.tolist()
-    names = [raw[no[i]:no[i + 1]].decode() for i in range(got.value)]
-    return FastaBatch(names, text[:nb.value], offsets[:got.value + 1])
+    ptr = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731   (read-only memory maps have no writable data_as)
+    h = C.c_void_p()
+    n_rec, n_bases, name_bytes = C.c_int64(), C.c_int64(), C.c_int64()
+    L.check(lib.jg_fasta_scan(ptr(text), text.size, int(threads), C.byref(h), C.byref(n_rec), C.byref(n_bases),
+                              C.byref(name_bytes)), "jg_fasta_scan")
+    try:
+        n = n_rec.value
+        bases = np.empty(n_bases.value, np.uint8) if want_bases else None
+        offsets, name_off = np.empty(n + 1, np.int64), np.empty(n + 1, np.int64)
+        names_buf = np.empty(max(name_bytes.value, 1), np.uint8)
+        rec_off = np.empty(n + 1, np.int64) if want_rec_off else None
+        L.check(lib.jg_fasta_fill(h, ptr(bases) if want_bases else None, ptr(offsets), ptr(names_buf), ptr(name_off),
+                                  ptr(rec_off) if want_rec_off else None), "jg_fasta_fill")
+    finally:
+        lib.jg_fasta_scan_free(h)
+    return _decode_names(names_buf[:name_bytes.value], name_off), bases, offsets, rec_off
+
+
+def load_fasta(path, threads: int = 0) -> FastaBatch:
+    """Native ingest on every core of the CPU quota (``jg_fasta_scan`` / ``jg_fasta_fill`` over a read-only memory map
+    of the file); same record rules as :func:`read_fasta`."""
+    names, bases, offsets, _ = _scan_fill(_read_text(path), threads)
+    return FastaBatch(names, bases, offsets)
 
 
 def _read_text(path) -> np.ndarray:
@@ -109,24 +116,9 @@ class FastaIndex:
         return len(self.names)
 
 
-def index_fasta(path) -> FastaIndex:
-    import ctypes as C
-
-    from . import _lib as L
-    lib = L.load()
-    text = _read_text(path)
-    ptr = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
-    n_rec, name_bytes = C.c_int64(), C.c_int64()
-    L.check(lib.jg_fasta_count(ptr(text), text.size, C.byref(n_rec), C.byref(name_bytes)), "jg_fasta_count")
-    n = n_rec.value
-    rec_off, seq_len = np.zeros(n + 1, np.int64), np.zeros(max(n, 1), np.int64)
-    names_buf, name_off = np.zeros(max(name_bytes.value, 1), np.uint8), np.zeros(n + 1, np.int64)
-    got = C.c_int64()
-    L.check(lib.jg_fasta_index(ptr(text), text.size, n, ptr(rec_off), ptr(seq_len), ptr(names_buf), ptr(name_off),
-                               C.byref(got)), "jg_fasta_index")
-    raw, no = names_buf.tobytes(), name_off.tolist()
-    return FastaIndex([raw[no[i]:no[i + 1]].decode() for i in range(got.value)], rec_off[:got.value + 1],
-                      seq_len[:got.value])
+def index_fasta(path, threads: int = 0) -> FastaIndex:
+    names, _, offsets, rec_off = _scan_fill(_read_text(path), threads, want_bases=False, want_rec_off=True)
+    return FastaIndex(names, rec_off, np.diff(offsets))
 
 
 def load_fasta_records(path, rec_off: np.ndarray, records) -> FastaBatch:
@@ -272,14 +264,21 @@ def safe_divide(numerator, denominator):
     return out
 
 
-def window_metadata(table: WindowTable, headers: list[str], counts: np.ndarray) -> dict[str, np.ndarray]:
+def normalise_headers(headers: list[str]) -> np.ndarray:
+    """io.py:109: ``name.strip().replace(",", "___")`` for every record, as an object array."""
+    return np.array([h.strip().replace(",", "___") for h in headers], dtype=object)
+
+
+def window_metadata(table: WindowTable, headers, counts: np.ndarray, normalised: bool = False) -> dict[str, np.ndarray]:
     """meta_0..meta_9 as ``InferModel.predict`` returns them (inference.py:365-367):
-    header, index, contig_end, i, seqlen, g, c, a, t, gc_skew (io.py:128-133)."""
-    hdr = np.array([h.strip().replace(",", "___") for h in headers], dtype=object)   # io.py:109
+    header, index, contig_end, i, seqlen, g, c, a, t, gc_skew (io.py:128-133).  ``meta_0`` is an object array that
+    shares the per-record strings (a fixed-width copy per window would cost more than every other field together);
+    ``normalised``: ``headers`` already is :func:`normalise_headers`' array."""
+    hdr = headers if normalised else normalise_headers(headers)
     g, c, a, t = (counts[:, i].astype(np.int64) for i in range(4))
     skew = safe_divide(g - c, g + c)
     return {
-        "meta_0": hdr[table.contig].astype(str) if len(table) else np.array([], dtype=str),
+        "meta_0": hdr[table.contig] if len(table) else np.array([], dtype=object),
         "meta_1": table.start.astype(np.int64),
         "meta_2": table.is_last.astype(np.int32),
         "meta_3": table.ordinal.astype(np.int64),

@@ -269,7 +269,7 @@ def pred_to_dict(y_pred: dict, **kwargs) -> tuple[dict, dict]:
     chain_first = np.append(seg.first, n_win)
     has_reliability = "reliability" in y_pred
 
-    headers = np.array(y_pred["meta_0"], dtype=str)[seg.first]
+    headers = np.asarray(y_pred["meta_0"])[seg.first].astype(str)      # (one string per contig, not per window)
     lengths = np.array(y_pred["meta_4"], dtype=np.int32)[seg.first]
     # nucleotide content; the reference labels the columns a,t,g,c = meta_7,8,6,5 and only
     # uses their sums (collect.py:319-324)
@@ -333,6 +333,43 @@ def pred_to_dict(y_pred: dict, **kwargs) -> tuple[dict, dict]:
                          gc_skews=np.split(np.asarray(y_pred["meta_9"]).astype(float), split_indices),
                          gcs=np.split(gcs_w, split_indices))
     return data, data_full
+
+
+class _SegView:
+    """The part of :class:`_Segments` that :class:`_Runs` reads, for segmentations merged from several batches."""
+
+    def __init__(self, first: np.ndarray, count: np.ndarray):
+        self.first, self.count, self.n = first, count, len(first)
+
+
+def merge_data(parts: list[dict]) -> dict:
+    """Concatenate the ``data`` (or ``data_full``) dicts :func:`pred_to_dict` returned for consecutive batches of
+    whole contigs into the dict one call over all of them returns (per-contig statistics do not depend on the batch)."""
+    parts = [p for p in parts if p]
+    if len(parts) == 1:
+        return parts[0]
+    if not parts:
+        return {}
+    out = {}
+    for key, v0 in parts[0].items():
+        vals = [p[key] for p in parts]
+        if isinstance(v0, _Runs):
+            offs = np.cumsum([0] + [len(v.calls) for v in vals[:-1]])
+            out[key] = _Runs(np.concatenate([v.calls for v in vals]),
+                             _SegView(np.concatenate([v.seg.first + o for v, o in zip(vals, offs)]),
+                                      np.concatenate([v.seg.count for v in vals])))
+        elif isinstance(v0, _Means):
+            out[key] = _Means(np.concatenate([v.means for v in vals]))
+        elif isinstance(v0, np.ndarray):
+            if v0.ndim == 2 and len({v.shape[1] for v in vals}) > 1:          # per-class counts of differing widths
+                width = max(v.shape[1] for v in vals)
+                vals = [np.pad(v, ((0, 0), (0, width - v.shape[1]))) for v in vals]
+            out[key] = np.concatenate(vals, axis=0)
+        elif isinstance(v0, list):
+            out[key] = [x for v in vals for x in v]
+        else:                                                                 # has_reliability, repeats, ood = None
+            out[key] = v0
+    return out
 
 
 class _Means:

@@ -191,71 +191,52 @@ def _shard_records(lengths: np.ndarray, fsize: int, stride: int | None, world: i
     return lpt_partition(w, world)
 
 
-def _record_groups(fa: "frag.FastaBatch", min_bases: int = 16_000_000) -> list[tuple[int, int]]:
-    """Contiguous record ranges [r0, r1) the host pipeline works in: a small first group so that the GPU starts
-    early, then growing ones (every group costs ~30 ms of host work between its launches): 6 / 14 / 30 / 50 % of
-    the bases.  Inputs under ``min_bases`` per group are not split that far."""
-    n, total = len(fa), int(fa.offsets[-1] - fa.offsets[0]) if len(fa) else 0
-    fractions = [f for f in (0.06, 0.20, 0.50) if f * total >= min_bases]
-    cuts = np.searchsorted(fa.offsets[:-1], fa.offsets[0] + np.array(fractions) * total) if fractions else []
-    bounds = sorted(set([0, n] + [int(c) for c in cuts]))
-    return [(a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+class _Aggregator:
+    """Per-contig aggregation of the long pass BESIDE the forward: ``advance(done)`` is called with the engine's progress
+    mark (output rows of windows [0, done) are final, ``HipDevice.windows_done``) and runs ``pred_to_dict`` on the contigs
+    whose windows are all below it, batch by batch; the reference aggregates after ``InferModel.predict`` has returned
+    (commands/predict.py:846).  Per-contig statistics do not depend on which other contigs share a batch, so the merged
+    result equals one ``pred_to_dict`` call over everything (tests/test_postprocess.py)."""
 
+    def __init__(self, table: "frag.WindowTable", names: list[str], out: dict, pred_kw: dict, min_batch: int):
+        self.table, self.out, self.kw = table, out, pred_kw
+        self.hdr = frag.normalise_headers(names)
+        n_rec = len(names)
+        per_rec = np.bincount(table.contig, minlength=n_rec).astype(np.int64) if len(table) else np.zeros(n_rec, np.int64)
+        self.ends = np.cumsum(per_rec[per_rec > 0])              # window index one past each contig's last window
+        self.w_done = 0                                           # windows aggregated so far (always a contig boundary)
+        self.min_batch = max(1, int(min_batch))
+        self.parts: list = []
+        self.busy_s = 0.0
 
-def _sub_batch(fa: "frag.FastaBatch", r0: int, r1: int) -> "frag.FastaBatch":
-    """Records [r0, r1) as a FastaBatch of its own (views, nothing is copied)."""
-    o0, o1 = int(fa.offsets[r0]), int(fa.offsets[r1])
-    return frag.FastaBatch(fa.names[r0:r1], fa.bases[o0:o1], fa.offsets[r0:r1 + 1] - o0)
-
-
-class _HostPipeline:
-    """Single-GPU host pipeline: a worker thread owns the engine (creates it, then classifies record groups as they
-    arrive) while the calling thread soft-masks the next group (DUST) and scans for terminal repeats on a second
-    stream - the library calls release the GIL, so ingest-side host work runs under the GPU's forward time instead
-    of in front of it.  Results come back in group (= FASTA) order."""
-
-    def __init__(self, make_engine, predict_kw: dict):
-        import queue
-        import threading
-        self.q = queue.Queue()
-        self.ready = threading.Event()
-        self.engine, self.error, self.outs = None, None, []
-        self.busy_s, self.setup_s = 0.0, 0.0
-        self._kw = predict_kw
-        self._make = make_engine
-        self.thread = threading.Thread(target=self._run, name="jaeger-gpu", daemon=True)
-        self.thread.start()
-
-    def _run(self):
-        try:
-            t0 = time.time()
-            self.engine = self._make()
-            self.setup_s = time.time() - t0
-        except BaseException as e:          # reported by the caller
-            self.error = ("engine", e, traceback.format_exc())
-            self.ready.set()
+    def advance(self, done: int, final: bool = False) -> None:
+        if len(self.ends) == 0:
             return
-        self.ready.set()
-        while True:
-            item = self.q.get()
-            if item is None:
-                return
-            if self.error is not None:
-                continue
-            try:
-                t0 = time.time()
-                self.outs.append(predict_batch(self.engine, item, **self._kw))
-                self.busy_s += time.time() - t0
-            except BaseException as e:
-                self.error = ("predict", e, traceback.format_exc())
+        k = int(np.searchsorted(self.ends, done, side="right"))
+        w1 = int(self.ends[k - 1]) if k else 0
+        if w1 <= self.w_done or (not final and w1 - self.w_done < self.min_batch):
+            return
+        t0 = time.time()
+        self.add(self.slice(self.w_done, w1))
+        self.w_done = w1
+        self.busy_s += time.time() - t0
 
-    def submit(self, sub_fa):
-        self.q.put(sub_fa)
+    def slice(self, w0: int, w1: int) -> dict:
+        """Engine outputs + window metadata of windows [w0, w1) in ``InferModel.predict``'s dict form."""
+        t = self.table
+        sub = frag.WindowTable(*(getattr(t, f)[w0:w1] for f in ("contig", "start", "length", "is_last", "ordinal", "seqlen")))
+        y = {k: v[w0:w1] for k, v in self.out.items() if k != "counts"}
+        y.update(frag.window_metadata(sub, self.hdr, self.out["counts"][w0:w1], normalised=True))
+        return y
 
-    def finish(self):
-        self.q.put(None)
-        self.thread.join()
+    def add(self, y_pred: dict) -> None:
+        from .postprocess import pred_to_dict
+        if y_pred and len(y_pred["meta_2"]):
+            self.parts.append(pred_to_dict(y_pred, **self.kw))
 
+    def result(self):
+        from .postprocess import merge_data
+        return merge_data([p[0] for p in self.parts]), merge_data([p[1] for p in self.parts])
 
 
 # ---- torchrun: contig-sharded prediction, one gather of f32 rows ---------------------------------------------
@@ -481,15 +462,6 @@ def run_core(**kwargs) -> int:
     user_min_len = kwargs.get("min_len")
     min_len = user_min_len or fsize
     fa, num, t_ingest = None, 0, 0.0
-    if world == 1:                      # (under torchrun rank 0 indexes the file and every rank reads its own contigs)
-        try:
-            t_ingest = time.time()
-            fa = frag.load_fasta(str(input_path))
-            t_ingest = time.time() - t_ingest
-            num = validate_fasta_entries(fa, min_len=min_len)
-        except Exception as e:
-            lg.error(e)
-            sys.exit(1)
     table_path, phage_path = out_dir / f"{file_base}.tsv", out_dir / f"{file_base}_phages.tsv"
     if table_path.exists() and not kwargs.get("overwrite"):
         lg.error("output file exists. enable --overwrite option to overwrite the output file.")
@@ -507,16 +479,28 @@ def run_core(**kwargs) -> int:
         matrix_path = kwargs.get("crf_transition_matrix")
         if matrix_path:
             crf_kw["crf_transition_matrix"] = json.loads(Path(matrix_path).read_text())
-    weights = None
-    wnpz = model_info.get("weights_npz")
-    if wnpz is not None:
-        from .weights import load_npz
-        weights = load_npz(wnpz)
     precision = "f32" if kwargs.get("exact_f32") else None
 
     def make_engine():
+        weights = None
+        wnpz = model_info.get("weights_npz")
+        if wnpz is not None:
+            from .weights import load_npz
+            weights = load_npz(wnpz)
         return JaegerHipEngine(model_info, weights=weights, device_id=local_rank, chunk=kwargs.get("chunk", 0),
                                precision=precision)
+
+    def ingest():
+        """(under torchrun rank 0 indexes the file and every rank reads its own contigs instead)"""
+        nonlocal fa, num, t_ingest
+        try:
+            t_ingest = time.time()
+            fa = frag.load_fasta(str(input_path))
+            t_ingest = time.time() - t_ingest
+            num = validate_fasta_entries(fa, min_len=min_len)
+        except Exception as e:
+            lg.error(e)
+            sys.exit(1)
 
     def engine_failed(e, tb):
         lg.debug(tb)
@@ -576,83 +560,86 @@ def run_core(**kwargs) -> int:
         y_pred, term_repeats, class_map = got["y_pred"], got["term_repeats"], got["class_map"]
         num, t_ingest, t_predict = got["num"], got["t_ingest"], got["t_predict"]
         engine = None
-    elif not kwargs.get("no_pipeline"):
-        # ---- one GPU: DUST, engine set-up and the terminal-repeat scan run beside the forward ---------------
-        if two_pass:
-            lg.info(f"Two-pass prediction: long contigs (>= {fsize} bp) then short contigs "
-                    f"({user_min_len}-{fsize - 1} bp)")
-        pipe = _HostPipeline(make_engine, dict(fsize=fsize, stride=stride, min_len=fsize if two_pass else min_len,
-                                               max_len=None, **common))
-        t_dust, n_masked = 0.0, 0
-        for r0, r1 in _record_groups(fa):
-            sub = _sub_batch(fa, r0, r1)
-            if dust:
-                t0 = time.time()
-                n_masked += frag.dust_mask(sub)
-                t_dust += time.time() - t0
-            pipe.submit(sub)
-        if dust:
-            lg.info(f"DUST (window 64, threshold 20): {n_masked} of {fa.bases.size} bases soft-masked in "
-                    f"{t_dust:.2f} s (beside the forward)")
-        pipe.ready.wait()
-        if pipe.error is not None and pipe.error[0] == "engine":
-            engine_failed(pipe.error[1], pipe.error[2])
-        engine = pipe.engine
-        log_setup(engine)
-        try:
-            from .engine import HipDevice
-            side = HipDevice(local_rank)                       # its own stream: the scan interleaves with the forward
-            term_repeats = scan_repeats(side)
-            side.close()
-        finally:
-            pipe.finish()
-        if pipe.error is not None:
-            lg.debug(pipe.error[2])
-            lg.error(f"an error {pipe.error[1]} occured during inference on MI355X #{local_rank}!")
-            sys.exit(1)
-        lg.info(f"GPU worker: model set-up {pipe.setup_s:.2f} s, {len(pipe.outs)} record groups classified in "
-                f"{pipe.busy_s:.2f} s")
-        y_pred = {}
-        for part in pipe.outs:
-            y_pred = _concat_predictions(y_pred, part)
-        if two_pass:
-            try:
-                y_short = predict_batch(engine, fa, fsize, stride, min_len=user_min_len, max_len=fsize - 1,
-                                        padded=True, **common)
-            except Exception as e:
-                lg.debug(traceback.format_exc())
-                lg.error(f"an error {e} occured during inference on MI355X #{local_rank}!")
-                sys.exit(1)
-            y_pred = _concat_predictions(y_pred, y_short)
-        t_predict = time.time() - t_predict
     else:
-        # ---- one GPU, --no-pipeline: mask, set up, scan and classify one after the other -------------------------
+        # ---- one GPU.  A worker thread owns the engine: it sets the model up while the FASTA is read (every core, native),
+        # then runs ONE fused call over all windows of the long pass (DUST on its uploaded spans, encoder, forward; the
+        # library streams the spans through pinned staging and publishes its progress).  Beside it the calling thread scans
+        # for terminal repeats on a stream of its own and aggregates the contigs whose windows are final, so that what is
+        # left behind the forward is the last batch and the TSV.  --no-pipeline runs the same steps one after the other.
+        from concurrent.futures import ThreadPoolExecutor
+        piped = not kwargs.get("no_pipeline")
+        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="jaeger-gpu") if piped else None
+        t_setup = time.time()
+        f_engine = pool.submit(make_engine) if piped else None
+        ingest()
         if dust:
             t_dust = time.time()
             n_masked = frag.dust_mask(fa)
             lg.info(f"DUST (window 64, threshold 20): {n_masked} of {fa.bases.size} bases soft-masked in "
                     f"{time.time() - t_dust:.2f} s")
         try:
-            engine = make_engine()
+            engine = f_engine.result() if piped else make_engine()
         except Exception as e:
             engine_failed(e, traceback.format_exc())
-        term_repeats = scan_repeats(engine.device)
-        log_setup(engine)
+        t_setup = time.time() - t_setup
+        class_map = engine.class_map
+        if two_pass:
+            lg.info(f"Two-pass prediction: long contigs (>= {fsize} bp) then short contigs "
+                    f"({user_min_len}-{fsize - 1} bp)")
+        table = frag.build_window_table(fa.lengths, fsize, stride, common["dynamic_stride"],
+                                        common["dynamic_stride_threshold"], fsize if two_pass else min_len, None)
+        n_long = len(table)
+        out = engine.model.host_outputs(n_long, want)
+        starts = fa.offsets[table.contig] + table.start
+        agg = _Aggregator(table, fa.names, out, dict(class_map=class_map, fsize=fsize, term_repeats=None,
+                                                     want_full=bool(kwargs.get("window_scores") or kwargs.get("prophage")),
+                                                     **crf_kw), min_batch=n_long // 8)
+
+        def classify():
+            t0 = time.time()
+            if n_long:
+                engine.predict_windows(fa.bases, starts, table.length, fsize, pre_cased=dust, want=want,
+                                       dust_records=fa.offsets if dust_dev else None, out=out)
+            return time.time() - t0
+
         try:
+            f_pred = pool.submit(classify) if piped else None
+            log_setup(engine)
+            if piped:
+                from .engine import HipDevice
+                side = HipDevice(local_rank)                   # its own stream: the scan interleaves with the forward
+                try:
+                    term_repeats = scan_repeats(side)
+                finally:
+                    side.close()
+                while not f_pred.done():
+                    agg.advance(engine.device.windows_done())
+                    time.sleep(0.004)
+                t_forward = f_pred.result()
+            else:
+                term_repeats = scan_repeats(engine.device)
+                t_forward = classify()
+            agg.advance(n_long, final=True)
             if two_pass:
-                lg.info(f"Two-pass prediction: long contigs (>= {fsize} bp) then short contigs "
-                        f"({user_min_len}-{fsize - 1} bp)")
-                y_long = predict_batch(engine, fa, fsize, stride, min_len=fsize, max_len=None, **common)
                 y_short = predict_batch(engine, fa, fsize, stride, min_len=user_min_len, max_len=fsize - 1,
                                         padded=True, **common)
-                y_pred = _concat_predictions(y_long, y_short)
-            else:
-                y_pred = predict_batch(engine, fa, fsize, stride, min_len=min_len, max_len=None, **common)
+                agg.add(y_short)
         except Exception as e:
             lg.debug(traceback.format_exc())
             lg.error(f"an error {e} occured during inference on MI355X #{local_rank}!")
             sys.exit(1)
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
         t_predict = time.time() - t_predict
+        n_windows = n_long + (len(y_short.get("meta_2", ())) if two_pass else 0)
+        n_bp = float(np.minimum(table.seqlen, fsize).sum()) + \
+            (float(np.minimum(np.asarray(y_short["meta_4"], np.int64), fsize).sum()) if two_pass and y_short else 0.0)
+        y_pred = None
+        if kwargs.get("save_embedding") or kwargs.get("save_nmd"):        # the per-window vectors with their headers
+            y_pred = _concat_predictions(agg.slice(0, n_long) if n_long else {}, y_short if two_pass else {})
+        lg.info(f"GPU worker: model set-up {t_setup:.2f} s (beside the FASTA ingest), {n_long} windows classified in "
+                f"{t_forward:.2f} s; {len(agg.parts)} aggregation batches, {agg.busy_s:.2f} s beside the forward")
     if class_map is None:
         class_map = engine.class_map
     if dust_dev and engine is not None:
@@ -661,8 +648,14 @@ def run_core(**kwargs) -> int:
     t_post = time.time()
 
     from .postprocess import pred_to_dict, write_output       # pandas: imported beside the forward (termini, above)
-    data, data_full = pred_to_dict(y_pred, class_map=class_map, fsize=fsize, term_repeats=term_repeats,
-                                   want_full=bool(kwargs.get("window_scores") or kwargs.get("prophage")), **crf_kw)
+    if world > 1:
+        data, data_full = pred_to_dict(y_pred, class_map=class_map, fsize=fsize, term_repeats=term_repeats,
+                                       want_full=bool(kwargs.get("window_scores") or kwargs.get("prophage")), **crf_kw)
+        n_windows = len(y_pred["meta_2"])
+        n_bp = float(np.minimum(np.asarray(y_pred["meta_4"], np.int64), fsize).sum())
+    else:
+        data, data_full = agg.result()
+        data["repeats"] = term_repeats
     n_written = write_output(data, labels=class_map.get("class"), indices=class_map.get("index"),
                              output_table_path=table_path, output_phage_table_path=phage_path,
                              reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))
@@ -704,15 +697,15 @@ def run_core(**kwargs) -> int:
         lg.info(f"generating fasta file {out_fasta}")
         n_seq = write_fasta_from_results(input_path, phage_path, out_fasta)
         lg.info(f"{n_seq} phage sequences written")
-    headers = y_pred.get("meta_0", np.array([], dtype=object))
-    if kwargs.get("save_embedding") and "embedding" in y_pred:
-        np.savez(out_dir / f"{file_base}_embedding.npz", embedding=y_pred["embedding"], headers=headers)
-    if kwargs.get("save_nmd") and "nmd" in y_pred:
-        np.savez(out_dir / f"{file_base}_nmd.npz", embedding=y_pred["nmd"], headers=headers)   # legacy key name
-    n_bp = float(np.minimum(np.asarray(y_pred["meta_4"], np.int64), fsize).sum()) if "meta_4" in y_pred else 0.0
+    if y_pred is not None:
+        headers = np.asarray(y_pred.get("meta_0", np.array([], dtype=object))).astype(str)
+        if kwargs.get("save_embedding") and "embedding" in y_pred:
+            np.savez(out_dir / f"{file_base}_embedding.npz", embedding=y_pred["embedding"], headers=headers)
+        if kwargs.get("save_nmd") and "nmd" in y_pred:
+            np.savez(out_dir / f"{file_base}_nmd.npz", embedding=y_pred["nmd"], headers=headers)   # legacy key name
     t_all = time.time() - t_start
-    lg.info(f"wall time(s) : {t_all:.2f}  ({len(y_pred['meta_2'])} windows; FASTA ingest {t_ingest:.2f} s, "
-            f"encode+forward {t_predict:.2f} s = {n_bp / 1e6 / max(t_predict, 1e-9):.1f} Mbp/s, aggregation+TSV "
+    lg.info(f"wall time(s) : {t_all:.2f}  ({n_windows} windows; FASTA ingest {t_ingest:.2f} s, "
+            f"encode+forward {t_predict:.2f} s = {n_bp / 1e6 / max(t_predict, 1e-9):.1f} Mbp/s, aggregation+TSV behind the forward "
             f"{time.time() - t_post:.2f} s; end to end {n_bp / 1e6 / max(t_all, 1e-9):.1f} Mbp/s)")
     if engine is not None:
         engine.close()

@@ -76,3 +76,60 @@ def test_selected_records_with_very_long_header_tokens(tmp_path):
         fb = frag.load_fasta_records(str(p), idx.rec_off, sel)
         assert fb.names == [names[i] for i in sel]
         assert [fb.sequence(i) for i in range(len(sel))] == [seqs[i] for i in sel]
+
+
+def _serial_parse(text: np.ndarray):
+    """jg_fasta_count + jg_fasta_parse (the single-thread ingest) -> (names, bases, offsets)."""
+    import ctypes as C
+    from jaeger_amd import _lib as L
+    lib = L.load()
+    text = text.copy()
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    n_rec, name_bytes = C.c_int64(), C.c_int64()
+    L.check(lib.jg_fasta_count(ptr(text), text.size, C.byref(n_rec), C.byref(name_bytes)))
+    out = np.zeros(max(text.size, 1), np.uint8)
+    offsets, name_off = np.zeros(n_rec.value + 1, np.int64), np.zeros(n_rec.value + 1, np.int64)
+    names_buf = np.zeros(max(name_bytes.value, 1), np.uint8)
+    got, nb = C.c_int64(), C.c_int64()
+    L.check(lib.jg_fasta_parse(ptr(text), text.size, n_rec.value, ptr(out), ptr(offsets), ptr(names_buf), ptr(name_off),
+                               C.byref(got), C.byref(nb)))
+    raw, no = names_buf.tobytes(), name_off.tolist()
+    return [raw[no[i]:no[i + 1]].decode() for i in range(got.value)], out[:nb.value], offsets[:got.value + 1]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_parallel_ingest_equals_the_serial_parser(seed):
+    """jg_fasta_scan / jg_fasta_fill with 1 - 13 slices vs jg_fasta_parse on random files: junk in front of the first
+    header, CRLF, blank and whitespace-only lines, indented lines, spaces inside a line, empty records, a header as the
+    last line, no trailing newline - slices that start inside any of these."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    parts = []
+    if seed % 2:
+        parts.append(b"junk line\nACGT\n\n")
+    for r in range(int(rng.integers(1, 40))):
+        eol = b"\r\n" if rng.random() < 0.3 else b"\n"
+        parts.append(b">" + (b"rec%d" % r if rng.random() < 0.9 else b"") + (b" desc x" if rng.random() < 0.5 else b"") + eol)
+        for _ in range(int(rng.integers(0, 12))):
+            u = rng.random()
+            if u < 0.1:
+                parts.append(eol)
+            elif u < 0.15:
+                parts.append(b"  \t " + eol)
+            else:
+                line = np.frombuffer(b"ACGTNacgt", np.uint8)[rng.integers(0, 9, int(rng.integers(1, 90)))].tobytes()
+                if u < 0.25:
+                    line = b" " + line[:len(line) // 2] + b" " + line[len(line) // 2:] + b"\t"
+                parts.append(line + eol)
+    data = b"".join(parts)
+    if seed % 3 == 0:
+        data = data.rstrip(b"\r\n")
+    text = np.frombuffer(data, np.uint8)
+    want = _serial_parse(text)
+    for threads in (1, 2, 3, 5, 8, 13):
+        names, bases, offsets, rec_off = frag._scan_fill(text, threads, want_rec_off=True)
+        assert names == want[0], threads
+        np.testing.assert_array_equal(bases, want[1])
+        np.testing.assert_array_equal(offsets, want[2])
+        assert all(data[o:o + 1] == b">" for o in rec_off[:-1].tolist()) and rec_off[-1] == len(data)
+    names, bases, offsets, _ = frag._scan_fill(text, 0)          # automatic thread count
+    assert names == want[0] and np.array_equal(bases, want[1]) and np.array_equal(offsets, want[2])

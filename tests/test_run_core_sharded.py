@@ -18,9 +18,28 @@ from conftest import ROOT, make_model_dir
 class _StandInModel:
     precision = "stand-in"
 
+    def __init__(self, n_classes):
+        self.n_classes = n_classes
+
+    def host_outputs(self, n_win, want=("prediction", "reliability"), counts=True):
+        out = {"prediction": np.zeros((n_win, self.n_classes), np.float32), "reliability": np.zeros((n_win, 1), np.float32)}
+        out = {k: v for k, v in out.items() if k in want}
+        if counts:
+            out["counts"] = np.zeros((n_win, 4), np.int32)
+        return out
+
+
+class _StandInDevice:
+    """JG_STAT_WINDOWS_DONE of the stand-in: rows below the mark are final while predict_windows is still running."""
+    done = 0
+
+    def windows_done(self):
+        return self.done
+
 
 class _StandInEngine:
-    """Same surface as JaegerHipEngine for run_core: class_map, string_processor_config, predict_windows, device."""
+    """Same surface as JaegerHipEngine for run_core: class_map, string_processor_config, model.host_outputs,
+    predict_windows(out=...), device.windows_done."""
 
     def __init__(self, path_dict=None, **kw):
         import yaml
@@ -28,13 +47,14 @@ class _StandInEngine:
         self.class_map = {"num_classes": len(classes), "class": [c["class"] for c in classes],
                           "index": [c["label"] for c in classes]}
         self.string_processor_config = {"crop_size_codons": None, "crop_size_nt": None}
-        self.model = _StandInModel()
-        self.device = None
+        self.model = _StandInModel(len(classes))
+        self.device = _StandInDevice()
 
     dust_masked_total = 0
 
     def predict_windows(self, bases, win_start, win_len, fsize, l_pad=None, pre_cased=False,
-                        want=("prediction", "reliability"), dust_records=None):
+                        want=("prediction", "reliability"), dust_records=None, out=None):
+        import time
         if dust_records is not None:
             # what jg_engine_set_dust does on the device: DUST on a COPY of the bases by their record table, then the
             # encoder respects the case (the host scan gives the same masks bit for bit: tests/test_gpu_dust.py)
@@ -45,9 +65,9 @@ class _StandInEngine:
             self.dust_masked_total += frag.dust_mask(tmp, threads=1)
             bases, pre_cased = tmp.bases, True
         n = len(win_start)
-        pred = np.zeros((n, self.class_map["num_classes"]), np.float32)
-        rel = np.zeros((n, 1), np.float32)
-        counts = np.zeros((n, 4), np.int32)
+        res = out if out is not None else self.model.host_outputs(n, want)
+        pred, rel, counts = res["prediction"], res["reliability"], res["counts"]
+        self.device.done = 0
         for i, (s, ln) in enumerate(zip(np.asarray(win_start).tolist(), np.asarray(win_len).tolist())):
             w = np.asarray(bases[s:s + ln])
             up = w & 0xDF if not pre_cased else w
@@ -56,7 +76,11 @@ class _StandInEngine:
             h = np.cumsum(w.astype(np.int64) * (np.arange(ln) % 7 + 1))[-1] if ln else 0
             pred[i] = [((h >> (3 * k)) % 97) / 9.0 - 5.0 for k in range(pred.shape[1])]
             rel[i, 0] = ((h >> 5) % 31) / 5.0 - 3.0
-        return {"prediction": pred, "reliability": rel, "counts": counts}
+            if out is not None and i % 3 == 2:           # progress in steps of three windows, slow enough to be polled
+                self.device.done = i + 1
+                time.sleep(0.01)
+        self.device.done = n
+        return res
 
     def close(self):
         pass
@@ -121,10 +145,22 @@ def test_sharded_run_core_equals_single_process(tmp_path, min_len, monkeypatch):
     keep = (E.JaegerHipEngine, E.HipDevice, T.scan_for_terminal_repeats, T.terminal_repeat_table)
     try:
         n_single = _run(tmp_path / "single", tmp_path / "in.fasta", tmp_path / "m", min_len)
-        # the single-GPU host pipeline (worker thread owns the engine, record groups masked beside the forward)
+        # the single-GPU host pipeline (worker thread owns the engine; the calling thread aggregates finished contigs in
+        # batches beside the forward - here every two windows or more)
         import jaeger_amd.predict as P
-        monkeypatch.setattr(P, "_record_groups", lambda fa, **k: [(0, 4), (4, 5), (5, 11), (11, len(fa))])
+        real_agg = P._Aggregator
+        batches = []
+
+        class SmallBatches(real_agg):
+            def __init__(self, *a, **k):
+                k["min_batch"] = 2
+                super().__init__(*a, **k)
+                batches.append(self)
+
+        monkeypatch.setattr(P, "_Aggregator", SmallBatches)
         n_piped = _run(tmp_path / "piped", tmp_path / "in.fasta", tmp_path / "m", min_len, no_pipeline=False)
+        monkeypatch.setattr(P, "_Aggregator", real_agg)
+        assert len(batches) == 1 and len(batches[0].parts) >= 3        # aggregation really ran in several batches
         # --dust-host: the host pass over the FASTA image instead of DUST inside the fused calls (record tables of the
         # whole-buffer and of the compacted short-contig batches): same TSV
         n_host = _run(tmp_path / "hostdust", tmp_path / "in.fasta", tmp_path / "m", min_len, dust_host=True)
