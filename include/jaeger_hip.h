@@ -132,8 +132,11 @@ int jg_engine_sync(jg_engine *e);
  * JG_OPT_CONV_PC (default 0): which kernel runs the 128 -> 128 channel five-tap convs of the residual stacks
  * (layers.py:1882-1915): 0 = the two-workgroup kernel, 1 = the producer / consumer kernel (jg_conv_pc.hip), 2 = the
  * two-workgroup kernel with the producer / consumer experiment's pipelined main loop.  Same results bit for bit - the
- * switch exists for A/B timing and for the test that asserts exactly that. */
-enum { JG_OPT_STREAM_BYTES = 1, JG_OPT_CONV_PC = 2 };
+ * switch exists for A/B timing and for the test that asserts exactly that.
+ * JG_OPT_TERMINI_EXACT (default 0): 1 = jg_terminal_repeats runs every alignment through the kernel that carries length and
+ * gap count through the dynamic programme, instead of only those the packed score-only pass leaves open (score > 100);
+ * same table either way (tests/test_gpu_termini.py). */
+enum { JG_OPT_STREAM_BYTES = 1, JG_OPT_CONV_PC = 2, JG_OPT_TERMINI_EXACT = 3 };
 int jg_engine_set_option(jg_engine *e, int key, int64_t value);
 /* statistics of the engine's last jg_predict_windows call: number of streamed groups (0 = not streamed), bytes sent
  * through the staging buffers, peak bytes of bases resident on the device.  JG_STAT_WINDOWS_DONE may be read from

@@ -66,8 +66,12 @@ def main():
 @click.option("--refine", is_flag=True, help="[unsupported here]")
 @click.option("--exact-f32", is_flag=True, help="run every convolution on the exact-f32 MFMA kernels")
 @click.option("--chunk", type=int, default=0, help="windows per device pass (0 = library default)")
-@click.option("--no-pipeline", is_flag=True, help="run DUST, model set-up, repeat scan and forward one after the other "
-                                                   "(single-GPU runs overlap them by default)")
+@click.option("--no-pipeline", is_flag=True, help="run model set-up, repeat scan, forward and aggregation one after the "
+                                                   "other (single-GPU runs overlap them by default)")
+@click.option("--trust-project", is_flag=True, help="take the layer plan from <name>_project.yaml and the weights from the "
+                                                    "weights file even when a <name>_graph/ SavedModel is there (skips its "
+                                                    "census check and its variable bundle)")
+@click.option("--stream-bytes", type=int, default=None, help="span budget of the host -> HBM base ingest (default 32 MiB)")
 @click.option("--legacy-data", type=click.Path(exists=True), default=None,
               help="reference data directory (config.json, models/default/) for -m default")
 def predict(**kwargs):

@@ -6,7 +6,16 @@
 // (traceback columns) and the gap count in the query row.  Those three are carried through the DP here
 // as auxiliary values of each state's best path, so no traceback matrix is stored.
 //
-// One workgroup per (contig, DTR|ITR) job.  Thread t owns the query rows [t*R, (t+1)*R) (R <= 16) and walks
+// Two kernels.  termini_fast_kernel (below the exact one) scores BOTH alignments of a record in one wave, packed as two
+// unsigned 16-bit lanes per register, without the auxiliary values: 7 instructions per cell instead of 35.  A best score
+// <= 100 fixes everything else: under match +2 / mismatch -100 / gap open 100 a path that never exceeds 100 cannot hold a
+// mismatch or a gap (the score behind one would be <= 0), so the alignment is an exact-match run of score / 2 columns,
+// no gaps, and its end cell is the first cell in (column, row) order that closes a run of that length - the wave reports
+// the column and the 64-row strip, the host finds the row among the strip's rows.  Only alignments scoring above 100
+// (real repeats of more than 50 bases) go through termini_kernel.  Same five numbers either way (tests/test_gpu_termini.py
+// runs every case through both).
+//
+// termini_kernel: one workgroup per (contig, DTR|ITR) job.  Thread t owns the query rows [t*R, (t+1)*R) (R <= 16) and walks
 // its strip column by column one step behind thread t-1 (a systolic wavefront): the only values that cross
 // threads are the H / F states of each strip's last row, double-buffered in LDS, one barrier per step.
 // Letters are compared case-insensitively and only A/C/G/T can match (parasail.matrix_create("ACGT", 2, -100)).
@@ -144,6 +153,171 @@ __global__ __launch_bounds__(TT) void termini_kernel(const uint8_t *__restrict__
   }
 }
 
+
+// ---- fast path: score, end column and row strip of both alignments of a record, one wave per record -----------------
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+struct TermRec {
+  int64_t q_off;   // query = bases[q_off + i]; DTR ref[j] = bases[r_off + j]; ITR ref[j] = complement(bases[r_off + n - 1 - j])
+  int64_t r_off;
+  int32_t n;
+  int32_t pad_;
+};
+
+struct TermFast {
+  int32_t score[2], col[2], lane[2];   // [0] DTR, [1] ITR; col / lane = -1 when the score is 0
+};
+
+__device__ __forceinline__ us2 sat_sub(us2 a, unsigned short b) { return __builtin_elementwise_sub_sat(a, (us2){b, b}); }
+__device__ __forceinline__ us2 pk_max(us2 a, us2 b) { return __builtin_elementwise_max(a, b); }
+
+// rows per lane of the fast kernel's instantiations; a record runs on the smallest one that covers its scan length
+__host__ __device__ inline int fast_rows(int n) {
+  const int need = (n + 63) >> 6;
+  const int cls[8] = {7, 8, 12, 16, 24, 32, 48, 64};
+  for (int k = 0; k < 8; ++k)
+    if (cls[k] >= need) return cls[k];
+  return 64;
+}
+
+// packed-u16 mismatch penalty: 0 where the two codes of a half agree, 102 (= match - mismatch) where they differ.  Written
+// as two instructions by hand: the compiler turns min(x, 1) * 102 into a compare / select / permute chain of five
+__device__ __forceinline__ unsigned pk_penalty(unsigned x, unsigned k102) {
+  unsigned m, p;
+  asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(m) : "v"(x));
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(p) : "v"(m), "v"(k102));
+  return p;
+}
+
+// Lane t owns query rows [t R, (t + 1) R) and walks its strip column by column one step behind lane t - 1 (the systolic
+// wavefront of termini_kernel inside ONE wave: strip edges cross lanes by DPP wave_shr, no LDS traffic, no barrier).
+// States are unsigned and floored at 0: H is >= 0 by definition, and an E / F below 0 can neither win a maximum against
+// H >= 0 nor turn positive again by extension, so max(., 0) of them gives the same H everywhere.  Rows beyond the scan
+// length and columns outside the matrix carry letters that match nothing: their cells only ever hold decayed copies of
+// real scores, which cannot exceed the maximum they came from.
+template <int R>
+__global__ __launch_bounds__(256) void termini_fast_kernel(const uint8_t *__restrict__ bases, const TermRec *__restrict__ recs,
+                                                           TermFast *__restrict__ out, int n_recs) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rec = blockIdx.x * 4 + wave;
+  unsigned *ref = reinterpret_cast<unsigned *>(smem) + wave * (64 * R);   // ref[j] = DTR code | ITR code << 16
+  const bool live = rec < n_recs;
+  const TermRec job = recs[live ? rec : 0];
+  const int n = live ? job.n : 0;
+  for (int j = lane; j < n; j += 64) {
+    const int d = base_code(bases[job.r_off + j]);
+    int c = base_code(bases[job.r_off + n - 1 - j]);
+    if (c < 4) c = 3 - c;
+    ref[j] = (unsigned)d | ((unsigned)c << 16);
+  }
+  __syncthreads();
+  const int i0 = lane * R;
+  unsigned q2[R];
+  us2 hl[R], el[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = i0 + r;
+    int c = 5;                                                     // 5: the row does not exist
+    if (i < n) { c = base_code(bases[job.q_off + i]); if (c == 4) c = 6; }   // 6: a letter that matches nothing
+    q2[r] = (unsigned)c * 0x10001u;
+    hl[r] = (us2){0, 0};
+    el[r] = (us2){0, 0};
+  }
+  const unsigned k102 = (unsigned)(S_MATCH - S_MISMATCH) * 0x10001u;
+  unsigned best = 0, pub_h = 0, pub_f = 0, prev_up = 0;
+  int col_lo = -1, col_hi = -1;
+  const int steps = n > 0 ? n + 63 : 0;
+  for (int step = 0; step < steps; ++step) {
+    const int j = step - lane;
+    const unsigned rc2 = (j >= 0 && j < n) ? ref[j] : 0x00040004u;   // outside the matrix: a letter that matches nothing
+    const unsigned up_hu = __builtin_amdgcn_update_dpp(0u, pub_h, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 reads 0
+    const unsigned up_fu = __builtin_amdgcn_update_dpp(0u, pub_f, 0x138, 0xf, 0xf, false);
+    us2 dg = __builtin_bit_cast(us2, prev_up);
+    prev_up = up_hu;
+    us2 up_h = __builtin_bit_cast(us2, up_hu), up_f = __builtin_bit_cast(us2, up_fu);
+    us2 cm = (us2){0, 0};
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const us2 pen = __builtin_bit_cast(us2, pk_penalty(q2[r] ^ rc2, k102));
+      const us2 hd = __builtin_elementwise_sub_sat(dg + (us2){S_MATCH, S_MATCH}, pen);
+      const us2 e = pk_max(sat_sub(el[r], G_EXT), sat_sub(hl[r], G_OPEN));
+      const us2 f = pk_max(sat_sub(up_f, G_EXT), sat_sub(up_h, G_OPEN));
+      const us2 h = pk_max(hd, pk_max(e, f));
+      cm = pk_max(cm, h);
+      dg = hl[r];
+      hl[r] = h;
+      el[r] = e;
+      up_h = h;
+      up_f = f;
+    }
+    pub_h = __builtin_bit_cast(unsigned, up_h);
+    pub_f = __builtin_bit_cast(unsigned, up_f);
+    const unsigned nb = __builtin_bit_cast(unsigned, pk_max(__builtin_bit_cast(us2, best), cm));
+    if (nb != best) {                                             // a strictly higher score in either half: its first column
+      if ((nb & 0xffffu) != (best & 0xffffu)) col_lo = j;
+      if ((nb >> 16) != (best >> 16)) col_hi = j;
+      best = nb;
+    }
+  }
+  // best cell per half over the wave: max score, then smallest column, then smallest lane (= smallest rows)
+  unsigned long long k0 = (best & 0xffffu) ? ((unsigned long long)(best & 0xffffu) << 32) | ((unsigned long long)(0xffff - col_lo) << 16) | (unsigned)(63 - lane) : 0ull;
+  unsigned long long k1 = (best >> 16) ? ((unsigned long long)(best >> 16) << 32) | ((unsigned long long)(0xffff - col_hi) << 16) | (unsigned)(63 - lane) : 0ull;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o0 = __shfl_xor(k0, off, 64), o1 = __shfl_xor(k1, off, 64);
+    k0 = o0 > k0 ? o0 : k0;
+    k1 = o1 > k1 ? o1 : k1;
+  }
+  if (live && lane == 0) {
+    TermFast o;
+    o.score[0] = (int)(k0 >> 32); o.col[0] = k0 ? 0xffff - (int)((k0 >> 16) & 0xffff) : -1; o.lane[0] = k0 ? 63 - (int)(k0 & 0xffff) : -1;
+    o.score[1] = (int)(k1 >> 32); o.col[1] = k1 ? 0xffff - (int)((k1 >> 16) & 0xffff) : -1; o.lane[1] = k1 ? 63 - (int)(k1 & 0xffff) : -1;
+    out[rec] = o;
+  }
+}
+
+// One thread per (record, DTR | ITR): turn the wave's (score, column, strip) into the five numbers of TermOut when the
+// score is <= 100 - the alignment is an exact-match run of score / 2 columns ending in that column, and its row is the
+// first row of the strip that closes such a run; len = -1 marks an alignment that needs termini_kernel (score > 100).
+__global__ void termini_finish_kernel(const uint8_t *__restrict__ bases, const TermRec *__restrict__ recs,
+                                      const TermFast *__restrict__ fast, TermOut *__restrict__ out, int n_recs) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * n_recs) return;
+  const int rec = idx >> 1, itr = idx & 1;
+  const TermRec job = recs[rec];
+  const int n = job.n, S = fast[rec].score[itr], j = fast[rec].col[itr];
+  TermOut o{S, 0, 0, -1, -1};
+  if (S > 100) {
+    o.len = -1;
+  } else if (S > 0) {
+    const int L = S / 2, R = fast_rows(n), i0 = fast[rec].lane[itr] * R;
+    o.len = L;
+    o.end_r = j;
+    for (int i = i0; i < i0 + R && i < n && o.end_q < 0; ++i) {
+      if (i < L - 1 || j < L - 1) continue;
+      bool run = true;
+      for (int k = 0; k < L && run; ++k) {
+        const int a = base_code(bases[job.q_off + i - k]);
+        int b = itr ? base_code(bases[job.r_off + n - 1 - (j - k)]) : base_code(bases[job.r_off + j - k]);
+        if (itr && b < 4) b = 3 - b;
+        run = a < 4 && a == b;
+      }
+      if (run) o.end_q = i;
+    }
+  }
+  out[idx] = o;
+}
+
+template <int R>
+static int launch_fast(const uint8_t *d_bases, const TermRec *d_recs, TermFast *d_out, int n_recs, hipStream_t s) {
+  if (n_recs <= 0) return JG_OK;
+  hipLaunchKernelGGL(termini_fast_kernel<R>, dim3((unsigned)((n_recs + 3) / 4)), dim3(256), (size_t)4 * 64 * R * 4, s, d_bases,
+                     d_recs, d_out, n_recs);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
 }  // namespace
 
 // results: (n_records, 10) int32 rows = DTR(score, len, fgaps, end_q, end_r), ITR(score, len, fgaps, end_q, end_r);
@@ -155,7 +329,7 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
              JG_ERR_INVALID, "jg_terminal_repeats: bad arguments");
   JG_HIP(hipSetDevice(e->dev));
   hipStream_t s = e->stream;
-  std::vector<TermJob> jobs;
+  std::vector<TermRec> recs;
   std::vector<int64_t> owner;
   std::vector<uint8_t> ends;          // host bases: only the two scanned ends of every record go to the device
   int max_n = 0;
@@ -175,48 +349,94 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
       r_off = (int64_t)ends.size();
       ends.insert(ends.end(), bases + offsets[r + 1] - scan, bases + offsets[r + 1]);
     }
-    for (int itr = 0; itr < 2; ++itr) {
-      jobs.push_back(TermJob{q_off, r_off, scan, itr});
-      owner.push_back(r * 2 + itr);
-    }
+    recs.push_back(TermRec{q_off, r_off, scan, 0});
+    owner.push_back(r);
   }
-  if (jobs.empty()) return JG_OK;
+  if (recs.empty()) return JG_OK;
   JG_REQUIRE(max_n <= TT * RMAX, JG_ERR_UNSUPPORTED, "jg_terminal_repeats: scan length %d", max_n);
   {
-    // longest jobs first: a 4 000-base scan costs 100x a 400-base one, and workgroups are dispatched in index order -
-    // in FASTA order the last long jobs run alone at the end of the launch
-    std::vector<size_t> order(jobs.size());
+    // longest scans first: workgroups are dispatched in index order, and the kernel variants below take contiguous ranges
+    std::vector<size_t> order(recs.size());
     for (size_t k = 0; k < order.size(); ++k) order[k] = k;
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return jobs[a].n > jobs[b].n; });
-    std::vector<TermJob> sj(jobs.size());
-    std::vector<int64_t> so(jobs.size());
-    for (size_t k = 0; k < order.size(); ++k) { sj[k] = jobs[order[k]]; so[k] = owner[order[k]]; }
-    jobs.swap(sj);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return recs[a].n > recs[b].n; });
+    std::vector<TermRec> sr(recs.size());
+    std::vector<int64_t> so(recs.size());
+    for (size_t k = 0; k < order.size(); ++k) { sr[k] = recs[order[k]]; so[k] = owner[order[k]]; }
+    recs.swap(sr);
     owner.swap(so);
   }
+  const int n_recs = (int)recs.size();
   const uint8_t *d_bases = bases;
-  void *tmp_bases = nullptr, *d_jobs = nullptr, *d_out = nullptr;
+  void *tmp_bases = nullptr, *d_recs = nullptr, *d_fast = nullptr, *d_out = nullptr, *d_jobs = nullptr, *d_out2 = nullptr;
+  struct Cleanup {
+    void **p[6];
+    ~Cleanup() { for (void **q : p) if (*q) (void)hipFree(*q); }
+  } cleanup{{&tmp_bases, &d_recs, &d_fast, &d_out, &d_jobs, &d_out2}};
   if (bases_loc == JG_PTR_HOST) {
     JG_HIP(hipMalloc(&tmp_bases, std::max<size_t>(ends.size(), 1)));
     JG_HIP(hipMemcpyAsync(tmp_bases, ends.data(), ends.size(), hipMemcpyHostToDevice, s));
     d_bases = static_cast<const uint8_t *>(tmp_bases);
   }
-  JG_HIP(hipMalloc(&d_jobs, jobs.size() * sizeof(TermJob)));
-  JG_HIP(hipMalloc(&d_out, jobs.size() * sizeof(TermOut)));
-  JG_HIP(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(TermJob), hipMemcpyHostToDevice, s));
-  const size_t smem = (size_t)((max_n + 15) & ~15) + 2 * TT * sizeof(int4) + TT * 12;
-  hipLaunchKernelGGL(termini_kernel, dim3((unsigned)jobs.size()), dim3(TT), smem, s, d_bases,
-                     static_cast<const TermJob *>(d_jobs), static_cast<TermOut *>(d_out));
-  JG_HIP(hipGetLastError());
-  std::vector<TermOut> host(jobs.size());
-  JG_HIP(hipMemcpyAsync(host.data(), d_out, jobs.size() * sizeof(TermOut), hipMemcpyDeviceToHost, s));
+  JG_HIP(hipMalloc(&d_recs, recs.size() * sizeof(TermRec)));
+  JG_HIP(hipMalloc(&d_fast, recs.size() * sizeof(TermFast)));
+  JG_HIP(hipMalloc(&d_out, recs.size() * 2 * sizeof(TermOut)));
+  JG_HIP(hipMemcpyAsync(d_recs, recs.data(), recs.size() * sizeof(TermRec), hipMemcpyHostToDevice, s));
+  // pass 1: both scores of every record, one wave each; records sorted by scan length, one launch per strip height
+  {
+    const TermRec *dr = static_cast<const TermRec *>(d_recs);
+    TermFast *df = static_cast<TermFast *>(d_fast);
+    int a = 0, rc = JG_OK;
+    while (a < n_recs && rc == JG_OK) {          // records are sorted by scan length: one launch per run of a strip height
+      const int rows = fast_rows(recs[(size_t)a].n);
+      int b = a;
+      while (b < n_recs && fast_rows(recs[(size_t)b].n) == rows) ++b;
+      switch (rows) {
+        case 7: rc = launch_fast<7>(d_bases, dr + a, df + a, b - a, s); break;
+        case 8: rc = launch_fast<8>(d_bases, dr + a, df + a, b - a, s); break;
+        case 12: rc = launch_fast<12>(d_bases, dr + a, df + a, b - a, s); break;
+        case 16: rc = launch_fast<16>(d_bases, dr + a, df + a, b - a, s); break;
+        case 24: rc = launch_fast<24>(d_bases, dr + a, df + a, b - a, s); break;
+        case 32: rc = launch_fast<32>(d_bases, dr + a, df + a, b - a, s); break;
+        case 48: rc = launch_fast<48>(d_bases, dr + a, df + a, b - a, s); break;
+        default: rc = launch_fast<64>(d_bases, dr + a, df + a, b - a, s); break;
+      }
+      a = b;
+    }
+    if (rc != JG_OK) return rc;
+    hipLaunchKernelGGL(termini_finish_kernel, dim3((unsigned)((2 * n_recs + 255) / 256)), dim3(256), 0, s, d_bases, dr, df,
+                       static_cast<TermOut *>(d_out), n_recs);
+    JG_HIP(hipGetLastError());
+  }
+  std::vector<TermOut> host(recs.size() * 2);
+  JG_HIP(hipMemcpyAsync(host.data(), d_out, host.size() * sizeof(TermOut), hipMemcpyDeviceToHost, s));
   JG_HIP(hipStreamSynchronize(s));
-  for (size_t k = 0; k < jobs.size(); ++k) {
-    int32_t *dst = results + (owner[k] / 2) * 10 + (owner[k] % 2) * 5;
+  // pass 2: the alignments that scored above 100 (real repeats) through the kernel that carries length and gaps
+  std::vector<TermJob> jobs;
+  std::vector<size_t> slot;
+  int max_n2 = 0;
+  for (size_t k = 0; k < host.size(); ++k)
+    if (host[k].len < 0 || e->termini_exact) {
+      const TermRec &rc = recs[k / 2];
+      jobs.push_back(TermJob{rc.q_off, rc.r_off, rc.n, (int32_t)(k & 1)});
+      slot.push_back(k);
+      max_n2 = std::max(max_n2, rc.n);
+    }
+  if (!jobs.empty()) {
+    JG_HIP(hipMalloc(&d_jobs, jobs.size() * sizeof(TermJob)));
+    JG_HIP(hipMalloc(&d_out2, jobs.size() * sizeof(TermOut)));
+    JG_HIP(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(TermJob), hipMemcpyHostToDevice, s));
+    const size_t smem = (size_t)((max_n2 + 15) & ~15) + 2 * TT * sizeof(int4) + TT * 12;
+    hipLaunchKernelGGL(termini_kernel, dim3((unsigned)jobs.size()), dim3(TT), smem, s, d_bases,
+                       static_cast<const TermJob *>(d_jobs), static_cast<TermOut *>(d_out2));
+    JG_HIP(hipGetLastError());
+    std::vector<TermOut> exact(jobs.size());
+    JG_HIP(hipMemcpyAsync(exact.data(), d_out2, jobs.size() * sizeof(TermOut), hipMemcpyDeviceToHost, s));
+    JG_HIP(hipStreamSynchronize(s));
+    for (size_t k = 0; k < jobs.size(); ++k) host[slot[k]] = exact[k];
+  }
+  for (size_t k = 0; k < host.size(); ++k) {
+    int32_t *dst = results + owner[k / 2] * 10 + (k % 2) * 5;
     dst[0] = host[k].score; dst[1] = host[k].len; dst[2] = host[k].fgaps; dst[3] = host[k].end_q; dst[4] = host[k].end_r;
   }
-  (void)hipFree(d_jobs);
-  (void)hipFree(d_out);
-  if (tmp_bases) (void)hipFree(tmp_bases);
   return JG_OK;
 }

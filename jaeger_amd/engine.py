@@ -295,7 +295,9 @@ class JaegerHipEngine:
     nnlib/inference.py:307-325), ``weights`` (Keras-3 ``.weights.h5``) or ``weights_npz`` (canonical names).  The layer
     plan comes from ``project.yaml``; the weights come from the graph's own variable bundle when there is one
     (``<name>_graph/variables``, mapped by object-graph order and variable names - ``weights.load_savedmodel_bundle``),
-    else from the weights file.  When the graph also holds ``saved_model.pb`` its census (Conv2D count, dilations,
+    else from the weights file (also when the bundle's keys cannot be mapped: loud warning).  ``trust_project=True``
+    (``JAEGER_TRUST_PROJECT=1``, ``--trust-project``) skips the bundle and the census and takes the plan from the YAML and
+    the weights from the file, as round 2 did.  When the graph also holds ``saved_model.pb`` its census (Conv2D count, dilations,
     batch-norm epsilons, GELU form, variable shapes) is compared with the plan first and a disagreement refuses the
     model: an engine that silently computed something else than the graph the reference runs is worse than none.
     Alternatively pass ``model_cfg`` + ``weights`` (canonical-name dict) directly.
@@ -304,7 +306,7 @@ class JaegerHipEngine:
     def __init__(self, path_dict: dict | None = None, *, model_cfg: dict | None = None,
                  weights: dict[str, np.ndarray] | None = None, device_id: int = 0,
                  use_xla: bool = False, return_embedding: bool = False, chunk: int = 0,
-                 precision: str | None = None):
+                 precision: str | None = None, trust_project: bool | None = None):
         self.use_xla = use_xla                      # accepted for signature parity; no-op
         self.return_embedding = return_embedding
         self.chunk = chunk
@@ -318,16 +320,24 @@ class JaegerHipEngine:
             cfg = yaml.safe_load(Path(project).read_text()) or {}
             model_cfg = cfg.get("model")
             if weights is None:
+                import os
+
                 from .weights import load_weights
+                if trust_project is None:
+                    trust_project = os.environ.get("JAEGER_TRUST_PROJECT", "0") not in ("", "0")
                 graph = path_dict.get("graph")
-                if graph is not None and (Path(graph) / "saved_model.pb").exists() \
+                have_file = path_dict.get("weights") is not None or path_dict.get("weights_npz") is not None
+                if not trust_project and graph is not None and (Path(graph) / "saved_model.pb").exists() \
                         and (Path(graph) / "variables" / "variables.index").exists():
                     from .verify import verify_model
                     findings = verify_model(graph, build_plan(model_cfg))
                     if findings:
-                        raise ValueError(f"{graph}: the SavedModel the reference would execute disagrees with the layer plan "
-                                         f"compiled from {project}:\n  " + "\n  ".join(findings))
-                weights = load_weights(path_dict, build_plan(model_cfg))
+                        raise ValueError(
+                            f"{graph}: the SavedModel the reference would execute disagrees with the layer plan compiled from "
+                            f"{project}:\n  " + "\n  ".join(findings) +
+                            ("\n(to run the project.yaml plan with the weights file anyway: trust_project=True / "
+                             "JAEGER_TRUST_PROJECT=1 / --trust-project)" if have_file else ""))
+                weights = load_weights(path_dict, build_plan(model_cfg), trust_project=bool(trust_project))
         if model_cfg is None or weights is None:
             raise ValueError("JaegerHipEngine: provide path_dict or model_cfg + weights")
         self.plan: ModelPlan = build_plan(model_cfg)

@@ -241,6 +241,7 @@ class _Aggregator:
 
 # ---- torchrun: contig-sharded prediction, one gather of f32 rows ---------------------------------------------
 SHARD_STATS: dict = {}        # filled by the sharded path (tests read it): local / total bases of this rank
+LAST_RUN: dict = {}           # stage split of the last single-GPU run_core of this process (bench.py's e2e leg reads it)
 
 
 def _coll_device(local_rank: int):
@@ -419,6 +420,7 @@ def run_core(**kwargs) -> int:
     from .engine import JaegerHipEngine
 
     t_start = time.time()
+    LAST_RUN.clear()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(kwargs.get("physicalid", 0))))
@@ -487,8 +489,11 @@ def run_core(**kwargs) -> int:
         if wnpz is not None:
             from .weights import load_npz
             weights = load_npz(wnpz)
-        return JaegerHipEngine(model_info, weights=weights, device_id=local_rank, chunk=kwargs.get("chunk", 0),
-                               precision=precision)
+        eng = JaegerHipEngine(model_info, weights=weights, device_id=local_rank, chunk=kwargs.get("chunk", 0),
+                              precision=precision, trust_project=True if kwargs.get("trust_project") else None)
+        if kwargs.get("stream_bytes"):              # span budget of the host -> HBM ingest (default 32 MiB)
+            eng.device.set_stream_bytes(int(kwargs["stream_bytes"]))
+        return eng
 
     def ingest():
         """(under torchrun rank 0 indexes the file and every rank reads its own contigs instead)"""
@@ -534,6 +539,7 @@ def run_core(**kwargs) -> int:
         from .termini import scan_for_terminal_repeats
         t_term = time.time()
         rep = scan_for_terminal_repeats(device, fa, fsize)
+        LAST_RUN["terminal_repeats_s"] = round(time.time() - t_term, 3)
         lg.info(f"terminal repeats: {int(rep['terminal_repeats'].notna().sum())} of {len(rep)} "
                 f"contigs in {time.time() - t_term:.2f} s")
         return rep
@@ -640,6 +646,9 @@ def run_core(**kwargs) -> int:
             y_pred = _concat_predictions(agg.slice(0, n_long) if n_long else {}, y_short if two_pass else {})
         lg.info(f"GPU worker: model set-up {t_setup:.2f} s (beside the FASTA ingest), {n_long} windows classified in "
                 f"{t_forward:.2f} s; {len(agg.parts)} aggregation batches, {agg.busy_s:.2f} s beside the forward")
+        LAST_RUN.update(model_setup_and_ingest_s=round(t_setup, 3), ingest_s=round(t_ingest, 3), forward_s=round(t_forward, 3),
+                        aggregation_batches=len(agg.parts), aggregation_beside_forward_s=round(agg.busy_s, 3),
+                        windows=n_windows, pipelined=bool(piped))
     if class_map is None:
         class_map = engine.class_map
     if dust_dev and engine is not None:
@@ -656,9 +665,11 @@ def run_core(**kwargs) -> int:
     else:
         data, data_full = agg.result()
         data["repeats"] = term_repeats
+    LAST_RUN["merge_s"] = round(time.time() - t_post, 3)
     n_written = write_output(data, labels=class_map.get("class"), indices=class_map.get("index"),
                              output_table_path=table_path, output_phage_table_path=phage_path,
                              reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))
+    LAST_RUN["tsv_s"] = round(time.time() - t_post - LAST_RUN["merge_s"], 3)
     lg.info(f"processed {n_written}/{num} sequences")
     if kwargs.get("window_scores"):
         np.savez(out_dir / f"{file_base}_window_scores.npz", headers=data_full["headers"],
@@ -704,6 +715,7 @@ def run_core(**kwargs) -> int:
         if kwargs.get("save_nmd") and "nmd" in y_pred:
             np.savez(out_dir / f"{file_base}_nmd.npz", embedding=y_pred["nmd"], headers=headers)   # legacy key name
     t_all = time.time() - t_start
+    LAST_RUN.update(behind_forward_s=round(time.time() - t_post, 3), wall_s=round(t_all, 3))
     lg.info(f"wall time(s) : {t_all:.2f}  ({n_windows} windows; FASTA ingest {t_ingest:.2f} s, "
             f"encode+forward {t_predict:.2f} s = {n_bp / 1e6 / max(t_predict, 1e-9):.1f} Mbp/s, aggregation+TSV behind the forward "
             f"{time.time() - t_post:.2f} s; end to end {n_bp / 1e6 / max(t_all, 1e-9):.1f} Mbp/s)")

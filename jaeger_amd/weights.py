@@ -231,16 +231,30 @@ def bundle_checkpoint_keys(plan: ModelPlan) -> dict[str, str]:
     return keys
 
 
-def load_weights(path_dict: dict, plan: ModelPlan) -> dict[str, np.ndarray]:
+def load_weights(path_dict: dict, plan: ModelPlan, trust_project: bool = False) -> dict[str, np.ndarray]:
     """Weights of a model entry (AvailableModels keys, utils/misc.py:346-392).  The SavedModel's own variable bundle
-    (``graph``) comes first - it is what the reference runs; then the canonical ``.npz``, then a Keras-3 ``.weights.h5``."""
+    (``graph``) comes first - it is what the reference runs; then the canonical ``.npz``, then a Keras-3 ``.weights.h5``.
+    A bundle whose keys cannot be mapped onto the plan (an export with other object paths than the ones this loader has
+    seen) is not fatal when the entry also holds a weights file: that file is used instead, with a loud warning naming
+    what failed.  ``trust_project`` skips the bundle altogether."""
     graph = path_dict.get("graph")
-    if graph is not None and (Path(graph) / "variables" / "variables.index").exists():
-        return load_savedmodel_bundle(graph, plan)
-    w = path_dict.get("weights") or path_dict.get("weights_npz")     # AvailableModels keys (predict.py)
+    w = path_dict.get("weights_npz") or path_dict.get("weights")     # AvailableModels keys (predict.py)
+    bundle_error = None
+    if not trust_project and graph is not None and (Path(graph) / "variables" / "variables.index").exists():
+        try:
+            return load_savedmodel_bundle(graph, plan)
+        except Exception as e:                 # unknown key scheme, missing variable, shape that disagrees with the plan
+            if w is None:
+                raise
+            bundle_error = e
     if w is None:
         raise FileNotFoundError("model entry has no weights (a <name>_graph/variables bundle, *.weights.h5 or canonical *.npz)")
     w = Path(w)
+    if bundle_error is not None:
+        import warnings
+        warnings.warn(f"{graph}/variables could not be mapped onto the layer plan ({type(bundle_error).__name__}: {bundle_error}); "
+                      f"falling back to {w}.  The SavedModel is what the reference executes - check the model with "
+                      f"`jaeger_amd verify-model` before trusting these weights.", RuntimeWarning, stacklevel=2)
     if w.suffix == ".npz":
         return load_npz(w)
     return load_keras3_h5(w, plan)

@@ -16,7 +16,14 @@ sys.path.insert(0, str(ROOT / "tests"))
 from bench import synth_contigs  # noqa: E402
 from conftest import make_model_dir  # noqa: E402
 
+import os
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
+extra = {}
+if os.environ.get("JAEGER_STREAM_BYTES"):
+    extra["stream_bytes"] = int(os.environ["JAEGER_STREAM_BYTES"])
+if os.environ.get("JAEGER_NO_PIPELINE"):
+    extra["no_pipeline"] = True
+do_prof = not os.environ.get("JAEGER_NO_CPROFILE")
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 tmp = Path("/dev/shm/jaeger_r4_e2e")
 tmp.mkdir(exist_ok=True)
@@ -41,13 +48,13 @@ for name, (mdir, fsize) in models.items():
     for r in range(reps):
         t0 = time.perf_counter()
         run_core(input=str(fa), output=str(tmp / f"out_{name}"), model_path=str(mdir), fsize=fsize, stride=fsize,
-                 overwrite=True, dustmask=True, verbose=0, batch=96, rc=0.1, pc=3)
+                 overwrite=True, dustmask=True, verbose=0, batch=96, rc=0.1, pc=3, **extra)
         dt = time.perf_counter() - t0
         print(f"== {name}: run {r}: {dt:.3f} s = {mbp / dt:.1f} Mbp/s", flush=True)
         log = sorted((tmp / f"out_{name}").rglob("*_jaeger.log"))[-1]
         for line in log.read_text().splitlines()[-6:]:
             print("   ", line.split("[jaeger]")[-1].strip())
-if which in ("both", "baseline500"):
+if do_prof and which in ("both", "baseline500"):
     mdir, fsize = models["baseline500"]
     pr = cProfile.Profile()
     pr.enable()

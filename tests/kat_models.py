@@ -87,17 +87,19 @@ def ood_expected(logits, nmd, eps: float = 1e-10) -> np.ndarray:
 
 
 def ood_signal_case():
-    """A model whose logits are KAT_LOGITS and whose NMD vector is KAT_NMD for two constant-id windows, with an identity
-    reliability head: ``reliability`` = [nmd | the five signals]."""
-    cfg = _base(2, [{"name": "nmd", "config": {}}], "max", 3, identity_head=False)
+    """A model whose logits are KAT_LOGITS and whose NMD vector is KAT_NMD (+ two zero channels: the engine's convs take
+    channel counts in multiples of 4, and zeros change neither the norm nor the logits) for two constant-id windows, with
+    an identity reliability head: ``reliability`` = [nmd (4) | the five signals]."""
+    cfg = _base(4, [{"name": "nmd", "config": {}}], "max", 3, identity_head=False)
     cfg["reliability_model"] = {"mode": "nmd_plus_signals", "signals": list(SIGNALS), "hidden_layers": [
-        {"name": "dense", "config": {"units": 7, "activation": None, "use_bias": False}}]}
-    table = np.zeros((65, 2), np.float32)
-    table[1], table[2] = KAT_NMD[0], KAT_NMD[1]              # window w is all id w + 1: its rows are constant
+        {"name": "dense", "config": {"units": 9, "activation": None, "use_bias": False}}]}
+    table = np.zeros((65, 4), np.float32)
+    table[1, :2], table[2, :2] = KAT_NMD[0], KAT_NMD[1]      # window w is all id w + 1: its rows are constant
     # logits = pooled @ K + b with pooled = KAT_NMD rows: K = KAT_NMD^-1 @ KAT_LOGITS (f64 solve, rounded to f32)
-    kernel = np.linalg.solve(KAT_NMD, KAT_LOGITS)
-    w = {"embedding/embeddings": table, "rep/0/moving_mean": np.zeros(2, np.float32),
+    kernel = np.zeros((4, 3))
+    kernel[:2] = np.linalg.solve(KAT_NMD, KAT_LOGITS)
+    w = {"embedding/embeddings": table, "rep/0/moving_mean": np.zeros(4, np.float32),
          "classifier/0/kernel": kernel.astype(np.float32), "classifier/0/bias": np.zeros(3, np.float32),
-         "reliability/0/kernel": np.eye(7, dtype=np.float32)}
+         "reliability/0/kernel": np.eye(9, dtype=np.float32)}
     ids = np.stack([np.full((6, 24), 1), np.full((6, 24), 2)])
     return cfg, w, ids

@@ -5,6 +5,7 @@ import sys
 from pathlib import Path
 
 import numpy as np
+import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
 
@@ -18,6 +19,24 @@ def test_lpt_partition_balances_and_keeps_order():
     assert sorted(np.concatenate(parts).tolist()) == list(range(1000))
     assert max(loads) - min(loads) <= int(w.max())
     assert all((np.diff(p) > 0).all() for p in parts)
+
+
+def test_lpt_partition_eight_parts_with_empty_and_unequal_shards():
+    """8 ranks (one node): fewer contigs than ranks leaves shards empty, a dominant contig leaves them unequal; the
+    partition still covers every contig once, keeps FASTA order inside a shard, and restore_order undoes it."""
+    from jaeger_amd.dist import lpt_partition, restore_order
+    for rows in (np.array([5, 1, 9, 2, 7], np.int64),                  # 5 contigs on 8 ranks: 3 empty shards
+                 np.array([400, 1, 1, 2, 1, 3, 1, 1, 2, 1, 1, 5], np.int64)):   # one contig holds 95 % of the windows
+        groups = lpt_partition(rows, 8)
+        assert len(groups) == 8 and sorted(np.concatenate(groups).tolist()) == list(range(len(rows)))
+        assert all((np.diff(g) > 0).all() for g in groups if len(g) > 1)
+        loads = np.array([int(rows[g].sum()) for g in groups])
+        assert loads.max() == max(int(rows.max()), loads.max()) and (loads == 0).sum() == max(0, 8 - len(rows))
+        full = np.arange(int(rows.sum()) * 2, dtype=np.float32).reshape(-1, 2)
+        first = np.cumsum(rows) - rows
+        parts = [np.concatenate([full[first[i]:first[i] + rows[i]] for i in g]) if len(g) else np.zeros((0, 2), np.float32)
+                 for g in groups]
+        np.testing.assert_array_equal(restore_order(parts, groups, rows), full)
 
 
 def test_restore_order_roundtrip():
@@ -38,12 +57,13 @@ def _worker(rank, world, port, out_dir):
     from jaeger_amd.dist import gather_rows, lpt_partition, restore_order
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rows = np.array([3, 1, 4, 1, 5, 9, 2, 6], np.int64)              # windows per contig
+    # windows per contig; with 4 ranks only three contigs exist: LPT leaves one rank an EMPTY shard, the others unequal ones
+    rows = np.array([3, 1, 4, 1, 5, 9, 2, 6], np.int64) if world == 2 else np.array([17, 3, 11], np.int64)
     first = np.cumsum(rows) - rows
     groups = lpt_partition(rows, world)
     mine = groups[rank]
     # each rank "classifies" its contigs: logits = window index (so order is checkable)
-    local = np.concatenate([np.arange(first[i], first[i] + rows[i]) for i in mine]).astype(np.float32)
+    local = np.concatenate([np.arange(first[i], first[i] + rows[i]) for i in mine] + [np.zeros(0)]).astype(np.float32)
     local = np.stack([local, local * 2], axis=1)
     got = gather_rows(torch.from_numpy(local), dst=0)
     if rank == 0:
@@ -55,13 +75,14 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_gather_rows_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_rows_world2(tmp_path, world):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     full = np.load(tmp_path / "full.npy")
     n = 31
     np.testing.assert_array_equal(full[:, 0], np.arange(n, dtype=np.float32))

@@ -183,6 +183,38 @@ def test_bench_two_ranks_gather_equals_single_rank_runs(tmp_path):
     assert np.abs(got).max() > 0
 
 
+def test_bench_eight_ranks_unequal_shards_gather_equals_single_rank_runs(tmp_path):
+    """The first real 8-GPU launch in miniature: eight ranks (here sharing the box's one GPU, gloo instead of RCCL) with
+    UNEQUAL shards and one EMPTY shard; rank 0's padded gather is, bit for bit, the eight single-rank runs back to back,
+    and the line carries the per-rank split (windows min / max, compute and gather time of the slowest rank)."""
+    shards = [200, 0, 150, 40, 200, 7, 120, 64]
+    base = [sys.executable, str(ROOT / "bench.py"), "--config", "frag1m", "--steps", "1", "--warmup", "1",
+            "--no-cpu-baseline", "--no-exact-f32", "--no-e2e", "--rank-contigs", ",".join(map(str, shards))]
+    both = tmp_path / "all.npy"
+    res = subprocess.run(base + ["--gpus", "8", "--oversubscribe", "--dump-gather", str(both)], capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["per_rank"]["windows"] == shards
+    assert line["config"]["windows_per_gpu_min"] == 0 and line["config"]["windows_per_gpu_max"] == 200
+    pr = line["per_rank"]
+    assert pr["ms_per_step_slowest"] >= pr["ms_per_step_fastest"] > 0 and pr["gather_ms_per_step"]["max"] > 0
+    parts = []
+    for r, n in enumerate(shards):
+        if n == 0:
+            continue
+        one = tmp_path / f"r{r}.npy"
+        res = subprocess.run(base + ["--rank-seed", str(r), "--dump-gather", str(one)], capture_output=True, text=True,
+                             timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        parts.append(np.load(one))
+        assert parts[-1].shape[0] == n
+    got = np.load(both)
+    assert got.shape[0] == sum(shards)
+    np.testing.assert_array_equal(got, np.concatenate(parts, axis=0))
+    assert np.abs(got).max() > 0
+
+
 def test_bench_failing_rank_is_reported_and_times_out(tmp_path):
     """A rank that dies surfaces its stderr and a non-zero exit; ranks that hang are killed after --rank-timeout."""
     import os

@@ -60,11 +60,12 @@ def test_ood_signal_formulas():
     cfg, w, ids = ood_signal_case()
     out = _run(cfg, w, ids)
     np.testing.assert_allclose(out["prediction"], KAT_LOGITS, rtol=1e-6)
-    nmd = out["nmd"][:, :2]
-    np.testing.assert_allclose(nmd, KAT_NMD, rtol=1e-6, atol=1e-6)
+    nmd = out["nmd"][:, :4]
+    np.testing.assert_allclose(nmd[:, :2], KAT_NMD, rtol=1e-6, atol=1e-6)
+    assert not nmd[:, 2:].any()
     rel = out["reliability"]
-    assert rel.shape == (2, 7)
-    np.testing.assert_array_equal(rel[:, :2], nmd)                                   # identity head: [nmd | signals]
+    assert rel.shape == (2, 9)
+    np.testing.assert_array_equal(rel[:, :4], nmd)                                   # identity head: [nmd | signals]
     # the reference's tolerance, against the formulas applied to the logits / NMD vector the engine itself returned
-    np.testing.assert_allclose(rel[:, 2:], ood_expected(out["prediction"], nmd), rtol=1e-6)
-    np.testing.assert_allclose(rel[:, 2:], ood_expected(KAT_LOGITS, KAT_NMD), rtol=1e-5)
+    np.testing.assert_allclose(rel[:, 4:], ood_expected(out["prediction"], nmd), rtol=1e-6)
+    np.testing.assert_allclose(rel[:, 4:], ood_expected(KAT_LOGITS, KAT_NMD), rtol=1e-5)

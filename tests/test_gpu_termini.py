@@ -35,7 +35,10 @@ def _cases():
     return out
 
 
-def test_kernel_matches_smith_waterman():
+@pytest.mark.parametrize("exact", [0, 1])
+def test_kernel_matches_smith_waterman(exact):
+    """exact = 0: the packed score-only pass + the exact kernel for alignments scoring above 100 (the default);
+    exact = 1: every alignment through the exact kernel (JG_OPT_TERMINI_EXACT)."""
     from jaeger_amd import fragment as frag
     from jaeger_amd import _lib as L
     from jaeger_amd.engine import HipDevice
@@ -47,6 +50,7 @@ def test_kernel_matches_smith_waterman():
     bases, offsets = frag.concat_records([cases[k].encode() for k in names])
     fa = frag.FastaBatch(names, bases, offsets)
     dev = HipDevice(0)
+    L.check(dev.lib.jg_engine_set_option(dev.handle, L.JG_OPT_TERMINI_EXACT, exact))
     res = np.full((len(names), 10), -1, np.int32)
     ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     L.check(dev.lib.jg_terminal_repeats(dev.handle, ptr(bases), bases.size, L.JG_PTR_HOST, ptr(offsets), len(names),
@@ -89,3 +93,45 @@ def test_short_records_are_skipped():
     df = scan_for_terminal_repeats(dev, frag.FastaBatch(["a,b", "c"], bases, offsets), 2000)
     dev.close()
     assert list(df.contig_id) == ["c"]
+
+
+def test_fast_pass_equals_exact_kernel_on_random_records():
+    """Both passes on 3 000 records (scan lengths 400 - 4 000, every strip-height class of the packed kernel, planted
+    repeats of 8 - 45 bases that stay below the score-100 line, N runs, lower case, a few real repeats): the same
+    (n, 10) table, end cells included; and the 500-bp record shape (scan 400 on a 500-base record: overlapping ends)."""
+    from jaeger_amd import fragment as frag
+    from jaeger_amd import _lib as L
+    from jaeger_amd.termini import terminal_repeat_table
+    from jaeger_amd.engine import HipDevice
+    from oracle.termini import reverse_complement
+    rng = np.random.Generator(np.random.PCG64(7))
+    seqs = []
+    for r in range(3000):
+        n = int(np.exp(rng.uniform(np.log(500), np.log(160_000))))
+        s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+        u = rng.random()
+        if u < 0.5 and n > 1200:                       # a short repeat between the two scanned ends (direct or inverted)
+            k = int(rng.integers(8, 46))
+            a, b = int(rng.integers(0, 350 - k)), n - int(rng.integers(k, 350))
+            piece = bytes(s[a:a + k])
+            s[b:b + k] = np.frombuffer(piece if u < 0.25 else reverse_complement(piece.decode()).encode(), np.uint8)
+        elif u < 0.53 and n > 3000:                    # a real one
+            k = int(rng.integers(60, 300))
+            s[n - k:] = s[:k]
+        if rng.random() < 0.2:
+            p = int(rng.integers(0, n - 20))
+            s[p:p + int(rng.integers(1, 20))] = ord("N")
+        if rng.random() < 0.2:
+            p = int(rng.integers(0, n - 50))
+            s[p:p + 50] |= 0x20
+        seqs.append(bytes(s))
+    bases, offsets = frag.concat_records(seqs)
+    fa = frag.FastaBatch([f"r{i}" for i in range(len(seqs))], bases, offsets)
+    dev = HipDevice(0)
+    fast = terminal_repeat_table(dev, fa, 500)
+    L.check(dev.lib.jg_engine_set_option(dev.handle, L.JG_OPT_TERMINI_EXACT, 1))
+    exact = terminal_repeat_table(dev, fa, 500)
+    dev.close()
+    assert (exact[:, 0] > 100).sum() > 30 and ((exact[:, 0] > 24) & (exact[:, 0] <= 100)).sum() > 300
+    bad = np.nonzero((fast != exact).any(axis=1))[0]
+    assert bad.size == 0, (bad[:5], fast[bad[:5]], exact[bad[:5]])

@@ -124,9 +124,10 @@ def test_ood_signal_formulas():
     out = F.forward(cfg, w, ids)
     np.testing.assert_allclose(out["prediction"], KAT_LOGITS, rtol=1e-6)
     np.testing.assert_allclose(out["nmd"][:, :2], KAT_NMD, rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(out["reliability"][:, :2], out["nmd"][:, :2], rtol=0, atol=0)
-    np.testing.assert_allclose(out["reliability"][:, 2:], ood_expected(out["prediction"], out["nmd"][:, :2]), rtol=1e-6)
-    np.testing.assert_allclose(out["reliability"][:, 2:], want, rtol=1e-5)
+    assert not out["nmd"][:, 2:4].any()
+    np.testing.assert_allclose(out["reliability"][:, :4], out["nmd"][:, :4], rtol=0, atol=0)
+    np.testing.assert_allclose(out["reliability"][:, 4:], ood_expected(out["prediction"], out["nmd"][:, :4]), rtol=1e-6)
+    np.testing.assert_allclose(out["reliability"][:, 4:], want, rtol=1e-5)
 
 
 def test_f32_oracle_close_to_f64():

@@ -208,3 +208,33 @@ def test_bundle_loader_refuses_instead_of_guessing(tmp_path):
     reshaped[kern] = np.zeros(base[kern].shape[:-1] + (base[kern].shape[-1] + 1,), np.float32)
     with pytest.raises(ValueError, match="shape"):
         load_savedmodel_bundle(write(reshaped, "c"), plan)
+
+
+def test_unmappable_bundle_falls_back_to_the_weights_file_loudly(tmp_path):
+    """a bundle under another key scheme (here ``layers/...`` object paths and a renamed variable) must not
+    turn a model directory that loaded from its weights file into a hard error: ``load_weights`` falls back to the file
+    with a warning that names the failure; without a file the error stands; ``trust_project`` skips the bundle."""
+    from conftest import load_model_cfg
+    from jaeger_amd import savedmodel_lite as S
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import bundle_checkpoint_keys, load_weights, random_weights, save_npz
+    plan = build_plan(load_model_cfg("baseline500"))
+    w_bundle, w_file = random_weights(plan, seed=11), random_weights(plan, seed=12)
+    keys = bundle_checkpoint_keys(plan)
+    odd = {keys[k].replace("_operations/", "layers/functional/layers/").replace("/gamma/", "/scale/"): v
+           for k, v in w_bundle.items()}
+    S.write_bundle(tmp_path / "m_graph" / "variables", odd)
+    npz = tmp_path / "m.weights.npz"
+    save_npz(npz, w_file)
+    with pytest.warns(RuntimeWarning, match="could not be mapped onto the layer plan"):
+        got = load_weights({"graph": tmp_path / "m_graph", "weights_npz": npz}, plan)
+    for k in w_file:
+        np.testing.assert_array_equal(got[k], w_file[k])
+    with pytest.raises(ValueError):
+        load_weights({"graph": tmp_path / "m_graph"}, plan)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = load_weights({"graph": tmp_path / "m_graph", "weights_npz": npz}, plan, trust_project=True)
+    for k in w_file:
+        np.testing.assert_array_equal(got[k], w_file[k])
