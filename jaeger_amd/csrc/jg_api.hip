@@ -1916,11 +1916,15 @@ static void stream_groups(const int64_t *win_start, const int32_t *win_len, int6
                           std::vector<StreamGroup> &groups) {
   int64_t i = 0;
   while (i < n_win) {
+    // ramp: the first span is an eighth of the budget and the second a half, so that the compute stream has work after a
+    // millisecond of staging instead of after a whole span (nothing hides the first span's copy, upload and DUST pass)
+    const size_t gi = groups.size();
+    const int64_t cap = gi == 0 ? std::max<int64_t>(budget / 8, 4096) : (gi == 1 ? std::max<int64_t>(budget / 2, 4096) : budget);
     StreamGroup g{i, i, win_start[i], win_start[i] + win_len[i]};
     int64_t j = i + 1;
     for (; j < n_win; ++j) {
       const int64_t b1 = std::max(g.b1, win_start[j] + win_len[j]);
-      if (b1 - g.b0 > budget) break;
+      if (b1 - g.b0 > cap) break;
       g.b1 = b1;
     }
     if (j < n_win && j - i >= chunk && (j - i) % chunk != 0) {

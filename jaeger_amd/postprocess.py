@@ -353,7 +353,9 @@ def merge_data(parts: list[dict]) -> dict:
     out = {}
     for key, v0 in parts[0].items():
         vals = [p[key] for p in parts]
-        if isinstance(v0, _Runs):
+        if isinstance(v0, _Summaries):
+            out[key] = _Summaries([t for v in vals for t in v.texts])
+        elif isinstance(v0, _Runs):
             offs = np.cumsum([0] + [len(v.calls) for v in vals[:-1]])
             out[key] = _Runs(np.concatenate([v.calls for v in vals]),
                              _SegView(np.concatenate([v.seg.first + o for v, o in zip(vals, offs)]),
@@ -370,6 +372,22 @@ def merge_data(parts: list[dict]) -> dict:
         else:                                                                 # has_reliability, repeats, ood = None
             out[key] = v0
     return out
+
+
+class _Summaries:
+    """The contigs' run-length strings, already built (``_Runs.summaries`` per aggregation batch, beside the forward)."""
+
+    def __init__(self, texts: list[str]):
+        self.texts = texts
+
+    def __len__(self):
+        return len(self.texts)
+
+
+def window_letters(class_map: dict) -> dict:
+    """Letter of every class in ``window_summary``: first character, upper case only for virus / phage (helpers.py:73-108)."""
+    cm = {int(k): v for k, v in zip(class_map.get("index"), class_map.get("class"))}
+    return {k: (v[0].upper() if v.lower() in ("virus", "phage") else v[0].lower()) for k, v in cm.items()}
 
 
 class _Means:
@@ -438,7 +456,9 @@ def generate_summary(data, **kwargs) -> pd.DataFrame:
         columns["score"] = data["pred_sum"]
         columns["var"] = data["pred_var"]
     frag = data["frag_pred"]
-    if isinstance(frag, _Runs):
+    if isinstance(frag, _Summaries):
+        columns["window_summary"] = frag.texts
+    elif isinstance(frag, _Runs):
         letter = {k: (v[0].upper() if v.lower() in ("virus", "phage") else v[0].lower()) for k, v in class_map.items()}
         columns["window_summary"] = frag.summaries(letter)
     else:

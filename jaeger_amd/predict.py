@@ -230,9 +230,12 @@ class _Aggregator:
         return y
 
     def add(self, y_pred: dict) -> None:
-        from .postprocess import pred_to_dict
+        from .postprocess import _Summaries, pred_to_dict, window_letters
         if y_pred and len(y_pred["meta_2"]):
-            self.parts.append(pred_to_dict(y_pred, **self.kw))
+            data, full = pred_to_dict(y_pred, **self.kw)
+            # the run-length strings of the batch's contigs (a Python string per run) belong beside the forward too
+            data["frag_pred"] = _Summaries(data["frag_pred"].summaries(window_letters(self.kw["class_map"])))
+            self.parts.append((data, full))
 
     def result(self):
         from .postprocess import merge_data
@@ -612,16 +615,31 @@ def run_core(**kwargs) -> int:
             f_pred = pool.submit(classify) if piped else None
             log_setup(engine)
             if piped:
+                import threading
+
                 from .engine import HipDevice
-                side = HipDevice(local_rank)                   # its own stream: the scan interleaves with the forward
-                try:
-                    term_repeats = scan_repeats(side)
-                finally:
-                    side.close()
+                scan: dict = {}
+
+                def scan_side():                              # a thread and a stream of its own: the scan interleaves with the
+                    try:                                       # forward on the GPU and with the aggregation on the host
+                        side = HipDevice(local_rank)
+                        try:
+                            scan["frame"] = scan_repeats(side)
+                        finally:
+                            side.close()
+                    except BaseException as e:
+                        scan["error"] = e
+
+                th = threading.Thread(target=scan_side, name="jaeger-termini", daemon=True)
+                th.start()
                 while not f_pred.done():
                     agg.advance(engine.device.windows_done())
                     time.sleep(0.004)
                 t_forward = f_pred.result()
+                th.join()
+                if "error" in scan:
+                    raise scan["error"]
+                term_repeats = scan["frame"]
             else:
                 term_repeats = scan_repeats(engine.device)
                 t_forward = classify()
