@@ -135,8 +135,10 @@ int jg_engine_sync(jg_engine *e);
  * switch exists for A/B timing and for the test that asserts exactly that.
  * JG_OPT_TERMINI_EXACT (default 0): 1 = jg_terminal_repeats runs every alignment through the kernel that carries length and
  * gap count through the dynamic programme, instead of only those the packed score-only pass leaves open (score > 100);
- * same table either way (tests/test_gpu_termini.py). */
-enum { JG_OPT_STREAM_BYTES = 1, JG_OPT_CONV_PC = 2, JG_OPT_TERMINI_EXACT = 3 };
+ * same table either way (tests/test_gpu_termini.py).
+ * JG_OPT_DUST_ON_COPY_STREAM (default 1): the DUST pass of a streamed span runs on the copy stream behind the span's upload
+ * (beside the previous group's convolutions) or, 0, on the compute stream in front of the span's encoder; same masks. */
+enum { JG_OPT_STREAM_BYTES = 1, JG_OPT_CONV_PC = 2, JG_OPT_TERMINI_EXACT = 3, JG_OPT_DUST_ON_COPY_STREAM = 4 };
 int jg_engine_set_option(jg_engine *e, int key, int64_t value);
 /* statistics of the engine's last jg_predict_windows call: number of streamed groups (0 = not streamed), bytes sent
  * through the staging buffers, peak bytes of bases resident on the device.  JG_STAT_WINDOWS_DONE may be read from

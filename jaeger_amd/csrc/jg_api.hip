@@ -97,6 +97,9 @@ extern "C" int jg_engine_set_option(jg_engine *e, int key, int64_t value) {
     case JG_OPT_TERMINI_EXACT:
       e->termini_exact = value != 0;
       return JG_OK;
+    case JG_OPT_DUST_ON_COPY_STREAM:
+      e->dust_on_copy = value != 0;
+      return JG_OK;
     default:
       jg_set_error("jg_engine_set_option: unknown key %d", key);
       return JG_ERR_INVALID;
@@ -2003,7 +2006,7 @@ static int predict_streamed(jg_model *m, const uint8_t *bases, int64_t n_bases, 
     memcpy(e->pin[b], bases + h0, (size_t)(h1 - h0));
     if (span_used[b]) JG_HIP(hipStreamWaitEvent(e->copy_stream, e->enc_done[b], 0));   // the device span's last reader is done
     JG_HIP(hipMemcpyAsync(e->dbase[b], e->pin[b], (size_t)(h1 - h0), hipMemcpyHostToDevice, e->copy_stream));
-    if (dust) {
+    if (dust && e->dust_on_copy) {
       // DUST on the copy stream, behind the span's upload: a vector / LDS kernel that shares the CUs with the matrix-core
       // convolutions of the previous group instead of standing in front of this group's encoder on the compute stream
       const int drc = jg_launch_dust(static_cast<uint8_t *>(e->dbase[b]), h0, h1 - h0, e->d_rec_off, e->n_rec, e->dust_window,
@@ -2027,7 +2030,13 @@ static int predict_streamed(jg_model *m, const uint8_t *bases, int64_t n_bases, 
     memcpy(p_len, win_len + g.w0, (size_t)nw * 4);
     char *dw = static_cast<char *>(m->d_win);
     JG_HIP(hipMemcpyAsync(dw, io_b, (size_t)(win_cap * 8 + nw * 4), hipMemcpyHostToDevice, s));
-    JG_HIP(hipStreamWaitEvent(s, e->h2d_done[b], 0));          // (uploaded and, with records attached, soft-masked)
+    JG_HIP(hipStreamWaitEvent(s, e->h2d_done[b], 0));          // (uploaded and - JG_OPT_DUST_ON_COPY_STREAM - soft-masked)
+    if (dust && !e->dust_on_copy) {
+      const int64_t h1 = std::min(n_bases, g.b1 + ctx);
+      const int drc = jg_launch_dust(static_cast<uint8_t *>(e->dbase[b]), h0, h1 - h0, e->d_rec_off, e->n_rec, e->dust_window,
+                                     e->dust_threshold, g.b0, g.b1, e->d_dust_cnt, s);
+      if (drc != JG_OK) return drc;
+    }
     int32_t *d_counts = counts == nullptr ? nullptr : (host_out ? m->d_counts : counts + g.w0 * 4);
     int erc = jg_launch_encode(static_cast<const uint8_t *>(e->dbase[b]), reinterpret_cast<const int64_t *>(dw),
                                reinterpret_cast<const int32_t *>(dw + win_cap * 8), nw, fsize, m->d_lut, flags, l_pad,

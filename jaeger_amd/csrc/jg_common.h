@@ -164,6 +164,7 @@ struct jg_engine {
   double cls_ms[4] = {}, cls_flops[4] = {};     // the same split by kernel family (JG_PROF_*)
   int64_t cls_launches[4] = {};
   int n_cu = 256;
+  int dust_on_copy = 1;           // JG_OPT_DUST_ON_COPY_STREAM: streamed spans are soft-masked on the copy stream (1) or in front of their encoder (0)
   int termini_exact = 0;          // JG_OPT_TERMINI_EXACT: every terminal-repeat alignment through the length / gap carrying kernel
   int conv_pc = 0;                // JG_OPT_CONV_PC: producer / consumer kernel for the 128-channel five-tap convs
   // streamed ingest of host-resident bases (jg_predict_windows): spans above `stream_bytes` go through two pinned

@@ -477,10 +477,10 @@ def generate_summary(data, **kwargs) -> pd.DataFrame:
     return df
 
 
-def _to_tsv(df: pd.DataFrame, path) -> None:
-    """``df.to_csv(path, sep="\t", index=False, float_format="%.3f")`` with the float columns formatted by one
-    vectorised ``%`` per column instead of pandas' per-value Python formatter (same text: ``"%.3f" % float(v)``,
-    empty for NaN)."""
+def _tsv_text(df: pd.DataFrame, header: bool = True) -> str:
+    """``df.to_csv(sep="\t", index=False, float_format="%.3f")`` as text, with the float columns formatted by one
+    vectorised ``%`` per column instead of pandas' per-value Python formatter (same text: ``"%.3f" % float(v)``, empty
+    for NaN)."""
     out = {}
     for col in df.columns:
         v = df[col]
@@ -491,25 +491,61 @@ def _to_tsv(df: pd.DataFrame, path) -> None:
             out[col] = txt
         else:
             out[col] = v
-    pd.DataFrame(out, columns=df.columns).to_csv(path, sep="\t", index=False)
+    return pd.DataFrame(out, columns=df.columns).to_csv(None, sep="\t", index=False, header=header)
+
+
+def _to_tsv(df: pd.DataFrame, path) -> None:
+    with open(path, "w", newline="") as fh:
+        fh.write(_tsv_text(df))
+
+
+class TableWriter:
+    """``write_output`` (collect.py:561-608) in pieces: batches of whole contigs are appended to ``<base>.tsv`` and - the rows
+    that pass the phage filters - to ``<base>_phages.tsv`` as they are aggregated, so that only the last batch is formatted
+    behind the forward.  Every step of ``write_output`` is row-wise (left merge with the repeat table, the ``N% < 0.3``
+    filter, the phage query, the column formats), so the files equal the ones a single call writes, byte for byte
+    (tests/test_postprocess.py); the phage file only comes into being with its first row, as in the reference."""
+
+    def __init__(self, labels, indices, output_table_path, output_phage_table_path, reliability_cutoff=0.5, phage_score=1,
+                 refined_contig=None):
+        self.kw = dict(labels=labels, indices=indices, refined_contig=refined_contig)
+        self.table_path, self.phage_path = output_table_path, output_phage_table_path
+        self.rc, self.pc = reliability_cutoff, phage_score
+        lower = [label.lower() for label in labels]
+        self.viral = labels[lower.index("phage")] if "phage" in lower else \
+            (labels[lower.index("virus")] if "virus" in lower else "phage")
+        self.fh = self.fh_phage = None
+        self.rows = 0
+        self.header_written = False
+
+    def append(self, data: dict) -> None:
+        df = generate_summary(data, **self.kw).query("`N%` < 0.3")
+        if self.fh is None:
+            self.fh = open(self.table_path, "w", newline="")
+        self.fh.write(_tsv_text(df, header=not self.header_written))
+        self.header_written = True
+        clause = f" and (reliability_score > {self.rc})" if data.get("has_reliability", True) else ""
+        phage_df = df.query(f'(prediction == "{self.viral}") and ({self.viral}_score > {self.pc}){clause}')
+        if not phage_df.empty:
+            first = self.fh_phage is None
+            if first:
+                self.fh_phage = open(self.phage_path, "w", newline="")
+            self.fh_phage.write(_tsv_text(phage_df, header=first))
+        self.rows += len(df)
+
+    def close(self) -> int:
+        for fh in (self.fh, self.fh_phage):
+            if fh is not None:
+                fh.close()
+        return self.rows
 
 
 def write_output(data: dict, reliability_cutoff: float = 0.5, phage_score=1, **kwargs) -> int:
     """Write ``<base>.tsv`` and (if non-empty) ``<base>_phages.tsv`` (collect.py:561-608)."""
-    df = generate_summary(data, **kwargs).query("`N%` < 0.3")
-    _to_tsv(df, kwargs.get("output_table_path"))
-    classes = kwargs.get("labels", [])
-    lower = [label.lower() for label in classes]
-    viral_label = "phage"
-    if "phage" in lower:
-        viral_label = classes[lower.index("phage")]
-    elif "virus" in lower:
-        viral_label = classes[lower.index("virus")]
-    clause = f" and (reliability_score > {reliability_cutoff})" if data.get("has_reliability", True) else ""
-    phage_df = df.query(f'(prediction == "{viral_label}") and ({viral_label}_score > {phage_score}){clause}')
-    if not phage_df.empty:
-        _to_tsv(phage_df, kwargs.get("output_phage_table_path"))
-    return len(df)
+    w = TableWriter(kwargs.get("labels", []), kwargs.get("indices"), kwargs.get("output_table_path"),
+                    kwargs.get("output_phage_table_path"), reliability_cutoff, phage_score, kwargs.get("refined_contig"))
+    w.append(data)
+    return w.close()
 
 
 def write_fasta_from_results(input_fasta, output_tsv, output_fasta, width: int = 70) -> int:

@@ -208,6 +208,7 @@ class _Aggregator:
         self.min_batch = max(1, int(min_batch))
         self.parts: list = []
         self.busy_s = 0.0
+        self.flushed = 0                                          # parts already handed to the table writer
 
     def advance(self, done: int, final: bool = False) -> None:
         if len(self.ends) == 0:
@@ -237,9 +238,20 @@ class _Aggregator:
             data["frag_pred"] = _Summaries(data["frag_pred"].summaries(window_letters(self.kw["class_map"])))
             self.parts.append((data, full))
 
-    def result(self):
+    def flush(self, writer, term_repeats) -> None:
+        """Hand the batches aggregated so far to the table writer (needs the repeat table: the left merge of
+        collect.py:527-532 is part of a row)."""
+        t0 = time.time()
+        while self.flushed < len(self.parts):
+            data = self.parts[self.flushed][0]
+            data["repeats"] = term_repeats
+            writer.append(data)
+            self.flushed += 1
+        self.busy_s += time.time() - t0
+
+    def result_full(self):
         from .postprocess import merge_data
-        return merge_data([p[0] for p in self.parts]), merge_data([p[1] for p in self.parts])
+        return merge_data([p[1] for p in self.parts])
 
 
 # ---- torchrun: contig-sharded prediction, one gather of f32 rows ---------------------------------------------
@@ -496,6 +508,9 @@ def run_core(**kwargs) -> int:
                               precision=precision, trust_project=True if kwargs.get("trust_project") else None)
         if kwargs.get("stream_bytes"):              # span budget of the host -> HBM ingest (default 32 MiB)
             eng.device.set_stream_bytes(int(kwargs["stream_bytes"]))
+        if kwargs.get("dust_stream") is not None:   # A/B: 1 = DUST on the copy stream (default), 0 = on the compute stream
+            from . import _lib as L
+            L.check(eng.device.lib.jg_engine_set_option(eng.device.handle, L.JG_OPT_DUST_ON_COPY_STREAM, int(kwargs["dust_stream"])))
         return eng
 
     def ingest():
@@ -586,20 +601,36 @@ def run_core(**kwargs) -> int:
             n_masked = frag.dust_mask(fa)
             lg.info(f"DUST (window 64, threshold 20): {n_masked} of {fa.bases.size} bases soft-masked in "
                     f"{time.time() - t_dust:.2f} s")
-        try:
-            engine = f_engine.result() if piped else make_engine()
-        except Exception as e:
-            engine_failed(e, traceback.format_exc())
-        t_setup = time.time() - t_setup
-        class_map = engine.class_map
         if two_pass:
             lg.info(f"Two-pass prediction: long contigs (>= {fsize} bp) then short contigs "
                     f"({user_min_len}-{fsize - 1} bp)")
         table = frag.build_window_table(fa.lengths, fsize, stride, common["dynamic_stride"],
                                         common["dynamic_stride_threshold"], fsize if two_pass else min_len, None)
         n_long = len(table)
-        out = engine.model.host_outputs(n_long, want)
         starts = fa.offsets[table.contig] + table.start
+        try:
+            engine = f_engine.result() if piped else make_engine()
+        except Exception as e:
+            engine_failed(e, traceback.format_exc())
+        t_setup = time.time() - t_setup
+        class_map = engine.class_map
+        out = engine.model.host_outputs(n_long, want)
+
+        class _LazyWriter:                              # (pandas is imported at the first batch, beside the forward)
+            w = None
+            header_written = False
+
+            def append(self, data):
+                if self.w is None:
+                    from .postprocess import TableWriter
+                    self.w = TableWriter(class_map.get("class"), class_map.get("index"), table_path, phage_path,
+                                         reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))
+                self.w.append(data)
+
+            def close(self):
+                return self.w.close() if self.w is not None else 0
+
+        writer = _LazyWriter()
         agg = _Aggregator(table, fa.names, out, dict(class_map=class_map, fsize=fsize, term_repeats=None,
                                                      want_full=bool(kwargs.get("window_scores") or kwargs.get("prophage")),
                                                      **crf_kw), min_batch=n_long // 8)
@@ -631,9 +662,13 @@ def run_core(**kwargs) -> int:
                         scan["error"] = e
 
                 th = threading.Thread(target=scan_side, name="jaeger-termini", daemon=True)
+                if kwargs.get("_scan_after"):                 # (timing experiments: the repeat scan behind the forward)
+                    f_pred.result()
                 th.start()
                 while not f_pred.done():
                     agg.advance(engine.device.windows_done())
+                    if "frame" in scan:                       # rows of finished batches go to the table beside the forward
+                        agg.flush(writer, scan["frame"])
                     time.sleep(0.004)
                 t_forward = f_pred.result()
                 th.join()
@@ -674,19 +709,21 @@ def run_core(**kwargs) -> int:
                 f"fused calls")
     t_post = time.time()
 
-    from .postprocess import pred_to_dict, write_output       # pandas: imported beside the forward (termini, above)
+    from .postprocess import pred_to_dict, write_output
     if world > 1:
         data, data_full = pred_to_dict(y_pred, class_map=class_map, fsize=fsize, term_repeats=term_repeats,
                                        want_full=bool(kwargs.get("window_scores") or kwargs.get("prophage")), **crf_kw)
         n_windows = len(y_pred["meta_2"])
         n_bp = float(np.minimum(np.asarray(y_pred["meta_4"], np.int64), fsize).sum())
+        LAST_RUN["merge_s"] = round(time.time() - t_post, 3)
+        n_written = write_output(data, labels=class_map.get("class"), indices=class_map.get("index"),
+                                 output_table_path=table_path, output_phage_table_path=phage_path,
+                                 reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))
     else:
-        data, data_full = agg.result()
-        data["repeats"] = term_repeats
-    LAST_RUN["merge_s"] = round(time.time() - t_post, 3)
-    n_written = write_output(data, labels=class_map.get("class"), indices=class_map.get("index"),
-                             output_table_path=table_path, output_phage_table_path=phage_path,
-                             reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))
+        agg.flush(writer, term_repeats)                # what is left: the last batch (and the short-contig pass)
+        n_written = writer.close()
+        data_full = agg.result_full()
+        LAST_RUN["merge_s"] = 0.0
     LAST_RUN["tsv_s"] = round(time.time() - t_post - LAST_RUN["merge_s"], 3)
     lg.info(f"processed {n_written}/{num} sequences")
     if kwargs.get("window_scores"):

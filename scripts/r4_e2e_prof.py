@@ -21,6 +21,12 @@ which = sys.argv[1] if len(sys.argv) > 1 else "both"
 extra = {}
 if os.environ.get("JAEGER_STREAM_BYTES"):
     extra["stream_bytes"] = int(os.environ["JAEGER_STREAM_BYTES"])
+if os.environ.get("JAEGER_DUST_STREAM"):
+    extra["dust_stream"] = int(os.environ["JAEGER_DUST_STREAM"])
+if os.environ.get("JAEGER_NO_DUST"):
+    extra["dustmask_off"] = True
+if os.environ.get("JAEGER_SCAN_AFTER"):
+    extra["_scan_after"] = True
 if os.environ.get("JAEGER_NO_PIPELINE"):
     extra["no_pipeline"] = True
 do_prof = not os.environ.get("JAEGER_NO_CPROFILE")
@@ -48,7 +54,8 @@ for name, (mdir, fsize) in models.items():
     for r in range(reps):
         t0 = time.perf_counter()
         run_core(input=str(fa), output=str(tmp / f"out_{name}"), model_path=str(mdir), fsize=fsize, stride=fsize,
-                 overwrite=True, dustmask=True, verbose=0, batch=96, rc=0.1, pc=3, **extra)
+                 overwrite=True, dustmask=not extra.pop('dustmask_off', False) if False else ('dustmask_off' not in extra), verbose=0, batch=96, rc=0.1, pc=3,
+                 **{k: v for k, v in extra.items() if k != 'dustmask_off'})
         dt = time.perf_counter() - t0
         print(f"== {name}: run {r}: {dt:.3f} s = {mbp / dt:.1f} Mbp/s", flush=True)
         log = sorted((tmp / f"out_{name}").rglob("*_jaeger.log"))[-1]

@@ -126,6 +126,52 @@ def test_vectorised_aggregation_equals_per_contig_restatement(n_cls, with_rel, c
         assert all(np.array_equal(a, b) for a, b in zip(fp["gcs"], fo["gcs"]))
 
 
+@pytest.mark.parametrize("n_cls,with_rel,crf", [(6, True, None), (3, False, 2.0), (4, True, 0.7)])
+def test_batchwise_aggregation_and_table_writer_equal_one_call(n_cls, with_rel, crf, tmp_path):
+    """run_core aggregates whole contigs in batches beside the forward and appends their rows to the tables as it goes
+    (``merge_data``, ``TableWriter``): same per-contig arrays and the same TSV / phage-TSV bytes as ONE ``pred_to_dict`` +
+    ``write_output`` call over everything - also when a batch contributes no row, and with run-length strings prebuilt."""
+    from jaeger_amd import postprocess as P
+    rng = np.random.default_rng(5 * n_cls + (3 if with_rel else 0))
+    names = (CLASSES + ["x", "y"])[:max(n_cls, 2)]
+    idx = list(range(len(names)))
+    cm = {"num_classes": len(names), "class": names, "index": idx}
+    y, rep = _random_case(rng, 211, n_cls, with_rel)
+    kw = dict(class_map=cm, fsize=1500, term_repeats=None)
+    if crf is not None:
+        kw.update(crf_switch_cost=crf, crf_prior="biological")
+    whole, full_whole = P.pred_to_dict(y, **kw)
+    whole["repeats"] = rep
+    one, one_ph = tmp_path / "one.tsv", tmp_path / "one_ph.tsv"
+    n_one = P.write_output(whole, labels=names, indices=idx, output_table_path=one, output_phage_table_path=one_ph,
+                           reliability_cutoff=0.1, phage_score=1)
+    ends = np.nonzero(np.asarray(y["meta_2"]) == 1)[0] + 1            # contig boundaries in window units
+    cuts = [0, int(ends[0]), int(ends[0]), int(ends[17]), int(ends[100]), int(ends[-1])]     # a 1-contig batch (all N: no row), an empty one
+    w = P.TableWriter(names, idx, tmp_path / "b.tsv", tmp_path / "b_ph.tsv", reliability_cutoff=0.1, phage_score=1)
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if a == b:
+            continue
+        data, full = P.pred_to_dict({k: v[a:b] for k, v in y.items()}, **kw)
+        data["frag_pred"] = P._Summaries(data["frag_pred"].summaries(P.window_letters(cm)))
+        data["repeats"] = rep
+        parts.append((data, full))
+        w.append(data)
+    assert w.close() == n_one
+    assert (tmp_path / "b.tsv").read_bytes() == one.read_bytes()
+    assert (tmp_path / "b_ph.tsv").exists() == one_ph.exists()
+    if one_ph.exists():
+        assert (tmp_path / "b_ph.tsv").read_bytes() == one_ph.read_bytes()
+    merged, merged_full = P.merge_data([p[0] for p in parts]), P.merge_data([p[1] for p in parts])
+    for key in ("headers", "length", "pred_sum", "pred_var", "entropy", "energy", "consensus", "host_contam",
+                "prophage_contam", "per_class_counts"):
+        a, b = np.asarray(merged[key]), np.asarray(whole[key])
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=(a.dtype.kind == "f")), key
+    assert merged["frag_pred"].texts == whole["frag_pred"].summaries(P.window_letters(cm))
+    assert len(merged_full["predictions"]) == len(full_whole["predictions"]) == 211
+    assert all(np.array_equal(a, b) for a, b in zip(merged_full["gcs"], full_whole["gcs"]))
+
+
 def test_write_fasta_from_results(tmp_path):
     """--getsequences (collect.py:613-639): records named in the phage table, as read, 70 bases per line."""
     from jaeger_amd.postprocess import write_fasta_from_results
