@@ -540,39 +540,14 @@ static int prepare_small(jg_model *m, const float *weights) {
   JgSmallNet *sn = new JgSmallNet();
   for (JgSmallLayer &ly : sn->layer) ly.add = ly.aff2 = ly.save = ly.tap = 0;
   std::vector<float> epi((size_t)(nc + 1) * 4 * 32, 0.f);
-  std::vector<double> wscale((size_t)nc + 1, 1.0);
   bool ok = true;
-  // split-f16 weight fragments of the k = 3 convs
+  // split-f16 weight fragments of the k = 3 convs: built behind the fold below (the first affine's scale goes into them)
   std::vector<uint16_t> frag((size_t)nc * 12 * 64 * 8, 0);
-  for (int q = 1; q <= nc && ok; ++q) {
-    const jg_op &c = m->ops[convs[q]];
-    const float *w = weights + c.w_off;               // (3, 32, 32) f32 (cin even, cout multiple of 32: no padding)
-    float maxabs = 0.f;
-    for (int e = 0; e < 3 * 32 * 32; ++e) maxabs = std::max(maxabs, fabsf(w[e]));
-    int sexp = 0;
-    if (maxabs > 0.f) {
-      int e2;
-      frexpf(maxabs, &e2);
-      sexp = 3 - e2;                                  // scaled max in [4, 8): the lo halves stay normal
-    }
-    const float sc = ldexpf(1.f, sexp);
-    wscale[(size_t)q] = ldexp(1.0, -sexp);
-    for (int t = 0; t < 3; ++t)
-      for (int cc = 0; cc < 2; ++cc)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 8; ++j) {
-            const int co = lane & 31, ci = cc * 16 + (lane >> 5) * 8 + j;
-            const float v = w[((size_t)t * 32 + ci) * 32 + co] * sc;
-            const float hi = f16_value(v);
-            const size_t base = ((((size_t)(q - 1) * 3 + t) * 2 + cc) * 2) * 64 * 8;
-            frag[base + (size_t)lane * 8 + j] = f16_bits(hi);
-            frag[base + 64 * 8 + (size_t)lane * 8 + j] = f16_bits(v - hi);
-          }
-  }
+  std::vector<double> scale1((size_t)(nc + 1) * 32, 1.0), shift1((size_t)(nc + 1) * 32, 0.0);
   // epilogue parameters: fold BIAS / BN chains (f64), match  affine [ADD] GELU [affine GELU]
   for (int q = 0; q <= nc && ok; ++q) {
     const jg_op &c = m->ops[convs[q]];
-    std::vector<double> s1(32, wscale[(size_t)q]), t1(32, 0.0), s2(32, 1.0), t2(32, 0.0);
+    std::vector<double> s1(32, 1.0), t1(32, 0.0), s2(32, 1.0), t2(32, 0.0);
     int st = 0;
     auto fold = [&](std::vector<double> &sc, std::vector<double> &sh) {
       bool any = false;
@@ -624,11 +599,29 @@ static int prepare_small(jg_model *m, const float *weights) {
     }
     if (st != c.n_stages) { ok = false; break; }
     for (int n = 0; n < 32; ++n) {
-      epi[((size_t)q * 4 + 0) * 32 + n] = (float)s1[n];
+      // the first affine lives in the weights (scale) and in the accumulators' initial value (shift): jg_small.hip
+      scale1[(size_t)q * 32 + n] = s1[n];
+      shift1[(size_t)q * 32 + n] = t1[n];
+      epi[((size_t)q * 4 + 0) * 32 + n] = 1.0f;
       epi[((size_t)q * 4 + 1) * 32 + n] = (float)t1[n];
       epi[((size_t)q * 4 + 2) * 32 + n] = (float)s2[n];
       epi[((size_t)q * 4 + 3) * 32 + n] = (float)t2[n];
     }
+  }
+  for (int q = 1; q <= nc && ok; ++q) {
+    const jg_op &c = m->ops[convs[q]];
+    const float *w = weights + c.w_off;               // (3, 32, 32) f32 (cin even, cout multiple of 32: no padding)
+    for (int t = 0; t < 3; ++t)
+      for (int cc = 0; cc < 2; ++cc)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int co = lane & 31, ci = cc * 16 + (lane >> 5) * 8 + j;
+            const float v = (float)((double)w[((size_t)t * 32 + ci) * 32 + co] * scale1[(size_t)q * 32 + co]);
+            const float hi = f16_value(v);
+            const size_t base = ((((size_t)(q - 1) * 3 + t) * 2 + cc) * 2) * 64 * 8;
+            frag[base + (size_t)lane * 8 + j] = f16_bits(hi);
+            frag[base + 64 * 8 + (size_t)lane * 8 + j] = f16_bits(v - hi);      // (may be an f16 subnormal: the MFMA honours those)
+          }
   }
   // a shortcut saved by layer r is read by exactly the next ADD: saves must not overlap
   if (ok) {
@@ -662,8 +655,12 @@ static int prepare_small(jg_model *m, const float *weights) {
         double acc = 0.0;
         for (int ci = 0; ci < c0.cin; ++ci)
           acc += (double)emb[(size_t)id * c0.cin + ci] * (double)w0[((size_t)t * cin_pad + ci) * 32 + n];
-        lut[((size_t)t * vr + id) * 32 + n] = (float)acc;
+        lut[((size_t)t * vr + id) * 32 + n] = (float)(acc * scale1[(size_t)n]);
       }
+  // every output position reads exactly one row of tap 0 (a codon's, the masked id 0's or the padding row `vocab`):
+  // the first affine's shift rides on all of them
+  for (int id = 0; id < vr; ++id)
+    for (int n = 0; n < 32; ++n) lut[(size_t)id * 32 + n] = (float)((double)lut[(size_t)id * 32 + n] + shift1[(size_t)n]);
   JG_HIP(hipMalloc(reinterpret_cast<void **>(&sn->d_lut), lut.size() * sizeof(float)));
   JG_HIP(hipMemcpy(sn->d_lut, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
   JG_HIP(hipMalloc(reinterpret_cast<void **>(&sn->d_epi), epi.size() * sizeof(float)));

@@ -115,23 +115,34 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define JG_SDBG(bit) false
 #endif
 
-// the lane's 16 channels' parameters of a layer, read once per layer (broadcast LDS reads; a read per block and channel
-// group left the wave waiting on LDS latency twenty times a layer)
+// Since round 4 a layer's first affine (bias / batch norm in front of the GELU) is not an epilogue stage any more: its
+// scale is folded into the layer's weights (f64 on the host, then split into hi / lo - gfx950's MFMA honours f16
+// subnormal inputs, scripts/ubench/mfma_denorm.hip, so the weights need no power-of-two pre-scale whose undoing would cost
+// the instruction the fold saves) and its shift is the INITIAL VALUE of the accumulators (the MFMA's C operand): sixteen registers per layer,
+// read from LDS a layer ahead, copied where the block used to be cleared (reading LDS right in front of a block's first MFMA
+// measured 0.9 % slower than the unfolded kernel: a lone wave waits out the LDS latency).  The first layer's table carries scale and
+// shift in its rows.  Left per layer: the second affine of a stack end (P2), read once per layer (broadcast LDS reads).
 template <bool P2>
 struct EpiParams {
-  f32x4 s1[4], t1[4], s2[P2 ? 4 : 1], t2[P2 ? 4 : 1];
+  f32x4 s2[P2 ? 4 : 1], t2[P2 ? 4 : 1];
   __device__ __forceinline__ void load(const float *epi, int h) {
+    if constexpr (P2) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      s1[g] = *reinterpret_cast<const f32x4 *>(epi + 0 * C + g * 8 + h * 4);
-      t1[g] = *reinterpret_cast<const f32x4 *>(epi + 1 * C + g * 8 + h * 4);
-      if constexpr (P2) {
+      for (int g = 0; g < 4; ++g) {
         s2[g] = *reinterpret_cast<const f32x4 *>(epi + 2 * C + g * 8 + h * 4);
         t2[g] = *reinterpret_cast<const f32x4 *>(epi + 3 * C + g * 8 + h * 4);
       }
     }
   }
 };
+// accumulators of a block start from the layer's shift (t1 row of its epilogue table: channel 8 g + 4 h + i in register 4 g + i)
+__device__ __forceinline__ void acc_init(f32x16 &c, const float *epi, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 t = *reinterpret_cast<const f32x4 *>(epi + 1 * C + g * 8 + h * 4);
+    c[4 * g + 0] = t[0]; c[4 * g + 1] = t[1]; c[4 * g + 2] = t[2]; c[4 * g + 3] = t[3];
+  }
+}
 
 // A stage boundary: nothing is scheduled across it.  The epilogue below is written stage by stage - the same
 // instruction for the eight channel pairs of a block, then the next instruction for all of them - because a lone wave per
@@ -176,11 +187,7 @@ __device__ __forceinline__ void epi_math(const f32x16 &c, f32x16 &scb, const Epi
   (void)dbg;
   f32x2 x[8];
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int g = p >> 1, i = (p & 1) * 2;
-    x[p] = f32x2{c[2 * p], c[2 * p + 1]} * f32x2{q.s1[g][i], q.s1[g][i + 1]} + f32x2{q.t1[g][i], q.t1[g][i + 1]};
-  }
-  JG_STAGE();
+  for (int p = 0; p < 8; ++p) x[p] = f32x2{c[2 * p], c[2 * p + 1]};       // (scale in the weights, shift in the C operand)
   if constexpr (ADD) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) x[p] = x[p] + f32x2{scb[2 * p], scb[2 * p + 1]};
@@ -303,10 +310,9 @@ static __device__ unsigned long long jg_small_stamp[12];
 template <bool LAST, bool TAP, bool PMAX>
 __device__ __forceinline__ void mfma_slots(f32x16 &cc, const half8 (&w)[3][2][2], const half8 (&fr)[12], const float (&v)[16],
                                            OutRegs (&o)[4], const int b, const bool keep, char *act, int n, int h,
-                                           float &vmax, float (&pool)[16], float (&tapv)[16], int dbg) {
+                                           float &vmax, float (&pool)[16], float (&tapv)[16], int dbg, const f32x16 &c0) {
   constexpr int K = out_chunks<LAST, TAP>();
-  const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  cc = z;
+  cc = c0;                                   // the shift of the layer these MFMAs belong to (read from LDS a layer / a block ahead)
 #pragma unroll
   for (int i = 0; i < 18; ++i) {
     mfma_one(i, cc, w, fr, dbg);
@@ -336,6 +342,8 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], co
   half8 fr[12];
   EpiParams<false> q;
   q.load(epi, h);
+  f32x16 tnext;
+  acc_init(tnext, epi + 4 * C, h);                      // the first k = 3 layer's shift (its block 0 rides in the last slots)
   const char *fp = act + n * ROWB + h * 16;
   JG_FENCE();
 #pragma unroll
@@ -349,7 +357,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NB], f32x16 (&sc)[NB], co
 #pragma unroll
       for (int k = 0; k < K; ++k) epi_out_chunk<false, TAP, false>(k, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
     } else {
-      mfma_slots<false, TAP, false>(cc, w, fr, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
+      mfma_slots<false, TAP, false>(cc, w, fr, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg, tnext);   // the next layer's block 0
     }
     JG_FENCE();      // one block at a time: hoisted loads of later blocks would spill
   }
@@ -370,6 +378,9 @@ __device__ __forceinline__ void conv_layer(half8 (&w)[3][2][2], const half8 *wn,
   JG_SST(8);
   EpiParams<P2> q;
   q.load(epi, h);
+  f32x16 tcur, tnext;
+  acc_init(tcur, epi, h);
+  if constexpr (!LAST) acc_init(tnext, epi + 4 * C, h);
   JG_SST(9);
   const char *fp = act + n * ROWB + h * 16;
   float v[16];
@@ -383,7 +394,7 @@ __device__ __forceinline__ void conv_layer(half8 (&w)[3][2][2], const half8 *wn,
     OutRegs o[4];
     const bool keep = (mout.w[b >> 1] >> ((b & 1) * 32 + n)) & 1ull;
     if (b + 1 < NB) {
-      mfma_slots<LAST, TAP, PMAX>(cc, w, fr, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
+      mfma_slots<LAST, TAP, PMAX>(cc, w, fr, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg, tcur);
       if (b + 2 < NB) {
         read_frags(fr, fp, b + 2);                      // rows 32 b + 63 ..: in front of block b + 1's stores
       } else {
@@ -395,7 +406,7 @@ __device__ __forceinline__ void conv_layer(half8 (&w)[3][2][2], const half8 *wn,
       epi_math<P2, ADD, SAVE>(cc, sc[b + 1], q, dbg, v);
       JG_SST(4);
     } else if constexpr (!LAST) {
-      mfma_slots<LAST, TAP, PMAX>(cc, w, fr, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg);
+      mfma_slots<LAST, TAP, PMAX>(cc, w, fr, v, o, b, keep, act, n, h, vmax, pool, tapv, dbg, tnext);   // next layer's block 0
       JG_STAGE();
       JG_SST(3);
     } else {

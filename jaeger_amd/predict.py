@@ -499,6 +499,13 @@ def run_core(**kwargs) -> int:
     precision = "f32" if kwargs.get("exact_f32") else None
 
     def make_engine():
+        t_eng = time.time()
+        try:
+            return _make_engine()
+        finally:
+            LAST_RUN["engine_create_s"] = round(time.time() - t_eng, 3)
+
+    def _make_engine():
         weights = None
         wnpz = model_info.get("weights_npz")
         if wnpz is not None:
@@ -608,6 +615,7 @@ def run_core(**kwargs) -> int:
                                         common["dynamic_stride_threshold"], fsize if two_pass else min_len, None)
         n_long = len(table)
         starts = fa.offsets[table.contig] + table.start
+        LAST_RUN["ingest_and_table_s"] = round(time.time() - t_setup, 3)
         try:
             engine = f_engine.result() if piped else make_engine()
         except Exception as e:
@@ -633,7 +641,7 @@ def run_core(**kwargs) -> int:
         writer = _LazyWriter()
         agg = _Aggregator(table, fa.names, out, dict(class_map=class_map, fsize=fsize, term_repeats=None,
                                                      want_full=bool(kwargs.get("window_scores") or kwargs.get("prophage")),
-                                                     **crf_kw), min_batch=n_long // 8)
+                                                     **crf_kw), min_batch=n_long // 16)
 
         def classify():
             t0 = time.time()
