@@ -489,6 +489,10 @@ __device__ __forceinline__ void row_reduce_store(const float (&p)[16], const boo
   if (lane == 0) dst[C] = (float)count;
 }
 
+// Round 4, measured beside the affine fold and dropped: the residual shortcut folded into the accumulators' initial value as
+// well (shift + shortcut block by eight packed adds where the block is initialised, no add in the epilogue): bit-compatible,
+// and it gave back the fold's whole 2 % (0.742 vs 0.722 ms per launch, three interleaved pairs) - the packed adds sit in
+// front of a block's first MFMA, where a lone wave has nothing to run beside them.
 // Round-3 experiments that did NOT pay and are not in this file (git history has them):
 //   * the layer program as a compile-time constant (layer loop unrolled, every layer's variant chosen at compile time,
 //     nothing carried around a loop through the 16-way switch): bit-identical, 3 990 vs 3 990 Mbp/s interleaved;
