@@ -173,8 +173,7 @@ def kernel_hash() -> str:
     import hashlib
     h = hashlib.sha256()
     src = ROOT / "jaeger_amd" / "csrc"
-    for name in ("jg_common.h", "jg_conv_dev.h", "jg_conv_f16.hip", "jg_conv_f16_impl.h", "jg_conv_pc.hip", "jg_small.h",
-                 "jg_small.hip"):
+    for name in ("jg_common.h", "jg_conv_dev.h", "jg_conv_f16.hip", "jg_conv_f16_impl.h", "jg_small.h", "jg_small.hip"):
         h.update((src / name).read_bytes())
     return h.hexdigest()[:16]
 
@@ -354,9 +353,9 @@ def main():
                     help="tests only: rank 0 writes the gathered (or, with one rank, its own) logits of the last step to "
                          "this .npy file")
     ap.add_argument("--conv-pc", type=int, choices=[0, 1, 2], default=0,
-                    help="A/B switch: 128-channel five-tap convs on the two-workgroup kernel (0, the default), on the "
-                         "producer / consumer kernel (1) or on the two-workgroup kernel with the pipelined main loop (2); "
-                         "same results bit for bit")
+                    help="experiments only (libjaeger_hip_exp.so): 128-channel five-tap convs on the two-workgroup kernel (0, the "
+                         "default and the only one in the shipped library), on the producer / consumer kernel (1) or on "
+                         "the two-workgroup kernel with the pipelined main loop (2); same results bit for bit")
     ap.add_argument("--timed-dbg", type=int, default=None,
                     help="experiments only (libjaeger_hip_exp.so): set the conv kernel's JG_DBG ablation mask after "
                          "the warm-up steps (the timed steps then read real activations; their results are wrong)")

@@ -129,7 +129,8 @@ int jg_engine_sync(jg_engine *e);
  * spans of bases.  This is the
  * "host-DRAM -> HBM streamed" ingest of BASELINE.json configs[4]; the reference streams Python strings through
  * tf.data instead (commands/predict.py:186-245).
- * JG_OPT_CONV_PC (default 0): which kernel runs the 128 -> 128 channel five-tap convs of the residual stacks
+ * JG_OPT_CONV_PC (default 0; values other than 0 only in the experiment build, JG_ERR_UNSUPPORTED in the shipped library):
+ * which kernel runs the 128 -> 128 channel five-tap convs of the residual stacks
  * (layers.py:1882-1915): 0 = the two-workgroup kernel, 1 = the producer / consumer kernel (jg_conv_pc.hip), 2 = the
  * two-workgroup kernel with the producer / consumer experiment's pipelined main loop.  Same results bit for bit - the
  * switch exists for A/B timing and for the test that asserts exactly that.

@@ -92,6 +92,11 @@ extern "C" int jg_engine_set_option(jg_engine *e, int key, int64_t value) {
       return JG_OK;
     case JG_OPT_CONV_PC:
       JG_REQUIRE(value >= 0 && value <= 2, JG_ERR_INVALID, "jg_engine_set_option: JG_OPT_CONV_PC takes 0, 1 or 2, got %lld", (long long)value);
+#ifndef JG_EXPERIMENT
+      JG_REQUIRE(value == 0, JG_ERR_UNSUPPORTED, "jg_engine_set_option: JG_OPT_CONV_PC = %lld needs the experiment build (make -C jaeger_amd/csrc "
+                 "exp; JAEGER_HIP_LIB=jaeger_amd/libjaeger_hip_exp.so): the producer / consumer kernels are not in the shipped library",
+                 (long long)value);
+#endif
       e->conv_pc = (int)value;
       return JG_OK;
     case JG_OPT_TERMINI_EXACT:

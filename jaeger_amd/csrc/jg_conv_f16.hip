@@ -17,8 +17,10 @@ int jg_conv_f16_part_x10(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_x11(jg_engine *e, const ConvHArgs &a, hipStream_t s);    // k = 9
 int jg_conv_f16_part_x12(jg_engine *e, const ConvHArgs &a, hipStream_t s);
 int jg_conv_f16_part_x13(jg_engine *e, const ConvHArgs &a, hipStream_t s);
+#ifdef JG_EXPERIMENT                                                           /* the producer / consumer kernel: experiment build only */
 bool jg_conv_pc_supports(const ConvHArgs &a);                                  // jg_conv_pc.hip
 int jg_conv_pc_launch(jg_engine *e, const ConvHArgs &a, hipStream_t s);
+#endif
 
 namespace {
 constexpr int HM = 256, HN = 128, HT = 256, NT = 1, A_ITERS = 5, W_ITEMS = 2 * 2 * HN, LUT_RS = 68;   // as in jg_conv_f16_impl.h
@@ -144,10 +146,13 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     JG_REQUIRE(!a.flat, JG_ERR_UNSUPPORTED, "conv_f16x3: window-packed tiling is only built for k = 5");
     return a.k == 7 ? jg_conv_f16_part_x10(e, a, s) : jg_conv_f16_part_x13(e, a, s);
   }
-  // the residual stacks' 128 -> 128 five-tap convs: producer / consumer kernel (math waves + DMA / epilogue helper waves);
-  // JG_OPT_CONV_PC = 0 keeps them on the two-workgroup kernel below (same results bit for bit)
+#ifdef JG_EXPERIMENT
+  // the residual stacks' 128 -> 128 five-tap convs on the producer / consumer kernel (math waves + DMA / epilogue helper
+  // waves; round 3's committed negative, profiles/r3_pc_experiments.md): experiment build only, JG_OPT_CONV_PC = 1;
+  // same results bit for bit as the two-workgroup kernel below
   static const bool no_pc = jg_exp_env("JG_NO_PC") != nullptr;
   if (e->conv_pc == 1 && !no_pc && a.dbg == 0 && jg_conv_pc_supports(a)) return jg_conv_pc_launch(e, a, s);
+#endif
   if (a.flat) {
     JG_REQUIRE(a.k == 5 && a.ostride == 1, JG_ERR_UNSUPPORTED, "conv_f16x3: window-packed tiling is only built for k = 5, stride 1");
     return jg_conv_f16_part_flat(e, a, s);

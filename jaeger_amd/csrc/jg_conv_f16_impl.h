@@ -1316,7 +1316,9 @@ int launch_ke(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
 template <int K, unsigned EP, bool FLAT>
 int launch_hot(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   if constexpr (K == 5) {
+#ifdef JG_EXPERIMENT      /* (the pipelined main loop of the producer / consumer experiment: not in the shipped library) */
     if (e->conv_pc == 2 && a.dil == 3 && a.cc_in % 2 == 0 && a.dbg == 0) return launch_ke<5, EP, FLAT, 128, true, true>(e, a, s);
+#endif
     return launch_ke<5, EP, FLAT, 128, true>(e, a, s);
   } else {
     return launch_ke<K, EP, FLAT>(e, a, s);

@@ -82,8 +82,9 @@ class HipDevice:
         L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_STREAM_BYTES, int(nbytes)), "jg_engine_set_option")
 
     def set_conv_pc(self, on: bool):
-        """128 -> 128 five-tap convs on the producer / consumer kernel (default) or on the two-workgroup kernel
-        (JG_OPT_CONV_PC); the two give the same results bit for bit."""
+        """Experiment build only (libjaeger_hip_exp.so): 128 -> 128 five-tap convs on the producer / consumer kernel (1) or
+        on the two-workgroup kernel with the pipelined main loop (2) instead of the two-workgroup kernel (0, the default
+        and the only one in the shipped library); same results bit for bit (JG_OPT_CONV_PC)."""
         L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_CONV_PC, int(on)), "jg_engine_set_option")
 
     def windows_done(self) -> int:

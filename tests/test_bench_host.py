@@ -37,12 +37,11 @@ def test_kernel_hash_is_stable_and_source_sensitive(tmp_path, monkeypatch):
     src = ROOT / "jaeger_amd" / "csrc"
     fake = tmp_path / "jaeger_amd" / "csrc"
     fake.mkdir(parents=True)
-    for name in ("jg_common.h", "jg_conv_dev.h", "jg_conv_f16.hip", "jg_conv_f16_impl.h", "jg_conv_pc.hip", "jg_small.h",
-                 "jg_small.hip"):
+    for name in ("jg_common.h", "jg_conv_dev.h", "jg_conv_f16.hip", "jg_conv_f16_impl.h", "jg_small.h", "jg_small.hip"):
         (fake / name).write_bytes((src / name).read_bytes())
     monkeypatch.setattr(bench, "ROOT", tmp_path)
     assert bench.kernel_hash() == h1
-    (fake / "jg_conv_pc.hip").write_bytes((src / "jg_conv_pc.hip").read_bytes() + b"\n")
+    (fake / "jg_small.hip").write_bytes((src / "jg_small.hip").read_bytes() + b"\n")
     assert bench.kernel_hash() != h1
 
 
@@ -50,8 +49,7 @@ def test_kernel_hash_is_stable_and_source_sensitive(tmp_path, monkeypatch):
 def test_pmc_fields_only_for_the_build_they_were_collected_on(tmp_path, monkeypatch, same_build):
     src = ROOT / "jaeger_amd" / "csrc"
     (tmp_path / "jaeger_amd" / "csrc").mkdir(parents=True)
-    for name in ("jg_common.h", "jg_conv_dev.h", "jg_conv_f16.hip", "jg_conv_f16_impl.h", "jg_conv_pc.hip", "jg_small.h",
-                 "jg_small.hip"):
+    for name in ("jg_common.h", "jg_conv_dev.h", "jg_conv_f16.hip", "jg_conv_f16_impl.h", "jg_small.h", "jg_small.hip"):
         (tmp_path / "jaeger_amd" / "csrc" / name).write_bytes((src / name).read_bytes())
     monkeypatch.setattr(bench, "ROOT", tmp_path)
     here = bench.kernel_hash()

@@ -445,9 +445,20 @@ def test_producer_consumer_conv_matches_two_workgroup_kernel(name, fsize, n_win,
     """The producer / consumer kernel of the residual stacks (jg_conv_pc.hip) keeps the two-workgroup kernel's
     arithmetic order: every output must be bit-identical with JG_OPT_CONV_PC off, for row-tiled (1500 bp) and
     window-packed (2000 / 1000 bp) launches, ragged windows, N runs and several chunkings - and repeatable."""
+    from jaeger_amd import _lib
     from jaeger_amd.engine import JaegerHipEngine, frame_length
     from oracle import encoder as oenc
     from oracle import forward as ofwd
+    if "_exp" not in _lib.lib_path().name:
+        # round 4: the producer / consumer kernels (round 3's committed negative) are compiled into the experiment build
+        # only; the shipped library refuses the option instead of silently running the default kernel
+        from jaeger_amd.engine import HipDevice
+        dev = HipDevice(0)
+        with pytest.raises(_lib.JaegerHipError, match="experiment build"):
+            dev.set_conv_pc(1)
+        dev.set_conv_pc(0)
+        dev.close()
+        pytest.skip("needs libjaeger_hip_exp.so (make -C jaeger_amd/csrc exp; JAEGER_HIP_LIB=...)")
     cfg = load_model_cfg(name)
     weights = ofwd.random_weights(cfg, seed=38341)
     rng = np.random.Generator(np.random.PCG64(77 + fsize))
