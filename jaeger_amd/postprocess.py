@@ -99,43 +99,45 @@ _CRF_PRIOR_TIERS = (
 )
 
 
+def _pair_matrix(names: list[str], pairs: dict) -> tuple[np.ndarray, np.ndarray]:
+    """(values, given) of a symmetric pair table over ``names``: ``pairs`` maps frozenset({a, b}) -> value; pairs that
+    name an absent class are skipped.  Pure array code: one comparison grid per listed pair."""
+    idx = {n: i for i, n in enumerate(names)}
+    n = len(names)
+    rows = np.array([(idx[a], idx[b], v) for (a, b), v in ((tuple(k), v) for k, v in pairs.items()) if a in idx and b in idx],
+                    dtype=np.float64).reshape(-1, 3)
+    values, given = np.zeros((n, n)), np.zeros((n, n), bool)
+    i, j = rows[:, 0].astype(int), rows[:, 1].astype(int)
+    values[i, j] = values[j, i] = rows[:, 2]
+    given[i, j] = given[j, i] = True
+    return values, given
+
+
 def default_transition_prior(class_names: list[str]) -> np.ndarray:
-    """Symmetric prior matrix P, zero diagonal, neutral cost 1.0 for unlisted pairs; class names
-    that are absent are skipped (helpers.py:316-344)."""
+    """Symmetric prior matrix P of the CRF (helpers.py:316-344): the listed co-occurrence tiers, 1.0 for every other
+    pair of distinct classes, 0 on the diagonal."""
     names = [str(n).lower() for n in class_names]
-    prior = np.ones((len(names), len(names)), dtype=np.float64)
-    np.fill_diagonal(prior, 0.0)
-    for value, pairs in _CRF_PRIOR_TIERS:
-        for a, b in pairs:
-            if a in names and b in names:
-                i, j = names.index(a), names.index(b)
-                prior[i, j] = prior[j, i] = value
-    return prior
+    tiers = {frozenset(p): v for v, ps in _CRF_PRIOR_TIERS for p in ps}
+    values, given = _pair_matrix(names, {tuple(sorted(k)): v for k, v in tiers.items()})
+    return np.where(np.eye(len(names), dtype=bool), 0.0, np.where(given, values, 1.0))
 
 
 def build_transition_costs(class_names: list[str], switch_cost: float, prior: str = "biological",
                            user_matrix: dict | None = None) -> np.ndarray:
-    """``lambda * P`` (helpers.py:347-395): ``user_matrix`` ({"bacteria": {"phage": 0.5}}, applied
-    symmetrically, unknown names ignored) overrides ``prior`` ("biological" | "uniform")."""
+    """``lambda * P`` (helpers.py:347-395): ``user_matrix`` ({"bacteria": {"phage": 0.5}}, applied symmetrically in the
+    order given, unknown names ignored) overrides ``prior`` ("biological" | "uniform")."""
     names = [str(n).lower() for n in class_names]
-    n = len(names)
+    off_diag = ~np.eye(len(names), dtype=bool)
     if user_matrix:
-        p = np.ones((n, n), dtype=np.float64)
-        np.fill_diagonal(p, 0.0)
-        for a, row in user_matrix.items():
-            a = str(a).lower()
-            if a not in names or not isinstance(row, dict):
-                continue
-            for b, value in row.items():
-                b = str(b).lower()
-                if b not in names:
-                    continue
-                i, j = names.index(a), names.index(b)
-                p[i, j] = p[j, i] = float(value)
-        np.fill_diagonal(p, 0.0)
+        p = off_diag.astype(np.float64)
+        entries = [(str(a).lower(), str(b).lower(), float(v)) for a, row in user_matrix.items() if isinstance(row, dict)
+                   for b, v in row.items()]
+        for a, b, v in entries:                      # later entries win, as when the reference assigns them in turn
+            if a in names and b in names:
+                p[names.index(a), names.index(b)] = p[names.index(b), names.index(a)] = v
+        p = np.where(off_diag, p, 0.0)
     elif prior == "uniform":
-        p = np.ones((n, n), dtype=np.float64)
-        np.fill_diagonal(p, 0.0)
+        p = off_diag.astype(np.float64)
     else:
         p = default_transition_prior(names)
     return float(switch_cost) * p

@@ -234,10 +234,14 @@ def _norm_vars(norm_type: str, c: int) -> dict[str, tuple]:
 
 
 def onehot_depth(model_cfg: dict) -> int:
-    """max(codon_id) + 1 (seqops/encode.py:297-302)."""
-    from jaeger_amd import maps
+    """max(codon_id) + 1 (seqops/encode.py:297-302).  The id maps come from ``tests/golden/maps.json`` - the vectors
+    ``tests/golden/make_golden.py`` dumped from the reference's ``seqops/maps.py`` - not from the product's ``jaeger_amd.maps``:
+    the checker's one-hot depth must not depend on the code under test."""
+    import json
+    from pathlib import Path
     name = (model_cfg.get("string_processor", {}) or {}).get("codon_id", "CODON_ID")
-    return max(maps.NAMED_MAPS[name]) + 1
+    table = json.loads((Path(__file__).resolve().parents[1] / "tests" / "golden" / "maps.json").read_text())
+    return max(table[name]) + 1
 
 
 def vocab_size(model_cfg: dict) -> int:
