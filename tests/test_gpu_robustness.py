@@ -89,3 +89,50 @@ def test_f16x3_scale_sweep_against_f64():
     for name, mag, mode, e_gpu, e_cpu, ok in rows:
         print(f"| {name} | {mag:.3g} | {mode}{'' if ok else ' **FAIL**'} | {e_gpu:.2e} | {e_cpu:.2e} |")
     assert not bad, bad
+
+
+def test_range_guard_inside_the_streamed_pipeline():
+    """The host -> HBM pipeline of jg_predict_windows keeps two groups in flight and reads the f16 range guard back per
+    group: when it trips (here: conv kernels x10, logits ~1e13), the pipeline drains, falls back to the exact-f32 kernels
+    and restarts from the group that tripped it - every window of the call must then equal an exact-f32 run, bit for bit,
+    whichever group it was in, and the progress mark must have reached the end."""
+    from jaeger_amd.engine import JaegerHipEngine
+    from oracle import forward as ofwd
+    cfg = load_model_cfg("brain")
+    base = ofwd.random_weights(cfg, seed=38341)
+    w = {k: (v * np.float32(10.0) if (k.startswith("rep/") and k.endswith("/kernel") and v.ndim == 3) else v.copy())
+         for k, v in base.items()}
+    rng = np.random.Generator(np.random.PCG64(5))
+    fsize, n_win = 1500, 700
+    seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=fsize * n_win).copy()
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    want = ("prediction", "reliability")
+    with pytest.warns(UserWarning):
+        ref_eng = JaegerHipEngine(model_cfg=copy.deepcopy(cfg), weights=w, precision="f32")
+    ref = ref_eng.predict_windows(seq, starts, lens, fsize, want=want)
+    ref_eng.close()
+    with pytest.warns(UserWarning):
+        eng = JaegerHipEngine(model_cfg=copy.deepcopy(cfg), weights=w, precision="f16x3")
+    eng.chunk = 64
+    eng.device.set_stream_bytes(128 * 1024)            # ~85 windows per span: a dozen groups, 1 - 2 passes each
+    got = eng.predict_windows(seq, starts, lens, fsize, want=want)
+    stats = eng.device.stream_stats()
+    assert stats["groups"] >= 6 and eng.model.precision == "f32"          # streamed, and the guard tripped
+    assert eng.device.windows_done() == n_win
+    for k in want + ("counts",):
+        np.testing.assert_array_equal(got[k], ref[k])
+    # a healthy model through the same pipeline stays on the fast path
+    with pytest.warns(UserWarning):
+        ok = JaegerHipEngine(model_cfg=copy.deepcopy(cfg), weights=base, precision="f16x3")
+    ok.chunk = 64
+    ok.device.set_stream_bytes(128 * 1024)
+    a = ok.predict_windows(seq, starts, lens, fsize, want=want)
+    assert ok.model.precision == "f16x3" and ok.device.stream_stats()["groups"] >= 6
+    ok.device.set_stream_bytes(1 << 30)
+    b = ok.predict_windows(seq, starts, lens, fsize, want=want)
+    assert ok.device.stream_stats()["groups"] == 0
+    for k in want + ("counts",):
+        np.testing.assert_array_equal(a[k], b[k])
+    eng.close()
+    ok.close()
