@@ -24,6 +24,13 @@ from .plan import ModelPlan, build_plan
 from .program import Program, compile_plan
 
 
+def _yaml_load(text: str):
+    """``yaml.safe_load`` on libyaml's loader when PyYAML was built with it (ten times faster: the project YAML is on
+    the critical path of a run's first milliseconds); same safe constructor set."""
+    loader = getattr(yaml, "CSafeLoader", None)
+    return yaml.load(text, Loader=loader) if loader is not None else yaml.safe_load(text)
+
+
 def frame_length(nucleotides: int) -> int:
     """Codons per frame of a ``nucleotides``-long crop (seqops/crop.py:44-61)."""
     nt = int(nucleotides)
@@ -318,7 +325,7 @@ class JaegerHipEngine:
             project = path_dict.get("project")
             if project is None:
                 raise ValueError("JaegerHipEngine needs the model's *_project.yaml (layer plan source)")
-            cfg = yaml.safe_load(Path(project).read_text()) or {}
+            cfg = _yaml_load(Path(project).read_text()) or {}
             model_cfg = cfg.get("model")
             if weights is None:
                 import os
@@ -371,7 +378,7 @@ class JaegerHipEngine:
         if path is None:
             return None
         with open(path) as f:
-            cm = yaml.safe_load(f)["classes"]
+            cm = _yaml_load(f.read())["classes"]
         return {"num_classes": len(cm), "class": [i["class"] for i in cm], "index": [i["label"] for i in cm]}
 
     # -- InferModel.predict -----------------------------------------------------
