@@ -312,28 +312,58 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
   const int cw = min(cch, a.cin_pad - c0);                        // multiple of 8
   if (c0 != 0) __syncthreads();                                   // every wave is done with the previous pass's rows
   // ---- stage the input rows (mask multiply / embedding gather / zero K padding fused) -----------------------------
+  // In batches of SU pieces per thread, phase by phase: the position bytes (mask or codon id) of a batch are requested
+  // together, then its 16-byte data loads, then the LDS stores.  (Round 4: written piece by piece the loop compiled to
+  // byte load -> wait -> data load -> wait -> store, ten times per thread and tile - two dependent memory round trips per
+  // piece, ~20 us of pure latency in front of a tile's 17 us of matrix-core work.)
   {
+    constexpr int SU = 5;
     const int c4 = cw >> 2;
     const int total = rows_in * c4;
-    for (int idx = tid; idx < total; idx += NT) {
-      const int r = idx / c4, cq = idx - r * c4;
-      const int p = p0 + r;
-      const int c = c0 + cq * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p >= 0 && p < a.L_in && c < a.cin) {                    // (cin is a multiple of 4)
-        const size_t pos = (size_t)row * a.L_in + p;
-        if (a.ids != nullptr) {
-          const int id = a.ids[pos];
-          if (id != 0 || !a.mask_from_ids)
-            v = *reinterpret_cast<const float4 *>(a.emb + (size_t)id * a.cin + c);
-        } else if (a.mask_in == nullptr || a.mask_in[pos] != 0) {
-          // (activations are read once per launch: non-temporal, so that they do not displace the weights in L2)
-          typedef float f32x4 __attribute__((ext_vector_type(4)));
-          const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.x + pos * a.cin + c));
-          v = make_float4(t[0], t[1], t[2], t[3]);
+    for (int base = tid; base < total; base += NT * SU) {
+      int dst[SU];                 // LDS float offset of the piece, -1: no piece
+      size_t src[SU];              // element offset of its source (activation tensor or embedding table)
+      unsigned char byte[SU];
+      bool inr[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int idx = base + u * NT;
+        const int r = idx / c4, cq = idx - r * c4;
+        const int p = p0 + r;
+        const int c = c0 + cq * 4;
+        dst[u] = idx < total ? r * ldr + cq * 4 : -1;
+        inr[u] = idx < total && p >= 0 && p < a.L_in && c < a.cin;          // (cin is a multiple of 4)
+        const size_t pos = (size_t)row * a.L_in + (inr[u] ? p : 0);
+        const int cs = inr[u] ? c : 0;                                       // (a valid address for pieces that are padding)
+        src[u] = a.ids != nullptr ? (size_t)cs : pos * a.cin + cs;
+        byte[u] = 1;
+        if (inr[u]) {
+          if (a.ids != nullptr) byte[u] = a.ids[pos];
+          else if (a.mask_in != nullptr) byte[u] = a.mask_in[pos];
         }
       }
-      *reinterpret_cast<float4 *>(smem + r * ldr + cq * 4) = v;
+      // (every load is issued - at a clamped, valid address where the piece is padding or masked - and the zero is
+      // selected afterwards: loads under divergent branches are waited for one by one)
+      float4 v[SU];
+      if (a.ids != nullptr) {
+#pragma unroll
+        for (int u = 0; u < SU; ++u) v[u] = *reinterpret_cast<const float4 *>(a.emb + (size_t)byte[u] * a.cin + src[u]);
+#pragma unroll
+        for (int u = 0; u < SU; ++u)
+          if (!inr[u] || (byte[u] == 0 && a.mask_from_ids)) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 t[SU];
+        // (activations are read once per launch: non-temporal, so that they do not displace the weights in L2)
+#pragma unroll
+        for (int u = 0; u < SU; ++u) t[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.x + src[u]));
+#pragma unroll
+        for (int u = 0; u < SU; ++u)
+          v[u] = (inr[u] && byte[u] != 0) ? make_float4(t[u][0], t[u][1], t[u][2], t[u][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<float4 *>(smem + dst[u]) = v[u];
     }
   }
   __syncthreads();
@@ -347,15 +377,19 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
   const auto a_at = [&](int tt, int gg, int tm) {
     return *reinterpret_cast<const float4 *>(abase + (tt * a.dil + tm * 32 * a.stride) * ldr + gg * 8);
   };
-  float4 b0[TN], b1[TN], a0[TM];
+#ifndef JG_F32_WPF
+#define JG_F32_WPF 2            /* weight quads in flight ahead of the step that uses them */
+#endif
+  constexpr int WPF = JG_F32_WPF;
+  float4 bq[WPF][TN], a0[TM];
   int tb = 0, gb = 0, ta = 0, ga = 0;
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) b0[tn] = w_at(0, 0, tn);
-  if (++gb == gpass) { gb = 0; ++tb; }
-  if (steps > 1) {
+  for (int d = 0; d < WPF; ++d) {
+    if (d < steps) {
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) b1[tn] = w_at(tb, gb, tn);
-    if (++gb == gpass) { gb = 0; ++tb; }
+      for (int tn = 0; tn < TN; ++tn) bq[d][tn] = w_at(tb, gb, tn);
+      if (++gb == gpass) { gb = 0; ++tb; }
+    }
   }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) a0[tm] = a_at(0, 0, tm);
@@ -364,12 +398,13 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
     float4 bv[TN], av[TM];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-      bv[tn] = b0[tn];
-      b0[tn] = b1[tn];
-    }
-    if (sidx + 2 < steps) {
+      bv[tn] = bq[0][tn];
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) b1[tn] = w_at(tb, gb, tn);
+      for (int d = 0; d + 1 < WPF; ++d) bq[d][tn] = bq[d + 1][tn];
+    }
+    if (sidx + WPF < steps) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) bq[WPF - 1][tn] = w_at(tb, gb, tn);
       if (++gb == gpass) { gb = 0; ++tb; }
     }
 #pragma unroll

@@ -603,6 +603,29 @@ def run_core(**kwargs) -> int:
         t_setup = time.time()
         f_engine = pool.submit(make_engine) if piped else None
         ingest()
+        scan: dict = {}
+        th = None
+        if piped:
+            # the terminal-repeat scan starts as soon as the bases are there - a thread and a stream of its own - so that most
+            # of it runs while the model is still being set up: beside the forward its workgroups only get the CUs in the gaps
+            # between the network's launches (the conv and small-window kernels take a CU's whole LDS), and the rows of
+            # finished batches cannot go to the table before the repeat columns exist
+            import threading
+
+            def scan_side():
+                try:
+                    from .engine import HipDevice
+                    side = HipDevice(local_rank)
+                    try:
+                        scan["frame"] = scan_repeats(side)
+                    finally:
+                        side.close()
+                except BaseException as e:
+                    scan["error"] = e
+
+            th = threading.Thread(target=scan_side, name="jaeger-termini", daemon=True)
+            if not kwargs.get("_scan_after"):
+                th.start()
         if dust:
             t_dust = time.time()
             n_masked = frag.dust_mask(fa)
@@ -654,25 +677,9 @@ def run_core(**kwargs) -> int:
             f_pred = pool.submit(classify) if piped else None
             log_setup(engine)
             if piped:
-                import threading
-
-                from .engine import HipDevice
-                scan: dict = {}
-
-                def scan_side():                              # a thread and a stream of its own: the scan interleaves with the
-                    try:                                       # forward on the GPU and with the aggregation on the host
-                        side = HipDevice(local_rank)
-                        try:
-                            scan["frame"] = scan_repeats(side)
-                        finally:
-                            side.close()
-                    except BaseException as e:
-                        scan["error"] = e
-
-                th = threading.Thread(target=scan_side, name="jaeger-termini", daemon=True)
                 if kwargs.get("_scan_after"):                 # (timing experiments: the repeat scan behind the forward)
                     f_pred.result()
-                th.start()
+                    th.start()
                 while not f_pred.done():
                     agg.advance(engine.device.windows_done())
                     if "frame" in scan:                       # rows of finished batches go to the table beside the forward
