@@ -13,6 +13,10 @@
 // Written for 64-lane wavefronts; no other target is supported.
 #include <math.h>
 
+#include <stdio.h>
+
+#include <type_traits>
+
 #include "jg_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -106,6 +110,89 @@ __device__ __forceinline__ float4 jg_apply_stages(float4 v, const StageArg *st, 
     }
   }
   return v;
+}
+
+
+// The same stage list applied to the RPT positions one thread of the exact-f32 conv owns (same channel quad n, rows
+// r0, r0 + RSTEP, ...), STAGE-MAJOR: a stage's per-channel parameters are loaded once instead of once per position, and
+// the residual shortcut's RPT loads are issued together.  Position-major (one jg_apply_stages call per row) every row
+// paid its own chain of dependent loads - bias, four batch-norm vectors, the shortcut from HBM - and the epilogue was a
+// quarter to two fifths of a workgroup's life (cycle stamps, round 4).  Element-wise operations and the NMD sums run in
+// the same order per element as before: bit-identical results.  (Measured beside it and dropped: the parameter vectors of a
+// tile's channel block staged in the LDS left beside the accumulator exchange, -3 %; the shortcut of all of a thread's rows
+// requested at the top of the epilogue, -12 %, or at the top of each row group, -0.5 %; a leading [bias, batch norm] pair's vectors loaded once per thread, -2 % -
+// under the 128-register cap of four waves per SIMD both cost the main loop
+// more than the epilogue gains.)
+template <int RPT>
+__device__ __forceinline__ void jg_apply_stages_rows(float4 (&v)[RPT], const bool (&ok)[RPT], const StageArg *st, int n_stages,
+                                                     int n, const size_t (&o)[RPT], const float (&mk)[RPT], float4 *nmd_acc,
+                                                     float4 *nmd_acc2) {
+  bool tapped = false;
+  for (int s = 0; s < n_stages; ++s) {
+    const StageArg &g = st[s];
+    const auto vec = [&](const float *gp, int) { return *reinterpret_cast<const float4 *>(gp + n); };
+    switch (g.kind) {
+      case JG_ST_BIAS: {
+        const float4 b = vec(g.p0, 0);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) { v[i].x += b.x; v[i].y += b.y; v[i].z += b.z; v[i].w += b.w; }
+      } break;
+      case JG_ST_BN: {
+        const float4 mu = vec(g.p0, 0), is = vec(g.p1, 1), ga = vec(g.p2, 2), be = vec(g.p3, 3);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+          v[i].x = ga.x * ((v[i].x - mu.x) * is.x) + be.x;
+          v[i].y = ga.y * ((v[i].y - mu.y) * is.y) + be.y;
+          v[i].z = ga.z * ((v[i].z - mu.z) * is.z) + be.z;
+          v[i].w = ga.w * ((v[i].w - mu.w) * is.w) + be.w;
+        }
+      } break;
+      case JG_ST_DYT: {
+        const float4 ga = vec(g.p2, 0), be = vec(g.p3, 1);
+        const float al = g.f0;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+          const float mm = g.arg ? mk[i] : 1.0f;
+          v[i].x = (tanhf(al * v[i].x) * ga.x + be.x) * mm;
+          v[i].y = (tanhf(al * v[i].y) * ga.y + be.y) * mm;
+          v[i].z = (tanhf(al * v[i].z) * ga.z + be.z) * mm;
+          v[i].w = (tanhf(al * v[i].w) * ga.w + be.w) * mm;
+        }
+      } break;
+      case JG_ST_ADD: {
+        float4 r[RPT];
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) r[i] = *reinterpret_cast<const float4 *>(g.p0 + (ok[i] ? o[i] : o[0]));   // (o[0] is always a real row)
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) { v[i].x += r[i].x; v[i].y += r[i].y; v[i].z += r[i].z; v[i].w += r[i].w; }
+      } break;
+      case JG_ST_ACT:
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+          v[i].x = jg_apply_act(v[i].x, g.arg);
+          v[i].y = jg_apply_act(v[i].y, g.arg);
+          v[i].z = jg_apply_act(v[i].z, g.arg);
+          v[i].w = jg_apply_act(v[i].w, g.arg);
+        }
+        break;
+      case JG_ST_NMD: {
+        float4 *acc = (tapped && nmd_acc2 != nullptr) ? nmd_acc2 : nmd_acc;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i)
+          if (ok[i]) {
+            acc->x += v[i].x * mk[i]; acc->y += v[i].y * mk[i];
+            acc->z += v[i].z * mk[i]; acc->w += v[i].w * mk[i];
+          }
+        tapped = true;
+      } break;
+      case JG_ST_MASKMUL:
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) { v[i].x *= mk[i]; v[i].y *= mk[i]; v[i].z *= mk[i]; v[i].w *= mk[i]; }
+        break;
+      default:
+        break;
+    }
+  }
 }
 
 
@@ -277,9 +364,20 @@ int jg_launch_mask(const uint8_t *in, int rows, int L_in, int L_out, int k, int 
 // round trip: + 1.5 % over one group ahead; the A fragment is read from LDS one group ahead).
 // Accumulators go through LDS once so the epilogue runs on float4 channel
 // quads with fully coalesced stores.
+#ifdef JG_F32_STAMP      /* experiment: per-phase shader cycles of wave 0 of every workgroup (staging, main loop, exchange, epilogue) */
+static __device__ unsigned long long jg_f32_stamp[8];
+#define JG_FST(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&jg_f32_stamp[i], n_ - fst_t); fst_t = n_; } } while (0)
+#else
+#define JG_FST(i)
+#endif
 template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
+// (64-position tiles are 40 KB of LDS: four workgroups per CU only if a wave stays within 128 registers)
+__global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(TM == 1 ? 4 : 2)))
+void conv_f32_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef JG_F32_STAMP
+  unsigned long long fst_t = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
   constexpr int LDC = BN + 4;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -317,7 +415,7 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
   // byte load -> wait -> data load -> wait -> store, ten times per thread and tile - two dependent memory round trips per
   // piece, ~20 us of pure latency in front of a tile's 17 us of matrix-core work.)
   {
-    constexpr int SU = 5;
+    constexpr int SU = 5;               // (ten = the whole tile in one batch: 19.9 vs 24.5 Mbp/s - 40 more live registers)
     const int c4 = cw >> 2;
     const int total = rows_in * c4;
     for (int base = tid; base < total; base += NT * SU) {
@@ -366,7 +464,9 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
         if (dst[u] >= 0) *reinterpret_cast<float4 *>(smem + dst[u]) = v[u];
     }
   }
+  JG_FST(0);
   __syncthreads();
+  JG_FST(1);
   // ---- MFMA main loop over (tap, 8-channel group of this pass) ---------------------------------------------------
   const int gpass = cw >> 3, g0 = c0 >> 3;
   const int steps = a.k * gpass;
@@ -425,8 +525,9 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
       }
   }
   }
+  JG_FST(2);
   __syncthreads();  // every wave is done reading the input rows
-
+  JG_FST(3);
   // ---- accumulators -> LDS C tile ---------------------------------------------
   // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -439,7 +540,9 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
         const int nl = (wn * TN + tn) * 32 + i;
         smem[ml * LDC + nl] = acc[tm][tn][r];
       }
+  JG_FST(4);
   __syncthreads();
+  JG_FST(5);
 
   // ---- fused epilogue on channel quads ------------------------------------------
   constexpr int QN = BN / 4;          // channel quads per tile row
@@ -448,19 +551,37 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_f32_kernel(ConvArgs a) {
   const int n = n_blk + q * 4;
   float4 nmd_acc = make_float4(0.f, 0.f, 0.f, 0.f), nmd_acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (n < a.cout) {
-    for (int ml = r0; ml < BM; ml += RSTEP) {
-      const int m = m0 + ml;
-      if (m >= a.L_out) break;
-      const size_t pos = (size_t)row * a.L_out + m;
-      const float mk = a.mask_out != nullptr ? (a.mask_out[pos] != 0 ? 1.f : 0.f) : 1.f;
-      const size_t o = pos * a.cout + n;
-      float4 v = *reinterpret_cast<const float4 *>(smem + ml * LDC + q * 4);
-      v = jg_apply_stages(v, a.st, a.n_stages, n, o, mk, &nmd_acc, &nmd_acc2);
+    // positions per thread: rows r0, r0 + RSTEP, ... of the tile, one channel quad; handled HR at a time (eight at once cost
+    // 196 registers = two waves per SIMD instead of four)
+    constexpr int RPT = BM / RSTEP, HR = RPT < 4 ? RPT : 4;
+    static_assert(RPT % HR == 0, "rows per thread");
+#pragma unroll 1
+    for (int i0 = 0; i0 < RPT; i0 += HR) {
+      float4 v[HR];
+      size_t o[HR];
+      float mk[HR];
+      bool ok[HR];
+#pragma unroll
+      for (int i = 0; i < HR; ++i) {
+        const int ml = r0 + (i0 + i) * RSTEP, m = m0 + ml;
+        ok[i] = m < a.L_out;
+        const size_t pos = (size_t)row * a.L_out + (ok[i] ? m : m0);
+        o[i] = pos * a.cout + n;
+        mk[i] = (a.mask_out != nullptr && ok[i]) ? (a.mask_out[pos] != 0 ? 1.f : 0.f) : 1.f;
+        v[i] = *reinterpret_cast<const float4 *>(smem + ml * LDC + q * 4);
+      }
+      if (!ok[0]) break;                  // rows ascend: the rest of the thread's rows lie beyond the frame as well
+      jg_apply_stages_rows<HR>(v, ok, a.st, a.n_stages, n, o, mk, &nmd_acc, &nmd_acc2);
       typedef float f32x4 __attribute__((ext_vector_type(4)));
-      const f32x4 t = {v.x, v.y, v.z, v.w};
-      __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(a.y + o));
+#pragma unroll
+      for (int i = 0; i < HR; ++i)
+        if (ok[i]) {
+          const f32x4 t = {v[i].x, v[i].y, v[i].z, v[i].w};
+          __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(a.y + o[i]));
+        }
     }
   }
+  JG_FST(6);
   // NMD taps (up to two per conv): deterministic in-block reduction over the RSTEP row groups, one partial per
   // (row, tile) written to each stage's partial-sum buffer.
   float *nmd_out[2] = {nullptr, nullptr};
@@ -541,6 +662,17 @@ static int launch_conv_t(const ConvArgs &a, hipStream_t s) {
   dim3 grid((unsigned)((size_t)a.rows * a.tiles_m), (unsigned)((a.cout + BN - 1) / BN));
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, b);
   JG_HIP(hipGetLastError());
+#ifdef JG_F32_STAMP
+  {
+    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    JG_HIP(hipStreamSynchronize(s));
+    JG_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(jg_f32_stamp), sizeof(h)));
+    JG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(jg_f32_stamp), z, sizeof(z)));
+    const double w = (double)grid.x * grid.y;
+    fprintf(stderr, "F32STAMP k=%d cin=%d wgs=%.0f cycles/wg (100 MHz ticks x ?): stage %.0f barrier %.0f main %.0f barrier %.0f exchange %.0f barrier %.0f epilogue %.0f\n",
+            a.k, a.cin, w, h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w);
+  }
+#endif
   return JG_OK;
 }
 
@@ -552,7 +684,17 @@ int jg_launch_conv(jg_engine *e, const ConvArgs &a, hipStream_t s) {
   const bool bm64 = jg_conv_tile_m_for(a.L_out, a.k, a.cin, a.stride, a.dil) == 64;
   JG_REQUIRE(a.tiles_m == (a.L_out + (bm64 ? 63 : 127)) / (bm64 ? 64 : 128), JG_ERR_INVALID,
              "conv: tiles_m=%d does not match the tile size chosen for L_out=%d", a.tiles_m, a.L_out);
+#ifndef JG_F32_SHAPE
+#define JG_F32_SHAPE 0
+#endif
+  // 64 x 128 tiles: wave layout (WM x WN waves, TM x TN 32 x 32 blocks each)
+#if JG_F32_SHAPE == 1
+  if (a.cout_pad % 128 == 0) return bm64 ? launch_conv_t<1, 4, 2, 1>(a, s) : launch_conv_t<2, 2, 2, 2>(a, s);
+#elif JG_F32_SHAPE == 2
+  if (a.cout_pad % 128 == 0) return bm64 ? launch_conv_t<1, 2, 2, 2>(a, s) : launch_conv_t<2, 2, 2, 2>(a, s);
+#else
   if (a.cout_pad % 128 == 0) return bm64 ? launch_conv_t<2, 2, 1, 2>(a, s) : launch_conv_t<2, 2, 2, 2>(a, s);
+#endif
   if (a.cout_pad % 64 == 0) return bm64 ? launch_conv_t<2, 2, 1, 1>(a, s) : launch_conv_t<2, 2, 2, 1>(a, s);
   return bm64 ? launch_conv_t<2, 1, 1, 1>(a, s) : launch_conv_t<4, 1, 1, 1>(a, s);
 }

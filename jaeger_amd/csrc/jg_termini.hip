@@ -24,6 +24,7 @@
 // tie-breaking is unpinned (scores are unique; lengths can differ only between co-optimal alignments).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -329,10 +330,15 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
              JG_ERR_INVALID, "jg_terminal_repeats: bad arguments");
   JG_HIP(hipSetDevice(e->dev));
   hipStream_t s = e->stream;
+  // one pass over the records: scan lengths, and whether the two scanned ends of every record (what a host buffer's upload is
+  // cut down to: 32 MB for 10 000 contigs of 400 Mbp) are most of the buffer anyway (a million 500-bp records: 800 MB of
+  // ends for 500 MB of bases) - then the buffer goes up as it is
   std::vector<TermRec> recs;
   std::vector<int64_t> owner;
-  std::vector<uint8_t> ends;          // host bases: only the two scanned ends of every record go to the device
+  recs.reserve((size_t)n_records);
+  owner.reserve((size_t)n_records);
   int max_n = 0;
+  int64_t ends_bytes = 0;
   for (int64_t r = 0; r < n_records; ++r) {
     const int64_t len = offsets[r + 1] - offsets[r];
     JG_REQUIRE(len >= 0 && offsets[r + 1] <= n_bases, JG_ERR_INVALID, "jg_terminal_repeats: record %lld outside the base buffer",
@@ -342,28 +348,38 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
     int scan = (int)std::min<int64_t>(std::max<int64_t>((int64_t)((double)len * 0.04), 400), 4000);
     if (scan > len) scan = (int)len;                   // str slicing clamps (termini.py:121-133)
     max_n = std::max(max_n, scan);
-    int64_t q_off = offsets[r], r_off = offsets[r + 1] - scan;
-    if (bases_loc == JG_PTR_HOST) {
-      q_off = (int64_t)ends.size();
-      ends.insert(ends.end(), bases + offsets[r], bases + offsets[r] + scan);
-      r_off = (int64_t)ends.size();
-      ends.insert(ends.end(), bases + offsets[r + 1] - scan, bases + offsets[r + 1]);
-    }
-    recs.push_back(TermRec{q_off, r_off, scan, 0});
+    ends_bytes += 2 * (int64_t)scan;
+    recs.push_back(TermRec{offsets[r], offsets[r + 1] - scan, scan, 0});
     owner.push_back(r);
   }
   if (recs.empty()) return JG_OK;
   JG_REQUIRE(max_n <= TT * RMAX, JG_ERR_UNSUPPORTED, "jg_terminal_repeats: scan length %d", max_n);
   {
-    // longest scans first: workgroups are dispatched in index order, and the kernel variants below take contiguous ranges
-    std::vector<size_t> order(recs.size());
-    for (size_t k = 0; k < order.size(); ++k) order[k] = k;
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return recs[a].n > recs[b].n; });
-    std::vector<TermRec> sr(recs.size());
-    std::vector<int64_t> so(recs.size());
-    for (size_t k = 0; k < order.size(); ++k) { sr[k] = recs[order[k]]; so[k] = owner[order[k]]; }
+    // one launch per strip height of the packed kernel: records bucketed by it, tallest first (workgroups are dispatched in
+    // index order, and a 4 000-base scan costs a hundred 400-base ones); FASTA order inside a bucket
+    const int cls[8] = {64, 48, 32, 24, 16, 12, 8, 7};
+    std::vector<TermRec> sr;
+    std::vector<int64_t> so;
+    sr.reserve(recs.size());
+    so.reserve(recs.size());
+    for (int c = 0; c < 8; ++c)
+      for (size_t k = 0; k < recs.size(); ++k)
+        if (fast_rows(recs[k].n) == cls[c]) { sr.push_back(recs[k]); so.push_back(owner[k]); }
     recs.swap(sr);
     owner.swap(so);
+  }
+  std::vector<uint8_t> ends;
+  const bool whole = bases_loc == JG_PTR_HOST && ends_bytes * 10 >= n_bases * 6;
+  if (bases_loc == JG_PTR_HOST && !whole) {
+    ends.resize((size_t)ends_bytes);
+    int64_t at = 0;
+    for (TermRec &rc : recs) {
+      memcpy(ends.data() + at, bases + rc.q_off, (size_t)rc.n);
+      memcpy(ends.data() + at + rc.n, bases + rc.r_off, (size_t)rc.n);
+      rc.q_off = at;
+      rc.r_off = at + rc.n;
+      at += 2 * (int64_t)rc.n;
+    }
   }
   const int n_recs = (int)recs.size();
   const uint8_t *d_bases = bases;
@@ -373,8 +389,10 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
     ~Cleanup() { for (void **q : p) if (*q) (void)hipFree(*q); }
   } cleanup{{&tmp_bases, &d_recs, &d_fast, &d_out, &d_jobs, &d_out2}};
   if (bases_loc == JG_PTR_HOST) {
-    JG_HIP(hipMalloc(&tmp_bases, std::max<size_t>(ends.size(), 1)));
-    JG_HIP(hipMemcpyAsync(tmp_bases, ends.data(), ends.size(), hipMemcpyHostToDevice, s));
+    const uint8_t *src = whole ? bases : ends.data();
+    const size_t nb = whole ? (size_t)n_bases : ends.size();
+    JG_HIP(hipMalloc(&tmp_bases, std::max<size_t>(nb, 1)));
+    JG_HIP(hipMemcpyAsync(tmp_bases, src, nb, hipMemcpyHostToDevice, s));
     d_bases = static_cast<const uint8_t *>(tmp_bases);
   }
   JG_HIP(hipMalloc(&d_recs, recs.size() * sizeof(TermRec)));
