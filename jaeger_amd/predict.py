@@ -191,6 +191,24 @@ def _shard_records(lengths: np.ndarray, fsize: int, stride: int | None, world: i
     return lpt_partition(w, world)
 
 
+class _LazyTableWriter:
+    """``postprocess.TableWriter`` created at its first batch: pandas is then imported beside the forward, not in front of it."""
+
+    def __init__(self, class_map: dict, table_path, phage_path, reliability_cutoff, phage_score):
+        self._args = (class_map.get("class"), class_map.get("index"), table_path, phage_path)
+        self._kw = dict(reliability_cutoff=reliability_cutoff, phage_score=phage_score)
+        self.w = None
+
+    def append(self, data: dict) -> None:
+        if self.w is None:
+            from .postprocess import TableWriter
+            self.w = TableWriter(*self._args, **self._kw)
+        self.w.append(data)
+
+    def close(self) -> int:
+        return self.w.close() if self.w is not None else 0
+
+
 class _Aggregator:
     """Per-contig aggregation of the long pass BESIDE the forward: ``advance(done)`` is called with the engine's progress
     mark (output rows of windows [0, done) are final, ``HipDevice.windows_done``) and runs ``pred_to_dict`` on the contigs
@@ -624,8 +642,7 @@ def run_core(**kwargs) -> int:
                     scan["error"] = e
 
             th = threading.Thread(target=scan_side, name="jaeger-termini", daemon=True)
-            if not kwargs.get("_scan_after"):
-                th.start()
+            th.start()
         if dust:
             t_dust = time.time()
             n_masked = frag.dust_mask(fa)
@@ -647,21 +664,7 @@ def run_core(**kwargs) -> int:
         class_map = engine.class_map
         out = engine.model.host_outputs(n_long, want)
 
-        class _LazyWriter:                              # (pandas is imported at the first batch, beside the forward)
-            w = None
-            header_written = False
-
-            def append(self, data):
-                if self.w is None:
-                    from .postprocess import TableWriter
-                    self.w = TableWriter(class_map.get("class"), class_map.get("index"), table_path, phage_path,
-                                         reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))
-                self.w.append(data)
-
-            def close(self):
-                return self.w.close() if self.w is not None else 0
-
-        writer = _LazyWriter()
+        writer = _LazyTableWriter(class_map, table_path, phage_path, kwargs.get("rc", 0.5), kwargs.get("pc", 1))
         agg = _Aggregator(table, fa.names, out, dict(class_map=class_map, fsize=fsize, term_repeats=None,
                                                      want_full=bool(kwargs.get("window_scores") or kwargs.get("prophage")),
                                                      **crf_kw), min_batch=n_long // 16)
@@ -677,9 +680,6 @@ def run_core(**kwargs) -> int:
             f_pred = pool.submit(classify) if piped else None
             log_setup(engine)
             if piped:
-                if kwargs.get("_scan_after"):                 # (timing experiments: the repeat scan behind the forward)
-                    f_pred.result()
-                    th.start()
                 while not f_pred.done():
                     agg.advance(engine.device.windows_done())
                     if "frame" in scan:                       # rows of finished batches go to the table beside the forward

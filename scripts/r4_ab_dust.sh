@@ -7,6 +7,5 @@ res
 run "default (DUST on the copy stream)" "JAEGER_DUST_STREAM=1"
 run "DUST on the compute stream" "JAEGER_DUST_STREAM=0"
 run "no DUST" "JAEGER_NO_DUST=1"
-run "no DUST, repeat scan behind the forward" "JAEGER_NO_DUST=1 JAEGER_SCAN_AFTER=1"
 run "default again" "JAEGER_DUST_STREAM=1"
 res

@@ -25,8 +25,6 @@ if os.environ.get("JAEGER_DUST_STREAM"):
     extra["dust_stream"] = int(os.environ["JAEGER_DUST_STREAM"])
 if os.environ.get("JAEGER_NO_DUST"):
     extra["dustmask_off"] = True
-if os.environ.get("JAEGER_SCAN_AFTER"):
-    extra["_scan_after"] = True
 if os.environ.get("JAEGER_NO_PIPELINE"):
     extra["no_pipeline"] = True
 do_prof = not os.environ.get("JAEGER_NO_CPROFILE")
