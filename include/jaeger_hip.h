@@ -287,6 +287,18 @@ int jg_dust_mask(uint8_t *bases, const int64_t *offsets, int64_t n_records, int3
 int jg_dust_mask_device(jg_engine *e, uint8_t *d_bases, int64_t n_bases, const int64_t *offsets, int offsets_loc,
                         int64_t n_records, int32_t window, int32_t threshold, int64_t *n_masked, void *stream);
 
+/* ---- result table text (host only; replaces df.to_csv(path, sep="\t", index=False, float_format="%.3f") of
+ * postprocess/collect.py:578-580 and 602-607 for the rows of `rows` (NULL: rows 0 .. n_rows - 1), without a header line) --
+ * Column c is cols[c] read as kinds[c]: JG_COL_STRING = UTF-8 strings laid end to end with ONE separator byte behind each,
+ * string r = bytes [starts[c][r], starts[c][r + 1] - 1) (copied as they are: the caller keeps strings the csv writer would
+ * quote - tab, double quote, line break - away from this call); JG_COL_INT = int64; JG_COL_FLOAT = float64, printed as
+ * CPython's "%.3f" % v (exact value, round-half-even) and as nothing for NaN; JG_COL_BOOL = uint8, "True" / "False".
+ * *text (n_bytes bytes, no terminator) is released by jg_table_free.  n_threads <= 0: every usable core. */
+enum { JG_COL_STRING = 0, JG_COL_INT = 1, JG_COL_FLOAT = 2, JG_COL_BOOL = 3 };
+int jg_table_format(int32_t n_cols, const int32_t *kinds, const void *const *cols, const int64_t *const *starts,
+                    const int64_t *rows, int64_t n_rows, int32_t n_threads, char **text, int64_t *n_bytes);
+void jg_table_free(char *text);
+
 /* ---- CRF window decoding (host only; replaces the per-contig loop over postprocess/helpers.py:398-449
  * viterbi_decode that postprocess/collect.py:343-346 runs for `jaeger predict --crf`) ---------------
  * logits (n_windows, n_classes) f32 row-major; chain c covers windows [first[c], first[c+1]) (first has

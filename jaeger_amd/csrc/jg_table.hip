@@ -1,0 +1,126 @@
+// Result-table text (host only): the bytes pandas writes for
+//   df.to_csv(path, sep="\t", index=False, float_format="%.3f")          (postprocess/collect.py:578-580, 602-607)
+// from typed columns, on every core the process may use.  A run over an assembly of short contigs spends more time in
+// pandas' per-value Python formatter than in the forward (one million 500-bp records: 5.0 s of 7.3 s), so the rows are
+// rendered here: floats by an exact "%.3f" (below), integers, booleans ("True" / "False"), strings copied as they are.
+// What the csv writer would QUOTE (a tab, a quote, a line break inside a string) is the caller's to detect - it then
+// formats that batch with pandas (jaeger_amd/postprocess.py: _tsv_bytes).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "jg_common.h"
+
+namespace {
+
+inline char *put_u64(char *p, uint64_t v) {
+  char tmp[24];
+  int n = 0;
+  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (n) *p++ = tmp[--n];
+  return p;
+}
+
+// "%.3f" % v as CPython / glibc print it: the decimal expansion of the EXACT binary value, rounded half-even at the
+// third place.  a * 1000 = x + e exactly (e from the fused multiply-add), and for x < 2^52 both x - floor(x) and 0.5 are
+// multiples of ulp(x) while |e| <= ulp(x) / 2, so the comparison with one half is decided by (x - floor(x)) - 0.5 alone
+// unless that is zero, and then by the sign of e; an exact tie goes to the even neighbour.
+inline char *put_f3(char *p, double v) {
+  if (std::isnan(v)) return p;                                       // na_rep = ""
+  const double a = std::fabs(v);
+  if (!(a < 4.0e12)) return p + snprintf(p, 400, "%.3f", v);         // inf and the range where ulp(x) > 1/2
+  if (std::signbit(v)) *p++ = '-';                                   // "-0.000" keeps its sign, as printf does
+  uint64_t n = 0;
+  if (a >= 4.0e-4) {
+    const double x = a * 1000.0, e = std::fma(a, 1000.0, -x), q = std::floor(x), t = (x - q) - 0.5;
+    n = (uint64_t)q;
+    if (t > 0.0 || (t == 0.0 && (e > 0.0 || (e == 0.0 && (n & 1))))) ++n;
+  }
+  p = put_u64(p, n / 1000);
+  const unsigned f = (unsigned)(n % 1000);
+  *p++ = '.';
+  *p++ = (char)('0' + f / 100);
+  *p++ = (char)('0' + f / 10 % 10);
+  *p++ = (char)('0' + f % 10);
+  return p;
+}
+
+}  // namespace
+
+extern "C" int jg_table_format(int32_t n_cols, const int32_t *kinds, const void *const *cols, const int64_t *const *starts,
+                               const int64_t *rows, int64_t n_rows, int32_t n_threads, char **text, int64_t *n_bytes) {
+  JG_REQUIRE(n_cols > 0 && kinds != nullptr && cols != nullptr && starts != nullptr && n_rows >= 0 && text != nullptr &&
+                 n_bytes != nullptr,
+             JG_ERR_INVALID, "jg_table_format: bad arguments");
+  for (int c = 0; c < n_cols; ++c)
+    JG_REQUIRE(kinds[c] >= JG_COL_STRING && kinds[c] <= JG_COL_BOOL && cols[c] != nullptr &&
+                   (kinds[c] != JG_COL_STRING || starts[c] != nullptr),
+               JG_ERR_INVALID, "jg_table_format: column %d: kind %d / missing data", c, kinds[c]);
+  int nt = n_threads > 0 ? n_threads : jg_usable_cores();
+  nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(nt, 256), n_rows / 2048 + 1));
+  std::vector<std::string> part((size_t)nt);
+  auto work = [&](int tix) {
+    const int64_t r0 = n_rows * tix / nt, r1 = n_rows * (tix + 1) / nt;
+    std::string &out = part[(size_t)tix];
+    // rows are short (a few hundred bytes); strings may be long (a window summary), so size each row before it is written
+    size_t fixed = 0;
+    for (int c = 0; c < n_cols; ++c) fixed += kinds[c] == JG_COL_STRING ? 1 : (kinds[c] == JG_COL_FLOAT ? 400 : 24);
+    size_t used = 0;
+    for (int64_t i = r0; i < r1; ++i) {
+      const int64_t r = rows ? rows[i] : i;
+      size_t need = fixed;
+      for (int c = 0; c < n_cols; ++c)
+        if (kinds[c] == JG_COL_STRING) need += (size_t)(starts[c][r + 1] - 1 - starts[c][r]);
+      if (out.size() < used + need) out.resize(std::max(out.size() * 2, used + need + (size_t)(r1 - i) * 64));
+      char *p = &out[used];
+      for (int c = 0; c < n_cols; ++c) {
+        if (c) *p++ = '\t';
+        switch (kinds[c]) {
+          case JG_COL_STRING: {
+            const int64_t a = starts[c][r], b = starts[c][r + 1] - 1;        // one separator byte behind every string
+            memcpy(p, (const char *)cols[c] + a, (size_t)(b - a));
+            p += b - a;
+            break;
+          }
+          case JG_COL_INT: {
+            const int64_t v = ((const int64_t *)cols[c])[r];
+            if (v < 0) *p++ = '-';
+            p = put_u64(p, v < 0 ? 0 - (uint64_t)v : (uint64_t)v);
+            break;
+          }
+          case JG_COL_FLOAT: p = put_f3(p, ((const double *)cols[c])[r]); break;
+          default: {
+            const bool v = ((const uint8_t *)cols[c])[r] != 0;
+            memcpy(p, v ? "True" : "False", v ? 4 : 5);
+            p += v ? 4 : 5;
+          }
+        }
+      }
+      *p++ = '\n';
+      used = (size_t)(p - out.data());
+    }
+    out.resize(used);
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto &t : th) t.join();
+  }
+  size_t total = 0;
+  for (const auto &s : part) total += s.size();
+  char *buf = (char *)malloc(total ? total : 1);
+  JG_REQUIRE(buf != nullptr, JG_ERR_NOMEM, "jg_table_format: out of memory (%zu bytes)", total);
+  size_t at = 0;
+  for (const auto &s : part) { memcpy(buf + at, s.data(), s.size()); at += s.size(); }
+  *text = buf;
+  *n_bytes = (int64_t)total;
+  return JG_OK;
+}
+
+extern "C" void jg_table_free(char *text) { free(text); }

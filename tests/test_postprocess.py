@@ -182,3 +182,34 @@ def test_write_fasta_from_results(tmp_path):
     assert n == 2
     seq_b = "ACGT" * 40
     assert (tmp_path / "out.fasta").read_text() == ">a\nACGTacgtNNGG\n>b\n" + seq_b[:70] + "\n" + seq_b[70:140] + "\n" + seq_b[140:] + "\n"
+
+
+def test_native_table_text_equals_pandas():
+    """jg_table_format (the library's TSV renderer) against pandas' own to_csv(float_format="%.3f"): floats incl. the
+    x.xxx5 ties, NaN, infinities, negative zero; integers; booleans; strings with NaN holes and non-ASCII names; and
+    the fall-back for fields the csv writer quotes."""
+    from jaeger_amd.postprocess import _tsv_bytes
+    rng = np.random.default_rng(5)
+    n = 20000
+    f = np.concatenate([rng.normal(size=n - 20) * 10.0 ** rng.integers(-6, 9, n - 20),
+                        [0.0, -0.0, np.nan, np.inf, -np.inf, 1e15, -3.9e12, 4.1e12, 0.0625, 0.1875, 0.0005, 0.0015, 0.0025,
+                         -0.0005, 1e-300, 5e-324, 0.9995, 0.99949999, 2.5e-4, 4e-4]])
+    ties = (rng.integers(-10 ** 7, 10 ** 7, n) * 2 + 1) / 2000.0
+    names = np.array([f"contig_{i}" if i % 7 else f"cöntig {i}|x=1" for i in range(n)], dtype=object)
+    holes = names.copy()
+    holes[::3] = np.nan
+    holes[1::3] = None
+    df = pd.DataFrame({"contig_id": names, "length": rng.integers(-5, 10 ** 12, n), "f": f, "ties": ties,
+                       "up": np.nextafter(ties, np.inf), "down": np.nextafter(ties, -np.inf),
+                       "f32": rng.normal(size=n).astype(np.float32), "flag": rng.random(n) < 0.5,
+                       "small": rng.integers(0, 200, n).astype(np.int16), "terminal_repeats": holes})
+    want = df.to_csv(None, sep="\t", index=False, float_format="%.3f").encode("utf-8")
+    assert _tsv_bytes(df) == want
+    assert _tsv_bytes(df, header=False) == want.split(b"\n", 1)[1]
+    assert _tsv_bytes(df.iloc[:0]) == df.iloc[:0].to_csv(None, sep="\t", index=False, float_format="%.3f").encode()
+    for bad in ('a"b', "a\tb", "a\nb"):                       # quoted by the csv writer: pandas writes these tables
+        q = df.iloc[:50].copy()
+        q.iloc[7, 0] = bad
+        assert _tsv_bytes(q) == q.to_csv(None, sep="\t", index=False, float_format="%.3f").encode("utf-8")
+    mixed = pd.DataFrame({"a": np.array(["x", 3, 2.5], dtype=object), "b": [1.0, 2.0, 3.0]})
+    assert _tsv_bytes(mixed) == mixed.to_csv(None, sep="\t", index=False, float_format="%.3f").encode("utf-8")
