@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -63,7 +64,9 @@ extern "C" int jg_table_format(int32_t n_cols, const int32_t *kinds, const void 
   int nt = n_threads > 0 ? n_threads : jg_usable_cores();
   nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(nt, 256), n_rows / 2048 + 1));
   std::vector<std::string> part((size_t)nt);
+  std::vector<char> failed((size_t)nt, 0);                             // an exception must not leave a worker thread
   auto work = [&](int tix) {
+   try {
     const int64_t r0 = n_rows * tix / nt, r1 = n_rows * (tix + 1) / nt;
     std::string &out = part[(size_t)tix];
     // rows are short (a few hundred bytes); strings may be long (a window summary), so size each row before it is written
@@ -104,6 +107,9 @@ extern "C" int jg_table_format(int32_t n_cols, const int32_t *kinds, const void 
       used = (size_t)(p - out.data());
     }
     out.resize(used);
+   } catch (const std::exception &) {
+     failed[(size_t)tix] = 1;
+   }
   };
   if (nt == 1) {
     work(0);
@@ -112,6 +118,7 @@ extern "C" int jg_table_format(int32_t n_cols, const int32_t *kinds, const void 
     for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
     for (auto &t : th) t.join();
   }
+  for (char f : failed) JG_REQUIRE(!f, JG_ERR_NOMEM, "jg_table_format: out of memory while rendering %lld rows", (long long)n_rows);
   size_t total = 0;
   for (const auto &s : part) total += s.size();
   char *buf = (char *)malloc(total ? total : 1);
