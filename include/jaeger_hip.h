@@ -51,7 +51,10 @@ typedef enum {
   JG_OP_NMD_FINAL = 6, /* NMDLayer mean - moving_mean              nmd.py:52-77        */
   JG_OP_OODSIG = 7,    /* OODSignalLayer                           layers.py:1632-1667 */
   JG_OP_MAXPOOL1D = 8, /* MaxPooling1D(2) of the legacy tower      v1/layers.py:154-207*/
-  JG_OP_FRAMESUM = 9   /* legacy frame Add                         v1/layers.py:399-423*/
+  JG_OP_FRAMESUM = 9,  /* legacy frame Add                         v1/layers.py:399-423*/
+  JG_OP_STRANDS = 10   /* a branched (shared-weight) model over the k strands of a nucleotide input: every strand is a
+                          program row of its own (ids (W, k, L), one frame per row); arg = how the strands' predictions
+                          merge (jg_merge_kind); the embedding output is their average.  builder.py:1195-1266, :776-791 */
 } jg_op_kind;
 
 typedef enum {
@@ -78,6 +81,7 @@ typedef enum {
 typedef enum { JG_MASK_ANY = 0, JG_MASK_MAJORITY = 1, JG_MASK_STRICT = 2 } jg_mask_mode;
 typedef enum { JG_PAD_VALID = 0, JG_PAD_SAME = 1 } jg_padding;
 typedef enum { JG_POOL_MAX = 0, JG_POOL_AVG = 1, JG_POOL_MAX_NOMASK = 2 } jg_pool_kind;
+typedef enum { JG_MERGE_AVERAGE = 0, JG_MERGE_SUM = 1, JG_MERGE_MAX = 2 } jg_merge_kind;
 
 /* buffer slot constants */
 #define JG_BUF_NONE (-1)
@@ -191,27 +195,35 @@ int jg_model_describe(const jg_model *m, char *buf, int64_t cap);
  *   win_len    n_win window lengths (<= fsize; shorter = whole-contig window)
  *   fsize      crop_size the frame offset is derived from (encode.py:232-236)
  *   lut65      65-byte table: entry 16*b0+4*b1+b2 (TCAG=0..3) -> codon_id+1; [64] unused
- *   soft_mask  0: upper-case before lookup/counting (masking=False, dustmask off)
+ *   soft_mask  0: upper-case before lookup/counting (masking=False, dustmask off); bit 0: bases are pre-cased (lower case
+ *              = soft-masked, not counted); bit 1: ids are case sensitive (string_processor.masking = true);
+ *              bit 2 (JG_ENC_NUCLEOTIDE): input_type="nucleotide" (encode.py:265-271, _map_nucleotide :36-41,
+ *              _map_complement :28-33) - ids (n_win, 2, l_pad) u8, row 0 the window's first min(len, fsize) bases as
+ *              A,G,C,T (either case) -> 1,2,3,4, row 1 the reverse complement of those bases, 0 = any other byte /
+ *              padding (the all-zero one-hot row); l_pad counts bases; lut65 is not read
  *   l_pad      codons per frame row in the output (>= frame length of the longest window when the
  *              window table is on the host, >= frame length of fsize when it is on the device)
  * outputs (device or host per out_loc):
  *   ids        (n_win, 6, l_pad) u8, rows f1,f2,f3,r1,r2,r3, 0 = invalid / padding
  *   counts     (n_win, 4) i32 upper-case G,C,A,T counts of each window
  */
+enum { JG_ENC_PRECASED = 1, JG_ENC_CASE_SENSITIVE = 2, JG_ENC_NUCLEOTIDE = 4 };
 int jg_encode(jg_engine *e, const uint8_t *bases, int64_t n_bases, int bases_loc,
               const int64_t *win_start, const int32_t *win_len, int win_loc, int64_t n_win,
               int32_t fsize, const uint8_t *lut65, int32_t soft_mask, int32_t l_pad,
               uint8_t *ids, int32_t *counts, int out_loc, void *stream);
 
 /* Replaces InferModel.predict's per-batch serving_default call
- * (nnlib/inference.py:355-363): ids (n_win, 6, l) u8 -> per-window outputs.
+ * (nnlib/inference.py:355-363): ids (n_win, 6, l) u8 - (n_win, 2, l) for a two-strand nucleotide model
+ * (JG_OP_STRANDS) - -> per-window outputs.
  * Any output pointer may be NULL.  Output widths are those of the program
  * (jg_model_vec_width).  `chunk` = windows per launch group (0 = default). */
 int jg_forward(jg_model *m, const uint8_t *ids, int ids_loc, int64_t n_win, int32_t l,
                float *prediction, float *reliability, float *embedding, float *nmd,
                int out_loc, int32_t chunk, void *stream);
 
-/* encode + forward on device-resident bases in one call (no id tensor round trip). */
+/* encode + forward on device-resident bases in one call (no id tensor round trip).  A two-strand nucleotide model
+ * encodes with JG_ENC_NUCLEOTIDE whatever soft_mask says; l_pad then counts bases. */
 int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_bases, int bases_loc,
                        const int64_t *win_start, const int32_t *win_len, int win_loc,
                        int64_t n_win, int32_t fsize, const uint8_t *lut65, int32_t soft_mask,

@@ -313,8 +313,11 @@ static int validate_program(const jg_model *m) {
     auto slot_ok = [](int s, bool allow_ids) {
       return (s >= 0 && s < JG_MAX_BUFS) || s == JG_BUF_NONE || (allow_ids && s == JG_BUF_IDS);
     };
-    JG_REQUIRE(op.kind >= JG_OP_CONV && op.kind <= JG_OP_FRAMESUM, JG_ERR_INVALID,
+    JG_REQUIRE(op.kind >= JG_OP_CONV && op.kind <= JG_OP_STRANDS, JG_ERR_INVALID,
                "op %zu: unknown kind %d", i, op.kind);
+    if (op.kind == JG_OP_STRANDS)
+      JG_REQUIRE(i + 1 == m->ops.size() && op.k >= 2 && op.k <= 8 && op.arg >= JG_MERGE_AVERAGE && op.arg <= JG_MERGE_MAX,
+                 JG_ERR_INVALID, "op %zu: a strands op closes the program, merges 2 - 8 strands by average / sum / max", i);
     JG_REQUIRE(slot_ok(op.in_buf, true) && slot_ok(op.out_buf, false) && slot_ok(op.in_mask, true) &&
                    slot_ok(op.out_mask, false),
                JG_ERR_INVALID, "op %zu: buffer slot out of range", i);
@@ -401,7 +404,7 @@ static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
     switch (op.kind) {
       case JG_OP_CONV: {
         Shape in;
-        if (op.in_buf == JG_BUF_IDS) { in.frames = 6; in.L = l; in.C = op.cin; }
+        if (op.in_buf == JG_BUF_IDS) { in.frames = m->id_frames; in.L = l; in.C = op.cin; }
         else in = sh[op.in_buf];
         JG_REQUIRE(in.C == op.cin, JG_ERR_INVALID, "op %zu: conv expects %d channels, input has %d",
                    i, op.cin, in.C);
@@ -420,12 +423,12 @@ static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
                                                            (int64_t)in.frames * tiles * op.cout);
       } break;
       case JG_OP_MASK: {
-        const int L_in = op.in_mask == JG_BUF_IDS ? l : (mlen[op.in_mask] / 6);
+        const int L_in = op.in_mask == JG_BUF_IDS ? l : (mlen[op.in_mask] / m->id_frames);
         int lo, pl;
         conv_geometry(L_in, op.k, op.stride, op.dilation, op.padding, &lo, &pl);
         JG_REQUIRE(op.out_mask >= 0 && lo > 0, JG_ERR_INVALID, "op %zu: bad mask op", i);
-        mlen[op.out_mask] = 6 * lo;
-        msk_elems[op.out_mask] = std::max<int64_t>(msk_elems[op.out_mask], (int64_t)6 * lo);
+        mlen[op.out_mask] = m->id_frames * lo;
+        msk_elems[op.out_mask] = std::max<int64_t>(msk_elems[op.out_mask], (int64_t)m->id_frames * lo);
       } break;
       case JG_OP_ELTWISE: {
         const Shape in = sh[op.in_buf];
@@ -1158,6 +1161,11 @@ extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const 
   m->vocab = vocab;
   int rc = validate_program(m);
   if (rc != JG_OK) { delete m; return rc; }
+  if (m->ops.back().kind == JG_OP_STRANDS) {
+    m->strands = m->ops.back().k;
+    m->id_frames = 1;
+    m->merge_kind = m->ops.back().arg;
+  }
   hipError_t err = hipMalloc(&m->d_w, (size_t)n_weights * sizeof(float));
   if (err != hipSuccess) {
     jg_set_error("jg_model_create: weights hipMalloc -> %s", hipGetErrorString(err));
@@ -1207,6 +1215,8 @@ extern "C" int jg_model_destroy(jg_model *m) {
   (void)hipStreamSynchronize(m->e->stream);
   free_workspace(m);
   free_small(m);
+  for (int i = 0; i < JG_MAX_VECS; ++i)
+    if (m->merged[i]) (void)hipFree(m->merged[i]);
   if (m->d_w) (void)hipFree(m->d_w);
   if (m->d_ids) (void)hipFree(m->d_ids);
   if (m->d_counts) (void)hipFree(m->d_counts);
@@ -1308,7 +1318,8 @@ static int grow(T **p, int64_t *cap, int64_t need_bytes) {
   return JG_OK;
 }
 
-// Run the op program over `nw` windows whose ids (nw, 6, l) are on the device.
+// Run the op program over `nw` windows whose ids (nw, 6, l) are on the device (a two-strand model: nw = strand rows,
+// ids (nw, 1, l)).
 static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream_t s) {
   jg_engine *e = m->e;
   Shape sh[JG_MAX_BUFS];
@@ -1391,7 +1402,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
     switch (op.kind) {
       case JG_OP_CONV: {
         Shape in;
-        if (op.in_buf == JG_BUF_IDS) { in.frames = 6; in.L = l; in.C = op.cin; }
+        if (op.in_buf == JG_BUF_IDS) { in.frames = m->id_frames; in.L = l; in.C = op.cin; }
         else in = sh[op.in_buf];
         int lo, pl;
         conv_geometry(in.L, op.k, op.stride, op.dilation, op.padding, &lo, &pl);
@@ -1529,13 +1540,13 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         sh[op.out_buf] = Shape{in.frames, lo, op.cout};
       } break;
       case JG_OP_MASK: {
-        const int L_in = op.in_mask == JG_BUF_IDS ? l : mlen[op.in_mask] / 6;
+        const int L_in = op.in_mask == JG_BUF_IDS ? l : mlen[op.in_mask] / m->id_frames;
         int lo, pl;
         conv_geometry(L_in, op.k, op.stride, op.dilation, op.padding, &lo, &pl);
         const uint8_t *src = op.in_mask == JG_BUF_IDS ? d_ids : m->msk[op.in_mask];
-        rc = jg_launch_mask(src, nw * 6, L_in, lo, op.k, op.stride, op.dilation, pl, op.mask_mode,
+        rc = jg_launch_mask(src, nw * m->id_frames, L_in, lo, op.k, op.stride, op.dilation, pl, op.mask_mode,
                             m->msk[op.out_mask], s);
-        mlen[op.out_mask] = 6 * lo;
+        mlen[op.out_mask] = m->id_frames * lo;
       } break;
       case JG_OP_ELTWISE: {
         const Shape in = sh[op.in_buf];
@@ -1608,6 +1619,8 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
                               nw, (unsigned)op.arg, op.f0, m->vec[op.out_vec], m->vec_w[op.out_vec],
                               op.vec_off, s);
         break;
+      case JG_OP_STRANDS:      // the strands' rows are merged into the window's behind the program (forward_chunks)
+        break;
       default:
         jg_set_error("op %zu: kind %d not implemented", i, op.kind);
         return JG_ERR_UNSUPPORTED;
@@ -1654,9 +1667,21 @@ static int copy_out(jg_model *m, int slot, int width, float *dst, int64_t row0, 
   JG_REQUIRE(m->vec[slot] != nullptr, JG_ERR_INVALID,
              "output requested but the model does not produce vector slot %d", slot);
   const hipMemcpyKind kind = out_loc == JG_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-  JG_HIP(hipMemcpy2DAsync(dst + row0 * width, (size_t)width * sizeof(float), m->vec[slot],
-                          (size_t)m->vec_w[slot] * sizeof(float), (size_t)width * sizeof(float),
-                          (size_t)nw, kind, s));
+  const float *src = m->vec[slot];
+  size_t src_ld = (size_t)m->vec_w[slot];
+  if (m->strands > 1) {
+    // branched model: the vector slot holds one row per strand; the window's row is their merge (the prediction by the
+    // classifier's merge layer, every other output by Average - builder.py:776-791)
+    const int rc = grow(&m->merged[slot], &m->merged_cap[slot], (int64_t)nw * width * (int64_t)sizeof(float));
+    if (rc != JG_OK) return rc;
+    const int mrc = jg_launch_strand_merge(src, (int)src_ld, nw, m->strands, width, slot == 2 ? m->merge_kind : JG_MERGE_AVERAGE,
+                                           m->merged[slot], s);
+    if (mrc != JG_OK) return mrc;
+    src = m->merged[slot];
+    src_ld = (size_t)width;
+  }
+  JG_HIP(hipMemcpy2DAsync(dst + row0 * width, (size_t)width * sizeof(float), src, src_ld * sizeof(float),
+                          (size_t)width * sizeof(float), (size_t)nw, kind, s));
   return JG_OK;
 }
 
@@ -1681,7 +1706,7 @@ static int forward_chunks(jg_model *m, const uint8_t *d_ids, int64_t n_win, int 
   const int w_emb = jg_model_vec_width(m, 2), w_nmd = jg_model_vec_width(m, 3);
   for (int64_t w0 = 0; w0 < n_win; w0 += chunk) {
     const int nw = (int)std::min<int64_t>(chunk, n_win - w0);
-    int rc = run_chunk(m, d_ids + w0 * 6 * (int64_t)l, nw, l, s);
+    int rc = run_chunk(m, d_ids + w0 * m->strands * m->id_frames * (int64_t)l, nw * m->strands, l, s);
     if (rc != JG_OK) return rc;
     if ((rc = copy_out(m, 2, w_pred, prediction, w0, nw, out_loc, s)) != JG_OK) return rc;
     if ((rc = copy_out(m, 3, w_rel, reliability, w0, nw, out_loc, s)) != JG_OK) return rc;
@@ -1696,7 +1721,7 @@ static int forward_device_ids(jg_model *m, const uint8_t *d_ids, int64_t n_win, 
                               int out_loc, int chunk, hipStream_t s) {
   chunk = effective_chunk(m, chunk, l, n_win);
   JG_REQUIRE((int64_t)chunk * 6 <= 0x7fffffff / 8, JG_ERR_INVALID, "chunk too large");
-  int rc = ensure_workspace(m, chunk, l);
+  int rc = ensure_workspace(m, (int64_t)chunk * m->strands, l);
   if (rc != JG_OK) return rc;
   for (int attempt = 0; attempt < 2; ++attempt) {
     if ((rc = forward_chunks(m, d_ids, n_win, l, prediction, reliability, embedding, nmd, out_loc, chunk, s)) != JG_OK)
@@ -1726,7 +1751,7 @@ extern "C" int jg_forward(jg_model *m, const uint8_t *ids, int ids_loc, int64_t 
   hipStream_t s = pick_stream(e, stream);
   const uint8_t *d_ids = ids;
   if (ids_loc == JG_PTR_HOST) {
-    const int64_t bytes = n_win * 6 * (int64_t)l;
+    const int64_t bytes = n_win * m->strands * m->id_frames * (int64_t)l;
     int rc = grow(&m->d_ids, &m->d_ids_cap, bytes);
     if (rc != JG_OK) return rc;
     JG_HIP(hipMemcpyAsync(m->d_ids, ids, (size_t)bytes, hipMemcpyHostToDevice, s));
@@ -1757,17 +1782,18 @@ static int encode_common(jg_engine *e, jg_model *scratch_owner, const uint8_t *b
   // per call); without one (jg_encode) the copies are temporary
   // l_pad must hold the longest frame: known exactly for host-side window tables (the short-contig
   // pass pads to the longest window of a batch, commands/predict.py:236-245), fsize-derived otherwise
-  int need = frame_len(fsize);
+  const bool nt_ids = (flags & JG_ENC_NUCLEOTIDE) != 0;       // a row holds bases, not codons
+  int need = nt_ids ? fsize : frame_len(fsize);
   if (win_loc == JG_PTR_HOST && fsize >= 3) {
     const int off3 = (fsize % 3 == 0) ? -2 : ((fsize % 3 == 1) ? -1 : 0);
     int longest = 0;
     for (int64_t i = 0; i < n_win; ++i) longest = std::max(longest, std::min(win_len[i], fsize));
     const int usable = longest - 5 + off3;
-    need = usable > 0 ? (usable + 2) / 3 : 0;
+    need = nt_ids ? longest : (usable > 0 ? (usable + 2) / 3 : 0);
   }
   JG_REQUIRE(fsize >= 3 && l_pad >= need && l_pad >= 1, JG_ERR_INVALID,
-             "encode: l_pad=%d is smaller than the %d codons the longest window yields (fsize %d)", l_pad,
-             need, fsize);
+             "encode: l_pad=%d is smaller than the %d %s the longest window yields (fsize %d)", l_pad,
+             need, nt_ids ? "bases" : "codons", fsize);
   const uint8_t *d_bases = bases;
   if (bases_loc == JG_PTR_HOST) {
     void *p = nullptr;
@@ -1831,7 +1857,7 @@ extern "C" int jg_encode(jg_engine *e, const uint8_t *bases, int64_t n_bases, in
   std::vector<void *> to_free;
   uint8_t *d_ids = ids;
   int32_t *d_counts = counts;
-  const int64_t id_bytes = n_win * 6 * (int64_t)l_pad;
+  const int64_t id_bytes = n_win * ((soft_mask & JG_ENC_NUCLEOTIDE) ? 2 : 6) * (int64_t)l_pad;
   void *d_lut = nullptr;
   JG_HIP(hipMalloc(&d_lut, 80));
   to_free.push_back(d_lut);
@@ -1991,7 +2017,7 @@ static int predict_streamed(jg_model *m, const uint8_t *bases, int64_t n_bases, 
   if ((rc = grow(&m->d_win, &m->d_win_cap, win_cap * 12)) != JG_OK) return rc;
   if (counts != nullptr && host_out)
     if ((rc = grow(&m->d_counts, &m->d_counts_cap, win_cap * 16)) != JG_OK) return rc;
-  if ((rc = ensure_workspace(m, fchunk, l_pad)) != JG_OK) return rc;
+  if ((rc = ensure_workspace(m, (int64_t)fchunk * m->strands, l_pad)) != JG_OK) return rc;
   JG_HIP(hipMemcpyAsync(m->d_lut, lut65, 65, hipMemcpyHostToDevice, s));
   JG_HIP(hipStreamSynchronize(s));               // (lut65 is the caller's pageable memory; nothing else waits in the loop)
   e->streamed_groups = (int64_t)groups.size();
@@ -2122,7 +2148,7 @@ static int predict_streamed(jg_model *m, const uint8_t *bases, int64_t n_bases, 
     JG_HIP(hipMemsetAsync(m->d_overflow, 0, sizeof(int), s));
     m->precision = 0;
     m->f16_reason = "an activation left the f16 range at run time";
-    if ((rc = ensure_workspace(m, fchunk, l_pad)) != JG_OK) return rc;
+    if ((rc = ensure_workspace(m, (int64_t)fchunk * m->strands, l_pad)) != JG_OK) return rc;
     first = redo;
   }
   JG_HIP(hipStreamSynchronize(s));
@@ -2146,6 +2172,7 @@ extern "C" int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_b
   e->streamed_bytes = 0;
   e->peak_dev_bases = bases_loc == JG_PTR_HOST ? n_bases : 0;
   e->windows_done.store(0, std::memory_order_release);
+  if (m->strands > 1) soft_mask |= JG_ENC_NUCLEOTIDE;       // a two-strand model reads nucleotide ids (n_win, 2, l_pad)
   if (bases_loc == JG_PTR_HOST && win_loc == JG_PTR_HOST && n_bases > e->stream_bytes) {
     // streamed ingest needs a start-sorted window list (the fragmenter's FASTA order is) inside the buffer
     bool sorted = true;
@@ -2160,9 +2187,10 @@ extern "C" int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_b
     if (sorted) {
       const int off3 = (fsize % 3 == 0) ? -2 : ((fsize % 3 == 1) ? -1 : 0);
       const int usable = longest - 5 + off3;
-      const int need = usable > 0 ? (usable + 2) / 3 : 0;
+      const int need = m->strands > 1 ? longest : (usable > 0 ? (usable + 2) / 3 : 0);
       JG_REQUIRE(fsize >= 3 && l_pad >= need && l_pad >= 1, JG_ERR_INVALID,
-                 "encode: l_pad=%d is smaller than the %d codons the longest window yields (fsize %d)", l_pad, need, fsize);
+                 "encode: l_pad=%d is smaller than the %d %s the longest window yields (fsize %d)", l_pad, need,
+                 m->strands > 1 ? "bases" : "codons", fsize);
       return predict_streamed(m, bases, n_bases, win_start, win_len, n_win, fsize, lut65, soft_mask, l_pad,
                               prediction, reliability, embedding, nmd, counts, out_loc, chunk, s);
     }

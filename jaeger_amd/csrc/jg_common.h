@@ -259,6 +259,13 @@ struct jg_model {
   float *pool_part = nullptr;       // fused max-pool partial rows (split-f16 path)
   int64_t pool_part_cap = 0;
   std::vector<int> pool_fused_by;   // per op: conv op index that produces this OP_POOL's partials, or -1
+  // nucleotide two-strand models (JG_OP_STRANDS): ids (W, strands, L), every strand runs through the program as a row of
+  // its own with ONE frame; the strands' outputs are merged into the window's behind the last op
+  int strands = 1;
+  int id_frames = 6;                // frames per program row of the id tensor: 6 codon frames, or 1 (a strand)
+  int merge_kind = 0;               // jg_merge_kind of the prediction
+  float *merged[JG_MAX_VECS] = {};
+  int64_t merged_cap[JG_MAX_VECS] = {};
   int part_rows[JG_MAX_BUFS] = {};  // split-f16 path: partial rows per window the last conv wrote to each NMD slot
   int pool_rows = 0;                // same for the fused max pool
 };
@@ -292,6 +299,7 @@ int jg_launch_pool_final(const float *part, int rows_per_win, int n_win, int c, 
 int jg_launch_f32_to_f16s(const float *x, int64_t rows, int L, int c, uint4 *y, hipStream_t s, int *overflow);
 int jg_launch_f16s_to_f32(const uint4 *x, int64_t rows, int L, int c, float *y, hipStream_t s);
 int jg_launch_maxpool1d_f16s(const uint4 *x, int rows, int L_in, int L_out, int c, uint4 *y, hipStream_t s);
+int jg_launch_strand_merge(const float *x, int x_ld, int n_win, int strands, int width, int kind, float *y, hipStream_t s);
 int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,
                        hipStream_t s);
 int jg_launch_dust(uint8_t *d_bases, int64_t origin, int64_t span_len, const int64_t *d_rec_off, int64_t n_rec,

@@ -204,7 +204,7 @@ __device__ __forceinline__ void jg_apply_stages_rows(float4 (&v)[RPT], const boo
 // LDS, and every (frame, codon slot) is then a 3-code LDS read + one lookup in
 // the LDS-resident 64-entry codon table.  flags bit0: bytes are already cased
 // (lower case = soft-masked: not counted); bit1: ids are case sensitive
-// (string_processor.masking = true, encode.py:259-261).
+// (string_processor.masking = true, encode.py:259-261); bit2: nucleotide ids (n_win, 2, l_pad) instead of codon ids.
 __global__ __launch_bounds__(256) void encode_kernel(const uint8_t *__restrict__ bases,
                                                      const int64_t *__restrict__ win_start,
                                                      const int32_t *__restrict__ win_len, int fsize,
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void encode_kernel(const uint8_t *__restrict__
     uint8_t ch = bases[start + i];
     uint8_t up = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch;
     const uint8_t cnt_ch = (flags & 1) ? ch : up;  // io.py:104 upper() unless pre-cased
-    const uint8_t id_ch = (flags & 2) ? cnt_ch : up;
+    const uint8_t id_ch = (flags & 2) && !(flags & 4) ? cnt_ch : up;   // the nucleotide map holds both cases (encode.py:36-41)
     cg += cnt_ch == 'G'; cc += cnt_ch == 'C'; ca += cnt_ch == 'A'; ct += cnt_ch == 'T';
     uint8_t cd = 4;
     if (id_ch == 'T') cd = 0;
@@ -248,6 +248,24 @@ __global__ __launch_bounds__(256) void encode_kernel(const uint8_t *__restrict__
   }
   __syncthreads();
   if (counts != nullptr && tid < 4) counts[w * 4 + tid] = scnt[tid];
+  if (flags & 4) {
+    // input_type "nucleotide" (encode.py:265-271): rows = forward strand, reverse complement of the SAME cropped bases;
+    // A,G,C,T -> 0,1,2,3 (+1 here, 0 = the all-zero one-hot row of any other byte and of the padding)
+    uint8_t *out2 = ids + w * 2 * (int64_t)l_pad;
+    for (int idx = tid; idx < 2 * l_pad; idx += 256) {
+      const int f = idx >= l_pad, i = idx - f * l_pad;
+      uint8_t v = 0;
+      if (i < n) {
+        uint8_t cd = f ? code[n - 1 - i] : code[i];
+        if (cd < 4) {
+          if (f) cd ^= 2;                                   // complement: T <-> A, C <-> G
+          v = (uint8_t)((0x02010304u >> (8 * cd)) & 0xff);  // codes T,C,A,G = 0..3 -> ids 4,3,1,2
+        }
+      }
+      out2[idx] = v;
+    }
+    return;
+  }
   // frame length: ceil((n-5+off)/3), off from crop_size % 3 (encode.py:232-236, :279-284)
   const int off3 = (fsize % 3 == 0) ? -2 : ((fsize % 3 == 1) ? -1 : 0);
   const int usable = n - 5 + off3;
@@ -1236,6 +1254,33 @@ int jg_launch_maxpool1d_f16s(const uint4 *x, int rows, int L_in, int L_out, int 
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(maxpool1d_f16s_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, total, L_in, L_out, y);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+// Merge of a branched model's strand outputs (tf.keras.layers.Average / Add / Maximum over the branch outputs,
+// builder.py:1251-1262; the embedding output is always their Average, :779-780): x (n_win * strands, x_ld) -> y (n_win, width)
+__global__ __launch_bounds__(256) void strand_merge_kernel(const float *__restrict__ x, int x_ld, int64_t total, int strands,
+                                                           int width, int kind, float *__restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t w = i / width;
+  const int c = (int)(i - w * width);
+  const float *src = x + w * strands * (int64_t)x_ld + c;
+  float acc = src[0];
+  for (int q = 1; q < strands; ++q) {
+    const float v = src[(int64_t)q * x_ld];
+    acc = kind == JG_MERGE_MAX ? fmaxf(acc, v) : acc + v;
+  }
+  if (kind == JG_MERGE_AVERAGE) acc = acc / (float)strands;
+  y[i] = acc;
+}
+
+int jg_launch_strand_merge(const float *x, int x_ld, int n_win, int strands, int width, int kind, float *y, hipStream_t s) {
+  const int64_t total = (int64_t)n_win * width;
+  if (total == 0) return JG_OK;
+  hipLaunchKernelGGL(strand_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x_ld, total, strands,
+                     width, kind, y);
   JG_HIP(hipGetLastError());
   return JG_OK;
 }

@@ -173,13 +173,15 @@ class HipDevice:
 
     def encode(self, bases: np.ndarray, win_start: np.ndarray, win_len: np.ndarray, fsize: int,
                lut: np.ndarray, flags: int = 0, l_pad: int | None = None):
-        """``jg_encode`` with host buffers -> (ids (W,6,l_pad) u8, counts (W,4) i32)."""
+        """``jg_encode`` with host buffers -> (ids (W,6,l_pad) u8, counts (W,4) i32); with ``JG_ENC_NUCLEOTIDE`` in
+        ``flags`` the nucleotide ids (W,2,l_pad) of ``input_type: nucleotide`` (``l_pad`` counts bases)."""
         bases = np.ascontiguousarray(bases, np.uint8)
         ws = np.ascontiguousarray(win_start, np.int64)
         wl = np.ascontiguousarray(win_len, np.int32)
         n = ws.size
-        l_pad = frame_length(fsize) if l_pad is None else int(l_pad)
-        ids = np.zeros((n, 6, l_pad), np.uint8)
+        nt = bool(int(flags) & L.JG_ENC_NUCLEOTIDE)
+        l_pad = (int(fsize) if nt else frame_length(fsize)) if l_pad is None else int(l_pad)
+        ids = np.zeros((n, 2 if nt else 6, l_pad), np.uint8)
         counts = np.zeros((n, 4), np.int32)
         lut = np.ascontiguousarray(lut, np.uint8)
         L.check(self.lib.jg_encode(self.handle, _ptr(bases), bases.size, L.JG_PTR_HOST, _ptr(ws), _ptr(wl),
@@ -200,6 +202,7 @@ class HipModel:
                                          program.vocab, C.byref(self.handle)), "jg_model_create")
         self.widths = {name: self.lib.jg_model_vec_width(self.handle, i)
                        for i, name in enumerate(("prediction", "reliability", "embedding", "nmd"))}
+        self.strands = int(getattr(program, "strands", 1))      # > 1: nucleotide ids (W, strands, L), rows count bases
         device._models.add(self)
 
     def close(self):
@@ -235,6 +238,10 @@ class HipModel:
     def flops_per_window(self, l: int) -> float:
         return float(self.lib.jg_model_flops_per_window(self.handle, int(l)))
 
+    def row_length(self, nucleotides: int) -> int:
+        """Positions per id row of a window of ``nucleotides`` bases: codons per frame, or the bases themselves."""
+        return int(nucleotides) if self.strands > 1 else frame_length(nucleotides)
+
     def _host_outputs(self, n: int, want: Iterable[str]):
         outs = {}
         for name in ("prediction", "reliability", "embedding", "nmd"):
@@ -244,10 +251,12 @@ class HipModel:
 
     def forward(self, ids: np.ndarray, chunk: int = 0,
                 want=("prediction", "reliability", "embedding", "nmd")) -> dict[str, np.ndarray]:
-        """ids (W, 6, L) u8 on the host -> dict of host arrays (``jg_forward``)."""
+        """ids (W, 6, L) u8 on the host - (W, 2, L) nucleotide ids for a two-strand model - -> dict of host arrays
+        (``jg_forward``)."""
         ids = np.ascontiguousarray(ids, np.uint8)
-        n, six, l = ids.shape
-        assert six == 6
+        n, rows, l = ids.shape
+        if rows != (self.strands if self.strands > 1 else 6):
+            raise ValueError(f"id tensor has {rows} rows per window, the model takes {self.strands if self.strands > 1 else 6}")
         o = self._host_outputs(n, want)
         L.check(self.lib.jg_forward(self.handle, _ptr(ids), L.JG_PTR_HOST, n, l, _ptr(o["prediction"]),
                                     _ptr(o["reliability"]), _ptr(o["embedding"]), _ptr(o["nmd"]),
@@ -260,7 +269,7 @@ class HipModel:
         """``jg_predict_windows``.  With ``device_inputs`` the base / window buffers
         are raw device pointers (ints); outputs always land in host arrays - the caller's (``out``, from
         :meth:`host_outputs`: another thread may then read finished rows while the call runs) or fresh ones."""
-        l_pad = frame_length(fsize) if l_pad is None else int(l_pad)
+        l_pad = self.row_length(fsize) if l_pad is None else int(l_pad)
         res = out if out is not None else self.host_outputs(n_win, want, counts)
         o = {k: res.get(k) for k in ("prediction", "reliability", "embedding", "nmd")}
         cnt = res.get("counts")
@@ -369,8 +378,14 @@ class JaegerHipEngine:
             self.model.set_precision(precision)
         if return_embedding and self.model.widths["embedding"] == 0:
             raise ValueError("The selected model does not expose an 'embedding' output.")
-        self.lut = codon_lut(sp["codon_id"])
+        self.lut = codon_lut(sp["codon_id"]) if sp.get("codon_id") else np.zeros(65, np.uint8)
         self.encode_flags = 2 if sp.get("masking") else 0
+        if self.plan.strands > 1:
+            self.encode_flags |= L.JG_ENC_NUCLEOTIDE
+            if sp.get("input_type_note"):
+                import warnings
+                warnings.warn(sp["input_type_note"] + "; jaeger_amd feeds the nucleotide strands the graph was built for",
+                              stacklevel=2)
 
     @staticmethod
     def _load_class_map(path):
@@ -391,9 +406,10 @@ class JaegerHipEngine:
         for inputs, *meta in dataset:
             ids = np.asarray(inputs.get(key))
             if ids.ndim == 4:
-                # seq_onehot=True batches (B, 6, L, D) (seqops/encode.py:297-302): class c -> device id c + 1, an
-                # all-zero row (invalid codon / padding: what Masking(0.0) masks, builder.py:850-852) -> 0
-                if not self.string_processor_config.get("seq_onehot"):
+                # seq_onehot=True batches (B, 6, L, D) (seqops/encode.py:297-302) and the nucleotide one-hot strands
+                # (B, 2, L, 4) (:265-271): class c -> device id c + 1, an all-zero row (invalid codon / base, padding:
+                # what Masking(0.0) masks, builder.py:850-852) -> 0
+                if not self.string_processor_config.get("seq_onehot") and self.plan.strands == 1:
                     raise ValueError("one-hot batch given to a model that takes codon ids")
                 ids = np.where(ids.any(axis=-1), ids.argmax(axis=-1) + 1, 0)
             elif ids.ndim != 3:

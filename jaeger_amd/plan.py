@@ -112,6 +112,11 @@ class ModelPlan:
     # Dense(E); "onehot" = the one-hot rows themselves (embedding_size 0) (builder.py:844-880).  The one-hot forms
     # are the same gather with table row 0 = zeros (the all-zero one-hot row of an invalid codon, masked by Masking)
     embedding_kind: str = "embedding"
+    # input_type "nucleotide" (builder.py:881-882): a (2, L, 4) one-hot input whose two strands run through ONE
+    # shared-weight branch each - representation learner and classifier head - and are merged behind the head
+    # (builder.py:488-494, :563-590, :1195-1266).  strands > 1 marks such a plan; merge = the classifier's merge method
+    strands: int = 1
+    merge: str = "average"
 
     @property
     def nmd_dim(self) -> int:
@@ -134,7 +139,16 @@ def _block(layers: list[dict], prefix: str, cin: int, use_masking_default: bool,
         name = str(layer.get("name", "")).lower()
         cfg = dict(layer.get("config", {}) or {})
         p = f"{prefix}/{i}"
-        if name == "masked_conv1d":
+        if name == "conv1d":
+            # tf.keras.layers.Conv1D (builder.py:280): strides 1, padding "valid", dilation 1, bias, no activation, and no
+            # mask handling of its own - an incoming Keras mask is dropped
+            out.append(Conv(p, int(cfg["kernel_size"]), cin, int(cfg["filters"]), int(cfg.get("strides", 1)),
+                            str(cfg.get("padding", "valid")).lower(), int(cfg.get("dilation_rate", 1)),
+                            bool(cfg.get("use_bias", True)), cfg.get("activation"), False, "any"))
+            if out[-1].padding not in ("valid", "same"):
+                raise UnsupportedLayer(f"{p}: conv1d padding {out[-1].padding!r}")
+            cin = int(cfg["filters"])
+        elif name == "masked_conv1d":
             um = bool(cfg.get("use_masking", use_masking_default))   # builder.py:1019-1020
             mode = cfg.get("mask_mode", "any")
             if mode not in ("any", "majority", "strict"):
@@ -248,19 +262,20 @@ def build_plan(model_cfg: dict) -> ModelPlan:
     emb = model_cfg.get("embedding")
     if emb is None:
         raise ValueError("Missing 'embedding' section in config")   # builder.py:476
-    if sp["input_type"] != "translated":
-        raise UnsupportedLayer(f"input_type {sp['input_type']!r}: only 'translated' models are supported")
-    if sp.get("ngram_width", 3) != 3:
-        raise UnsupportedLayer("dicodon (ngram_width 6) encodings are not supported")
+    graph_input = str(emb.get("input_type", "translated")).lower()      # what the builder builds (builder.py:846,854-884)
+    branched = ["branch" in (model_cfg.get(section) or {}) for section in ("representation_learner", "classifier")]
+    if graph_input == "nucleotide" or any(branched):
+        return _build_strand_plan(model_cfg, sp, graph_input, branched)
     use_emb = bool(emb.get("use_embedding_layer", False))
     if use_emb == bool(sp.get("seq_onehot")):
         # Embedding needs ids, the Dense / pass-through branch needs one-hot rows (builder.py:856-880)
         raise UnsupportedLayer("use_embedding_layer and seq_onehot must be opposite (ids -> Embedding, one-hot -> Dense)")
     if emb.get("use_positional_embeddings", False):
         raise UnsupportedLayer("positional embeddings are not supported")
-    for section in ("representation_learner", "classifier"):
-        if "branch" in (model_cfg.get(section) or {}):
-            raise UnsupportedLayer(f"branched {section} is not supported")
+    if sp["input_type"] != "translated":
+        raise UnsupportedLayer(f"input_type {sp['input_type']!r} on a graph built for translated input")
+    if sp.get("ngram_width", 3) != 3:
+        raise UnsupportedLayer("dicodon (ngram_width 6) encodings are not supported")
     if "projection" in model_cfg:
         pass  # training-only head, not part of the serving graph outputs
     use_masking = bool(model_cfg.get("use_masking", True))          # builder.py:259
@@ -305,6 +320,62 @@ def build_plan(model_cfg: dict) -> ModelPlan:
         raise ValueError("reliability_model is configured but the representation learner "
                          "produced no NMD tensor")                                # builder.py:636-641
     return plan
+
+
+def _build_strand_plan(model_cfg: dict, sp: dict, graph_input: str, branched: list[bool]) -> ModelPlan:
+    """The branched nucleotide model (``train_config/nn_config_500bp_dvf.yaml``): ``embedding.input_type: nucleotide``
+    makes the input the (2, L, 4) one-hot strands themselves (builder.py:881-882; ``Masking`` passes the values through
+    and the first plain Keras layer drops its mask); ``representation_learner.branch`` is ONE ``_build_block`` model applied
+    to each strand (:1195-1266, :488-494), ``classifier.branch`` one head applied to each strand's vector with a closing
+    ``merge`` layer (:563-590); outputs ``prediction`` (merged) and ``embedding`` (Average of the strand vectors,
+    :776-791); no reliability head.  Compiled as rows of ONE frame: a strand is a program row, ``strands`` rows make a
+    window (program.py: ``OP_STRANDS``)."""
+    emb = model_cfg["embedding"]
+    if graph_input != "nucleotide" or not all(branched):
+        raise UnsupportedLayer("a branched representation learner / classifier is supported for the two-strand "
+                               "nucleotide model only (embedding.input_type: nucleotide, both sections branched)")
+    if emb.get("use_embedding_layer", False) or emb.get("use_positional_embeddings", False):
+        raise UnsupportedLayer("nucleotide input takes the one-hot strands as they are (no embedding layer)")
+    strands = int((emb.get("input_shape") or [2])[0] or 2)
+    if strands != 2:
+        raise UnsupportedLayer(f"nucleotide input has two strands (input_shape[0] = {strands})")
+    if model_cfg.get("reliability_model") is not None:
+        raise UnsupportedLayer("reliability head on a branched model (the reference's combined model has none, builder.py:776-791)")
+    if sp["input_type"] != "nucleotide":
+        # nnlib/inference.py:443-444 reads embedding.type: without it the reference's engine hands the TRANSLATED tensor
+        # to this nucleotide graph and exits; the graph decides here
+        sp["input_type_note"] = ("embedding.type is not 'nucleotide': the reference's InferModel would feed "
+                                 f"x[{sp['input_type']!r}] to this nucleotide graph (nnlib/inference.py:443-444)")
+        sp["input_type"] = "nucleotide"
+        if "crop_size" in sp:
+            sp["crop_units"] = "nucleotide"
+            sp["crop_size_nt"] = int(sp["crop_size"])
+            sp.pop("crop_size_codons", None)
+    sp["vocab_size"] = 5                                          # device ids: 0 = all-zero one-hot row, 1..4 = A, G, C, T
+    rep_cfg = model_cfg["representation_learner"]["branch"]
+    plain = {"conv1d", "dense", "dropout", "activation", "merge", *_ACT_ALIASES}   # stock Keras layers (builder.py:280-302)
+    for section in ("representation_learner", "classifier"):
+        for layer in model_cfg[section]["branch"].get("hidden_layers", []):
+            if str(layer.get("name", "")).lower() not in plain:
+                raise UnsupportedLayer(f"{section}.branch: layer {layer.get('name')!r} (a strand carries no mask and no "
+                                       "frame axis: conv1d / activation / dense / dropout only)")
+    rep, rep_c = _block(rep_cfg.get("hidden_layers", []), "rep", 4, False, None)
+    if not rep or not isinstance(rep[0], Conv):
+        raise UnsupportedLayer("the strand branch must start with a conv1d layer")
+    pooling = {"max1d": "max1d", "average1d": "average1d"}.get(str(rep_cfg.get("pooling", "")).lower())
+    if pooling is None:
+        raise UnsupportedLayer(f"strand branch pooling {rep_cfg.get('pooling')!r} (max1d / average1d: builder.py:1706-1707)")
+    hidden = list(model_cfg["classifier"]["branch"].get("hidden_layers", []))
+    if not hidden or str(hidden[-1].get("name", "")).lower() != "merge":
+        raise ValueError("Branched classifier must end with a 'merge' layer")           # builder.py:565-568
+    merge = str((hidden[-1].get("config") or {}).get("method", "average")).lower()    # builder.py:569-570
+    if merge not in ("average", "sum", "max"):
+        raise UnsupportedLayer(f"merge method {merge!r} (average / sum / max)")
+    cls, n_cls = _block(hidden[:-1], "classifier", rep_c, False, None)
+    return ModelPlan(vocab=5, embedding_dim=4, rep=rep, pooling=pooling, rep_channels=rep_c, classifier=cls,
+                     n_classes=n_cls, use_masking=False, string_processor=sp,
+                     class_label_map=list(model_cfg.get("class_label_map", []) or []), embedding_kind="onehot",
+                     strands=strands, merge=merge)
 
 
 def weight_shapes(plan: ModelPlan) -> dict[str, tuple]:

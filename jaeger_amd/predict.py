@@ -158,6 +158,8 @@ def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None,
         for i in range(0, len(table), batch):
             sl = slice(i, i + batch)
             lmax = int(max(0, -(-(int(table.length[sl].max()) - 5 + off3) // 3)))
+            if getattr(engine.model, "strands", 1) > 1:                       # nucleotide rows hold bases
+                lmax = int(table.length[sl].max())
             c0, c1 = int(cstart[i]), int(cstart[sl][-1] + wl[sl][-1])
             s_b, l_b = starts[sl], wl[sl]
             cut = np.nonzero(s_b[1:] != s_b[:-1] + l_b[:-1])[0] + 1          # where a new run of adjacent records starts

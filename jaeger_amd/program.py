@@ -90,6 +90,7 @@ class Program:
     has_reliability: bool
     nmd_dim: int
     embedding_dim: int
+    strands: int = 1     # > 1: ids (W, strands, L), one frame per program row (OP_STRANDS closes the program)
 
     def op_array(self):
         arr = (L.JgOp * len(self.ops))()
@@ -348,7 +349,10 @@ class _Compiler:
                 raise UnsupportedLayer(f"layer {layer!r} is not supported in the representation learner")
         if buf == L.JG_BUF_IDS:
             raise UnsupportedLayer("the representation learner has no conv layer")
-        kind = L.POOL_MAX if plan.pooling == "max" else L.POOL_AVG
+        # max1d / average1d: the stock Keras Global*Pooling1D of a strand branch (builder.py:1706-1707) - no mask, no sentinel
+        kind = L.POOL_MAX if plan.pooling in ("max", "max1d") else L.POOL_AVG      # (without a mask: plain max / mean)
+        if plan.pooling in ("max1d", "average1d"):
+            mask = L.JG_BUF_NONE
         self.ops.append(self._op(L.OP_POOL, in_buf=buf, in_mask=mask, out_vec=L.VEC_EMBEDDING, vec_off=0,
                                  cout=plan.rep_channels, arg=kind))
 
@@ -406,8 +410,13 @@ class _Compiler:
                                          cout=len(plan.reliability_signals), out_vec=L.VEC_NMD,
                                          vec_off=plan.nmd_dim, arg=order, f0=1e-10, stride=plan.nmd_dim))
             self._head(plan.reliability, L.VEC_NMD, L.VEC_RELIABILITY, L.VEC_SCRATCH0 + 4)
+        if plan.strands > 1:
+            # the heads above ran per strand (shared weights); the window's outputs are the strands' merged
+            # (tf.keras.layers.Average / Add / Maximum, builder.py:1251-1262; embedding: Average, :779-780)
+            self.ops.append(self._op(L.OP_STRANDS, k=plan.strands,
+                                     arg={"average": L.MERGE_AVERAGE, "sum": L.MERGE_SUM, "max": L.MERGE_MAX}[plan.merge]))
         return Program(self.ops, self.blob.finish(), plan.vocab, plan.n_classes,
-                       plan.reliability is not None, plan.nmd_dim, plan.rep_channels)
+                       plan.reliability is not None, plan.nmd_dim, plan.rep_channels, plan.strands)
 
 
 def compile_plan(plan: ModelPlan, weights: dict[str, np.ndarray]) -> Program:

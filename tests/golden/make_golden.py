@@ -45,7 +45,7 @@ def write_project_yamls(reference_root, here):
     import yaml
     names = {"brain": "nn_config_1500bp_nmd_merge_6_class_brain.yaml", "zeus": "nn_config_1500bp_nmd_merge_6_class_zeus.yaml",
              "baseline500": "nn_config_500bp_baseline.yaml", "nmdmerge500": "nn_config_500bp_nmd_merge.yaml",
-             "pyramid": "nn_config_baseline.yaml"}
+             "pyramid": "nn_config_baseline.yaml", "dvf500": "nn_config_500bp_dvf.yaml"}
     for name, fn in names.items():
         text = (reference_root / "train_config" / fn).read_text()
         cut = text.find("\ntraining:")
