@@ -391,6 +391,15 @@ static int validate_program(const jg_model *m) {
 
 // Dry-run the program at `l` codons per frame: per-slot element counts (per
 // window) and vector widths.  Also used to validate that shapes line up.
+// rows of l positions run on the table-net kernel (else - rows too long for the LDS image - layer by layer)
+static bool tab_usable(const jg_model *m, int l) {
+  if (m->tab_conv < 0) return false;
+  const jg_op &c = m->ops[(size_t)m->tab_conv];
+  int lo, pl;
+  conv_geometry(l, c.k, 1, c.dilation, c.padding, &lo, &pl);
+  return lo >= 1 && jg_tab_lds_bytes(c.k, m->tab_vocab, m->tab_cq, l, c.dilation) <= 160 * 1024;
+}
+
 static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
                        int64_t msk_elems[JG_MAX_BUFS], int64_t nmd_elems[JG_MAX_BUFS],
                        int vec_w[JG_MAX_VECS], double *flops) {
@@ -414,8 +423,9 @@ static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
                    "op %zu: conv output is empty at %d codons per frame (window too short)", i, in.L);
         JG_REQUIRE(op.out_buf >= 0, JG_ERR_INVALID, "op %zu: conv needs an output slot", i);
         sh[op.out_buf] = Shape{in.frames, lo, op.cout};
-        act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)in.frames * lo * op.cout);
         fl += 2.0 * op.k * op.cin * op.cout * (double)in.frames * lo;
+        if ((int)i == m->tab_conv && tab_usable(m, l)) break;      // table net: the activation never exists
+        act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)in.frames * lo * op.cout);
         const int tiles = std::max((lo + 63) / 64, 8 * ((lo + 255) / 256));
         for (int s = 0; s < op.n_stages; ++s)
           if (op.stages[s].kind == JG_ST_NMD)
@@ -692,6 +702,64 @@ static int prepare_small(jg_model *m, const float *weights) {
 
 // exact-f32 conv operands: weights grouped by 8 input channels so that a lane fetches the four
 // k-steps of a group with one 16-byte load (see conv_f32_kernel)
+// ---- table net (jg_kernels.hip: tab_conv_pool_kernel) ------------------------------------------------------------
+// The program matches when its first op is an UNMASKED stride-1 conv on the ids whose stages are [bias] [activation]
+// and whose output goes to an unmasked global pool and nowhere else: the strand branch of the nucleotide model
+// (conv1d -> relu -> max1d, train_config/nn_config_500bp_dvf.yaml).  Table entry (t, id) = embedding row id times W[t]
+// (f64 sums, rounded once): for one-hot input W[t][id - 1] itself, the zero row for id 0.
+static int prepare_tab(jg_model *m, const float *weights) {
+  if (m->ops.size() < 2) return JG_OK;
+  const jg_op &c = m->ops[0], &pl = m->ops[1];
+  if (c.kind != JG_OP_CONV || c.in_buf != JG_BUF_IDS || c.in_mask >= 0 || c.in_mask == JG_BUF_IDS || c.out_mask >= 0 ||
+      c.stride != 1 || c.n_stages > 2)
+    return JG_OK;
+  if (pl.kind != JG_OP_POOL || pl.in_buf != c.out_buf || pl.in_mask >= 0 || pl.in_mask == JG_BUF_IDS) return JG_OK;
+  int bias_off = -1, act = JG_ACT_NONE, seen = 0;
+  for (int q = 0; q < c.n_stages; ++q) {
+    const jg_stage &st = c.stages[q];
+    if (st.kind == JG_ST_BIAS && q == 0) { bias_off = (int)st.p0; ++seen; }
+    else if (st.kind == JG_ST_ACT && q == c.n_stages - 1) { act = st.arg; ++seen; }
+  }
+  if (seen != c.n_stages) return JG_OK;
+  for (size_t i = 2; i < m->ops.size(); ++i) {                    // the conv's output must have no other reader
+    const jg_op &o = m->ops[i];
+    if (o.in_buf == c.out_buf || o.out_buf == c.out_buf) return JG_OK;
+    for (int q = 0; q < o.n_stages; ++q)
+      if (o.stages[q].kind == JG_ST_ADD && o.stages[q].arg == c.out_buf) return JG_OK;
+  }
+  const int cq = (c.cout + 3) / 4;
+  const float *w = weights + c.w_off, *emb = weights + c.b_off;
+  // positions outside the sequence (SAME padding) add nothing: they select an all-zero table row - row 0 when the
+  // embedding's row 0 is zero (one-hot input), else a row appended behind the vocabulary
+  bool row0_zero = true;
+  for (int ci = 0; ci < c.cin; ++ci) row0_zero &= emb[ci] == 0.f;
+  const int V = m->vocab + (row0_zero ? 0 : 1);
+  if (V > 255 || cq > 256 || jg_tab_lds_bytes(c.k, V, cq, 64, c.dilation) > 160 * 1024) return JG_OK;
+  const int cin_pad = (c.cin + 1) & ~1, cout_pad = (c.cout + 31) / 32 * 32;
+  std::vector<float> tab((size_t)c.k * V * cq * 4, 0.f), bias((size_t)cq * 4, 0.f);
+  for (int t = 0; t < c.k; ++t)
+    for (int id = 0; id < m->vocab; ++id)
+      for (int n = 0; n < c.cout; ++n) {
+        double acc = 0.0;
+        for (int ci = 0; ci < c.cin; ++ci)
+          acc += (double)emb[(size_t)id * c.cin + ci] * (double)w[((size_t)t * cin_pad + ci) * cout_pad + n];
+        tab[((size_t)t * V + id) * cq * 4 + n] = (float)acc;
+      }
+  if (bias_off >= 0)
+    for (int n = 0; n < c.cout; ++n) bias[(size_t)n] = weights[bias_off + n];
+  JG_HIP(hipMalloc(reinterpret_cast<void **>(&m->tab_table), tab.size() * sizeof(float)));
+  JG_HIP(hipMemcpy(m->tab_table, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+  JG_HIP(hipMalloc(reinterpret_cast<void **>(&m->tab_bias), bias.size() * sizeof(float)));
+  JG_HIP(hipMemcpy(m->tab_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  m->tab_conv = 0;
+  m->tab_pool = 1;
+  m->tab_act = act;
+  m->tab_cq = cq;
+  m->tab_vocab = V;
+  m->tab_zero = row0_zero ? 0 : m->vocab;
+  return JG_OK;
+}
+
 static int prepare_f32(jg_model *m, const float *weights) {
   for (size_t i = 0; i < m->ops.size(); ++i) {
     const jg_op &op = m->ops[i];
@@ -731,6 +799,7 @@ static int prepare_f16(jg_model *m, const float *weights) {
     cur = i;
     ConvHPrep &hp = m->hprep[i];
     hp.f16_ok = false;
+    if ((int)i == m->tab_conv) { fail("runs as the table-net kernel (exact f32, ids to pooled vectors)"); continue; }
     // a 1x1 conv (the bypass of a strided / widening residual block) and a 3-tap conv (ResidualBlock's default kernel
     // size, layers.py:1787) ride the 5-tap kernel: weights in the middle taps, the matrix-core work of the others skipped
     hp.as_k5 = op.k >= 1 && op.k <= 4 && op.in_buf != JG_BUF_IDS;       // (2- and 4-tap convs the same way)
@@ -1176,6 +1245,8 @@ extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const 
   JG_HIP(hipMalloc(&m->d_lut, 80));
   JG_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_overflow), sizeof(int)));
   JG_HIP(hipMemset(m->d_overflow, 0, sizeof(int)));
+  rc = prepare_tab(m, weights);
+  if (rc != JG_OK) { jg_model_destroy(m); return rc; }
   rc = prepare_f16(m, weights);
   if (rc != JG_OK) { jg_model_destroy(m); return rc; }
   rc = prepare_f32(m, weights);
@@ -1217,6 +1288,8 @@ extern "C" int jg_model_destroy(jg_model *m) {
   free_small(m);
   for (int i = 0; i < JG_MAX_VECS; ++i)
     if (m->merged[i]) (void)hipFree(m->merged[i]);
+  if (m->tab_table) (void)hipFree(m->tab_table);
+  if (m->tab_bias) (void)hipFree(m->tab_bias);
   if (m->d_w) (void)hipFree(m->d_w);
   if (m->d_ids) (void)hipFree(m->d_ids);
   if (m->d_counts) (void)hipFree(m->d_counts);
@@ -1336,6 +1409,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
   // arithmetic of the per-layer path (with `small` the convs in front of the pool are skipped; rows too long for the
   // fused kernel run layer by layer on the narrow split-f16 kernels - 3-tap convs as tap-masked 5-tap ones)
   const int prec = m->precision;
+  const bool tab = tab_usable(m, l) && m->id_frames == 1;
   if (small) {
     JgSmallNet *sn = m->small;
     const int64_t rows = (int64_t)nw * 6;
@@ -1392,6 +1466,33 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         std::swap(m->act[slot], m->cvt_scratch);
         std::swap(m->act_cap[slot], m->cvt_cap);
       }
+    }
+    if (tab && (int)i == m->tab_pool) continue;
+    if (tab && (int)i == m->tab_conv) {
+      const jg_op &po = m->ops[(size_t)m->tab_pool];
+      int lo, pl;
+      conv_geometry(l, op.k, 1, op.dilation, op.padding, &lo, &pl);
+      JgTabArgs a;
+      memset(&a, 0, sizeof(a));
+      a.ids = d_ids; a.table = m->tab_table; a.bias = m->tab_bias;
+      a.out = m->vec[po.out_vec] + po.vec_off; a.out_ld = m->vec_w[po.out_vec];
+      a.rows = nw * m->id_frames; a.L = l; a.L_out = lo; a.pad_left = pl; a.k = op.k; a.dil = op.dilation;
+      a.vocab = m->tab_vocab; a.zero_id = m->tab_zero; a.cout = op.cout; a.cq = m->tab_cq; a.act = m->tab_act; a.pool_kind = po.arg;
+      JG_REQUIRE(m->id_frames == 1, JG_ERR_UNSUPPORTED, "table net: rows of one frame only");
+      ProfEvent pe;
+      if (e->profile) {
+        if ((rc = prof_event(e, &pe.a)) != JG_OK || (rc = prof_event(e, &pe.b)) != JG_OK) return rc;
+        pe.flops = 2.0 * op.k * op.cin * op.cout * (double)a.rows * lo;
+        pe.cls = JG_PROF_TABLE;
+        JG_HIP(hipEventRecord(pe.a, s));
+      }
+      if ((rc = jg_launch_tab_conv_pool(e, a, s)) != JG_OK) return rc;
+      if (e->profile) {
+        JG_HIP(hipEventRecord(pe.b, s));
+        e->pending.push_back(pe);
+      }
+      sh[op.out_buf] = Shape{m->id_frames, lo, op.cout};
+      continue;
     }
     if (small && (int)i == m->small->pool_op) {
       rc = jg_launch_small_pool_final(m->small->d_part, 6, m->small->n_slots, 0, nw, m->small->pool_kind, nullptr, 0.f,

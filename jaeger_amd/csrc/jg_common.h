@@ -266,6 +266,13 @@ struct jg_model {
   int merge_kind = 0;               // jg_merge_kind of the prediction
   float *merged[JG_MAX_VECS] = {};
   int64_t merged_cap[JG_MAX_VECS] = {};
+  // "table net": an unmasked first conv straight on the ids, bias / activation, and the global pool behind it - the whole
+  // representation learner of a strand branch - as ONE kernel (jg_kernels.hip: tab_conv_pool_kernel): the conv of a gathered
+  // table row is a sum of k rows of the table (k, vocab, cout) = emb @ W[t]; nothing but ids in, pooled vectors out
+  float *tab_table = nullptr;       // (k, vocab, cq) float4 quads, cq = ceil(cout / 4)
+  float *tab_bias = nullptr;        // (cq) quads (zeros without a bias stage)
+  int tab_conv = -1, tab_pool = -1; // ops replaced by the kernel (-1: the program does not match)
+  int tab_act = 0, tab_cq = 0, tab_vocab = 0, tab_zero = 0;   // table rows incl. an appended zero row when row 0 is not one
   int part_rows[JG_MAX_BUFS] = {};  // split-f16 path: partial rows per window the last conv wrote to each NMD slot
   int pool_rows = 0;                // same for the fused max pool
 };
@@ -299,6 +306,15 @@ int jg_launch_pool_final(const float *part, int rows_per_win, int n_win, int c, 
 int jg_launch_f32_to_f16s(const float *x, int64_t rows, int L, int c, uint4 *y, hipStream_t s, int *overflow);
 int jg_launch_f16s_to_f32(const uint4 *x, int64_t rows, int L, int c, float *y, hipStream_t s);
 int jg_launch_maxpool1d_f16s(const uint4 *x, int rows, int L_in, int L_out, int c, uint4 *y, hipStream_t s);
+struct JgTabArgs {
+  const uint8_t *ids;      // (rows, L)
+  const float *table, *bias;
+  float *out;              // (rows, out_ld)
+  int out_ld, rows, L, L_out, pad_left, k, dil, vocab, cout, cq, act, pool_kind;
+  int zero_id;             // table row that is all zeros in every tap (positions outside the sequence select it)
+};
+int64_t jg_tab_lds_bytes(int k, int vocab, int cq, int L, int dil);
+int jg_launch_tab_conv_pool(jg_engine *e, const JgTabArgs &a, hipStream_t s);
 int jg_launch_strand_merge(const float *x, int x_ld, int n_win, int strands, int width, int kind, float *y, hipStream_t s);
 int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,
                        hipStream_t s);

@@ -1258,6 +1258,134 @@ int jg_launch_maxpool1d_f16s(const uint4 *x, int rows, int L_in, int L_out, int 
   return JG_OK;
 }
 
+// ---------------------------------------------------------------------------
+// table net: ids -> conv (as table rows) -> bias -> activation -> global max / mean, one kernel
+// ---------------------------------------------------------------------------
+// Persistent grid of 1 024-thread workgroups, one row (a strand) per workgroup at a time.  The (k, vocab, cout) table sits
+// in LDS for the workgroup's life; a position's conv output is bias + the k table rows its ids select - one 16-byte LDS
+// read per tap and channel quad.  Lane groups of 64 / 128 / 256 lanes own the channel quads and split the positions between
+// them in blocks of four CONSECUTIVE positions: four independent id -> row chains per tap and thread and four waves per SIMD
+// hide the LDS latency that a single dependent chain pays in full (first form of this kernel: 555 ms per 200 000 windows
+// against 321 ms layer by layer).  The id row is stored with a halo of `zero_id` entries - SAME padding, and the overhang of the
+// last block - so that the inner loop has no bounds checks.  Bound: LDS bandwidth, 4 * k * cout bytes per position.
+#define JG_TAB_PB 4
+__global__ __launch_bounds__(1024) void tab_conv_pool_kernel(JgTabArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t tab_sm[];
+  const int cq = a.cq, tid = threadIdx.x, V = a.vocab;
+  float4 *tab = reinterpret_cast<float4 *>(tab_sm);
+  float4 *red = tab + (size_t)a.k * V * cq;
+  uint8_t *sid = reinterpret_cast<uint8_t *>(red + 1024);
+  const float4 *gt = reinterpret_cast<const float4 *>(a.table);
+  for (int i = tid; i < a.k * V * cq; i += 1024) tab[i] = gt[i];
+  const int lanes = cq <= 64 ? 64 : (cq <= 128 ? 128 : 256), groups = 1024 / lanes;
+  const int q = tid % lanes, g = tid / lanes;
+  const bool live = q < cq;
+  const float4 b4 = live ? reinterpret_cast<const float4 *>(a.bias)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool is_max = a.pool_kind != JG_POOL_AVG;
+  const int n_sid = a.L_out + JG_TAB_PB - 1 + (a.k - 1) * a.dil;       // entry i = sequence position i - pad_left
+  for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
+    __syncthreads();                                        // (table loaded; the previous row's ids and partials are done with)
+    const uint8_t *src = a.ids + (size_t)row * a.L;
+    for (int i = tid; i < n_sid; i += 1024) {
+      const int pos = i - a.pad_left;
+      sid[i] = pos >= 0 && pos < a.L ? src[pos] : (uint8_t)a.zero_id;
+    }
+    __syncthreads();
+    float4 pool = is_max ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+      for (int p = g * JG_TAB_PB; p < a.L_out; p += groups * JG_TAB_PB) {
+        float4 acc[JG_TAB_PB];
+#pragma unroll
+        for (int j = 0; j < JG_TAB_PB; ++j) acc[j] = b4;
+        if (a.dil == 1) {
+          // the ids of a block's taps through a sliding 8-byte register window: one aligned 32-bit LDS read per four taps
+          // instead of sixteen byte reads (the byte reads were a fifth of the kernel's LDS instructions)
+          const uint32_t *sw = reinterpret_cast<const uint32_t *>(sid + p);
+          uint64_t win = (uint64_t)sw[0] | ((uint64_t)sw[1] << 32);
+          int nxt = 2;
+          for (int t0 = 0; t0 < a.k; t0 += 4) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+              if (t0 + tt >= a.k) break;
+              const float4 *tr = tab + (size_t)(t0 + tt) * V * cq + q;
+#pragma unroll
+              for (int j = 0; j < JG_TAB_PB; ++j) {
+                const int id = (int)((win >> (8 * (tt + j))) & 0xff);
+                const float4 w = tr[id * cq];
+                acc[j].x += w.x; acc[j].y += w.y; acc[j].z += w.z; acc[j].w += w.w;
+              }
+            }
+            win = (win >> 32) | ((uint64_t)sw[nxt++] << 32);
+          }
+        } else {
+          const uint8_t *sp = sid + p;
+#pragma unroll 2
+          for (int t = 0; t < a.k; ++t) {
+            const float4 *tr = tab + (size_t)t * V * cq + q;
+#pragma unroll
+            for (int j = 0; j < JG_TAB_PB; ++j) {
+              const float4 w = tr[(int)sp[j] * cq];
+              acc[j].x += w.x; acc[j].y += w.y; acc[j].z += w.z; acc[j].w += w.w;
+            }
+            sp += a.dil;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < JG_TAB_PB; ++j) {
+          if (p + j >= a.L_out) break;
+          float4 v = acc[j];
+          v.x = jg_apply_act(v.x, a.act); v.y = jg_apply_act(v.y, a.act);
+          v.z = jg_apply_act(v.z, a.act); v.w = jg_apply_act(v.w, a.act);
+          if (is_max) {
+            pool.x = fmaxf(pool.x, v.x); pool.y = fmaxf(pool.y, v.y); pool.z = fmaxf(pool.z, v.z); pool.w = fmaxf(pool.w, v.w);
+          } else {
+            pool.x += v.x; pool.y += v.y; pool.z += v.z; pool.w += v.w;
+          }
+        }
+      }
+    }
+    red[tid] = pool;
+    __syncthreads();
+    if (g == 0 && live) {
+      for (int gg = 1; gg < groups; ++gg) {
+        const float4 o = red[gg * lanes + q];
+        if (is_max) {
+          pool.x = fmaxf(pool.x, o.x); pool.y = fmaxf(pool.y, o.y); pool.z = fmaxf(pool.z, o.z); pool.w = fmaxf(pool.w, o.w);
+        } else {
+          pool.x += o.x; pool.y += o.y; pool.z += o.z; pool.w += o.w;
+        }
+      }
+      if (!is_max) {
+        const float d = (float)a.L_out;
+        pool.x /= d; pool.y /= d; pool.z /= d; pool.w /= d;
+      }
+      float *dst = a.out + (size_t)row * a.out_ld + q * 4;
+      const float v[4] = {pool.x, pool.y, pool.z, pool.w};
+      for (int c = 0; c < 4; ++c)
+        if (q * 4 + c < a.cout) dst[c] = v[c];
+    }
+  }
+}
+
+// LDS image: table, 1 024 partial pools, the id row with its halo (L + k * dil + 3 covers every padding split)
+int64_t jg_tab_lds_bytes(int k, int vocab, int cq, int L, int dil) {
+  return (int64_t)k * vocab * cq * 16 + 1024 * 16 + ((L + k * dil + JG_TAB_PB + 8 + 15) & ~15);   // (+ 8: the id window reads a word ahead)
+}
+
+int jg_launch_tab_conv_pool(jg_engine *e, const JgTabArgs &a, hipStream_t s) {
+  if (a.rows == 0) return JG_OK;
+  const int64_t smem = jg_tab_lds_bytes(a.k, a.vocab, a.cq, a.L, a.dil);
+  JG_REQUIRE(smem <= 160 * 1024 && a.cq <= 256 && a.L_out >= 1 && a.zero_id >= 0 && a.zero_id < a.vocab, JG_ERR_UNSUPPORTED,
+             "table net: %lld bytes of LDS / %d channel quads / %d positions", (long long)smem, a.cq, a.L_out);
+  if (smem > 48 * 1024)
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tab_conv_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+  const int grid = (int)std::min<int64_t>(a.rows, e->n_cu);
+  hipLaunchKernelGGL(tab_conv_pool_kernel, dim3((unsigned)grid), dim3(1024), (size_t)smem, s, a);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
 // Merge of a branched model's strand outputs (tf.keras.layers.Average / Add / Maximum over the branch outputs,
 // builder.py:1251-1262; the embedding output is always their Average, :779-780): x (n_win * strands, x_ld) -> y (n_win, width)
 __global__ __launch_bounds__(256) void strand_merge_kernel(const float *__restrict__ x, int x_ld, int64_t total, int strands,

@@ -110,6 +110,38 @@ def test_dvf500_average_pool_and_gelu_branch():
     _case(cfg, 40, 500, seed=6)
 
 
+def test_dvf500_same_padding_dilated_branch():
+    """'same' padding and a dilated kernel: taps outside the strand add nothing (table-net kernel's pad_left path)."""
+    cfg = copy.deepcopy(load_model_cfg("dvf500"))
+    cfg["representation_learner"]["branch"] = {"hidden_layers": [
+        {"name": "conv1d", "config": {"filters": 100, "kernel_size": 6, "padding": "same", "dilation_rate": 3}},
+        {"name": "sigmoid"}], "pooling": "max1d"}
+    cfg["classifier"]["branch"]["hidden_layers"] = [
+        {"name": "dense", "config": {"units": 3}}, {"name": "merge", "config": {"method": "average"}}]
+    _case(cfg, 40, 400, seed=7, short=True)
+
+
+def test_dvf_wide_conv_runs_layer_by_layer():
+    """800 filters x 10 taps do not fit the table-net kernel's LDS image: the same program runs conv -> pool on the
+    exact-f32 kernels (the path every strand model took before that kernel existed)."""
+    from jaeger_amd.engine import JaegerHipEngine
+    from oracle import strands as ost
+    cfg = copy.deepcopy(load_model_cfg("dvf500"))
+    cfg["representation_learner"]["branch"]["hidden_layers"][0]["config"]["filters"] = 800
+    for layer in cfg["classifier"]["branch"]["hidden_layers"]:
+        if layer["name"] == "dense" and layer["config"]["units"] == 500:
+            layer["config"]["units"] = 64
+    _case(cfg, 16, 500, seed=8)
+    with pytest.warns(UserWarning):
+        eng = JaegerHipEngine(model_cfg=cfg, weights=ost.random_weights(cfg), device_id=0)
+    assert "table-net" not in eng.model.describe()
+    eng.close()
+    with pytest.warns(UserWarning):
+        eng = JaegerHipEngine(model_cfg=load_model_cfg("dvf500"), weights=ost.random_weights(load_model_cfg("dvf500")), device_id=0)
+    assert "table-net" in eng.model.describe()
+    eng.close()
+
+
 def test_dvf500_streamed_pipeline_equals_one_call(tmp_path):
     """Host buffers above the span budget go through the two-deep pipeline: same rows as the resident call."""
     from jaeger_amd.engine import JaegerHipEngine
