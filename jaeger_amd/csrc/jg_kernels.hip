@@ -998,10 +998,59 @@ __global__ __launch_bounds__(256) void dense_narrow_kernel(const float *__restri
   }
 }
 
+// Wide heads (the strand model's 500 -> 500 layer): a workgroup takes WT windows x 256 outputs, the windows' inputs sit in
+// LDS, and every weight a thread loads serves WT windows (the kernel above loads one weight per multiply-add: 5 TFLOP/s).
+// Same sums in the same order as dense_kernel - bit-identical results.
+template <int WT>
+__global__ __launch_bounds__(256) void dense_tiled_kernel(const float *__restrict__ in, int in_ld, const float *__restrict__ w,
+                                                          const float *__restrict__ b, int n_win, int cin, int cout, int act,
+                                                          float *__restrict__ out, int out_ld) {
+  extern __shared__ __attribute__((aligned(16))) float dense_xs[];
+  const int cin_pad = (cin + 3) & ~3, tid = threadIdx.x;
+  const int w0 = blockIdx.x * WT, o = blockIdx.y * 256 + tid;
+  const int nw = n_win - w0 < WT ? n_win - w0 : WT;
+  for (int idx = tid; idx < WT * cin_pad; idx += 256) {
+    const int wi = idx / cin_pad, i = idx - wi * cin_pad;
+    dense_xs[idx] = wi < nw && i < cin ? in[(size_t)(w0 + wi) * in_ld + i] : 0.f;
+  }
+  __syncthreads();
+  if (o >= cout) return;
+  float acc[WT];
+#pragma unroll
+  for (int wi = 0; wi < WT; ++wi) acc[wi] = 0.f;
+  for (int i = 0; i < cin_pad; i += 4) {
+    float wv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wv[c] = i + c < cin ? w[(size_t)(i + c) * cout + o] : 0.f;
+#pragma unroll
+    for (int wi = 0; wi < WT; ++wi) {
+      const float4 x = *reinterpret_cast<const float4 *>(dense_xs + wi * cin_pad + i);
+      float a = acc[wi];
+      a = fmaf(x.x, wv[0], a);
+      a = fmaf(x.y, wv[1], a);
+      a = fmaf(x.z, wv[2], a);
+      a = fmaf(x.w, wv[3], a);
+      acc[wi] = a;
+    }
+  }
+  const float bias = b != nullptr ? b[o] : 0.f;
+#pragma unroll
+  for (int wi = 0; wi < WT; ++wi)
+    if (wi < nw) out[(size_t)(w0 + wi) * out_ld + o] = jg_apply_act(b != nullptr ? acc[wi] + bias : acc[wi], act);
+}
+
 int jg_launch_dense(const float *in, int in_ld, const float *w, const float *b, int n_win, int cin,
                     int cout, int act, float *out, int out_ld, hipStream_t s) {
   const int64_t total = (int64_t)n_win * cout;
   if (total == 0) return JG_OK;
+  constexpr int WT = 8;
+  if (cout >= 64 && cin >= 64 && n_win >= WT && (size_t)WT * ((cin + 3) & ~3) * sizeof(float) <= 48 * 1024) {
+    const size_t smem = (size_t)WT * ((cin + 3) & ~3) * sizeof(float);
+    hipLaunchKernelGGL(dense_tiled_kernel<WT>, dim3((unsigned)((n_win + WT - 1) / WT), (unsigned)((cout + 255) / 256)), dim3(256),
+                       smem, s, in, in_ld, w, b, n_win, cin, cout, act, out, out_ld);
+    JG_HIP(hipGetLastError());
+    return JG_OK;
+  }
   if (cout <= 8 && cin >= 64) {
     hipLaunchKernelGGL(dense_narrow_kernel<8>, dim3((unsigned)((n_win + 3) / 4)), dim3(256), 0, s, in, in_ld, w, b,
                        n_win, cin, cout, act, out, out_ld);
