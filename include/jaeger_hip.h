@@ -310,6 +310,12 @@ enum { JG_COL_STRING = 0, JG_COL_INT = 1, JG_COL_FLOAT = 2, JG_COL_BOOL = 3 };
 int jg_table_format(int32_t n_cols, const int32_t *kinds, const void *const *cols, const int64_t *const *starts,
                     const int64_t *rows, int64_t n_rows, int32_t n_threads, char **text, int64_t *n_bytes);
 void jg_table_free(char *text);
+/* window_summary strings (replaces get_window_summary of postprocess/helpers.py:73-108 over the run lengths of :8-40, one
+ * Python call per contig in postprocess/collect.py:520-523): contig c owns calls[first[c] .. first[c] + count[c]); every run of
+ * equal calls prints as its length followed by letters[class] (0 = no letter).  *text holds one NUL-terminated string per
+ * contig back to back (n_bytes in all); release with jg_table_free. */
+int jg_run_summaries(const int32_t *calls, int64_t n_calls, const int64_t *first, const int64_t *count, int64_t n_contigs,
+                     const uint8_t *letters, int32_t n_letters, int32_t n_threads, char **text, int64_t *n_bytes);
 
 /* ---- CRF window decoding (host only; replaces the per-contig loop over postprocess/helpers.py:398-449
  * viterbi_decode that postprocess/collect.py:343-346 runs for `jaeger predict --crf`) ---------------

@@ -131,3 +131,60 @@ extern "C" int jg_table_format(int32_t n_cols, const int32_t *kinds, const void 
 }
 
 extern "C" void jg_table_free(char *text) { free(text); }
+
+// window_summary of every contig (postprocess/helpers.py:8-40 run lengths, :73-108 letters): the per-window calls of contig c
+// are calls[first[c] .. first[c] + count[c]); each run of equal calls prints as its length followed by the class's letter
+// (letters[class] = 0: no letter), e.g. "12V3b".  One NUL-terminated string per contig, back to back.
+extern "C" int jg_run_summaries(const int32_t *calls, int64_t n_calls, const int64_t *first, const int64_t *count,
+                                int64_t n_contigs, const uint8_t *letters, int32_t n_letters, int32_t n_threads, char **text,
+                                int64_t *n_bytes) {
+  JG_REQUIRE(n_contigs >= 0 && n_calls >= 0 && (n_contigs == 0 || (calls != nullptr && first != nullptr && count != nullptr)) &&
+                 (n_letters == 0 || letters != nullptr) && text != nullptr && n_bytes != nullptr,
+             JG_ERR_INVALID, "jg_run_summaries: bad arguments");
+  for (int64_t c = 0; c < n_contigs; ++c)
+    JG_REQUIRE(first[c] >= 0 && count[c] >= 0 && first[c] + count[c] <= n_calls, JG_ERR_INVALID,
+               "jg_run_summaries: contig %lld covers calls [%lld, +%lld) of %lld", (long long)c, (long long)first[c],
+               (long long)count[c], (long long)n_calls);
+  int nt = n_threads > 0 ? n_threads : jg_usable_cores();
+  nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(nt, 256), n_contigs / 1024 + 1));
+  std::vector<std::string> part((size_t)nt);
+  std::vector<char> failed((size_t)nt, 0);
+  auto work = [&](int tix) {
+   try {
+    std::string &out = part[(size_t)tix];
+    char tmp[24];
+    for (int64_t c = n_contigs * tix / nt; c < n_contigs * (tix + 1) / nt; ++c) {
+      const int32_t *v = calls + first[c];
+      const int64_t n = count[c];
+      for (int64_t i = 0; i < n;) {
+        int64_t j = i + 1;
+        while (j < n && v[j] == v[i]) ++j;
+        char *e = put_u64(tmp, (uint64_t)(j - i));
+        if (v[i] >= 0 && v[i] < n_letters && letters[v[i]] != 0) *e++ = (char)letters[v[i]];
+        out.append(tmp, (size_t)(e - tmp));
+        i = j;
+      }
+      out.push_back('\0');
+    }
+   } catch (const std::exception &) {
+     failed[(size_t)tix] = 1;
+   }
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto &t : th) t.join();
+  }
+  for (char f : failed) JG_REQUIRE(!f, JG_ERR_NOMEM, "jg_run_summaries: out of memory");
+  size_t total = 0;
+  for (const auto &s : part) total += s.size();
+  char *buf = (char *)malloc(total ? total : 1);
+  JG_REQUIRE(buf != nullptr, JG_ERR_NOMEM, "jg_run_summaries: out of memory (%zu bytes)", total);
+  size_t at = 0;
+  for (const auto &s : part) { memcpy(buf + at, s.data(), s.size()); at += s.size(); }
+  *text = buf;
+  *n_bytes = (int64_t)total;
+  return JG_OK;
+}

@@ -415,6 +415,35 @@ class _Runs:
         return self.calls[a:a + int(self.seg.count[i])]
 
     def summaries(self, letter: dict) -> list[str]:
+        """Every contig's run-length string; rendered by the library (``jg_run_summaries``) when the letters are single
+        ASCII characters - a Python string per RUN was the largest single cost of the per-contig aggregation - else by
+        :meth:`summaries_py` (same strings, tests/test_postprocess.py)."""
+        calls, seg = self.calls, self.seg
+        if calls.size == 0:
+            return []
+        ids = [int(k) for k in letter]
+        if all(len(v) == 1 and v.isascii() for v in letter.values()) and (not ids or (min(ids) >= 0 and max(ids) < 256)):
+            import ctypes as C
+
+            from . import _lib
+            lib = _lib.load()
+            table = np.zeros(max(ids) + 1 if ids else 1, dtype=np.uint8)
+            for k, v in letter.items():
+                table[int(k)] = ord(v)
+            c32 = np.ascontiguousarray(calls, dtype=np.int32)
+            first = np.ascontiguousarray(seg.first, dtype=np.int64)
+            count = np.ascontiguousarray(seg.count, dtype=np.int64)
+            text, size = C.c_void_p(), C.c_int64()
+            _lib.check(lib.jg_run_summaries(c32.ctypes.data, c32.size, first.ctypes.data, count.ctypes.data, seg.n,
+                                            table.ctypes.data, table.size, 0, C.byref(text), C.byref(size)), "jg_run_summaries")
+            try:
+                blob = C.string_at(text, size.value)
+            finally:
+                lib.jg_table_free(text)
+            return blob.decode("ascii").split("\0")[:-1]
+        return self.summaries_py(letter)
+
+    def summaries_py(self, letter: dict) -> list[str]:
         calls, seg = self.calls, self.seg
         if calls.size == 0:
             return []

@@ -213,3 +213,21 @@ def test_native_table_text_equals_pandas():
         assert _tsv_bytes(q) == q.to_csv(None, sep="\t", index=False, float_format="%.3f").encode("utf-8")
     mixed = pd.DataFrame({"a": np.array(["x", 3, 2.5], dtype=object), "b": [1.0, 2.0, 3.0]})
     assert _tsv_bytes(mixed) == mixed.to_csv(None, sep="\t", index=False, float_format="%.3f").encode("utf-8")
+
+
+def test_native_run_summaries_equal_python_form():
+    """jg_run_summaries against the per-run Python strings: ragged contigs, long and one-window runs, classes without a
+    letter, an empty letter map; a multi-character letter falls back to the Python form."""
+    from jaeger_amd.postprocess import _Runs, _Segments
+    rng = np.random.default_rng(3)
+    for trial in range(6):
+        counts = rng.integers(1, 60, int(rng.integers(1, 2500)))
+        calls = rng.integers(0, 4, int(counts.sum()))
+        if trial % 2:
+            calls = np.repeat(rng.integers(0, 4, calls.size // 7 + 1), 7)[:calls.size]
+        runs = _Runs(calls, _Segments(np.cumsum(counts)[:-1], calls.size))
+        for letter in ({0: "b", 1: "V", 2: "e", 3: "a"}, {0: "b", 1: "V"}, {}, {0: "xx", 1: "V"}):
+            got = runs.summaries(letter)
+            assert got == runs.summaries_py(letter) and len(got) == len(counts)
+    one = _Runs(np.array([2, 2, 2, 1]), _Segments(np.array([], np.int64), 4))
+    assert one.summaries({1: "V", 2: "p"}) == ["3p1V"]
