@@ -562,7 +562,10 @@ def _string_column(values):
     try:
         blob = "\0".join(vals)
     except TypeError:
-        vals = ["" if v is None or v != v else v for v in vals]
+        try:
+            vals = ["" if v is None or v != v else v for v in vals]
+        except (TypeError, ValueError):                       # pd.NA and friends: truth value undefined
+            return None
         if not all(isinstance(v, str) for v in vals):
             return None
         blob = "\0".join(vals)

@@ -213,6 +213,9 @@ def test_native_table_text_equals_pandas():
         assert _tsv_bytes(q) == q.to_csv(None, sep="\t", index=False, float_format="%.3f").encode("utf-8")
     mixed = pd.DataFrame({"a": np.array(["x", 3, 2.5], dtype=object), "b": [1.0, 2.0, 3.0]})
     assert _tsv_bytes(mixed) == mixed.to_csv(None, sep="\t", index=False, float_format="%.3f").encode("utf-8")
+    ext = pd.DataFrame({"a": pd.array(["x", pd.NA, "z"], dtype="string"), "b": [1.0, 2.0, np.nan],
+                        "c": pd.array([1, pd.NA, 3], dtype="Int64")})          # extension dtypes: pandas writes them
+    assert _tsv_bytes(ext) == ext.to_csv(None, sep="\t", index=False, float_format="%.3f").encode("utf-8")
 
 
 def test_native_run_summaries_equal_python_form():
