@@ -167,8 +167,11 @@ def test_dvf500_streamed_pipeline_equals_one_call(tmp_path):
         np.testing.assert_array_equal(whole[k], streamed[k])
 
 
-def test_cli_dvf500_end_to_end(tmp_path):
-    """`jaeger predict` with the two-strand model: TSV of the GPU run against the oracle pipeline's per-window logits."""
+@pytest.mark.parametrize("dustmask", [False, True])
+def test_cli_dvf500_end_to_end(tmp_path, dustmask):
+    """`jaeger predict` with the two-strand model: TSV of the GPU run against the oracle pipeline's per-window logits.
+    With DUST on, soft-masked bases leave the G / C / A / T counts but not the nucleotide ids (both cases are keys of the
+    lookup, encode.py:36-41): same calls."""
     import pandas as pd
 
     from jaeger_amd import predict as P
@@ -178,10 +181,11 @@ def test_cli_dvf500_end_to_end(tmp_path):
     lengths = [2600, 500, 1234, 800, 5000]
     fa = tmp_path / "in.fasta"
     seqs = [_dna(rng, n, n_frac=0.003).tobytes() for n in lengths]
+    seqs[0] = seqs[0][:700] + b"A" * 300 + b"AC" * 100 + seqs[0][1200:]          # low complexity: DUST masks it
     fa.write_bytes(b"".join(b">c%d some text\n%s\n" % (i, s) for i, s in enumerate(seqs)))
     mdir = make_model_dir(tmp_path / "m", name="dvf500", model_name="jaeger_500bp_dvf")
     P.run_core(input=str(fa), output=str(tmp_path / "out"), model_path=str(mdir), fsize=500, stride=500, overwrite=True,
-               dustmask=False, verbose=0, batch=96, rc=0.1, pc=3)
+               dustmask=dustmask, verbose=0, batch=96, rc=0.1, pc=3)
     tsv = next((tmp_path / "out").rglob("in.tsv"))
     df = pd.read_csv(tsv, sep="\t")
     assert df["contig_id"].tolist() == [f"c{i}" for i in range(5)]
@@ -195,3 +199,8 @@ def test_cli_dvf500_end_to_end(tmp_path):
         calls = logits.argmax(1)
         for c, name in enumerate(labels):
             assert int(df.loc[i, f"#_{name}_windows"]) == int((calls == c).sum())
+    gc0 = float(df.loc[0, "G+C"])
+    if dustmask:
+        assert gc0 != pytest.approx(test_cli_dvf500_end_to_end.gc_plain, abs=1e-4)      # masked bases are not counted
+    else:
+        test_cli_dvf500_end_to_end.gc_plain = gc0
