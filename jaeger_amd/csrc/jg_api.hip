@@ -708,7 +708,7 @@ static int prepare_small(jg_model *m, const float *weights) {
 // (conv1d -> relu -> max1d, train_config/nn_config_500bp_dvf.yaml).  Table entry (t, id) = embedding row id times W[t]
 // (f64 sums, rounded once): for one-hot input W[t][id - 1] itself, the zero row for id 0.
 static int prepare_tab(jg_model *m, const float *weights) {
-  if (m->ops.size() < 2) return JG_OK;
+  if (m->ops.size() < 2 || m->id_frames != 1) return JG_OK;      // (rows of one frame: the pool is per row)
   const jg_op &c = m->ops[0], &pl = m->ops[1];
   if (c.kind != JG_OP_CONV || c.in_buf != JG_BUF_IDS || c.in_mask >= 0 || c.in_mask == JG_BUF_IDS || c.out_mask >= 0 ||
       c.stride != 1 || c.n_stages > 2)
@@ -1409,7 +1409,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
   // arithmetic of the per-layer path (with `small` the convs in front of the pool are skipped; rows too long for the
   // fused kernel run layer by layer on the narrow split-f16 kernels - 3-tap convs as tap-masked 5-tap ones)
   const int prec = m->precision;
-  const bool tab = tab_usable(m, l) && m->id_frames == 1;
+  const bool tab = tab_usable(m, l);
   if (small) {
     JgSmallNet *sn = m->small;
     const int64_t rows = (int64_t)nw * 6;
