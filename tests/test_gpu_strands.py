@@ -204,3 +204,30 @@ def test_cli_dvf500_end_to_end(tmp_path, dustmask):
         assert gc0 != pytest.approx(test_cli_dvf500_end_to_end.gc_plain, abs=1e-4)      # masked bases are not counted
     else:
         test_cli_dvf500_end_to_end.gc_plain = gc0
+
+
+def test_translated_unmasked_conv_then_pool_is_not_taken_by_the_table_net():
+    """A six-frame model whose first conv is unmasked and feeds the pool directly has the op pattern of a strand branch;
+    its pool runs over frames x positions, so it must stay on the layer-by-layer kernels."""
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("baseline500"))
+    cfg["use_masking"] = False
+    cfg["representation_learner"] = {"hidden_layers": [
+        {"name": "masked_conv1d", "config": {"filters": 32, "kernel_size": 7, "activation": "gelu", "use_masking": False}}],
+        "pooling": "max"}
+    cfg["classifier"]["input_shape"] = 32
+    weights = ofwd.random_weights(cfg, seed=5)
+    rng = np.random.default_rng(13)
+    fsize, n_win = 500, 40
+    seq = _dna(rng, fsize * n_win, n_frac=0.01)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0)
+    assert "table-net" not in eng.model.describe()
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    eng.close()
+    ids = oenc.encode_windows([seq[s:s + fsize].tobytes() for s in starts], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    assert float(np.abs(got["prediction"] - ref["prediction"]).max()) <= TOL
