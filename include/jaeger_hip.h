@@ -142,8 +142,11 @@ int jg_engine_sync(jg_engine *e);
  * gap count through the dynamic programme, instead of only those the packed score-only pass leaves open (score > 100);
  * same table either way (tests/test_gpu_termini.py).
  * JG_OPT_DUST_ON_COPY_STREAM (default 1): the DUST pass of a streamed span runs on the copy stream behind the span's upload
- * (beside the previous group's convolutions) or, 0, on the compute stream in front of the span's encoder; same masks. */
-enum { JG_OPT_STREAM_BYTES = 1, JG_OPT_CONV_PC = 2, JG_OPT_TERMINI_EXACT = 3, JG_OPT_DUST_ON_COPY_STREAM = 4 };
+ * (beside the previous group's convolutions) or, 0, on the compute stream in front of the span's encoder; same masks.
+ * JG_OPT_TABLE_NET_LDS (default 0): a strand branch's conv + pool ("table net") runs on the matrix cores (0) or, 1, as the
+ * exact-f32 LDS-table kernel - the form every shape the matrix-core kernel does not cover takes anyway. */
+enum { JG_OPT_STREAM_BYTES = 1, JG_OPT_CONV_PC = 2, JG_OPT_TERMINI_EXACT = 3, JG_OPT_DUST_ON_COPY_STREAM = 4,
+       JG_OPT_TABLE_NET_LDS = 5 };
 int jg_engine_set_option(jg_engine *e, int key, int64_t value);
 /* statistics of the engine's last jg_predict_windows call: number of streamed groups (0 = not streamed), bytes sent
  * through the staging buffers, peak bytes of bases resident on the device.  JG_STAT_WINDOWS_DONE may be read from

@@ -105,6 +105,9 @@ extern "C" int jg_engine_set_option(jg_engine *e, int key, int64_t value) {
     case JG_OPT_DUST_ON_COPY_STREAM:
       e->dust_on_copy = value != 0;
       return JG_OK;
+    case JG_OPT_TABLE_NET_LDS:
+      e->tab_lds_only = value != 0;
+      return JG_OK;
     default:
       jg_set_error("jg_engine_set_option: unknown key %d", key);
       return JG_ERR_INVALID;
@@ -751,6 +754,29 @@ static int prepare_tab(jg_model *m, const float *weights) {
   JG_HIP(hipMemcpy(m->tab_table, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
   JG_HIP(hipMalloc(reinterpret_cast<void **>(&m->tab_bias), bias.size() * sizeof(float)));
   JG_HIP(hipMemcpy(m->tab_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (row0_zero && jg_tab_mfma_supports(c.k, m->vocab, c.cout, c.dilation)) {
+    // the same table as MFMA A-operand fragments (jg_tabnet.hip): [32-channel tile][k-step of 4 taps][hi | lo][lane][8]
+    const int ks = (c.k + 3) / 4;
+    std::vector<uint16_t> frag((size_t)jg_tab_mfma_frag_halves(c.k), 0);
+    for (int tile = 0; tile < 16; ++tile)
+      for (int st = 0; st < ks; ++st)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int co = tile * 32 + (lane & 31), kk = (lane >> 5) * 8 + j, tap = 4 * st + kk / 4, nuc = kk % 4;
+            if (co >= c.cout || tap >= c.k) continue;
+            const float v = tab[((size_t)tap * V + (nuc + 1)) * cq * 4 + co];
+            const float hi = f16_value(v);
+            const size_t base = (((size_t)tile * ks + st) * 2) * 64 * 8;
+            frag[base + (size_t)lane * 8 + j] = f16_bits(hi);
+            frag[base + 64 * 8 + (size_t)lane * 8 + j] = f16_bits(v - hi);
+          }
+    std::vector<float> b512(512, 0.f);
+    for (int n = 0; n < c.cout; ++n) b512[(size_t)n] = bias[(size_t)n];
+    JG_HIP(hipMalloc(reinterpret_cast<void **>(&m->tab_wfrag), frag.size() * sizeof(uint16_t)));
+    JG_HIP(hipMemcpy(m->tab_wfrag, frag.data(), frag.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    JG_HIP(hipMalloc(reinterpret_cast<void **>(&m->tab_bias512), b512.size() * sizeof(float)));
+    JG_HIP(hipMemcpy(m->tab_bias512, b512.data(), b512.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   m->tab_conv = 0;
   m->tab_pool = 1;
   m->tab_act = act;
@@ -1288,6 +1314,8 @@ extern "C" int jg_model_destroy(jg_model *m) {
   free_small(m);
   for (int i = 0; i < JG_MAX_VECS; ++i)
     if (m->merged[i]) (void)hipFree(m->merged[i]);
+  if (m->tab_wfrag) (void)hipFree(m->tab_wfrag);
+  if (m->tab_bias512) (void)hipFree(m->tab_bias512);
   if (m->tab_table) (void)hipFree(m->tab_table);
   if (m->tab_bias) (void)hipFree(m->tab_bias);
   if (m->d_w) (void)hipFree(m->d_w);
@@ -1486,7 +1514,17 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         pe.cls = JG_PROF_TABLE;
         JG_HIP(hipEventRecord(pe.a, s));
       }
-      if ((rc = jg_launch_tab_conv_pool(e, a, s)) != JG_OK) return rc;
+      if (m->tab_wfrag != nullptr && (l + 64 + 16 * op.dilation) <= 60 * 1024 && !e->tab_lds_only) {
+        JgTabMArgs ma;
+        memset(&ma, 0, sizeof(ma));
+        ma.ids = d_ids; ma.wfrag = m->tab_wfrag; ma.bias = m->tab_bias512; ma.out = a.out; ma.out_ld = a.out_ld;
+        ma.rows = a.rows; ma.L = l; ma.L_out = lo; ma.pad_left = pl; ma.k = op.k; ma.dil = op.dilation; ma.cout = op.cout;
+        ma.act = m->tab_act; ma.pool_kind = po.arg;
+        rc = jg_launch_tab_mfma(e, ma, s);
+      } else {
+        rc = jg_launch_tab_conv_pool(e, a, s);
+      }
+      if (rc != JG_OK) return rc;
       if (e->profile) {
         JG_HIP(hipEventRecord(pe.b, s));
         e->pending.push_back(pe);

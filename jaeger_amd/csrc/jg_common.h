@@ -166,6 +166,7 @@ struct jg_engine {
   int n_cu = 256;
   int dust_on_copy = 1;           // JG_OPT_DUST_ON_COPY_STREAM: streamed spans are soft-masked on the copy stream (1) or in front of their encoder (0)
   int termini_exact = 0;          // JG_OPT_TERMINI_EXACT: every terminal-repeat alignment through the length / gap carrying kernel
+  int tab_lds_only = 0;           // JG_OPT_TABLE_NET_LDS: keep the table net on the LDS-table kernel
   int conv_pc = 0;                // JG_OPT_CONV_PC: producer / consumer kernel for the 128-channel five-tap convs
   // streamed ingest of host-resident bases (jg_predict_windows): spans above `stream_bytes` go through two pinned
   // staging buffers and two device buffers on a copy stream, record group by record group
@@ -272,6 +273,8 @@ struct jg_model {
   float *tab_table = nullptr;       // (k, vocab, cq) float4 quads, cq = ceil(cout / 4)
   float *tab_bias = nullptr;        // (cq) quads (zeros without a bias stage)
   int tab_conv = -1, tab_pool = -1; // ops replaced by the kernel (-1: the program does not match)
+  uint16_t *tab_wfrag = nullptr;    // matrix-core form of the table (nucleotide one-hot input): jg_tabnet.hip
+  float *tab_bias512 = nullptr;
   int tab_act = 0, tab_cq = 0, tab_vocab = 0, tab_zero = 0;   // table rows incl. an appended zero row when row 0 is not one
   int part_rows[JG_MAX_BUFS] = {};  // split-f16 path: partial rows per window the last conv wrote to each NMD slot
   int pool_rows = 0;                // same for the fused max pool
@@ -314,6 +317,17 @@ struct JgTabArgs {
   int zero_id;             // table row that is all zeros in every tap (positions outside the sequence select it)
 };
 int64_t jg_tab_lds_bytes(int k, int vocab, int cq, int L, int dil);
+// the same op on the matrix cores (jg_tabnet.hip): nucleotide one-hot rows only (vocab 5, table row 0 = zeros)
+struct JgTabMArgs {
+  const uint8_t *ids;      // (rows, L)
+  const uint16_t *wfrag;   // f16 weight fragments, hi | lo planes (jg_tab_mfma_frag_halves)
+  const float *bias;       // 512 floats (zero padded)
+  float *out;              // (rows, out_ld)
+  int out_ld, rows, L, L_out, pad_left, k, dil, cout, act, pool_kind;
+};
+bool jg_tab_mfma_supports(int k, int vocab, int cout, int dil);
+int64_t jg_tab_mfma_frag_halves(int k);
+int jg_launch_tab_mfma(jg_engine *e, const JgTabMArgs &a, hipStream_t s);
 int jg_launch_tab_conv_pool(jg_engine *e, const JgTabArgs &a, hipStream_t s);
 int jg_launch_strand_merge(const float *x, int x_ld, int n_win, int strands, int width, int kind, float *y, hipStream_t s);
 int jg_launch_framesum(const float *x, int n_win, int frames, int64_t per_frame, float *y,

@@ -88,6 +88,11 @@ class HipDevice:
         """Host base buffers above ``nbytes`` are streamed through pinned staging buffers (JG_OPT_STREAM_BYTES)."""
         L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_STREAM_BYTES, int(nbytes)), "jg_engine_set_option")
 
+    def set_table_net_lds(self, on: bool):
+        """A strand branch's conv + pool on the exact-f32 LDS-table kernel (True) instead of the matrix cores
+        (JG_OPT_TABLE_NET_LDS; tests and A/B timing)."""
+        L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_TABLE_NET_LDS, int(bool(on))), "jg_engine_set_option")
+
     def set_conv_pc(self, on: bool):
         """Experiment build only (libjaeger_hip_exp.so): 128 -> 128 five-tap convs on the producer / consumer kernel (1) or
         on the two-workgroup kernel with the pipelined main loop (2) instead of the two-workgroup kernel (0, the default

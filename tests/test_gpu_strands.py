@@ -47,7 +47,7 @@ def test_nucleotide_encoder_bit_exact():
     dev.close()
 
 
-def _case(cfg, n_win, fsize, seed, short=False, n_frac=0.01, chunk=0, precision=None):
+def _case(cfg, n_win, fsize, seed, short=False, n_frac=0.01, chunk=0, precision=None, lds=False):
     from jaeger_amd.engine import JaegerHipEngine
     from oracle import encoder as oenc
     from oracle import strands as ost
@@ -61,6 +61,7 @@ def _case(cfg, n_win, fsize, seed, short=False, n_frac=0.01, chunk=0, precision=
     with pytest.warns(UserWarning, match="embedding.type is not 'nucleotide'"):
         eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, chunk=chunk, precision=precision)
     assert eng.string_processor_config["input_type"] == "nucleotide" and eng.model.strands == 2
+    eng.device.set_table_net_lds(lds)        # the strand branch on the LDS-table kernel instead of the matrix cores
     got = eng.predict_windows(seq, starts, lens, fsize)
     windows = [seq[s:s + n].tobytes() for s, n in zip(starts, lens)]
     ids = ost.encode_nucleotide(windows, fsize, pad_to=fsize)
@@ -79,14 +80,16 @@ def _case(cfg, n_win, fsize, seed, short=False, n_frac=0.01, chunk=0, precision=
     return got
 
 
-def test_forward_dvf500_vs_oracle():
-    _case(load_model_cfg("dvf500"), 96, 500, seed=1)
+@pytest.mark.parametrize("lds", [False, True])
+def test_forward_dvf500_vs_oracle(lds):
+    _case(load_model_cfg("dvf500"), 96, 500, seed=1, lds=lds)
 
 
-def test_forward_dvf500_ragged_windows_and_chunks():
+@pytest.mark.parametrize("lds", [False, True])
+def test_forward_dvf500_ragged_windows_and_chunks(lds):
     """Windows shorter than the crop are zero padded to the row length (what padded_batch does to a batch whose longest
     window is fsize); three passes of 40 windows."""
-    _case(load_model_cfg("dvf500"), 100, 500, seed=2, short=True, n_frac=0.05, chunk=40)
+    _case(load_model_cfg("dvf500"), 100, 500, seed=2, short=True, n_frac=0.05, chunk=40, lds=lds)
 
 
 def test_forward_dvf500_exact_f32_and_other_fsize():
@@ -100,17 +103,19 @@ def test_forward_dvf500_merge_methods(method):
     _case(cfg, 24, 500, seed=4)
 
 
-def test_dvf500_average_pool_and_gelu_branch():
+@pytest.mark.parametrize("lds", [False, True])
+def test_dvf500_average_pool_and_gelu_branch(lds):
     cfg = copy.deepcopy(load_model_cfg("dvf500"))
     cfg["representation_learner"]["branch"] = {"hidden_layers": [
         {"name": "conv1d", "config": {"filters": 64, "kernel_size": 7, "activation": "gelu"}}], "pooling": "average1d"}
     cfg["classifier"]["branch"]["hidden_layers"] = [
         {"name": "dense", "config": {"units": 16}}, {"name": "tanh"}, {"name": "dense", "config": {"units": 3}},
         {"name": "merge", "config": {"method": "average"}}]
-    _case(cfg, 40, 500, seed=6)
+    _case(cfg, 40, 500, seed=6, lds=lds)
 
 
-def test_dvf500_same_padding_dilated_branch():
+@pytest.mark.parametrize("lds", [False, True])
+def test_dvf500_same_padding_dilated_branch(lds):
     """'same' padding and a dilated kernel: taps outside the strand add nothing (table-net kernel's pad_left path)."""
     cfg = copy.deepcopy(load_model_cfg("dvf500"))
     cfg["representation_learner"]["branch"] = {"hidden_layers": [
@@ -118,7 +123,7 @@ def test_dvf500_same_padding_dilated_branch():
         {"name": "sigmoid"}], "pooling": "max1d"}
     cfg["classifier"]["branch"]["hidden_layers"] = [
         {"name": "dense", "config": {"units": 3}}, {"name": "merge", "config": {"method": "average"}}]
-    _case(cfg, 40, 400, seed=7, short=True)
+    _case(cfg, 40, 400, seed=7, short=True, lds=lds)
 
 
 def test_dvf_wide_conv_runs_layer_by_layer():
