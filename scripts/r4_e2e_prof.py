@@ -45,7 +45,8 @@ mbp = bases.size / 1e6
 from jaeger_amd.predict import run_core  # noqa: E402
 
 models = {"brain": (make_model_dir(tmp / "m_brain"), 1500),
-          "baseline500": (make_model_dir(tmp / "m_b500", name="baseline500", model_name="jaeger_500bp_baseline"), 500)}
+          "baseline500": (make_model_dir(tmp / "m_b500", name="baseline500", model_name="jaeger_500bp_baseline"), 500),
+          "dvf500": (make_model_dir(tmp / "m_dvf", name="dvf500", model_name="jaeger_500bp_dvf"), 500)}
 for name, (mdir, fsize) in models.items():
     if which not in ("both", name):
         continue
