@@ -754,7 +754,9 @@ static int prepare_tab(jg_model *m, const float *weights) {
   JG_HIP(hipMemcpy(m->tab_table, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
   JG_HIP(hipMalloc(reinterpret_cast<void **>(&m->tab_bias), bias.size() * sizeof(float)));
   JG_HIP(hipMemcpy(m->tab_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
-  if (row0_zero && jg_tab_mfma_supports(c.k, m->vocab, c.cout, c.dilation)) {
+  bool f16_range = true;                                          // (a weight beyond the f16 range keeps the exact-f32 form)
+  for (float v : tab) f16_range &= std::fabs(v) < 32768.f;
+  if (row0_zero && f16_range && jg_tab_mfma_supports(c.k, m->vocab, c.cout, c.dilation)) {
     // the same table as MFMA A-operand fragments (jg_tabnet.hip): [32-channel tile][k-step of 4 taps][hi | lo][lane][8]
     const int ks = (c.k + 3) / 4;
     std::vector<uint16_t> frag((size_t)jg_tab_mfma_frag_halves(c.k), 0);
