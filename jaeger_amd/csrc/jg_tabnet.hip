@@ -42,6 +42,11 @@ __device__ __forceinline__ float vmax(float x, float y) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
   return r;
 }
+__device__ __forceinline__ float vmax3(float x, float y, float z) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  return r;
+}
 
 // one block of 32 positions: acc[c][r] = sum over the taps of one-hot(ids) x W (hi + lo) for position (r >> 2) * 8 + 4 hh + (r & 3)
 // of the block and channel n of tile c.  Positions are the MFMA's M axis (A operand, built here from two id bytes per k-step:
@@ -77,11 +82,17 @@ __device__ __forceinline__ void tab_fold(float (&pool)[TM_CT], const f32x16 (&ac
   for (int c = 0; c < TM_CT; ++c) {
     float v = pool[c];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float x = acc[c][r];
-      if (!LATE) x = tabm_act(x + bias[c], act);
-      if (left < 32) x = (r >> 2) * 8 + hh * 4 + (r & 3) < left ? x : (MAXP ? -INFINITY : 0.f);
-      v = MAXP ? vmax(v, x) : v + x;
+    for (int r = 0; r < 16; r += 2) {
+      float x = acc[c][r], y = acc[c][r + 1];
+      if (!LATE) {
+        x = tabm_act(x + bias[c], act);
+        y = tabm_act(y + bias[c], act);
+      }
+      if (left < 32) {
+        x = (r >> 2) * 8 + hh * 4 + (r & 3) < left ? x : (MAXP ? -INFINITY : 0.f);
+        y = (r >> 2) * 8 + hh * 4 + (r & 3) + 1 < left ? y : (MAXP ? -INFINITY : 0.f);
+      }
+      v = MAXP ? vmax3(v, x, y) : v + x + y;                      // (two positions per instruction: a third of the fold's issue slots)
     }
     pool[c] = v;
   }
@@ -89,7 +100,8 @@ __device__ __forceinline__ void tab_fold(float (&pool)[TM_CT], const f32x16 (&ac
 
 // MFMAs of one block interleaved with the vector work of the previous block's fold (an MFMA leaves 24 of its 32 cycles to
 // the vector pipe: MI355X guide, cycle constants).  Vector instructions per MFMA, measured on the DVF branch (200 000 windows,
-// whole call): 3 -> 26.3 ms, 4 -> 25.8, 5 -> 26.2, 6 -> 26.5, 9 -> 26.8; without the software pipeline (first form) 52.9
+// whole call): 3 -> 26.3 ms, 4 -> 25.8 (25.2 with two positions per v_max3_f32), 5 -> 26.2, 6 -> 26.5, 9 -> 26.8; without the
+// software pipeline (first form) 52.9
 template <int KS>
 __device__ __forceinline__ void tab_interleave() {
 #pragma unroll
