@@ -394,6 +394,8 @@ static int validate_program(const jg_model *m) {
 
 // Dry-run the program at `l` codons per frame: per-slot element counts (per
 // window) and vector widths.  Also used to validate that shapes line up.
+bool jg_tab_mfma_row_fits(int L_out, int k, int dil);       // jg_tabnet.hip: the matrix-core form's id image holds the row
+
 // rows of l positions run on the table-net kernel (else - rows too long for the LDS image - layer by layer)
 static bool tab_usable(const jg_model *m, int l) {
   if (m->tab_conv < 0) return false;
@@ -1516,7 +1518,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
         pe.cls = JG_PROF_TABLE;
         JG_HIP(hipEventRecord(pe.a, s));
       }
-      if (m->tab_wfrag != nullptr && (l + 64 + 16 * op.dilation) <= 60 * 1024 && !e->tab_lds_only) {
+      if (m->tab_wfrag != nullptr && jg_tab_mfma_row_fits(lo, op.k, op.dilation) && !e->tab_lds_only) {
         JgTabMArgs ma;
         memset(&ma, 0, sizeof(ma));
         ma.ids = d_ids; ma.wfrag = m->tab_wfrag; ma.bias = m->tab_bias512; ma.out = a.out; ma.out_ld = a.out_ld;

@@ -18,6 +18,8 @@
 #include "jg_common.h"
 #include "jg_conv_dev.h"
 
+bool jg_tab_mfma_row_fits(int L_out, int k, int dil);
+
 namespace {
 
 constexpr int TM_CT = 4;       // 32-channel tiles per wave (4 waves: up to 512 channels)
@@ -131,19 +133,35 @@ __global__ __launch_bounds__(256) void tab_mfma_kernel(JgTabMArgs a) {
   const int nb = (a.L_out + 31) >> 5;                             // blocks of 32 positions
   const int n_sid = nb * 32 + 4 * KS * a.dil;                     // entry i = sequence position i - pad_left
   const int left_last = a.L_out - (nb - 1) * 32;
-  for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
-    __syncthreads();
+  // the next row's ids travel from HBM while this row is computed: a thread keeps its (up to four) bytes in registers and
+  // drops them into the other half of the LDS image behind the row's last MFMA (one barrier per row, no load in its way)
+  const int sid_pitch = (n_sid + 15) & ~15;
+  auto fetch = [&](int row, uint8_t (&v)[4]) {
     const uint8_t *src = a.ids + (size_t)row * a.L;
-    for (int i = tid; i < n_sid; i += 256) {
-      const int pos = i - a.pad_left;
-      tm_sid[i] = pos >= 0 && pos < a.L ? src[pos] : (uint8_t)0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + 256 * q, pos = i - a.pad_left;
+      v[q] = row < a.rows && i < n_sid && pos >= 0 && pos < a.L ? src[pos] : (uint8_t)0;
     }
-    __syncthreads();
+  };
+  auto stash = [&](uint8_t *dst, const uint8_t (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (tid + 256 * q < n_sid) dst[tid + 256 * q] = v[q];
+  };
+  uint8_t nxt[4];
+  fetch(blockIdx.x, nxt);
+  stash(tm_sid, nxt);
+  int buf = 0;
+  for (int row = blockIdx.x; row < a.rows; row += gridDim.x, buf ^= 1) {
+    __syncthreads();                                              // this row's image is complete; the other half is free
+    fetch(row + gridDim.x, nxt);
+    const uint8_t *sid_row = tm_sid + buf * sid_pitch;
     float pool[TM_CT];
 #pragma unroll
     for (int c = 0; c < TM_CT; ++c) pool[c] = MAXP ? -INFINITY : 0.f;
     // software pipeline over the blocks: block b's MFMAs run while block b - 1's accumulators fold into the pool
-    const uint8_t *sp = tm_sid + n + 2 * hh * a.dil;
+    const uint8_t *sp = sid_row + n + 2 * hh * a.dil;
     f32x16 accA[TM_CT], accB[TM_CT];
     tab_block<KS>(W, sp, a.dil, accA);
     int b = 1;
@@ -174,13 +192,14 @@ __global__ __launch_bounds__(256) void tab_mfma_kernel(JgTabMArgs a) {
       else if (!MAXP) v = v / (float)a.L_out;
       if (hh == 0 && ch < a.cout) a.out[(size_t)row * a.out_ld + ch] = v;
     }
+    stash(tm_sid + (buf ^ 1) * sid_pitch, nxt);
   }
 }
 
 template <int KS>
 int launch_ks(jg_engine *e, const JgTabMArgs &a, bool late, hipStream_t s) {
-  const size_t smem = (size_t)((((a.L_out + 31) & ~31) + 4 * KS * a.dil + 15) & ~15);
-  JG_REQUIRE(smem <= 64 * 1024, JG_ERR_UNSUPPORTED, "table net: row of %d positions does not fit the id image", a.L_out);
+  const size_t smem = 2 * (size_t)((((a.L_out + 31) & ~31) + 4 * KS * a.dil + 15) & ~15);      // two rows' id images
+  JG_REQUIRE(jg_tab_mfma_row_fits(a.L_out, a.k, a.dil), JG_ERR_UNSUPPORTED, "table net: row of %d positions does not fit the id image", a.L_out);
   const int grid = (int)std::min<int64_t>(a.rows, (int64_t)2 * e->n_cu);
   if (late) hipLaunchKernelGGL((tab_mfma_kernel<KS, true, true>), dim3((unsigned)grid), dim3(256), smem, s, a);
   else if (a.pool_kind != JG_POOL_AVG) hipLaunchKernelGGL((tab_mfma_kernel<KS, false, true>), dim3((unsigned)grid), dim3(256), smem, s, a);
@@ -190,6 +209,9 @@ int launch_ks(jg_engine *e, const JgTabMArgs &a, bool late, hipStream_t s) {
 }
 
 }  // namespace
+
+// a row's id image (positions rounded up to blocks of 32 + the taps' reach) must fit the four bytes a thread prefetches
+bool jg_tab_mfma_row_fits(int L_out, int k, int dil) { return ((L_out + 31) & ~31) + 4 * ((k + 3) / 4) * dil <= 1024; }
 
 bool jg_tab_mfma_supports(int k, int vocab, int cout, int dil) {
   return vocab == 5 && k >= 1 && k <= 16 && cout >= 1 && cout <= 128 * TM_CT && dil >= 1 && dil <= 64;

@@ -96,6 +96,11 @@ def test_forward_dvf500_exact_f32_and_other_fsize():
     _case(load_model_cfg("dvf500"), 32, 300, seed=3, precision="f32")
 
 
+def test_forward_dvf500_long_rows_take_the_lds_form():
+    """Rows of 1 200 bases do not fit the matrix-core kernel's prefetched id image (1 024 bytes): the LDS-table kernel runs."""
+    _case(load_model_cfg("dvf500"), 12, 1200, seed=10, short=True)
+
+
 @pytest.mark.parametrize("method", ["sum", "max"])
 def test_forward_dvf500_merge_methods(method):
     cfg = copy.deepcopy(load_model_cfg("dvf500"))
