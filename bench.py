@@ -167,23 +167,62 @@ def visible_gpus() -> int:
     return len(list(dri.glob("renderD*"))) if dri.is_dir() else 0
 
 
-def kernel_hash() -> str:
-    """Fingerprint of the conv-kernel sources: the PMC summaries under profiles/ record it, and a bench line only
-    quotes counters that were collected on the build it is timing."""
+def kernel_hash(mode: str = "f16x3") -> str:
+    """Fingerprint of the sources of the kernels a line's dominant-kernel figures come from: the PMC summaries under
+    profiles/ record it, and a bench line only quotes counters that were collected on the build it is timing.  Split-f16
+    lines: the conv device headers, the instantiation file and the fused small-window kernel; exact-f32 lines add
+    ``jg_kernels.hip`` (``conv_f32_kernel``) - their hash is a different one on purpose."""
     import hashlib
     h = hashlib.sha256()
     src = ROOT / "jaeger_amd" / "csrc"
-    for name in ("jg_common.h", "jg_conv_dev.h", "jg_conv_f16.hip", "jg_conv_f16_impl.h", "jg_small.h", "jg_small.hip"):
+    names = ["jg_common.h", "jg_conv_dev.h", "jg_conv_f16.hip", "jg_conv_f16_impl.h", "jg_small.h", "jg_small.hip"]
+    if mode == "f32":
+        names.append("jg_kernels.hip")
+    for name in names:
         h.update((src / name).read_bytes())
     return h.hexdigest()[:16]
 
 
-def e2e_leg(cfg, weights, wl, fsize):
+def write_fasta_contigs(path, lengths, bases):
+    """Contigs of any length, 80 bases per line, headers ``>contig_<i> len=<n>``."""
+    with open(path, "wb") as fh:
+        off = 0
+        for i, n in enumerate(lengths.tolist()):
+            fh.write(b">contig_%d len=%d\n" % (i, n))
+            seq = bases[off:off + n].tobytes()
+            off += n
+            fh.write(b"\n".join(seq[j:j + 80] for j in range(0, n, 80)) + b"\n")
+
+
+def write_fasta_records(path, bases2d):
+    """``n`` records of one length (the fragment workloads as a file), one sequence line each, fixed-width headers
+    ``>r0000123`` - the whole file image is built as one numpy array (a million records in well under a second)."""
+    n, length = bases2d.shape
+    width = max(7, len(str(max(n - 1, 0))))
+    img = np.empty((n, 1 + 1 + width + 1 + length + 1), np.uint8)
+    img[:, 0] = ord(">")
+    img[:, 1] = ord("r")
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(width):
+        img[:, 2 + d] = (idx // 10 ** (width - 1 - d)) % 10 + ord("0")
+    img[:, 2 + width] = ord("\n")
+    img[:, 3 + width:3 + width + length] = bases2d
+    img[:, -1] = ord("\n")
+    with open(path, "wb") as fh:
+        fh.write(memoryview(img.reshape(-1)))
+
+
+def e2e_leg(cfg, weights, wl, fsize, records: int = 0, seed: int | None = None):
     """FASTA on tmpfs -> ``jaeger_amd.predict.run_core`` in-process (defaults: DUST on, host pipeline on) -> TSV:
     the end-to-end figure SURVEY 8(d) asks for next to the resident-input metric (commands/predict.py:488-860).
-    The file is the 10 000-contig mixture of BASELINE configs[1] (PCG64(20260923), log-uniform 1.5 - 200 kb) for every
-    model family - a realistic assembly, not the million single-window records of the kernel workloads.  The FASTA and
-    the model directory are written before the clock starts; the stage split is run_core's own (``LAST_RUN``)."""
+    ``records == 0``: the file is the 10 000-contig mixture of BASELINE configs[1] (PCG64(20260923), log-uniform
+    1.5 - 200 kb) for every model family - a realistic assembly.  ``records > 0``: the fragment workload itself as a file
+    (``records`` sequences of exactly ``fsize`` bases, PCG64(``seed``)) - per-record host work (names, window table,
+    aggregation, repeat scan, one TSV row per record) is what that run prices.  The FASTA and the model directory are
+    written before the clock starts; the stage split is run_core's own (``LAST_RUN``).  Two runs in this process: the
+    FIRST pays the file's first page-cache touch and whatever run_core imports lazily (the HIP runtime and the library are
+    already loaded by the bench itself - a CLI user's cold start is in DESIGN 6, not here), the second is warm; both are
+    reported by name and ``mbps`` is the better of the two (the protocol of round 4's lines)."""
     import shutil
     import tempfile
 
@@ -191,19 +230,18 @@ def e2e_leg(cfg, weights, wl, fsize):
 
     from jaeger_amd import predict as P
     from jaeger_amd.weights import save_npz
-    rng = np.random.Generator(np.random.PCG64(CONFIGS["default"]["seed"]))
-    lengths, bases = synth_contigs(rng, CONFIGS["default"]["contigs"])
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     tmp = Path(tempfile.mkdtemp(prefix="jaeger_bench_e2e_", dir=base))
     try:
         fa = tmp / "bench.fasta"
-        with open(fa, "wb") as fh:
-            off = 0
-            for i, n in enumerate(lengths.tolist()):
-                fh.write(b">contig_%d len=%d\n" % (i, n))
-                seq = bases[off:off + n].tobytes()
-                off += n
-                fh.write(b"\n".join(seq[j:j + 80] for j in range(0, n, 80)) + b"\n")
+        if records:
+            rng = np.random.Generator(np.random.PCG64(wl["seed"] if seed is None else seed))
+            bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, records * fsize, dtype=np.uint8)]
+            write_fasta_records(fa, bases.reshape(records, fsize))
+        else:
+            rng = np.random.Generator(np.random.PCG64(CONFIGS["default"]["seed"]))
+            lengths, bases = synth_contigs(rng, CONFIGS["default"]["contigs"])
+            write_fasta_contigs(fa, lengths, bases)
         mdir = tmp / "model_root" / "model"
         mdir.mkdir(parents=True)
         name = "bench_model"
@@ -212,20 +250,25 @@ def e2e_leg(cfg, weights, wl, fsize):
         save_npz(mdir / f"{name}.weights.npz", weights)
         out = tmp / "out"
         runs = []
-        for _ in range(2):                 # the first run also pays the file's first page-cache touch; both are reported
+        for _ in range(2):
             t0 = time.perf_counter()
             n_rows = P.run_core(input=str(fa), output=str(out), model_path=str(tmp / "model_root"), fsize=fsize, stride=fsize,
                                 overwrite=True, dustmask=True, verbose=0, batch=96, rc=0.1, pc=3)
             runs.append((time.perf_counter() - t0, dict(P.LAST_RUN)))
         dt, stages = min(runs, key=lambda r: r[0])
         tsv = next(out.rglob("bench.tsv"), None)
+        what = (f"{records} records of exactly {fsize} bp as a FASTA (tmpfs)" if records else
+                "10 000-contig synthetic FASTA (tmpfs)")
         return {"mbps": round(bases.size / dt / 1e6, 2), "seconds": round(dt, 3), "bp": int(bases.size),
+                "first_run_mbps": round(bases.size / runs[0][0] / 1e6, 2),
+                "second_run_mbps": round(bases.size / runs[1][0] / 1e6, 2),
                 "seconds_each_run": [round(r[0], 3) for r in runs], "tsv_rows": int(n_rows or 0),
                 "tsv_bytes": tsv.stat().st_size if tsv else 0, "stages": stages,
-                "what": "10 000-contig synthetic FASTA (tmpfs) -> parallel ingest -> one fused call (DUST on the GPU, window "
-                        "table, encode + forward, host buffers over PCIe through pinned staging) with the terminal-repeat "
-                        "scan and the per-contig aggregation beside it -> TSV; in-process run_core with its defaults, best "
-                        "of two runs; writing the FASTA / model directory is outside the clock"}
+                "what": what + " -> parallel ingest -> one fused call (DUST on the GPU, window table, encode + forward, "
+                        "host buffers over PCIe through pinned staging) with the terminal-repeat scan and the per-contig "
+                        "aggregation beside it -> TSV; in-process run_core with its defaults; mbps = the better of two "
+                        "runs in this process (first_run_mbps / second_run_mbps name them); writing the FASTA / model "
+                        "directory is outside the clock"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -233,14 +276,13 @@ def e2e_leg(cfg, weights, wl, fsize):
 def pmc_fields(name: str, mode: str, fsize: int, chunk: int, avg_launch_ms: float):
     """HBM traffic and matrix-core utilisation of the dominant kernel from the committed rocprofv3 --pmc summaries
     (profiles/pmc_traffic.json, profiles/mfma_util.json) - attached only when they were collected on THIS kernel build."""
-    out = {"traffic": None, "hbm_gbs": None, "mfma_busy_frac": None, "eff_clock_ghz": None, "pmc_kernel_hash": None,
-           "pmc_stale": None}
+    out = {"traffic": None, "hbm_gbs": None, "other_device": None, "pmc_kernel_hash": None, "pmc_stale": None}
     try:
         tr = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
         mu = json.loads((ROOT / "profiles" / "mfma_util.json").read_text())
     except (OSError, ValueError):
         return out
-    here = kernel_hash()
+    here = kernel_hash(mode)
     key = {"default": "conv_f16x3_kernel", "baseline500": "small_net_kernel"}.get(name)
     if key is None or mode != "f16x3" or chunk != 0:
         return out
@@ -254,8 +296,13 @@ def pmc_fields(name: str, mode: str, fsize: int, chunk: int, avg_launch_ms: floa
     out["traffic"] = t.get("traffic_bytes_per_launch")
     if out["traffic"] and avg_launch_ms > 0:
         out["hbm_gbs"] = round(out["traffic"] / (avg_launch_ms * 1e-3) / 1e9, 1)
-    out["mfma_busy_frac"] = m.get("mfma_busy_frac")
-    out["eff_clock_ghz"] = m.get("eff_clock_ghz")
+    # matrix-core busy share and effective clock are properties of the DEVICE the counters were collected on (and of a
+    # profiled run): they are quoted as such, next to the launch duration they belong to - this run's device is
+    # calibrated by `box` instead
+    out["other_device"] = {"mfma_busy_frac": m.get("mfma_busy_frac"), "eff_clock_ghz": m.get("eff_clock_ghz"),
+                           "avg_launch_ms_there": m.get("avg_launch_ms_sq_pass"),
+                           "note": "collected under rocprofv3 --pmc on another device (profiles/mfma_util.json), not on "
+                                   "the device this line was timed on"}
     return out
 
 
@@ -336,6 +383,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the short exact-f32 side measurement")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end FASTA -> TSV leg")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the other BASELINE configs (`also`: frag1m and baseline500 at 2 timed steps each)")
+    ap.add_argument("--no-box", action="store_true", help="skip the box calibration (bare MFMA loop behind the timed steps)")
+    ap.add_argument("--box-seconds", type=float, default=0.5)
     ap.add_argument("--no-profile", action="store_true",
                     help="experiments only: no HIP events around the conv launches (roofline fields read 0)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -390,21 +441,40 @@ def main():
     dev_t = torch.device("cuda", local_rank)
     coll_dev = torch.device("cpu") if (world > 1 and args.oversubscribe) else dev_t
 
+    ctx = dict(torch=torch, dist=dist, rank=rank, world=world, local_rank=local_rank, dev_t=dev_t, coll_dev=coll_dev)
+    line = measure(args, args.config, args.steps, args.warmup, ctx, headline=True)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure(args, name: str, steps: int, warmup: int, ctx: dict, headline: bool):
+    """One workload: ``warmup`` untimed steps, ``steps`` timed steps between fences, the line's fields on rank 0 (None on
+    the other ranks).  ``headline``: the run's own config - it carries the exact-f32 side measurement, the end-to-end
+    leg, the box calibration (straight behind the timed steps, before anything else touches the GPU), the other BASELINE
+    configs as ``also`` and the CPU baseline."""
+    import warnings
+
+    import yaml
+
+    from jaeger_amd import _lib
+    from jaeger_amd import dist as jdist
     from jaeger_amd.engine import JaegerHipEngine, frame_length
     from jaeger_amd.fragment import build_window_table
-    from jaeger_amd import dist as jdist
-    from jaeger_amd import _lib
     from jaeger_amd.plan import build_plan
     from jaeger_amd.weights import random_weights
 
-    wl = CONFIGS[args.config]
+    torch, dist = ctx["torch"], ctx["dist"]
+    rank, world, local_rank, dev_t, coll_dev = ctx["rank"], ctx["world"], ctx["local_rank"], ctx["dev_t"], ctx["coll_dev"]
+    wl = CONFIGS[name]
     cfg = yaml.safe_load((ROOT / "tests" / "golden" / f"{wl['model']}_project.yaml").read_text())["model"]
     weights = random_weights(build_plan(cfg), seed=38341)
     if wl.get("gain"):                  # He-uniform stand-in kernels blow a 36-conv residual pyramid's logits up to +-900
         for key in weights:
             if key.startswith("rep/") and key.endswith("/kernel"):
                 weights[key] = weights[key] * np.float32(wl["gain"])
-    import warnings
     warnings.simplefilter("ignore")
     eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=local_rank, chunk=args.chunk,
                           precision=args.precision)
@@ -416,9 +486,9 @@ def main():
               "JAEGER_HIP_LIB=jaeger_amd/libjaeger_hip_exp.so)", file=sys.stderr)
         sys.exit(2)
 
-    fsize = args.fsize or wl["fsize"]
-    n_contigs = args.contigs or wl["contigs"]
-    if args.rank_contigs:
+    fsize = (args.fsize if headline else None) or wl["fsize"]
+    n_contigs = (args.contigs if headline else None) or wl["contigs"]
+    if args.rank_contigs and headline:
         per_rank = [int(x) for x in args.rank_contigs.split(",")]
         n_contigs = per_rank[(rank if args.rank_seed is None else args.rank_seed) % len(per_rank)]
     l_pad = frame_length(fsize)
@@ -467,7 +537,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     fence()
     if args.timed_dbg is not None:
@@ -476,10 +546,14 @@ def main():
     split["compute_s"] = split["gather_s"] = 0.0
     t0 = time.perf_counter()
     gathered = None
-    for _ in range(args.steps):
+    for _ in range(steps):
         gathered = step()
     fence()
     dt = time.perf_counter() - t0
+    # the box calibration runs straight behind the timed steps, on the chip as the steps left it
+    box = None
+    if headline and world == 1 and not args.no_box and args.timed_dbg is None:
+        box = eng.device.box_calibrate(args.box_seconds)
     prof = eng.device.profile_read()
     eng.device.profile_enable(False)
     if args.timed_dbg is not None:
@@ -495,12 +569,13 @@ def main():
         per_rank = t.cpu().numpy()[None, :]
     dt_max, bp_total, win_total = float(per_rank[:, 0].max()), float(per_rank[:, 1].sum()), float(per_rank[:, 2].sum())
 
-    if rank == 0 and args.dump_gather:
+    if rank == 0 and args.dump_gather and headline:
         parts = [g.cpu().numpy() for g in gathered] if gathered is not None else [d_pred.cpu().numpy()]
         np.save(args.dump_gather, np.concatenate(parts, axis=0))
+    line = None
     if rank == 0:
-        steps = max(args.steps, 1)
-        value = bp_total * steps / dt_max / 1e6
+        n_steps = max(steps, 1)
+        value = bp_total * n_steps / dt_max / 1e6
         # dominant kernel = the matrix-core convolutions of the arithmetic in use (the first layer's table-lookup
         # kernel is reported beside it, not folded in: it runs no MFMA)
         dom = prof["mfma_f16x3"] if mode == "f16x3" else prof["mfma_f32"]
@@ -520,22 +595,21 @@ def main():
         # exact-f32 MFMA, or the f16 MFMA peak / 3 for the split-f16 scheme
         peak = F32_MFMA_PEAK_TFLOPS if mode == "f32" else F16_MFMA_PEAK_TFLOPS / 3.0
         # HBM traffic and matrix-core utilisation of the dominant kernel come from separate rocprofv3 --pmc passes
-        # (counters cannot be read from inside the process): scripts/gpu_r3_profiles.sh -> profiles/*.json, keyed by
+        # (counters cannot be read from inside the process): scripts/r5_profiles.sh -> profiles/*.json, keyed by
         # the kernel-source hash so that a stale summary is never quoted
-        pmc = pmc_fields(args.config if args.fsize is None else "", mode, fsize, args.chunk,
+        pmc = pmc_fields(name if (args.fsize is None or not headline) else "", mode, fsize, args.chunk,
                          dom["ms"] / max(dom["launches"], 1))
-        traffic = pmc["traffic"]
         all_s = prof["conv_ms"] / 1e3
         line = {
             "metric": f"Mbp/s classified ({fsize}bp frags)", "value": round(value, 3), "unit": "Mbp/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt_max / n_steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if mode == "f32" else "f16x3 (split-f16, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{wl['label']}, {fsize}bp windows stride {fsize}, {n_contigs} synthetic "
                                    + (f"fragments/GPU of exactly {fsize} bp" if wl["exact"] else
                                       "contigs/GPU log-uniform 1.5-200 kb"),
-                       "name": args.config,
+                       "name": name,
                        "windows_per_gpu": int(win_total / world), "bp_per_gpu": int(bp_total / world),
                        "windows_per_gpu_min": int(per_rank[:, 2].min()), "windows_per_gpu_max": int(per_rank[:, 2].max()),
                        "parallelism": f"contig-sharded x{world}, final {'gloo (test mode)' if args.oversubscribe and world > 1 else 'RCCL'} gather",
@@ -543,13 +617,14 @@ def main():
                                   "gathered); embedding / nmd vectors (InferModel.predict also returns them, 2.6 kB "
                                   "per window) are computed but not copied out in the timed region"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1),
-                         "unit": "TFLOP/s", "frac": round(ach / peak, 4) if peak else 0.0, "traffic": traffic,
-                         "hbm_gbs": pmc["hbm_gbs"], "mfma_busy_frac": pmc["mfma_busy_frac"],
-                         "eff_clock_ghz": pmc["eff_clock_ghz"], "kernel_hash": kernel_hash(),
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4) if peak else 0.0, "traffic": pmc["traffic"],
+                         "hbm_gbs": pmc["hbm_gbs"], "kernel_hash": kernel_hash(mode),
                          "pmc_kernel_hash": pmc["pmc_kernel_hash"], "pmc_stale": pmc["pmc_stale"],
+                         "pmc_other_device": pmc["other_device"],
                          "kernel": dom_name,
                          "launches": int(dom["launches"]),
                          "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
+                         "hip_events_in_timed_region": not args.no_profile,
                          "all_convs_incl_table_kernel": {
                              "achieved": round(prof["conv_flops"] / all_s / 1e12, 3) if all_s > 0 else 0.0,
                              "frac": round(prof["conv_flops"] / all_s / 1e12 / peak, 4) if all_s > 0 else 0.0,
@@ -559,15 +634,14 @@ def main():
         }
         # per-rank split of the timed steps: a weak-scaling efficiency below target is imbalance (compute spread between
         # ranks) or communication (the gather's share on the slowest rank) - readable from this line alone
-        st = max(args.steps, 1)
         slow = int(per_rank[:, 0].argmax())
         line["per_rank"] = {
-            "slowest_rank": slow, "ms_per_step_slowest": round(float(per_rank[slow, 0]) / st * 1e3, 3),
-            "ms_per_step_fastest": round(float(per_rank[:, 0].min()) / st * 1e3, 3),
-            "compute_ms_per_step": {"min": round(float(per_rank[:, 3].min()) / st * 1e3, 3),
-                                    "max": round(float(per_rank[:, 3].max()) / st * 1e3, 3)},
-            "gather_ms_per_step": {"min": round(float(per_rank[:, 4].min()) / st * 1e3, 3),
-                                   "max": round(float(per_rank[:, 4].max()) / st * 1e3, 3),
+            "slowest_rank": slow, "ms_per_step_slowest": round(float(per_rank[slow, 0]) / n_steps * 1e3, 3),
+            "ms_per_step_fastest": round(float(per_rank[:, 0].min()) / n_steps * 1e3, 3),
+            "compute_ms_per_step": {"min": round(float(per_rank[:, 3].min()) / n_steps * 1e3, 3),
+                                    "max": round(float(per_rank[:, 3].max()) / n_steps * 1e3, 3)},
+            "gather_ms_per_step": {"min": round(float(per_rank[:, 4].min()) / n_steps * 1e3, 3),
+                                   "max": round(float(per_rank[:, 4].max()) / n_steps * 1e3, 3),
                                    "what": "final gather of the logits incl. waiting for the slowest rank; 0 with one GPU"},
             "windows": [int(v) for v in per_rank[:, 2]]}
         if prof["fused_small"]["launches"]:
@@ -575,7 +649,13 @@ def main():
             line["roofline"]["fused_small_kernel"] = {
                 "launches": int(fs["launches"]), "avg_launch_ms": round(fs["ms"] / fs["launches"], 4),
                 "achieved": round(fs["flops"] / (fs["ms"] / 1e3) / 1e12, 3)}
-        if world == 1 and not args.no_exact_f32 and mode == "f16x3" and args.timed_dbg is None:
+        if box is not None:
+            # the headline relative to what THIS device's matrix cores deliver under load: comparable across boxes / rounds
+            box["value_per_box_tflop"] = round(value / box["mfma_loop_tflops"], 5) if box["mfma_loop_tflops"] else None
+            box["dominant_kernel_issued_f16_tflops_over_box"] = (
+                round(3.0 * ach / box["mfma_loop_tflops"], 4) if (mode == "f16x3" and box["mfma_loop_tflops"]) else None)
+            line["box"] = box
+        if world == 1 and headline and not args.no_exact_f32 and mode == "f16x3" and args.timed_dbg is None:
             # the exact-f32 MFMA arithmetic on a bounded sample of the same windows (about 2 s)
             n_s = int(min(n_win, max(256, 40e6 // fsize)))
             eng.model.set_precision("f32")
@@ -586,20 +666,50 @@ def main():
             torch.cuda.synchronize()
             line["exact_f32_mbps"] = round(float(win_len[:n_s].sum()) / (time.perf_counter() - t1) / 1e6, 2)
             eng.model.set_precision("f16x3")
-        if world == 1 and not args.no_e2e and args.timed_dbg is None:
+    flops_per_window = eng.model.flops_per_window(l_pad)
+    eng.close()
+    del d_bases, d_start, d_len, d_pred, d_rel, d_counts
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and args.timed_dbg is None:
+        if not args.no_e2e:
             try:
-                line["e2e"] = e2e_leg(cfg, weights, wl, fsize)
+                if headline or wl["model"] != CONFIGS[args.config]["model"]:
+                    line["e2e"] = e2e_leg(cfg, weights, wl, fsize)
+                else:
+                    line["e2e"] = "same model and file as the headline's e2e"
+                if not headline and wl["exact"]:
+                    # the fragment workload itself as a file: a record per window
+                    line["e2e_records"] = e2e_leg(cfg, weights, wl, fsize, records=n_contigs)
             except SystemExit as e:               # run_core exits on its own errors: report, do not lose the bench line
                 line["e2e"] = {"error": f"run_core exited with {e.code}"}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, weights, bases, offsets, fsize, eng.model.flops_per_window(l_pad))
-        else:
-            line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    eng.close()
+        if headline and not args.no_also:
+            # the other BASELINE configs in the same driver-run line (2 timed steps each): configs[2]'s per-GPU shard
+            # and configs[3]; a failure there must not lose the headline
+            line["also"] = {}
+            for other in ("default", "frag1m", "baseline500"):
+                if other == name:
+                    continue
+                try:
+                    sub = measure(args, other, 2, 1, ctx, headline=False)
+                    keep = {k: sub[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype") if k in sub}
+                    keep["workload"] = sub["config"]["workload"]
+                    keep["roofline"] = {k: sub["roofline"][k] for k in
+                                        ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "launches", "traffic",
+                                         "pmc_stale")}
+                    for k in ("e2e", "e2e_records"):
+                        if k in sub:
+                            keep[k] = sub[k]
+                    line["also"][other] = keep
+                except (Exception, SystemExit) as e:   # noqa: BLE001
+                    line["also"][other] = {"error": f"{type(e).__name__}: {e}"}
+        if headline:
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(cfg, weights, bases, offsets, fsize, flops_per_window)
+            else:
+                line["cpu_baseline"] = None
+    elif rank == 0 and headline:
+        line["cpu_baseline"] = None
+    return line
 
 
 if __name__ == "__main__":

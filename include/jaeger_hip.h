@@ -257,6 +257,14 @@ int jg_profile_read(jg_engine *e, double *conv_ms, int64_t *conv_launches, doubl
 enum { JG_PROF_MFMA_F16X3 = 0, JG_PROF_MFMA_F32 = 1, JG_PROF_TABLE = 2, JG_PROF_FUSED_SMALL = 3 };
 int jg_profile_read_class(jg_engine *e, int cls, double *ms, int64_t *launches, double *flops);
 
+/* Box calibration (bench.py's `box` object; no counterpart in the reference): about `seconds` (0 < seconds <= 30) of
+ * back-to-back launches of a bare v_mfma_f32_32x32x16_f16 loop on random register operands, two waves per SIMD on every
+ * CU, no memory traffic.  *tflops = dense f16 matrix-core rate of the last launch, *clock_ghz = the shader clock the chip
+ * held inside it (d s_memtime / d s_memrealtime x 100 MHz, median over workgroups).  info (optional, 5 doubles): launches,
+ * ms of the last launch, mean TFLOP/s over all launches, lowest / highest per-workgroup clock.  MI355X devices differ by
+ * up to 12 % on matrix-core-dense loops: a headline is comparable across boxes only relative to this figure. */
+int jg_box_calibrate(jg_engine *e, double seconds, double *tflops, double *clock_ghz, double *info);
+
 /* ---- FASTA ingest (host only; replaces the pyfastx iteration of seqops/io.py:98-103 and the
  * per-record Python strings of utils/fs.py:99-115) ------------------------------------------
  * jg_fasta_count : number of records (lines starting with '>') in a file image, and an upper bound of

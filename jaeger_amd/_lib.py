@@ -106,6 +106,7 @@ SYMBOLS = {
     "jg_profile_enable": (C.c_int, [_vp, C.c_int]),
     "jg_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "jg_profile_read_class": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "jg_box_calibrate": (C.c_int, [_vp, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), _vp]),
     "jg_terminal_repeats": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64, C.c_int32, _vp]),
     "jg_viterbi_decode": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int64, _vp, _vp]),
     "jg_dust_mask": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),

@@ -176,6 +176,20 @@ class HipDevice:
             out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value}
         return out
 
+    def box_calibrate(self, seconds: float = 0.5) -> dict:
+        """``jg_box_calibrate``: a bare ``v_mfma_f32_32x32x16_f16`` loop on random register operands for about ``seconds``
+        of back-to-back launches - the dense f16 matrix-core rate and the in-kernel shader clock THIS device holds under
+        load (MI355X devices differ by up to 12 % there)."""
+        tf, ghz = C.c_double(), C.c_double()
+        info = (C.c_double * 5)()
+        L.check(self.lib.jg_box_calibrate(self.handle, float(seconds), C.byref(tf), C.byref(ghz), info), "jg_box_calibrate")
+        return {"mfma_loop_tflops": round(tf.value, 1), "clock_ghz": round(ghz.value, 4), "launches": int(info[0]),
+                "last_launch_ms": round(info[1], 3), "mean_tflops": round(info[2], 1),
+                "clock_ghz_min": round(info[3], 4), "clock_ghz_max": round(info[4], 4), "seconds": float(seconds),
+                "what": "bare v_mfma_f32_32x32x16_f16 loop, random f16 operands in registers, two waves per SIMD on every "
+                        "CU, no memory traffic; TFLOP/s of the last launch by HIP events, clock = d s_memtime / "
+                        "d s_memrealtime x 100 MHz (median over workgroups)"}
+
     def encode(self, bases: np.ndarray, win_start: np.ndarray, win_len: np.ndarray, fsize: int,
                lut: np.ndarray, flags: int = 0, l_pad: int | None = None):
         """``jg_encode`` with host buffers -> (ids (W,6,l_pad) u8, counts (W,4) i32); with ``JG_ENC_NUCLEOTIDE`` in
