@@ -144,13 +144,17 @@ int jg_engine_sync(jg_engine *e);
  * JG_OPT_DUST_ON_COPY_STREAM (default 1): the DUST pass of a streamed span runs on the copy stream behind the span's upload
  * (beside the previous group's convolutions) or, 0, on the compute stream in front of the span's encoder; same masks.
  * JG_OPT_TABLE_NET_LDS (default 0): a strand branch's conv + pool ("table net") runs on the matrix cores (0) or, 1, as the
- * exact-f32 LDS-table kernel - the form every shape the matrix-core kernel does not cover takes anyway. */
+ * exact-f32 LDS-table kernel - the form every shape the matrix-core kernel does not cover takes anyway.
+ * JG_OPT_RESET_PROGRESS (value ignored): sets JG_STAT_WINDOWS_DONE back to 0.  A thread that polls the mark of a
+ * jg_predict_windows call ANOTHER thread is about to make calls this first (the call resets the mark itself, but only
+ * once it has been entered - a poller that starts earlier would read the previous call's final count). */
 enum { JG_OPT_STREAM_BYTES = 1, JG_OPT_CONV_PC = 2, JG_OPT_TERMINI_EXACT = 3, JG_OPT_DUST_ON_COPY_STREAM = 4,
-       JG_OPT_TABLE_NET_LDS = 5 };
+       JG_OPT_TABLE_NET_LDS = 5, JG_OPT_RESET_PROGRESS = 6 };
 int jg_engine_set_option(jg_engine *e, int key, int64_t value);
 /* statistics of the engine's last jg_predict_windows call: number of streamed groups (0 = not streamed), bytes sent
  * through the staging buffers, peak bytes of bases resident on the device.  JG_STAT_WINDOWS_DONE may be read from
- * ANOTHER thread while a jg_predict_windows call with host outputs is running: the output rows (and counts) of windows
+ * ANOTHER thread while a jg_predict_windows call with host outputs is running (reset it with JG_OPT_RESET_PROGRESS before
+ * the call is handed to its thread): the output rows (and counts) of windows
  * [0, value) are final and may be consumed - the reference only sees its results when InferModel.predict returns
  * (nnlib/inference.py:341-373); here per-contig aggregation runs beside the forward of later windows. */
 enum { JG_STAT_STREAM_GROUPS = 1, JG_STAT_STREAM_BYTES = 2, JG_STAT_PEAK_DEVICE_BASES = 3, JG_STAT_DUST_MASKED = 4,

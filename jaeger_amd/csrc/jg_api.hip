@@ -108,6 +108,9 @@ extern "C" int jg_engine_set_option(jg_engine *e, int key, int64_t value) {
     case JG_OPT_TABLE_NET_LDS:
       e->tab_lds_only = value != 0;
       return JG_OK;
+    case JG_OPT_RESET_PROGRESS:
+      e->windows_done.store(0, std::memory_order_release);
+      return JG_OK;
     default:
       jg_set_error("jg_engine_set_option: unknown key %d", key);
       return JG_ERR_INVALID;
@@ -634,6 +637,20 @@ static int prepare_small(jg_model *m, const float *weights) {
   for (int q = 1; q <= nc && ok; ++q) {
     const jg_op &c = m->ops[convs[q]];
     const float *w = weights + c.w_off;               // (3, 32, 32) f32 (cin even, cout multiple of 32: no padding)
+    // the folded weights w * scale1 go into f16 planes WITHOUT a power-of-two pre-scale: they must sit inside the f16
+    // range (a large batch-norm scale would turn hi into inf and lo into -inf: NaN logits), and the layer's largest
+    // weight must stay well above the subnormal quantum 2^-24 the lo plane resolves (hi + lo then still carries ~19 bits of
+    // it); otherwise the model stays on the generic split-f16 / exact-f32 kernels, which pre-scale per conv
+    double vmax = 0.0;
+    for (int t = 0; t < 3; ++t)
+      for (int ci = 0; ci < 32; ++ci)
+        for (int co = 0; co < 32; ++co) {
+          const double v = std::fabs((double)w[((size_t)t * 32 + ci) * 32 + co] * scale1[(size_t)q * 32 + co]);
+          if (!(v <= 65000.0)) ok = false;            // (also catches NaN)
+          vmax = std::max(vmax, v);
+        }
+    if (vmax != 0.0 && vmax < 0.015625) ok = false;
+    if (!ok) break;
     for (int t = 0; t < 3; ++t)
       for (int cc = 0; cc < 2; ++cc)
         for (int lane = 0; lane < 64; ++lane)
@@ -2307,8 +2324,9 @@ extern "C" int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_b
   JG_REQUIRE(m != nullptr && bases != nullptr && win_start != nullptr && win_len != nullptr &&
                  lut65 != nullptr && n_win >= 0,
              JG_ERR_INVALID, "jg_predict_windows: bad arguments");
-  if (n_win == 0) return JG_OK;
   jg_engine *e = m->e;
+  e->windows_done.store(0, std::memory_order_release);       // (also for an empty call: a poller must not see the previous call's mark)
+  if (n_win == 0) return JG_OK;
   JG_HIP(hipSetDevice(e->dev));
   hipStream_t s = pick_stream(e, stream);
   e->streamed_groups = 0;

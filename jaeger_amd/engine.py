@@ -104,6 +104,11 @@ class HipDevice:
         output rows and counts of windows [0, value) are final."""
         return int(self.lib.jg_engine_get_stat(self.handle, L.JG_STAT_WINDOWS_DONE))
 
+    def reset_progress(self):
+        """``windows_done()`` back to 0 (JG_OPT_RESET_PROGRESS): called before a ``predict_windows`` call is handed to another
+        thread, so that a poller which starts first never reads the previous call's final count."""
+        L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_RESET_PROGRESS, 0), "jg_engine_set_option")
+
     def stream_stats(self) -> dict:
         """Streaming statistics of the last ``jg_predict_windows`` call on this engine."""
         g = lambda k: int(self.lib.jg_engine_get_stat(self.handle, k))  # noqa: E731
@@ -302,7 +307,10 @@ class HipModel:
         return res
 
     def host_outputs(self, n_win: int, want=("prediction", "reliability", "embedding", "nmd"), counts=True) -> dict:
-        """Host arrays :meth:`predict_windows` fills: the model's outputs named in ``want`` (+ ``counts`` (n, 4) int32)."""
+        """Host arrays :meth:`predict_windows` fills: the model's outputs named in ``want`` (+ ``counts`` (n, 4) int32).
+        The engine's progress mark is reset here: whoever polls ``device.windows_done()`` for the call these arrays are
+        made for starts from 0, also on a reused engine."""
+        self.dev.reset_progress()
         res = {k: v for k, v in self._host_outputs(n_win, want).items() if v is not None}
         if counts:
             res["counts"] = np.zeros((n_win, 4), np.int32)

@@ -640,7 +640,9 @@ class TableWriter:
     that pass the phage filters - to ``<base>_phages.tsv`` as they are aggregated, so that only the last batch is formatted
     behind the forward.  Every step of ``write_output`` is row-wise (left merge with the repeat table, the ``N% < 0.3``
     filter, the phage query, the column formats), so the files equal the ones a single call writes, byte for byte
-    (tests/test_postprocess.py); the phage file only comes into being with its first row, as in the reference."""
+    (tests/test_postprocess.py); the phage file only comes into being with its first row, as in the reference.  Rows go to
+    ``<path>.partial`` and ``close()`` renames the files into place: a run that fails later (the forward, the repeat scan,
+    a later batch) leaves no truncated table at the final path - ``abort()`` closes and removes the partial files."""
 
     def __init__(self, labels, indices, output_table_path, output_phage_table_path, reliability_cutoff=0.5, phage_score=1,
                  refined_contig=None):
@@ -657,7 +659,7 @@ class TableWriter:
     def append(self, data: dict) -> None:
         df = generate_summary(data, **self.kw).query("`N%` < 0.3")
         if self.fh is None:
-            self.fh = open(self.table_path, "wb")
+            self.fh = open(f"{self.table_path}.partial", "wb")
         self.fh.write(_tsv_bytes(df, header=not self.header_written))
         self.header_written = True
         clause = f" and (reliability_score > {self.rc})" if data.get("has_reliability", True) else ""
@@ -665,15 +667,30 @@ class TableWriter:
         if not phage_df.empty:
             first = self.fh_phage is None
             if first:
-                self.fh_phage = open(self.phage_path, "wb")
+                self.fh_phage = open(f"{self.phage_path}.partial", "wb")
             self.fh_phage.write(_tsv_bytes(phage_df, header=first))
         self.rows += len(df)
 
     def close(self) -> int:
-        for fh in (self.fh, self.fh_phage):
+        import os
+        for fh, path in ((self.fh, self.table_path), (self.fh_phage, self.phage_path)):
             if fh is not None:
                 fh.close()
+                os.replace(f"{path}.partial", path)
+        self.fh = self.fh_phage = None
         return self.rows
+
+    def abort(self) -> None:
+        """Drop what has been written so far (the run failed): close the handles, remove the ``.partial`` files."""
+        import os
+        for fh, path in ((self.fh, self.table_path), (self.fh_phage, self.phage_path)):
+            if fh is not None:
+                fh.close()
+                try:
+                    os.unlink(f"{path}.partial")
+                except OSError:
+                    pass
+        self.fh = self.fh_phage = None
 
 
 def write_output(data: dict, reliability_cutoff: float = 0.5, phage_score=1, **kwargs) -> int:

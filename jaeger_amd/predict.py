@@ -210,6 +210,10 @@ class _LazyTableWriter:
     def close(self) -> int:
         return self.w.close() if self.w is not None else 0
 
+    def abort(self) -> None:
+        if self.w is not None:
+            self.w.abort()
+
 
 class _Aggregator:
     """Per-contig aggregation of the long pass BESIDE the forward: ``advance(done)`` is called with the engine's progress
@@ -526,12 +530,9 @@ def run_core(**kwargs) -> int:
             LAST_RUN["engine_create_s"] = round(time.time() - t_eng, 3)
 
     def _make_engine():
-        weights = None
-        wnpz = model_info.get("weights_npz")
-        if wnpz is not None:
-            from .weights import load_npz
-            weights = load_npz(wnpz)
-        eng = JaegerHipEngine(model_info, weights=weights, device_id=local_rank, chunk=kwargs.get("chunk", 0),
+        # the engine resolves the weights itself (weights.load_weights): the graph's variable bundle - what the reference
+        # executes - first, then the .weights.h5, then the canonical .npz
+        eng = JaegerHipEngine(model_info, device_id=local_rank, chunk=kwargs.get("chunk", 0),
                               precision=precision, trust_project=True if kwargs.get("trust_project") else None)
         if kwargs.get("stream_bytes"):              # span budget of the host -> HBM ingest (default 32 MiB)
             eng.device.set_stream_bytes(int(kwargs["stream_bytes"]))
@@ -701,6 +702,7 @@ def run_core(**kwargs) -> int:
                                         padded=True, **common)
                 agg.add(y_short)
         except Exception as e:
+            writer.abort()                  # rows of finished batches were appended beside the forward: no truncated table stays
             lg.debug(traceback.format_exc())
             lg.error(f"an error {e} occured during inference on MI355X #{local_rank}!")
             sys.exit(1)
@@ -737,8 +739,12 @@ def run_core(**kwargs) -> int:
                                  output_table_path=table_path, output_phage_table_path=phage_path,
                                  reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))
     else:
-        agg.flush(writer, term_repeats)                # what is left: the last batch (and the short-contig pass)
-        n_written = writer.close()
+        try:
+            agg.flush(writer, term_repeats)            # what is left: the last batch (and the short-contig pass)
+            n_written = writer.close()
+        except BaseException:
+            writer.abort()
+            raise
         data_full = agg.result_full()
         LAST_RUN["merge_s"] = 0.0
     LAST_RUN["tsv_s"] = round(time.time() - t_post - LAST_RUN["merge_s"], 3)

@@ -120,20 +120,27 @@ def load_keras3_h5(path, plan: ModelPlan) -> dict[str, np.ndarray]:
             by_group.setdefault(comps, {})[int(parts[-1])] = arr
     groups = {k: [g[i] for i in range(len(g))] for k, g in by_group.items() if g}
     block_paths = sorted({k[:-1] for k in groups if k[-1] in _BLOCK_SUBLAYERS and len(k) >= 2}, key=_natural_key)
-    loose = sorted((k for k in groups if not (k[-1] in _BLOCK_SUBLAYERS and k[:-1] in block_paths)), key=_natural_key)
+    # loose layers: Keras numbers auto names per class GLOBALLY in creation order (``masked_batch_norm``,
+    # ``masked_batch_norm_1`` ... wherever the layer sits), so the layer's own name decides first and its container only
+    # breaks ties (names given per container - ``dense`` in ``functional_8`` and in ``functional_9`` - keep path order)
+    loose = sorted((k for k in groups if not (k[-1] in _BLOCK_SUBLAYERS and k[:-1] in block_paths)),
+                   key=lambda k: (_natural_key(k[-1:]), _natural_key(k)))
     order = _layer_order(plan)
     plan_blocks: list[str] = []
     for prefix, _ in order:
         head, _, sub = prefix.rpartition("/")
         if sub in _BLOCK_SUBLAYERS and head not in plan_blocks:
             plan_blocks.append(head)
+
+    def describe(keys):
+        return "; ".join(f"{'/'.join(k)} {[tuple(a.shape) for a in groups[k]]}" for k in keys) or "none"
+
     if len(plan_blocks) != len(block_paths):
-        raise ValueError(f"{path}: {len(block_paths)} residual blocks in the file, the plan has {len(plan_blocks)}")
-    n_file, n_plan = len(groups), len(order)
-    if n_file != n_plan:
-        raise ValueError(f"{path}: {n_file} weighted layers in the file, the plan has {n_plan}")
+        raise ValueError(f"{path}: {len(block_paths)} residual blocks in the file ({', '.join('/'.join(b) for b in block_paths)}), "
+                         f"the plan has {len(plan_blocks)}")
     out = {}
     used: set = set()
+    missing: list[str] = []
     for prefix, leaves in order:
         want = [tuple(shapes[f"{prefix}/{v}"]) for v in leaves]
         head, _, sub = prefix.rpartition("/")
@@ -148,8 +155,21 @@ def load_keras3_h5(path, plan: ModelPlan) -> dict[str, np.ndarray]:
                     out[f"{prefix}/{v}"] = np.asarray(a, np.float32)
                 break
         else:
-            raise ValueError(f"{path}: no weight group matches {prefix} {want}")
+            missing.append(f"{prefix} {want}")
+    left = [k for k in sorted(groups, key=_natural_key) if k not in used]
+    if missing or left:
+        raise ValueError(f"{path}: the file does not line up with the layer plan - plan layers without a weight group: "
+                         f"{'; '.join(missing) or 'none'} - weight groups of the file no plan layer took: {describe(left)}")
     return out
+
+
+class BundleSchemeError(ValueError):
+    """A variable bundle whose checkpoint keys follow no object-path scheme this loader knows (``_operations/<n>/...`` or
+    ``layers/<n>/...``) or name variables no layer of the reference owns: the one bundle failure `load_weights` answers
+    with the weights file.  A bundle that IS understood and disagrees with the plan (a missing layer, a shape) stays fatal."""
+
+
+_KNOWN_VARIABLES = {"kernel", "bias", "embeddings", "gamma", "beta", "moving_mean", "moving_variance", "alpha"}
 
 
 def assign_groups(groups: list[tuple[tuple[str, ...], dict[str, np.ndarray]]], order: list[tuple[str, list[str]]],
@@ -158,6 +178,13 @@ def assign_groups(groups: list[tuple[tuple[str, ...], dict[str, np.ndarray]]], o
     a residual block's sub-layers are found by their attribute names under the block's own path (blocks paired in
     order), every other weighted layer takes the NEXT unused group, whose variable names and shapes must be exactly
     the layer's - the first disagreement is an error that names both sides."""
+    for path, have in groups:
+        if not (path[0] in ("_operations", "layers") and len(path) >= 2 and path[1].isdigit()):
+            raise BundleSchemeError(f"{source}: object path {'/'.join(path)} follows no known scheme "
+                                    f"(_operations/<n>/... or layers/<n>/...)")
+        odd = sorted(set(have) - _KNOWN_VARIABLES)
+        if odd:
+            raise BundleSchemeError(f"{source}: {'/'.join(path)} holds variables {odd} no layer of the plan's families owns")
     block_paths = []
     for path, _ in groups:
         if path[-1] in _BLOCK_SUBLAYERS and path[:-1] not in block_paths:
@@ -233,28 +260,34 @@ def bundle_checkpoint_keys(plan: ModelPlan) -> dict[str, str]:
 
 def load_weights(path_dict: dict, plan: ModelPlan, trust_project: bool = False) -> dict[str, np.ndarray]:
     """Weights of a model entry (AvailableModels keys, utils/misc.py:346-392).  The SavedModel's own variable bundle
-    (``graph``) comes first - it is what the reference runs; then the canonical ``.npz``, then a Keras-3 ``.weights.h5``.
-    A bundle whose keys cannot be mapped onto the plan (an export with other object paths than the ones this loader has
-    seen) is not fatal when the entry also holds a weights file: that file is used instead, with a loud warning naming
-    what failed.  ``trust_project`` skips the bundle altogether."""
+    (``graph``) comes first - it is what the reference runs; then the weights file: the Keras-3 ``.weights.h5`` the
+    reference's ``save_model`` writes beside the graph (nnlib/builder.py:1505-1509) before the canonical ``.npz`` this
+    package derives.  A bundle under a key SCHEME this loader does not know (:class:`BundleSchemeError`) is not fatal when
+    the entry also holds a weights file: that file is used, with a warning through the run log that names what failed.
+    A bundle that is understood and disagrees with the plan - a missing layer, another shape - stays an error (a model
+    directory whose file differs from the variables the reference executes must refuse, not predict something else);
+    ``trust_project`` skips the bundle altogether."""
     graph = path_dict.get("graph")
-    w = path_dict.get("weights_npz") or path_dict.get("weights")     # AvailableModels keys (predict.py)
-    bundle_error = None
+    w = path_dict.get("weights") or path_dict.get("weights_npz")     # AvailableModels keys (predict.py)
+    scheme_error = None
     if not trust_project and graph is not None and (Path(graph) / "variables" / "variables.index").exists():
         try:
             return load_savedmodel_bundle(graph, plan)
-        except Exception as e:                 # unknown key scheme, missing variable, shape that disagrees with the plan
+        except BundleSchemeError as e:
             if w is None:
                 raise
-            bundle_error = e
+            scheme_error = e
     if w is None:
         raise FileNotFoundError("model entry has no weights (a <name>_graph/variables bundle, *.weights.h5 or canonical *.npz)")
     w = Path(w)
-    if bundle_error is not None:
+    if scheme_error is not None:
+        import logging
         import warnings
-        warnings.warn(f"{graph}/variables could not be mapped onto the layer plan ({type(bundle_error).__name__}: {bundle_error}); "
-                      f"falling back to {w}.  The SavedModel is what the reference executes - check the model with "
-                      f"`jaeger_amd verify-model` before trusting these weights.", RuntimeWarning, stacklevel=2)
+        msg = (f"{graph}/variables could not be mapped onto the layer plan ({scheme_error}); falling back to {w}.  The "
+               f"SavedModel is what the reference executes - check the model with `jaeger_amd verify-model` before "
+               f"trusting these weights.")
+        logging.getLogger("Jaeger").warning(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
     if w.suffix == ".npz":
         return load_npz(w)
     return load_keras3_h5(w, plan)

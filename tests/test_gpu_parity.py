@@ -386,6 +386,73 @@ def test_small_window_table_too_large_for_lds_runs_layer_by_layer():
         assert np.abs(got[k] - ref[k]).max() <= TOL, k
 
 
+@pytest.mark.parametrize("gamma_scale,fused", [(1.0, True), (3.0e5, False), (1.0e-4, False)])
+def test_small_window_affine_fold_respects_the_f16_range(gamma_scale, fused):
+    """the fused small-window kernel folds the first affine's scale into its f16 weight planes without a
+    power-of-two pre-scale.  A batch-norm scale that pushes w * scale out of the f16 range (hi = inf, lo = -inf: NaN
+    logits) or under the lo plane's resolution must keep the model OFF the fused kernel - the per-conv kernels pre-scale -
+    and the results contract holds either way (moving statistics compensate: same function, same logits)."""
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = load_model_cfg("baseline500")
+    weights = ofwd.random_weights(cfg, seed=38341)
+    g = np.float32(gamma_scale)
+    for key in list(weights):                            # block norms: gamma x g on a conv whose kernel shrank by g
+        if "/block" in key and key.endswith("/bn1/gamma"):
+            weights[key] = weights[key] * g
+            weights[key.replace("gamma", "beta")] = weights[key.replace("gamma", "beta")] * g
+            ck = key.replace("/bn1/gamma", "/conv2/kernel")
+            weights[ck] = weights[ck] / g
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, precision="f16x3")
+    assert eng.model.placement()["small_fused"] == fused
+    rng = np.random.Generator(np.random.PCG64(43))
+    fsize, n_win = 500, 16
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.02)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    eng.close()
+    ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    assert np.isfinite(got["prediction"]).all()
+    assert np.abs(got["prediction"] - ref["prediction"]).max() <= TOL
+
+
+def test_progress_mark_is_reset_for_the_next_call():
+    """``windows_done`` of a finished call must not be what a poller of the NEXT call on the same engine reads
+    before that call has been entered: ``host_outputs`` (the arrays a call is made with) resets it, an empty call too."""
+    from jaeger_amd.engine import JaegerHipEngine
+    from oracle import forward as ofwd
+    cfg = load_model_cfg("baseline500")
+    eng = JaegerHipEngine(model_cfg=cfg, weights=ofwd.random_weights(cfg, seed=1))
+    rng = np.random.Generator(np.random.PCG64(44))
+    fsize, n_win = 500, 40
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.0)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    out = eng.model.host_outputs(n_win, ("prediction",))
+    assert eng.device.windows_done() == 0
+    eng.predict_windows(seq, starts, lens, fsize, want=("prediction",), out=out)
+    assert eng.device.windows_done() == n_win
+    eng.model.host_outputs(n_win, ("prediction",))
+    assert eng.device.windows_done() == 0
+    eng.predict_windows(seq, starts, lens, fsize, want=("prediction",))
+    assert eng.device.windows_done() == n_win
+    eng.predict_windows(seq, starts[:0], lens[:0], fsize, want=("prediction",))
+    assert eng.device.windows_done() == 0
+    eng.close()
+
+
+def test_box_calibration_reports_a_plausible_matrix_core_rate(device):
+    """``jg_box_calibrate`` (bench.py's ``box``): the bare f16 MFMA loop must land between the guide's tuned-GEMM figure
+    and the dense peak, at a shader clock inside the chip's range."""
+    box = device.box_calibrate(0.2)
+    assert 600.0 < box["mfma_loop_tflops"] < 2600.0, box
+    assert 1.0 < box["clock_ghz"] < 2.6 and box["clock_ghz_min"] <= box["clock_ghz"] <= box["clock_ghz_max"], box
+    assert box["launches"] >= 2
+
+
 def test_small_window_model_on_longer_rows_runs_layer_by_layer():
     """Rows beyond the fused kernel's 160 positions (fsize 1000 -> 332 codons) fall back to the per-layer path
     inside the same model, same results contract."""

@@ -131,6 +131,42 @@ def test_keras3_weights_h5_reader():
     assert all(np.array_equal(again[k], want[k]) for k in want)
 
 
+@pytest.mark.parametrize("layout", ["flat", "nested"])
+def test_keras3_weights_h5_both_export_generations(layout):
+    """First-contact safety for a real checkpoint: the two ``.weights.h5`` layouts the reference's converter documents
+    (scripts/convert_legacy_classifier_checkpoint.py:29-32,76-175) - custom ``ResidualBlockStack`` containers
+    (``layers/residual_block_stack[_N]/blocks/residual_block[_k]/{conv1,..}/vars/<i>``, blocks numbered per container) and
+    the older Functional sub-models (``layers/functional[_N]/layers/residual_block[_k]/...`` with block names counting on
+    across the sub-models, the head under ``layers/functional_8/layers/dense[_k]``) - written by the HDF5 library's h5import
+    (tests/golden/make_golden_h5.py) map onto the plan by type + order: two stacks, a 1x1 bypass, two stem convs and two
+    batch norms of identical shapes that only their auto-name order tells apart."""
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import load_keras3_h5, random_weights
+    plan = build_plan(load_model_cfg("stacks2"))
+    want = random_weights(plan, seed=2026)
+    got = load_keras3_h5(GOLDEN / f"stacks2_keras3_{layout}.weights.h5", plan)
+    assert set(got) == set(want)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    assert want["rep/0/kernel"].shape == want["rep/3/kernel"].shape and not np.array_equal(got["rep/0/kernel"], got["rep/3/kernel"])
+
+
+def test_keras3_weights_h5_mismatch_lists_what_is_left():
+    """A file that does not line up with the plan fails with BOTH sides named: the plan layers that found no weight group
+    and the groups of the file nobody took (here: the baseline500 file against the two-stack plan and the reverse)."""
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import load_keras3_h5
+    with pytest.raises(ValueError, match="residual blocks in the file"):
+        load_keras3_h5(GOLDEN / "baseline500_keras3.weights.h5", build_plan(load_model_cfg("stacks2")))
+    cfg = copy.deepcopy(load_model_cfg("stacks2"))
+    cfg["classifier"]["hidden_layers"][0]["config"]["units"] = 12          # the head's first Dense no longer fits its group
+    with pytest.raises(ValueError) as ei:
+        load_keras3_h5(GOLDEN / "stacks2_keras3_nested.weights.h5", build_plan(cfg))
+    msg = str(ei.value)
+    assert "plan layers without a weight group: classifier/0 [(16, 12), (12,)]; classifier/2 [(12, 3), (3,)]" in msg
+    assert "functional_8/dense [(16, 8), (8,)]" in msg and "functional_8/dense_1 [(8, 3), (3,)]" in msg
+
+
 def test_layernorm_cuts_the_epilogue_into_an_elementwise_op():
     """MaskedLayerNormalization reduces over the channels: the conv keeps the stages in front of it, an element-wise
     op led by the LN stage runs the norm and everything behind it (shortcut add, activation, NMD tap, next norm)."""

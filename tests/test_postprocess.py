@@ -157,7 +157,14 @@ def test_batchwise_aggregation_and_table_writer_equal_one_call(n_cls, with_rel, 
         data["repeats"] = rep
         parts.append((data, full))
         w.append(data)
+        # rows land in <path>.partial; nothing exists at the final path until close() (a failing run leaves no truncated table)
+        assert not (tmp_path / "b.tsv").exists() and (tmp_path / "b.tsv.partial").exists()
     assert w.close() == n_one
+    assert not (tmp_path / "b.tsv.partial").exists() and not (tmp_path / "b_ph.tsv.partial").exists()
+    w2 = P.TableWriter(names, idx, tmp_path / "c.tsv", tmp_path / "c_ph.tsv", reliability_cutoff=0.1, phage_score=1)
+    w2.append(parts[-1][0])
+    w2.abort()
+    assert not list(tmp_path.glob("c*"))
     assert (tmp_path / "b.tsv").read_bytes() == one.read_bytes()
     assert (tmp_path / "b_ph.tsv").exists() == one_ph.exists()
     if one_ph.exists():

@@ -238,3 +238,48 @@ def test_unmappable_bundle_falls_back_to_the_weights_file_loudly(tmp_path):
         got = load_weights({"graph": tmp_path / "m_graph", "weights_npz": npz}, plan, trust_project=True)
     for k in w_file:
         np.testing.assert_array_equal(got[k], w_file[k])
+
+
+def test_understood_bundle_that_disagrees_with_the_plan_stays_fatal(tmp_path, caplog):
+    """the file fallback is for an unknown key SCHEME only.  A bundle under the known scheme whose variables
+    disagree with the plan (a wrong shape, a missing layer) must refuse even when a weights file sits beside it - the
+    SavedModel is what the reference executes, a file that differs from it would predict something else - unless
+    ``trust_project`` says so; and the scheme fallback's warning also goes to the run log."""
+    import logging
+
+    from conftest import load_model_cfg
+    from jaeger_amd import savedmodel_lite as S
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import BundleSchemeError, bundle_checkpoint_keys, load_weights, random_weights, save_npz
+    plan = build_plan(load_model_cfg("baseline500"))
+    w = random_weights(plan, seed=11)
+    keys = bundle_checkpoint_keys(plan)
+    base = {keys[k]: v for k, v in w.items()}
+    kern = next(k for k in sorted(base) if k.endswith("/_kernel/.ATTRIBUTES/VARIABLE_VALUE") and base[k].ndim == 3)
+    reshaped = dict(base)
+    reshaped[kern] = np.zeros(base[kern].shape[:-1] + (base[kern].shape[-1] + 1,), np.float32)
+    S.write_bundle(tmp_path / "a_graph" / "variables", reshaped)
+    npz = tmp_path / "m.weights.npz"
+    save_npz(npz, w)
+    with pytest.raises(ValueError, match="shape") as ei:
+        load_weights({"graph": tmp_path / "a_graph", "weights_npz": npz}, plan)
+    assert not isinstance(ei.value, BundleSchemeError)
+    first_bias = next(k for k in sorted(base) if k.endswith("/bias/.ATTRIBUTES/VARIABLE_VALUE"))
+    S.write_bundle(tmp_path / "b_graph" / "variables", {k: v for k, v in base.items() if k != first_bias})
+    with pytest.raises(ValueError, match="holds|weighted layers"):
+        load_weights({"graph": tmp_path / "b_graph", "weights_npz": npz}, plan)
+    got = load_weights({"graph": tmp_path / "a_graph", "weights_npz": npz}, plan, trust_project=True)
+    assert all(np.array_equal(got[k], w[k]) for k in w)
+    # unknown scheme: falls back, and the run log hears about it
+    odd = {k.replace("_operations/", "model/layer_with_weights-"): v for k, v in base.items()}
+    S.write_bundle(tmp_path / "c_graph" / "variables", odd)
+    with caplog.at_level(logging.WARNING, logger="Jaeger"), pytest.warns(RuntimeWarning):
+        got = load_weights({"graph": tmp_path / "c_graph", "weights_npz": npz}, plan)
+    assert any("could not be mapped onto the layer plan" in r.getMessage() for r in caplog.records)
+    assert all(np.array_equal(got[k], w[k]) for k in w)
+    # the reference's own file (.weights.h5) outranks the derived .npz when both are present
+    from jaeger_amd.weights import load_keras3_h5  # noqa: F401
+    from conftest import GOLDEN
+    w500 = random_weights(plan, seed=500)
+    got = load_weights({"weights": GOLDEN / "baseline500_keras3.weights.h5", "weights_npz": npz}, plan)
+    assert all(np.array_equal(got[k], w500[k]) for k in w500)
