@@ -332,6 +332,19 @@ void jg_table_free(char *text);
 int jg_run_summaries(const int32_t *calls, int64_t n_calls, const int64_t *first, const int64_t *count, int64_t n_contigs,
                      const uint8_t *letters, int32_t n_letters, int32_t n_threads, char **text, int64_t *n_bytes);
 
+/* ---- per-contig reductions (host only; replaces the contig-by-contig np.mean / np.var of postprocess/collect.py:332-356 and
+ * the np.mean calls over every contig's entropy / energy / G+C / N% slice, :393-395, :319-327) -----------------------------
+ * Segment s covers rows [first[s], first[s] + count[s]) (count >= 1).  Both restate numpy's own summation order, so that the
+ * values - rounded to fp16 and printed with three decimals downstream - do not move by a bit:
+ * jg_segment_mean_var: x (n_rows, n_cols) f32 row-major -> mean, var (n_seg, n_cols) f32 (var may be NULL; ddof 0):
+ *                      rows added one after the other in f32 (n_cols = 1: pairwise, as numpy reduces a contiguous axis);
+ * jg_segment_mean_1d:  v (n) f32 (is_f64 = 0) or f64 (1) -> out (n_seg) of the same type, numpy's pairwise summation.
+ * n_threads <= 0: every usable core. */
+int jg_segment_mean_var(const float *x, int64_t n_rows, int32_t n_cols, const int64_t *first, const int64_t *count,
+                        int64_t n_seg, float *mean, float *var, int32_t n_threads);
+int jg_segment_mean_1d(const void *v, int32_t is_f64, int64_t n, const int64_t *first, const int64_t *count, int64_t n_seg,
+                       void *out, int32_t n_threads);
+
 /* ---- CRF window decoding (host only; replaces the per-contig loop over postprocess/helpers.py:398-449
  * viterbi_decode that postprocess/collect.py:343-346 runs for `jaeger predict --crf`) ---------------
  * logits (n_windows, n_classes) f32 row-major; chain c covers windows [first[c], first[c+1]) (first has

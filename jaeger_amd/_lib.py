@@ -124,6 +124,8 @@ SYMBOLS = {
     "jg_fasta_scan_free": (None, [_vp]),
     "jg_table_format": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, C.c_int64, C.c_int32, C.POINTER(_vp), C.POINTER(C.c_int64)]),
     "jg_table_free": (None, [_vp]),
+    "jg_segment_mean_var": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp, C.c_int64, _vp, _vp, C.c_int32]),
+    "jg_segment_mean_1d": (C.c_int, [_vp, C.c_int32, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int32]),
     "jg_run_summaries": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int32, C.c_int32, C.POINTER(_vp),
                                    C.POINTER(C.c_int64)]),
 }

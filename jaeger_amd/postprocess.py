@@ -206,22 +206,56 @@ class _Segments:
         for t, idx in self._groups:
             yield t, idx, self.first[idx][:, None] + np.arange(t, dtype=np.int64)[None, :]
 
+    # The three reductions below run natively (``jg_segment_mean_var`` / ``jg_segment_mean_1d``, csrc/jg_segments.hip: numpy's
+    # own summation order restated, every core) - a Python-level loop over the distinct window counts cost 0.15 s per
+    # 10 000 contigs, most of what ran beside (and behind) a short forward.  ``*_numpy`` are the grouped numpy forms they
+    # replace; tests/test_postprocess.py holds the two equal bit for bit.
     def mean_1d(self, v: np.ndarray) -> np.ndarray:
         """[np.mean(v[a:b]) for every contig] for a 1-D per-window array."""
+        v = np.asarray(v)
+        if v.dtype == np.float32 or v.dtype == np.float64:
+            return _native_mean_1d(np.ascontiguousarray(v), self.first, self.count)
+        return self.mean_1d_numpy(v)
+
+    def mean_flat(self, m: np.ndarray) -> np.ndarray:
+        """[np.mean(m[a:b]) for every contig] for an (N, C) array (mean over windows AND columns)."""
+        m = np.asarray(m)
+        if (m.dtype == np.float32 or m.dtype == np.float64) and m.ndim == 2:
+            c = m.shape[1]
+            return _native_mean_1d(np.ascontiguousarray(m).reshape(-1), self.first * c, self.count * c)
+        return self.mean_flat_numpy(m)
+
+    def mean_var_rows(self, m: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """[np.mean(m[a:b], axis=0)], [np.var(m[a:b], axis=0)] for an (N, C) array."""
+        m = np.asarray(m)
+        if m.dtype == np.float32 and m.ndim == 2 and m.shape[1] >= 1:
+            import ctypes as C
+
+            from . import _lib
+            m = np.ascontiguousarray(m)
+            mean = np.empty((self.n, m.shape[1]), np.float32)
+            var = np.empty_like(mean)
+            first, count = np.ascontiguousarray(self.first, np.int64), np.ascontiguousarray(self.count, np.int64)
+            _lib.check(_lib.load().jg_segment_mean_var(m.ctypes.data_as(C.c_void_p), m.shape[0], m.shape[1],
+                                                       first.ctypes.data_as(C.c_void_p), count.ctypes.data_as(C.c_void_p),
+                                                       self.n, mean.ctypes.data_as(C.c_void_p),
+                                                       var.ctypes.data_as(C.c_void_p), 0), "jg_segment_mean_var")
+            return mean, var
+        return self.mean_var_rows_numpy(m)
+
+    def mean_1d_numpy(self, v: np.ndarray) -> np.ndarray:
         out = np.empty(self.n, dtype=np.result_type(v.dtype, np.float32) if v.dtype.kind != "f" else v.dtype)
         for t, idx, rows in self.groups():
             out[idx] = np.mean(v[rows], axis=1)
         return out
 
-    def mean_flat(self, m: np.ndarray) -> np.ndarray:
-        """[np.mean(m[a:b]) for every contig] for an (N, C) array (mean over windows AND columns)."""
+    def mean_flat_numpy(self, m: np.ndarray) -> np.ndarray:
         out = np.empty(self.n, dtype=m.dtype)
         for t, idx, rows in self.groups():
             out[idx] = np.mean(m[rows].reshape(len(idx), -1), axis=1)
         return out
 
-    def mean_var_rows(self, m: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
-        """[np.mean(m[a:b], axis=0)], [np.var(m[a:b], axis=0)] for an (N, C) array."""
+    def mean_var_rows_numpy(self, m: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
         mean = np.empty((self.n, m.shape[1]), dtype=m.dtype)
         var = np.empty_like(mean)
         for t, idx, rows in self.groups():
@@ -229,6 +263,18 @@ class _Segments:
             mean[idx] = np.mean(block, axis=1)
             var[idx] = np.var(block, axis=1)
         return mean, var
+
+
+def _native_mean_1d(v: np.ndarray, first: np.ndarray, count: np.ndarray) -> np.ndarray:
+    import ctypes as C
+
+    from . import _lib
+    first, count = np.ascontiguousarray(first, np.int64), np.ascontiguousarray(count, np.int64)
+    out = np.empty(len(first), v.dtype)
+    _lib.check(_lib.load().jg_segment_mean_1d(v.ctypes.data_as(C.c_void_p), int(v.dtype == np.float64), v.size,
+                                              first.ctypes.data_as(C.c_void_p), count.ctypes.data_as(C.c_void_p), len(first),
+                                              out.ctypes.data_as(C.c_void_p), 0), "jg_segment_mean_1d")
+    return out
 
 
 def _frac_strings(flags: np.ndarray, seg: _Segments) -> np.ndarray:

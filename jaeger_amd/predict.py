@@ -460,6 +460,11 @@ def run_core(**kwargs) -> int:
 
     t_start = time.time()
     LAST_RUN.clear()
+    timeline: list = []                     # (event, seconds since run_core was entered): where the wall time of a short run goes
+    LAST_RUN["timeline"] = timeline
+
+    def mark(name):
+        timeline.append((name, round(time.time() - t_start, 4)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(kwargs.get("physicalid", 0))))
@@ -524,10 +529,12 @@ def run_core(**kwargs) -> int:
 
     def make_engine():
         t_eng = time.time()
+        mark("engine_setup_begin")
         try:
             return _make_engine()
         finally:
             LAST_RUN["engine_create_s"] = round(time.time() - t_eng, 3)
+            mark("engine_ready")
 
     def _make_engine():
         # the engine resolves the weights itself (weights.load_weights): the graph's variable bundle - what the reference
@@ -546,8 +553,10 @@ def run_core(**kwargs) -> int:
         nonlocal fa, num, t_ingest
         try:
             t_ingest = time.time()
+            mark("ingest_begin")
             fa = frag.load_fasta(str(input_path))
             t_ingest = time.time() - t_ingest
+            mark("ingest_done")
             num = validate_fasta_entries(fa, min_len=min_len)
         except Exception as e:
             lg.error(e)
@@ -584,8 +593,10 @@ def run_core(**kwargs) -> int:
     def scan_repeats(device):
         from .termini import scan_for_terminal_repeats
         t_term = time.time()
+        mark("repeat_scan_begin")
         rep = scan_for_terminal_repeats(device, fa, fsize)
         LAST_RUN["terminal_repeats_s"] = round(time.time() - t_term, 3)
+        mark("repeat_scan_done")
         lg.info(f"terminal repeats: {int(rep['terminal_repeats'].notna().sum())} of {len(rep)} "
                 f"contigs in {time.time() - t_term:.2f} s")
         return rep
@@ -658,6 +669,7 @@ def run_core(**kwargs) -> int:
                                         common["dynamic_stride_threshold"], fsize if two_pass else min_len, None)
         n_long = len(table)
         starts = fa.offsets[table.contig] + table.start
+        mark("window_table_done")
         LAST_RUN["ingest_and_table_s"] = round(time.time() - t_setup, 3)
         try:
             engine = f_engine.result() if piped else make_engine()
@@ -674,11 +686,15 @@ def run_core(**kwargs) -> int:
 
         def classify():
             t0 = time.time()
+            mark("fused_call_begin")
             if n_long:
                 engine.predict_windows(fa.bases, starts, table.length, fsize, pre_cased=dust, want=want,
                                        dust_records=fa.offsets if dust_dev else None, out=out)
+            mark("fused_call_done")
             return time.time() - t0
 
+        if piped and th is not None and kwargs.get("scan_first"):
+            th.join()                       # A/B: the repeat scan alone on the GPU, the forward behind it
         try:
             f_pred = pool.submit(classify) if piped else None
             log_setup(engine)
@@ -740,8 +756,10 @@ def run_core(**kwargs) -> int:
                                  reliability_cutoff=kwargs.get("rc", 0.5), phage_score=kwargs.get("pc", 1))
     else:
         try:
+            mark("last_flush_begin")
             agg.flush(writer, term_repeats)            # what is left: the last batch (and the short-contig pass)
             n_written = writer.close()
+            mark("tables_closed")
         except BaseException:
             writer.abort()
             raise
@@ -792,11 +810,15 @@ def run_core(**kwargs) -> int:
             np.savez(out_dir / f"{file_base}_embedding.npz", embedding=y_pred["embedding"], headers=headers)
         if kwargs.get("save_nmd") and "nmd" in y_pred:
             np.savez(out_dir / f"{file_base}_nmd.npz", embedding=y_pred["nmd"], headers=headers)   # legacy key name
+    mark("end")
     t_all = time.time() - t_start
     LAST_RUN.update(behind_forward_s=round(time.time() - t_post, 3), wall_s=round(t_all, 3))
     lg.info(f"wall time(s) : {t_all:.2f}  ({n_windows} windows; FASTA ingest {t_ingest:.2f} s, "
             f"encode+forward {t_predict:.2f} s = {n_bp / 1e6 / max(t_predict, 1e-9):.1f} Mbp/s, aggregation+TSV behind the forward "
             f"{time.time() - t_post:.2f} s; end to end {n_bp / 1e6 / max(t_all, 1e-9):.1f} Mbp/s)")
     if engine is not None:
-        engine.close()
+        # the engine's buffers (workspace, pinned staging) are released beside the caller: freeing them takes tens of
+        # milliseconds - a tenth of a short run - and nothing the caller gets depends on it
+        import threading
+        threading.Thread(target=engine.close, name="jaeger-engine-close").start()
     return n_written

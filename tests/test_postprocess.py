@@ -241,3 +241,35 @@ def test_native_run_summaries_equal_python_form():
             assert got == runs.summaries_py(letter) and len(got) == len(counts)
     one = _Runs(np.array([2, 2, 2, 1]), _Segments(np.array([], np.int64), 4))
     assert one.summaries({1: "V", 2: "p"}) == ["3p1V"]
+
+
+def test_native_segment_reductions_equal_numpy_bit_for_bit():
+    """``jg_segment_mean_var`` / ``jg_segment_mean_1d`` (csrc/jg_segments.hip) restate numpy's summation order: the means and
+    variances of every contig must equal BOTH the grouped numpy forms they replace and the per-contig calls the reference
+    makes (``np.mean(x[a:b], axis=0)`` etc., collect.py:332-356,393-395) bit for bit - every slice length from 1 to 1 100
+    (the pairwise scheme's three regimes), one to six columns, f32 and f64."""
+    from jaeger_amd.postprocess import _Segments
+    rng = np.random.default_rng(11)
+    counts = np.concatenate([np.arange(1, 1101), rng.integers(1, 40, 3000), [5000, 8193, 20001]])
+    rng.shuffle(counts)
+    n = int(counts.sum())
+    seg = _Segments(np.cumsum(counts)[:-1], n)
+    for dtype in (np.float32, np.float64):
+        v = (rng.standard_normal(n) * np.exp(rng.uniform(-6, 6, n))).astype(dtype)
+        got = seg.mean_1d(v)
+        assert got.dtype == dtype
+        np.testing.assert_array_equal(got, seg.mean_1d_numpy(v))
+        per = np.array([np.mean(v[a:a + c]) for a, c in zip(seg.first, seg.count)], dtype)
+        np.testing.assert_array_equal(got, per)
+    for c in (1, 2, 3, 4, 6):
+        m = (rng.standard_normal((n, c)) * 7).astype(np.float32)
+        mean, var = seg.mean_var_rows(m)
+        mean_np, var_np = seg.mean_var_rows_numpy(m)
+        np.testing.assert_array_equal(mean, mean_np)
+        np.testing.assert_array_equal(var, var_np)
+        for a, cnt in list(zip(seg.first, seg.count))[:400]:
+            np.testing.assert_array_equal(mean[np.searchsorted(seg.first, a)], np.mean(m[a:a + cnt], axis=0))
+            np.testing.assert_array_equal(var[np.searchsorted(seg.first, a)], np.var(m[a:a + cnt], axis=0))
+        np.testing.assert_array_equal(seg.mean_flat(m), seg.mean_flat_numpy(m))
+    m64 = rng.standard_normal((n, 2))
+    np.testing.assert_array_equal(seg.mean_flat(m64), seg.mean_flat_numpy(m64))
