@@ -433,7 +433,8 @@ static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
         sh[op.out_buf] = Shape{in.frames, lo, op.cout};
         fl += 2.0 * op.k * op.cin * op.cout * (double)in.frames * lo;
         if ((int)i == m->tab_conv && tab_usable(m, l)) break;      // table net: the activation never exists
-        act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)in.frames * lo * op.cout);
+        // (+ one position for an odd row: a phase-split tensor holds two phases of (lo + 1) / 2 positions)
+        act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)in.frames * (lo + (lo & 1)) * op.cout);
         const int tiles = std::max((lo + 63) / 64, 8 * ((lo + 255) / 256));
         for (int s = 0; s < op.n_stages; ++s)
           if (op.stages[s].kind == JG_ST_NMD)
@@ -1196,6 +1197,112 @@ static int prepare_f16(jg_model *m, const float *weights) {
   return JG_OK;
 }
 
+// Pass C - stride-2 convs without dropped work.  A strided residual block (layers.py:1882-1915: conv1 of 5 taps and the
+// 1x1 bypass, both stride 2, both reading the block's input) is evaluated by the split-f16 kernel at stride 1 with every
+// second output dropped.  When ALL readers of a tensor are such convs and a split-f16 conv writes it, the writer stores it
+// phase-split instead (ConvHArgs::psplit: even positions in the first cin channels, odd ones in the next cin, (L + 1) / 2
+// positions, mask-multiplied) and the readers run at stride 1: the 5-tap conv as a 3-tap conv over 2 x cin channels -
+//   y[m] = sum_t w_t x[2m + t - pl]  =  sum over q = t - pl of  w_t . phase(q mod 2)[m + floor(q / 2)]
+// (pl = TF's SAME left pad: 2 for an odd input length, 1 for an even one - two weight arrangements) - the 1x1 conv on the
+// even phase alone.  Same sums in another order of the taps: results agree to f32 rounding, no output is computed twice.
+static int plan_phase_split(jg_model *m, const float *weights) {
+  if (!m->f16_eligible) return JG_OK;
+  static const bool off = jg_exp_env("JG_NO_PSPLIT") != nullptr;
+  if (off) return JG_OK;
+  const size_t n = m->ops.size();
+  auto reads_buf = [&](size_t j, int buf) {
+    const jg_op &o = m->ops[j];
+    if ((o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM ||
+         o.kind == JG_OP_POOL || o.kind == JG_OP_NMD_FINAL) && o.in_buf == buf)
+      return true;
+    if (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE)
+      for (int q = 0; q < o.n_stages; ++q)
+        if (o.stages[q].kind == JG_ST_ADD && o.stages[q].arg == buf) return true;
+    return false;
+  };
+  auto writes_buf = [&](size_t j, int buf) {
+    const jg_op &o = m->ops[j];
+    return (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM) &&
+           o.out_buf == buf;
+  };
+  for (size_t p = 0; p < n; ++p) {
+    const jg_op &po = m->ops[p];
+    ConvHPrep &pp = m->hprep[p];
+    if (po.kind != JG_OP_CONV || !pp.f16_ok || !pp.out_f16s || pp.pool_op >= 0 || po.stride != 1 || po.out_buf < 0 ||
+        po.cout % 16 != 0 || (int)p == m->tab_conv)
+      continue;
+    std::vector<size_t> readers;
+    bool ok = true, mask_rewritten = false;
+    for (size_t j = p + 1; j < n && ok; ++j) {
+      const jg_op &o = m->ops[j];
+      if (reads_buf(j, po.out_buf)) {
+        const ConvHPrep &hr = m->hprep[j];
+        const bool conv_reader = o.kind == JG_OP_CONV && o.in_buf == po.out_buf && hr.f16_ok && o.stride == 2 &&
+                                 o.padding == JG_PAD_SAME && o.cin == po.cout && o.in_mask == po.out_mask &&
+                                 ((o.k == 5 && o.dilation == 1) || o.k == 1);
+        bool adds_it = false;
+        for (int q = 0; q < o.n_stages; ++q) adds_it |= o.stages[q].kind == JG_ST_ADD && o.stages[q].arg == po.out_buf;
+        bool cvt_here = false;
+        for (int q = 0; q < hr.n_cvt; ++q) cvt_here |= hr.cvt_slot[q] == po.out_buf;
+        // (the mask the writer multiplies by must still be the reader's input mask when it runs)
+        if (!conv_reader || adds_it || cvt_here || mask_rewritten) ok = false;
+        else readers.push_back(j);
+      }
+      if (o.kind == JG_OP_MASK && po.out_mask >= 0 && o.out_mask == po.out_mask) mask_rewritten = true;
+      if (writes_buf(j, po.out_buf)) break;
+    }
+    if (!ok || readers.empty()) continue;
+    // weights of the 5-tap readers, re-arranged for both parities of the input length
+    bool built = true;
+    for (size_t j : readers) {
+      const jg_op &o = m->ops[j];
+      ConvHPrep &hr = m->hprep[j];
+      if (o.k != 5) continue;
+      const int cin = o.cin, cin2 = 2 * cin, cout_pad32 = (o.cout + 31) / 32 * 32, cin_pad = (cin + 1) & ~1;
+      const float *w = weights + o.w_off;                  // (5, cin_pad, cout_pad32)
+      const float wscale = 1.0f / hr.acc_scale;            // the conv's own power-of-two scale (the epilogue table undoes it)
+      const int kk = 5, kc_total = cin2 / 8, cout_pad = 128;
+      const size_t half_items = (size_t)2 * kk * kc_total * cout_pad, n_items = half_items * hr.n_half;
+      hr.ps_half_items = (int64_t)half_items;
+      for (int par = 0; par < 2; ++par) {                   // par = input length & 1
+        const int pl = par ? 2 : 1;
+        std::vector<uint16_t> wh(n_items * 8, 0);
+        for (int t = 0; t < 5; ++t) {
+          const int q = t - pl, ph = ((q % 2) + 2) % 2, off3 = (q - ph) / 2 + 1;     // phase, tap of the 3-tap conv (0 .. 2)
+          const int tk = 1 + off3;                                                   // ... in the middle of the kernel's five
+          for (int c = 0; c < cin; ++c)
+            for (int nn = 0; nn < o.cout; ++nn) {
+              const float v = w[((size_t)t * cin_pad + c) * cout_pad32 + nn] * wscale;
+              const float hi = f16_value(v);
+              const int c2 = ph * cin + c;
+              const size_t base = (size_t)(nn / 128) * half_items;
+              const size_t item = base + (((size_t)0 * kk + tk) * kc_total + c2 / 8) * cout_pad + nn % 128;
+              const size_t item_lo = base + (((size_t)1 * kk + tk) * kc_total + c2 / 8) * cout_pad + nn % 128;
+              wh[item * 8 + c2 % 8] = f16_bits(hi);
+              wh[item_lo * 8 + c2 % 8] = f16_bits(v - hi);
+            }
+        }
+        if (hipMalloc(reinterpret_cast<void **>(&hr.d_wh_ps[par]), n_items * 16) != hipSuccess ||
+            hipMemcpy(hr.d_wh_ps[par], wh.data(), n_items * 16, hipMemcpyHostToDevice) != hipSuccess) {
+          built = false;
+          break;
+        }
+      }
+      if (!built) break;
+    }
+    if (!built) {
+      (void)hipGetLastError();
+      for (size_t j : readers)
+        for (int par = 0; par < 2; ++par)
+          if (m->hprep[j].d_wh_ps[par]) { (void)hipFree(m->hprep[j].d_wh_ps[par]); m->hprep[j].d_wh_ps[par] = nullptr; }
+      continue;
+    }
+    pp.ps_store = true;
+    for (size_t j : readers) m->hprep[j].ps_read = m->ops[j].k == 5 ? 1 : 2;
+  }
+  return JG_OK;
+}
+
 extern "C" int jg_model_set_precision(jg_model *m, int mode) {
   JG_REQUIRE(m != nullptr && (mode == 0 || mode == 1), JG_ERR_INVALID, "jg_model_set_precision: bad args");
   if (mode == 1 && !m->f16_eligible) {
@@ -1223,7 +1330,11 @@ extern "C" int jg_model_describe(const jg_model *m, char *buf, int64_t cap) {
     const ConvHPrep &hp = m->hprep[i];
     const char *where = m->small != nullptr ? "fused small-window kernel"
                         : (m->f16_eligible && hp.f16_ok)
-                            ? (hp.d_lut != nullptr ? "split-f16 (table lookup)" : hp.as_k5 ? "split-f16 (tap range of the 5-tap kernel)"
+                            ? (hp.d_lut != nullptr ? "split-f16 (table lookup)"
+                               : hp.ps_read == 1 ? "split-f16 (stride 2 as a 3-tap conv over the two phases of its phase-split input)"
+                               : hp.ps_read == 2 ? "split-f16 (stride 2 on the even phase of its phase-split input)"
+                               : hp.ps_store ? (hp.cw != 128 ? "split-f16 (narrow tile, phase-split store)" : "split-f16 (phase-split store)")
+                               : hp.as_k5 ? "split-f16 (tap range of the 5-tap kernel)"
                                : hp.cw != 128 ? "split-f16 (narrow tile)" : "split-f16")
                             : "exact-f32";
     static const char *const st_name[] = {"?", "bias", "bn", "dyt", "add", "act", "nmd", "maskmul", "ln"};
@@ -1296,6 +1407,8 @@ extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const 
   if (rc != JG_OK) { jg_model_destroy(m); return rc; }
   rc = prepare_f16(m, weights);
   if (rc != JG_OK) { jg_model_destroy(m); return rc; }
+  rc = plan_phase_split(m, weights);
+  if (rc != JG_OK) { jg_model_destroy(m); return rc; }
   rc = prepare_f32(m, weights);
   if (rc != JG_OK) { jg_model_destroy(m); return rc; }
   // the 32-channel small-window family has a fused kernel of its own (same split-f16 arithmetic): where the program
@@ -1349,6 +1462,7 @@ extern "C" int jg_model_destroy(jg_model *m) {
   if (m->pool_part) (void)hipFree(m->pool_part);
   for (auto &hp : m->hprep) {
     if (hp.d_wh) (void)hipFree(hp.d_wh);
+    for (int par = 0; par < 2; ++par) if (hp.d_wh_ps[par]) (void)hipFree(hp.d_wh_ps[par]);
     if (hp.d_embh) (void)hipFree(hp.d_embh);
     if (hp.d_epi) (void)hipFree(hp.d_epi);
     if (hp.d_w8) (void)hipFree(hp.d_w8);
@@ -1599,7 +1713,29 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           }
           a.cw = hp.cw;
           a.ostride = op.stride;
-          a.L_res = op.stride == 2 ? 2 * lo - 1 : lo;
+          a.cc_row = hp.cc_in;
+          int eff_stride = op.stride, eff_lin = in.L;
+          if (hp.ps_read != 0) {
+            // the input was stored phase-split and masked by its writer (plan_phase_split): this stride-2 conv runs at
+            // stride 1 over (L + 1) / 2 positions - five taps as three over the two phases, the 1x1 bypass on the even phase
+            eff_stride = 1;
+            eff_lin = (in.L + 1) / 2;                      // == lo (TF SAME at stride 2: ceil(L / 2))
+            a.mask_in = nullptr;
+            a.L_in = eff_lin;
+            a.cc_row = 2 * hp.cc_in;
+            a.k = 5; a.dil = 1; a.ostride = 1;
+            if (hp.ps_read == 1) {
+              a.cc_in = 2 * hp.cc_in;
+              a.wh = hp.d_wh_ps[in.L & 1];
+              a.tap_lo = 1; a.tap_hi = 3;
+              a.pad_left = 1 + a.tap_lo * a.dil;           // a 3-tap SAME conv pads one position on the left
+            } else {
+              a.tap_lo = a.tap_hi = 2;
+              a.pad_left = 0 + a.tap_lo * a.dil;
+            }
+          }
+          a.psplit = hp.ps_store ? 1 : 0;
+          a.L_res = eff_stride == 2 ? 2 * lo - 1 : lo;
           a.tiles_m = (a.L_res + jg_conv_f16_tile_m() - 1) / jg_conv_f16_tile_m();
           const int strips = hp.cw == 128 ? 2 : 4;               // wave strips per 256-position tile
           int strips_per_win = in.frames * a.tiles_m * strips;   // partial rows (128- / 64-position strips) per window
@@ -1612,8 +1748,8 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
             const int wp = (in.frames * fp + 127) / 128 * 128;
             const int64_t flat_tiles = ((int64_t)nw * wp + 255) / 256;
             const int64_t row_tiles = (int64_t)a.rows * a.tiles_m;
-            if (!no_flat && a.k == 5 && op.in_buf != JG_BUF_IDS && hp.d_lut == nullptr && op.stride == 1 && in.L == lo &&
-                ((op.cout == 128 && !hp.as_k5) ? jg_conv_f16_has_flat_pattern(hp.ep) : jg_conv_f16_has_narrow_pattern(hp.ep)) &&
+            if (!no_flat && a.k == 5 && op.in_buf != JG_BUF_IDS && hp.d_lut == nullptr && eff_stride == 1 && eff_lin == lo &&
+                ((op.cout == 128 && !hp.as_k5 && hp.ps_read == 0) ? jg_conv_f16_has_flat_pattern(hp.ep) : jg_conv_f16_has_narrow_pattern(hp.ep)) &&
                 (int64_t)nw * wp < (1 << 24) && flat_tiles * 100 <= row_tiles * 95) {
               a.flat = 1;
               a.flat_p = fp;
@@ -1662,7 +1798,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           rc = jg_launch_conv_f16(e, a, s);
           for (int hf = 1; hf < hp.n_half && rc == JG_OK; ++hf) {      // wider than 128 channels: one launch per 128
             a.ch0 = hf * 128;
-            a.wh = hp.d_wh + (int64_t)hf * hp.wh_half_items;
+            a.wh = hp.ps_read == 1 ? hp.d_wh_ps[in.L & 1] + (int64_t)hf * hp.ps_half_items : hp.d_wh + (int64_t)hf * hp.wh_half_items;
             a.epi = hp.d_epi + (int64_t)hf * hp.n_epi_rows * 2 * 128;
             rc = jg_launch_conv_f16(e, a, s);
           }

@@ -109,6 +109,12 @@ struct ConvHArgs {
   int *overflow;           // set to 1 when an output leaves the f16 range
   int rows, L_in, L_out;
   int cc_in, cout, cout_pad;   // cout_pad: output channels rounded up to 16 (F16S chunks of y / addh)
+  int cc_row;                  // 16-channel chunks per input ROW in memory (0 = cc_in): a 1x1 stride-2 bypass reads only the
+                               // even-phase half of a phase-split tensor
+  int psplit;                  // 1: the output is stored PHASE-SPLIT and mask-multiplied for the stride-2 convs that read it:
+                               // position p of channel chunk cc goes to chunk (p & 1) * cout_pad/16 + cc, position p >> 1 of a
+                               // tensor [rows][2 * cout_pad/16][4][(L_out + 1) / 2] - a stride-2 conv over L positions then is a
+                               // stride-1 conv over (L + 1) / 2 positions of twice the channels, no output computed and dropped
   int ch0;                     // first output channel of this launch (convs wider than 128 run one launch per 128)
   int cw;                      // channel width of a workgroup tile: 128, 64 or 32 (narrow convs: waves split positions only)
   int ostride;                 // 1, or 2: the conv is evaluated at stride 1 over L_res positions and even ones are kept
@@ -212,6 +218,12 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
   int pool_op = -1;         // index of the OP_POOL (masked max) fused into this conv's epilogue, or -1
   int act_kind = JG_ACT_GELU_TANH;   // activation of the op's ACT stages (the compiled patterns allow one kind per op)
   bool pool_f16s = false;   // (MAXPOOL1D ops) input and output are F16S tensors
+  // stride-2 convs without dropped work (phase-split tensors, ConvHArgs::psplit):
+  bool ps_store = false;    // (CONV ops) this conv's output is read by stride-2 convs only: stored phase-split and masked
+  int ps_read = 0;          // (CONV ops) 1: a 5-tap stride-2 conv run as a 3-tap stride-1 conv over the two phases (2 x cin
+                            // channels, re-arranged weights d_wh_ps); 2: a 1x1 stride-2 conv run at stride 1 on the even phase
+  uint4 *d_wh_ps[2] = {nullptr, nullptr};   // ps_read == 1: weights for an even / odd input length (TF's SAME split differs)
+  int64_t ps_half_items = 0;
   bool f16_ok = false;      // (CONV ops) runs on the split-f16 kernel when the model is in split-f16 mode
   int n_cvt = 0;            // layout conversions queued in front of this op (any op kind): slot, direction
   int cvt_slot[3] = {-1, -1, -1};

@@ -130,7 +130,10 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
   JG_REQUIRE(jg_conv_f16_supports(a.k, a.dil), JG_ERR_UNSUPPORTED,
              "conv_f16x3: k=%d dilation=%d outside the kernel's tiling", a.k, a.dil);
   // DMA offsets are 32-bit: the activation tensor of one launch must stay below 4 GiB
-  JG_REQUIRE((double)a.rows * a.cc_in * 4.0 * a.L_in * 16.0 < 4.0e9, JG_ERR_UNSUPPORTED,
+  if (a.cc_row == 0) const_cast<ConvHArgs &>(a).cc_row = a.cc_in;
+  JG_REQUIRE(a.cc_row >= a.cc_in && (!a.psplit || (a.out_f16s && a.pool_out == nullptr && a.ostride == 1)), JG_ERR_INVALID,
+             "conv_f16x3: phase-split geometry (cc_row %d, cc_in %d, psplit %d)", a.cc_row, a.cc_in, a.psplit);
+  JG_REQUIRE((double)a.rows * a.cc_row * 4.0 * a.L_in * 16.0 < 4.0e9, JG_ERR_UNSUPPORTED,
              "conv_f16x3: activation tensor of %d rows exceeds the 32-bit DMA offset range", a.rows);
   if (a.rows == 0 || a.L_out <= 0) return JG_OK;
   const_cast<ConvHArgs &>(a).dbg = jg_dbg_env();

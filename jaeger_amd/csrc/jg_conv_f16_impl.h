@@ -237,7 +237,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
         x_voff[it] = (byte * a.cc_in * 4 + ph) * 16;
         keep = byte != 0 || !a.mask_from_ids;
       } else {
-        x_voff[it] = (unsigned)(((rb * a.cc_in * 4 + (int)ph) * a.L_in + pc) * 16);
+        x_voff[it] = (unsigned)(((rb * a.cc_row * 4 + (int)ph) * a.L_in + pc) * 16);
         keep = byte != 0;
       }
       if (inr && keep) x_ok |= 1u << it;
@@ -932,6 +932,14 @@ void conv_f16x3_kernel(ConvHArgs a) {
         const int G = ((nb + ch0) >> 3) + 2 * j + h;
         return (unsigned)(((row * (a.cout_pad >> 4) + (G >> 1)) * 4 + (G & 1)) * a.L_out + mc);
       };
+      // where an output item goes: as item4, or - phase-split store - position p of chunk cc at chunk (p & 1) * CC + cc,
+      // position p >> 1 of rows that hold 2 * CC chunks of (L_out + 1) / 2 positions
+      const int L_st = a.psplit ? ((a.L_out + 1) >> 1) : a.L_out;      // positions per chunk row of the stored tensor
+      auto item4_out = [&](int row, int mc, int nb, int j) -> unsigned {
+        if (!a.psplit) return item4(row, mc, nb, j);
+        const int G = ((nb + ch0) >> 3) + 2 * j + h, CC = a.cout_pad >> 4;
+        return (unsigned)(((row * 2 * CC + (mc & 1) * CC + (G >> 1)) * 4 + (G & 1)) * L_st + (mc >> 1));
+      };
       // this lane's output position in block tm: row, clamped position, alive
       auto out_pos = [&](const Tile &tile, int tm, int &row, int &mc) -> bool {
         int p;
@@ -1102,6 +1110,10 @@ void conv_f16x3_kernel(ConvHArgs a) {
           if constexpr (N2 == 2) st_dyt(N1 ? 2 : 1, a.alpha2, a.dytmask2);
           if constexpr (EP & JG_EP_ACT2) st_gelu();
         }
+        if (a.psplit) {            // the stride-2 readers take their input mask from here (they read x * mask)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] *= mk;
+        }
         // results stay in the block's registers (F16S: re-split, lane-pair swapped and bit-cast,
         // dword 4j..4j+3 = hi item, 8+4j.. = lo item of group 2j+h); stored by store_block() once
         // every block's loads are done - no load ever queues behind a store
@@ -1148,7 +1160,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               if (GEN && nb + ch0 + 16 * j >= a.cout) continue;     // zero-padded channels of a narrow conv
-              const unsigned it4 = item4(orow, mc, nb, j);
+              const unsigned it4 = item4_out(orow, mc, nb, j);
               typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
               const u32x4 vhi = {__float_as_uint(x[4 * j]), __float_as_uint(x[4 * j + 1]),
                                  __float_as_uint(x[4 * j + 2]), __float_as_uint(x[4 * j + 3])};
@@ -1157,7 +1169,14 @@ void conv_f16x3_kernel(ConvHArgs a) {
               // the output (1.5 GB per launch) is read next by another launch, far beyond any cache:
               // streamed (nt) rather than write-allocated in L2 (+1.3 % measured)
               __builtin_nontemporal_store(vhi, reinterpret_cast<u32x4 *>(yh + it4));
-              __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)a.L_out));
+              __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)L_st));
+              if (a.psplit && (a.L_out & 1) && mc == a.L_out - 1) {
+                // an odd row length: the odd phase is one position short - its last slot (position L_out) reads as zero
+                const unsigned itz = it4 + (unsigned)((a.cout_pad >> 4) * 4 * L_st);
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                __builtin_nontemporal_store(z, reinterpret_cast<u32x4 *>(yh + itz));
+                __builtin_nontemporal_store(z, reinterpret_cast<u32x4 *>(yh + itz + 2u * (unsigned)L_st));
+              }
             }
           } else {
             float *yf = reinterpret_cast<float *>(a.y) + ((size_t)orow * a.L_out + mc) * a.cout + ch0 + nb + 4 * h;

@@ -218,6 +218,24 @@ def test_forward_pyramid_resnet_with_seven_and_nine_tap_blocks(ksize):
         assert err <= TOL, (k, err)
 
 
+def test_pyramid_strided_blocks_read_phase_split_tensors():
+    """Round 5: a stride-2 residual block's convs (5-tap conv1 and the 1x1 bypass) no longer compute every position and drop
+    half - the conv in front of the block stores its output phase-split and masked, the readers run at stride 1 (conv1 as a
+    3-tap conv over the two phases).  All three strided blocks of the pyramid take that form - input lengths 659 (odd),
+    330 (even), 165 (odd) at 2000 bp exercise both weight arrangements - and the parity tests above run through it."""
+    from jaeger_amd.engine import JaegerHipEngine
+    from oracle import forward as ofwd
+    cfg = load_model_cfg("pyramid")
+    eng = JaegerHipEngine(model_cfg=cfg, weights=ofwd.random_weights(cfg, seed=1), precision="f16x3")
+    text = eng.model.describe()
+    eng.close()
+    lines = text.splitlines()
+    assert sum("phase-split store" in ln for ln in lines) == 3, text
+    assert sum("3-tap conv over the two phases" in ln for ln in lines) == 3, text
+    assert sum("on the even phase" in ln for ln in lines) == 3, text
+    assert not any("stride=2" in ln and "phase" not in ln for ln in lines), text
+
+
 def test_forward_pyramid_resnet_short_windows_chunked():
     _forward_case("pyramid", 2000, 9, 22, n_frac=0.03, short=True, chunk=4, precision="f16x3", gain=0.85)
     _forward_case("pyramid", 900, 5, 23, n_frac=0.0, precision="f16x3", gain=0.85)
