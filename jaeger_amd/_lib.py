@@ -22,6 +22,7 @@ JG_OPT_TERMINI_EXACT = 3
 JG_OPT_DUST_ON_COPY_STREAM = 4
 JG_OPT_TABLE_NET_LDS = 5
 JG_OPT_RESET_PROGRESS = 6
+JG_OPT_FUSE_RESBLOCK = 7
 JG_COL_STRING, JG_COL_INT, JG_COL_FLOAT, JG_COL_BOOL = 0, 1, 2, 3     # jg_table_format column kinds
 JG_STAT_STREAM_GROUPS, JG_STAT_STREAM_BYTES, JG_STAT_PEAK_DEVICE_BASES, JG_STAT_DUST_MASKED, JG_STAT_WINDOWS_DONE = 1, 2, 3, 4, 5
 JG_MSTAT_CONVS, JG_MSTAT_CONVS_F16X3, JG_MSTAT_LAYOUT_CONVERSIONS, JG_MSTAT_SMALL_FUSED = 0, 1, 2, 3

@@ -108,6 +108,9 @@ extern "C" int jg_engine_set_option(jg_engine *e, int key, int64_t value) {
     case JG_OPT_TABLE_NET_LDS:
       e->tab_lds_only = value != 0;
       return JG_OK;
+    case JG_OPT_FUSE_RESBLOCK:
+      e->fuse_resblock = value != 0;
+      return JG_OK;
     case JG_OPT_RESET_PROGRESS:
       e->windows_done.store(0, std::memory_order_release);
       return JG_OK;
@@ -1303,6 +1306,120 @@ static int plan_phase_split(jg_model *m, const float *weights) {
   return JG_OK;
 }
 
+// Pass D - whole narrow residual blocks as one launch (jg_resblock.hip).  conv1 [bias, norm, GELU] and conv2 [bias, norm,
+// + block input, GELU] of a stride-1 block without bypass (layers.py:1882-1915), 32 channels, five taps, one dilation: the
+// intermediate tensor lives in LDS only.  conv1's op is skipped at run time, conv2's launch computes both; the mask ops
+// between them run as before (the kernel reads conv2's input mask from their output).
+static int plan_resblocks(jg_model *m, const float *weights) {
+  if (!m->f16_eligible) return JG_OK;
+  static const bool off = jg_exp_env("JG_NO_RESBLOCK") != nullptr;
+  if (off) return JG_OK;
+  const size_t n = m->ops.size();
+  auto reads_buf = [&](size_t j, int buf) {
+    const jg_op &o = m->ops[j];
+    if ((o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM ||
+         o.kind == JG_OP_POOL || o.kind == JG_OP_NMD_FINAL) && o.in_buf == buf)
+      return true;
+    if (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE)
+      for (int q = 0; q < o.n_stages; ++q)
+        if (o.stages[q].kind == JG_ST_ADD && o.stages[q].arg == buf) return true;
+    return false;
+  };
+  auto writes_buf = [&](size_t j, int buf) {
+    const jg_op &o = m->ops[j];
+    return (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM) &&
+           o.out_buf == buf;
+  };
+  // bias / batch-norm stages in front of the first other stage, folded with the weights' un-scale (as prepare_f16 does)
+  auto fold = [&](const jg_op &op, float acc_scale, float *sc, float *sh) {
+    std::vector<double> s((size_t)op.cout, (double)acc_scale), t((size_t)op.cout, 0.0);
+    for (int q = 0; q < op.n_stages; ++q) {
+      const jg_stage &st = op.stages[q];
+      if (st.kind == JG_ST_BIAS) {
+        for (int c = 0; c < op.cout; ++c) t[(size_t)c] += (double)weights[st.p0 + c];
+      } else if (st.kind == JG_ST_BN) {
+        for (int c = 0; c < op.cout; ++c) {
+          const double mu = weights[st.p0 + c], is = weights[st.p1 + c], g = weights[st.p2 + c], b = weights[st.p3 + c];
+          s[(size_t)c] = s[(size_t)c] * is * g;
+          t[(size_t)c] = (t[(size_t)c] - mu) * is * g + b;
+        }
+      } else {
+        break;
+      }
+    }
+    for (int c = 0; c < op.cout; ++c) { sc[c] = (float)s[(size_t)c]; sh[c] = (float)t[(size_t)c]; }
+  };
+  for (size_t ia = 0; ia < n; ++ia) {
+    const jg_op &A = m->ops[ia];
+    ConvHPrep &ha = m->hprep[ia];
+    if (A.kind != JG_OP_CONV || !ha.f16_ok || ha.rb_second >= 0 || ha.rb_first >= 0 || A.in_buf < 0 || A.stride != 1 ||
+        A.padding != JG_PAD_SAME || A.cin != A.cout || !jg_resblock_supports(A.cout, A.k, A.dilation) || !ha.out_f16s ||
+        ha.ep != JG_EP_ACT1 || ha.act_kind != JG_ACT_GELU_TANH || ha.pool_op >= 0 || ha.ps_store || ha.ps_read != 0 ||
+        ha.n_cvt != 0 || (int)ia == m->tab_conv)
+      continue;
+    // the only reader of conv1's output: conv2, before anything overwrites it (mask ops may sit in between)
+    size_t ib = n;
+    bool ok = true;
+    for (size_t j = ia + 1; j < n; ++j) {
+      if (reads_buf(j, A.out_buf)) {
+        if (ib == n && m->ops[j].kind == JG_OP_CONV && m->ops[j].in_buf == A.out_buf) ib = j;
+        else ok = false;
+      }
+      if (writes_buf(j, A.out_buf) && j != ib) break;
+      if (writes_buf(j, A.out_buf) && j == ib) { ok = false; break; }       // (in place: not a residual block)
+    }
+    if (!ok || ib == n) continue;
+    for (size_t j = ia + 1; j < ib && ok; ++j)                               // nothing but mask ops between the two
+      ok = m->ops[j].kind == JG_OP_MASK && m->ops[j].out_mask != A.in_mask && m->ops[j].out_mask != A.out_mask;
+    const jg_op &B = m->ops[ib];
+    ConvHPrep &hb = m->hprep[ib];
+    if (!ok || !hb.f16_ok || B.stride != 1 || B.padding != JG_PAD_SAME || B.k != A.k || B.dilation != A.dilation ||
+        B.cin != A.cout || B.cout != A.cout || B.in_mask != A.out_mask || !hb.out_f16s ||
+        hb.ep != (JG_EP_ADD | JG_EP_ACT1) || hb.act_kind != JG_ACT_GELU_TANH || hb.add_slot != A.in_buf ||
+        B.out_buf == A.in_buf || B.out_buf == A.out_buf || hb.pool_op >= 0 || hb.ps_read != 0 || hb.n_cvt != 0 ||
+        hb.nmd_slot >= 0 || ha.nmd_slot >= 0)
+      continue;
+    // weight fragments [conv][tap][chunk][plane][lane][8 halfs]: lane = (cin group of 8) x (output channel)
+    const int C = A.cout, K = A.k, cc_n = C / 16;
+    std::vector<uint16_t> frag((size_t)2 * K * cc_n * 2 * 64 * 8, 0);
+    std::vector<float> epi((size_t)4 * C, 0.f);
+    bool range_ok = true;
+    for (int c = 0; c < 2; ++c) {
+      const jg_op &op = c == 0 ? A : B;
+      const ConvHPrep &hp = c == 0 ? ha : hb;
+      const float *w = weights + op.w_off;                 // (k, cin_pad, cout_pad32)
+      const int cin_pad = (op.cin + 1) & ~1, cout_pad32 = (op.cout + 31) / 32 * 32;
+      const float wscale = 1.0f / hp.acc_scale;
+      for (int t = 0; t < K; ++t)
+        for (int cc = 0; cc < cc_n; ++cc)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int co = lane & 31, ci = cc * 16 + (lane >> 5) * 8 + j;
+              const float v = w[((size_t)t * cin_pad + ci) * cout_pad32 + co] * wscale;
+              const float hi = f16_value(v);
+              if (!(fabsf(v) <= 65000.f)) range_ok = false;
+              const size_t base = ((((size_t)c * K + t) * cc_n + cc) * 2) * 64 * 8;
+              frag[base + (size_t)lane * 8 + j] = f16_bits(hi);
+              frag[base + 64 * 8 + (size_t)lane * 8 + j] = f16_bits(v - hi);
+            }
+      fold(op, hp.acc_scale, epi.data() + (size_t)c * 2 * C, epi.data() + (size_t)c * 2 * C + C);
+    }
+    if (!range_ok) continue;
+    if (hipMalloc(reinterpret_cast<void **>(&hb.d_rb_wfrag), frag.size() * 2) != hipSuccess ||
+        hipMemcpy(hb.d_rb_wfrag, frag.data(), frag.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&hb.d_rb_epi), epi.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(hb.d_rb_epi, epi.data(), epi.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hb.d_rb_wfrag) { (void)hipFree(hb.d_rb_wfrag); hb.d_rb_wfrag = nullptr; }
+      if (hb.d_rb_epi) { (void)hipFree(hb.d_rb_epi); hb.d_rb_epi = nullptr; }
+      continue;
+    }
+    ha.rb_second = (int)ib;
+    hb.rb_first = (int)ia;
+  }
+  return JG_OK;
+}
+
 extern "C" int jg_model_set_precision(jg_model *m, int mode) {
   JG_REQUIRE(m != nullptr && (mode == 0 || mode == 1), JG_ERR_INVALID, "jg_model_set_precision: bad args");
   if (mode == 1 && !m->f16_eligible) {
@@ -1331,6 +1448,8 @@ extern "C" int jg_model_describe(const jg_model *m, char *buf, int64_t cap) {
     const char *where = m->small != nullptr ? "fused small-window kernel"
                         : (m->f16_eligible && hp.f16_ok)
                             ? (hp.d_lut != nullptr ? "split-f16 (table lookup)"
+                               : hp.rb_second >= 0 ? "split-f16 (fused residual block: computed by the block's second conv)"
+                               : hp.rb_first >= 0 ? (hp.ps_store ? "split-f16 (fused residual block, phase-split store)" : "split-f16 (fused residual block)")
                                : hp.ps_read == 1 ? "split-f16 (stride 2 as a 3-tap conv over the two phases of its phase-split input)"
                                : hp.ps_read == 2 ? "split-f16 (stride 2 on the even phase of its phase-split input)"
                                : hp.ps_store ? (hp.cw != 128 ? "split-f16 (narrow tile, phase-split store)" : "split-f16 (phase-split store)")
@@ -1409,6 +1528,8 @@ extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const 
   if (rc != JG_OK) { jg_model_destroy(m); return rc; }
   rc = plan_phase_split(m, weights);
   if (rc != JG_OK) { jg_model_destroy(m); return rc; }
+  rc = plan_resblocks(m, weights);
+  if (rc != JG_OK) { jg_model_destroy(m); return rc; }
   rc = prepare_f32(m, weights);
   if (rc != JG_OK) { jg_model_destroy(m); return rc; }
   // the 32-channel small-window family has a fused kernel of its own (same split-f16 arithmetic): where the program
@@ -1463,6 +1584,8 @@ extern "C" int jg_model_destroy(jg_model *m) {
   for (auto &hp : m->hprep) {
     if (hp.d_wh) (void)hipFree(hp.d_wh);
     for (int par = 0; par < 2; ++par) if (hp.d_wh_ps[par]) (void)hipFree(hp.d_wh_ps[par]);
+    if (hp.d_rb_wfrag) (void)hipFree(hp.d_rb_wfrag);
+    if (hp.d_rb_epi) (void)hipFree(hp.d_rb_epi);
     if (hp.d_embh) (void)hipFree(hp.d_embh);
     if (hp.d_epi) (void)hipFree(hp.d_epi);
     if (hp.d_w8) (void)hipFree(hp.d_w8);
@@ -1685,6 +1808,39 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           if ((rc = prof_event(e, &pe.a)) != JG_OK || (rc = prof_event(e, &pe.b)) != JG_OK) return rc;
           pe.flops = 2.0 * op.k * op.cin * op.cout * (double)nw * in.frames * lo;
           JG_HIP(hipEventRecord(pe.a, s));
+        }
+        const bool rb_on = prec == 1 && e->fuse_resblock != 0;
+        if (rb_on && m->hprep[i].f16_ok && m->hprep[i].rb_second >= 0) {
+          // first conv of a fused residual block: computed by the second conv's launch (jg_resblock.hip)
+          sh[op.out_buf] = Shape{in.frames, lo, op.cout};
+          if (e->profile) { e->pool.push_back(pe.a); e->pool.push_back(pe.b); }
+          break;
+        }
+        if (rb_on && m->hprep[i].f16_ok && m->hprep[i].rb_first >= 0) {
+          const ConvHPrep &hp = m->hprep[i];
+          const jg_op &first = m->ops[(size_t)hp.rb_first];
+          JgResBlockArgs ra;
+          memset(&ra, 0, sizeof(ra));
+          ra.xh = reinterpret_cast<const uint4 *>(m->act[first.in_buf]);
+          ra.y = reinterpret_cast<uint4 *>(m->act[op.out_buf]);
+          ra.m0 = first.in_mask >= 0 ? m->msk[first.in_mask] : nullptr;
+          ra.m1 = op.in_mask >= 0 ? m->msk[op.in_mask] : nullptr;
+          ra.m2 = op.out_mask >= 0 ? m->msk[op.out_mask] : nullptr;
+          ra.wfrag = hp.d_rb_wfrag;
+          ra.epi = hp.d_rb_epi;
+          ra.overflow = m->d_overflow;
+          ra.rows = nw * in.frames; ra.L = in.L; ra.dil = op.dilation;
+          jg_resblock_tiling(in.L, op.dilation, &ra.nb, &ra.tile_out, &ra.tiles_per_row);
+          ra.psplit = hp.ps_store ? 1 : 0;
+          if (e->profile) pe.flops *= 2.0;                   // both convs of the block
+          pe.cls = JG_PROF_MFMA_F16X3;
+          rc = jg_launch_resblock(e, ra, s);
+          if (e->profile && rc == JG_OK) {
+            JG_HIP(hipEventRecord(pe.b, s));
+            e->pending.push_back(pe);
+          }
+          sh[op.out_buf] = Shape{in.frames, lo, op.cout};
+          break;
         }
         if (prec == 1 && m->hprep[i].f16_ok) {
           const ConvHPrep &hp = m->hprep[i];

@@ -142,6 +142,24 @@ struct ConvHArgs {
   HStageArg hst[JG_MAX_STAGES];
 };
 
+// fused narrow residual block (jg_resblock.hip): conv1 -> affine -> GELU -> conv2 -> affine -> + x -> GELU in one launch
+struct JgResBlockArgs {
+  const uint4 *xh;        // block input, F16S [rows][2][4][L]
+  uint4 *y;               // block output, F16S of the same geometry - or phase-split and masked (psplit, see ConvHArgs)
+  const uint8_t *m0;      // (rows, L) input mask of conv1 (x * m0), or null
+  const uint8_t *m1;      // ... of conv2 (= conv1's output mask), or null
+  const uint8_t *m2;      // conv2's output mask: only read for a phase-split store, or null
+  const uint4 *wfrag;     // [2 convs][5 taps][2 chunks][2 planes][64 lanes] MFMA A-operand fragments (hi / lo f16, pre-scaled)
+  const float *epi;       // [2 convs][scale | shift][32] folded bias / batch-norm affines (incl. the weights' un-scale)
+  int *overflow;
+  int rows, L, dil;
+  int nb, tile_out, tiles_per_row;   // jg_resblock_tiling
+  int psplit;
+};
+bool jg_resblock_supports(int c, int k, int dil);
+void jg_resblock_tiling(int L, int dil, int *nb, int *tile_out, int *tiles);
+int jg_launch_resblock(jg_engine *e, const JgResBlockArgs &a, hipStream_t s);
+
 struct EltArgs {
   const float *x;
   float *y;
@@ -173,6 +191,7 @@ struct jg_engine {
   int dust_on_copy = 1;           // JG_OPT_DUST_ON_COPY_STREAM: streamed spans are soft-masked on the copy stream (1) or in front of their encoder (0)
   int termini_exact = 0;          // JG_OPT_TERMINI_EXACT: every terminal-repeat alignment through the length / gap carrying kernel
   int tab_lds_only = 0;           // JG_OPT_TABLE_NET_LDS: keep the table net on the LDS-table kernel
+  int fuse_resblock = 1;          // JG_OPT_FUSE_RESBLOCK: narrow residual blocks as one launch (jg_resblock.hip)
   int conv_pc = 0;                // JG_OPT_CONV_PC: producer / consumer kernel for the 128-channel five-tap convs
   // streamed ingest of host-resident bases (jg_predict_windows): spans above `stream_bytes` go through two pinned
   // staging buffers and two device buffers on a copy stream, record group by record group
@@ -224,6 +243,11 @@ struct ConvHPrep {          // per CONV op: split-f16 operands (built at model c
                             // channels, re-arranged weights d_wh_ps); 2: a 1x1 stride-2 conv run at stride 1 on the even phase
   uint4 *d_wh_ps[2] = {nullptr, nullptr};   // ps_read == 1: weights for an even / odd input length (TF's SAME split differs)
   int64_t ps_half_items = 0;
+  // a whole narrow residual block as one launch (jg_resblock.hip): conv1 is skipped, conv2's launch runs both
+  int rb_first = -1;        // (conv2 of a fused block) index of the block's conv1 op
+  int rb_second = -1;       // (conv1 of a fused block) index of the conv2 op whose launch computes this one too
+  uint4 *d_rb_wfrag = nullptr;
+  float *d_rb_epi = nullptr;
   bool f16_ok = false;      // (CONV ops) runs on the split-f16 kernel when the model is in split-f16 mode
   int n_cvt = 0;            // layout conversions queued in front of this op (any op kind): slot, direction
   int cvt_slot[3] = {-1, -1, -1};

@@ -104,6 +104,11 @@ class HipDevice:
         output rows and counts of windows [0, value) are final."""
         return int(self.lib.jg_engine_get_stat(self.handle, L.JG_STAT_WINDOWS_DONE))
 
+    def set_fuse_resblock(self, on: bool):
+        """Narrow residual blocks as one launch with the intermediate tensor in LDS (True, the default) or conv by conv
+        (JG_OPT_FUSE_RESBLOCK; A/B timing and tests)."""
+        L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_FUSE_RESBLOCK, int(bool(on))), "jg_engine_set_option")
+
     def reset_progress(self):
         """``windows_done()`` back to 0 (JG_OPT_RESET_PROGRESS): called before a ``predict_windows`` call is handed to another
         thread, so that a poller which starts first never reads the previous call's final count."""

@@ -236,6 +236,41 @@ def test_pyramid_strided_blocks_read_phase_split_tensors():
     assert not any("stride=2" in ln and "phase" not in ln for ln in lines), text
 
 
+def test_narrow_residual_blocks_run_fused_and_equal_the_layer_by_layer_path():
+    """Round 5: the pyramid's four 32-channel residual blocks run as ONE launch each (jg_resblock.hip: the intermediate
+    tensor stays in LDS, the shortcut comes out of the same input image).  Same split-f16 arithmetic in the same order as
+    the two conv launches it replaces: logits and side outputs must agree with the layer-by-layer path
+    (JG_OPT_FUSE_RESBLOCK = 0) to rounding, on windows with N runs (masked positions: the shortcut of a masked position is
+    read from HBM) and short windows (padding); both paths are inside the oracle gate in the tests above."""
+    from jaeger_amd.engine import JaegerHipEngine
+    from oracle import forward as ofwd
+    cfg = load_model_cfg("pyramid")
+    weights = ofwd.random_weights(cfg, seed=38341)
+    for key in weights:
+        if key.startswith("rep/") and key.endswith("/kernel"):
+            weights[key] = weights[key] * np.float32(0.85)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, precision="f16x3")
+    text = eng.model.describe()
+    assert sum("fused residual block" in ln and "second conv" not in ln for ln in text.splitlines()) == 4, text
+    assert sum("computed by the block's second conv" in ln for ln in text.splitlines()) == 4, text
+    assert sum("fused residual block, phase-split store" in ln for ln in text.splitlines()) == 1, text
+    rng = np.random.Generator(np.random.PCG64(52))
+    fsize, n_win = 2000, 40
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.03)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    lens[1::3] = rng.integers(fsize // 2, fsize, lens[1::3].size)
+    fused = eng.predict_windows(seq, starts, lens, fsize)
+    eng.device.set_fuse_resblock(False)
+    plain = eng.predict_windows(seq, starts, lens, fsize)
+    eng.close()
+    for k in ("prediction", "embedding", "nmd"):
+        if k in plain:
+            err = float(np.abs(fused[k] - plain[k]).max())
+            print(k, "fused vs layer by layer:", err, "bit-identical" if err == 0.0 else "")
+            assert err <= 2e-5, (k, err)
+
+
 def test_forward_pyramid_resnet_short_windows_chunked():
     _forward_case("pyramid", 2000, 9, 22, n_frac=0.03, short=True, chunk=4, precision="f16x3", gain=0.85)
     _forward_case("pyramid", 900, 5, 23, n_frac=0.0, precision="f16x3", gain=0.85)
