@@ -1901,7 +1901,12 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
             const int halo = (a.k - 1) * a.dil;
             const int gap = std::max(a.pad_left, halo - a.pad_left);
             const int fp = lo + gap;
-            const int wp = (in.frames * fp + 127) / 128 * 128;
+            // a window's pitch: a multiple of the strip height (128) when the conv leaves per-strip partial rows (NMD taps, the
+            // fused max pool: a strip must not straddle two windows), else only of 32 - at 83 positions and dilation 8
+            // (six frames of 99) 608 instead of 640 positions per window
+            const bool strip_rows = hp.nmd_slot >= 0 || hp.nmd_slot2 >= 0 || hp.pool_op >= 0;
+            const int wp_unit = strip_rows ? 128 : 32;
+            const int wp = (in.frames * fp + wp_unit - 1) / wp_unit * wp_unit;
             const int64_t flat_tiles = ((int64_t)nw * wp + 255) / 256;
             const int64_t row_tiles = (int64_t)a.rows * a.tiles_m;
             if (!no_flat && a.k == 5 && op.in_buf != JG_BUF_IDS && hp.d_lut == nullptr && eff_stride == 1 && eff_lin == lo &&

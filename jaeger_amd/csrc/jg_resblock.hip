@@ -129,18 +129,30 @@ __global__ __launch_bounds__(256, 2) void resblock32_kernel(JgResBlockArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[r] = 0.f;
       const uint4 *X = Ximg + hh * RX + 32 * wid + i;
+      // operands one step ahead of the matrix cores: a step's two LDS reads are requested before the previous step's three
+      // (dependent) MFMAs are issued and land in their shadow
+      uint4 vh = X[0], vl = X[2 * RX];
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // (the first step's operands)
 #pragma unroll
-      for (int cc = 0; cc < RB_CC; ++cc)
-#pragma unroll
-        for (int t = 0; t < RB_K; ++t) {
-          const half8 wh = *reinterpret_cast<const half8 *>(&wf[0][t][cc][0]);
-          const half8 wl = *reinterpret_cast<const half8 *>(&wf[0][t][cc][1]);
-          const uint4 vh = X[(cc * 4 + 0) * RX + t * d], vl = X[(cc * 4 + 2) * RX + t * d];
-          const half8 xh = *reinterpret_cast<const half8 *>(&vh), xl = *reinterpret_cast<const half8 *>(&vl);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, c, 0, 0, 0);
+      for (int st = 0; st < RB_CC * RB_K; ++st) {
+        const int cc = st / RB_K, t = st % RB_K;
+        uint4 nh = vh, nl = vl;
+        if (st + 1 < RB_CC * RB_K) {
+          const int c2 = (st + 1) / RB_K, t2 = (st + 1) % RB_K;
+          nh = X[(c2 * 4 + 0) * RX + t2 * d];
+          nl = X[(c2 * 4 + 2) * RX + t2 * d];
         }
+        const half8 wh = *reinterpret_cast<const half8 *>(&wf[0][t][cc][0]);
+        const half8 wl = *reinterpret_cast<const half8 *>(&wf[0][t][cc][1]);
+        const half8 xh = *reinterpret_cast<const half8 *>(&vh), xl = *reinterpret_cast<const half8 *>(&vl);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, c, 0, 0, 0);
+        if (st + 1 < RB_CC * RB_K) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the next step's two LDS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                 // ... then this step's MFMAs
+        vh = nh;
+        vl = nl;
+      }
       const float m1f = (mk & 2u) ? 1.f : 0.f;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {                // channel groups 2j and 2j + 1 of the block
@@ -181,19 +193,29 @@ __global__ __launch_bounds__(256, 2) void resblock32_kernel(JgResBlockArgs a) {
       const bool live = o < a.tile_out && p < a.L;
       // operand rows of dead lanes (past the tile's outputs) are clamped into the image: their results are dropped
       const uint4 *H = Himg + hh * RH;
+      uint4 vh = H[min(o, RH - 1)], vl = H[2 * RH + min(o, RH - 1)];
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-      for (int cc = 0; cc < RB_CC; ++cc)
-#pragma unroll
-        for (int t = 0; t < RB_K; ++t) {
-          const half8 wh = *reinterpret_cast<const half8 *>(&wf[1][t][cc][0]);
-          const half8 wl = *reinterpret_cast<const half8 *>(&wf[1][t][cc][1]);
-          const int r_ = min(o + t * d, RH - 1);
-          const uint4 vh = H[(cc * 4 + 0) * RH + r_], vl = H[(cc * 4 + 2) * RH + r_];
-          const half8 xh = *reinterpret_cast<const half8 *>(&vh), xl = *reinterpret_cast<const half8 *>(&vl);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, c, 0, 0, 0);
+      for (int st = 0; st < RB_CC * RB_K; ++st) {
+        const int cc = st / RB_K, t = st % RB_K;
+        uint4 nh = vh, nl = vl;
+        if (st + 1 < RB_CC * RB_K) {
+          const int c2 = (st + 1) / RB_K, t2 = (st + 1) % RB_K;
+          const int r_ = min(o + t2 * d, RH - 1);
+          nh = H[(c2 * 4 + 0) * RH + r_];
+          nl = H[(c2 * 4 + 2) * RH + r_];
         }
+        const half8 wh = *reinterpret_cast<const half8 *>(&wf[1][t][cc][0]);
+        const half8 wl = *reinterpret_cast<const half8 *>(&wf[1][t][cc][1]);
+        const half8 xh = *reinterpret_cast<const half8 *>(&vh), xl = *reinterpret_cast<const half8 *>(&vl);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, c, 0, 0, 0);
+        if (st + 1 < RB_CC * RB_K) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        vh = nh;
+        vl = nl;
+      }
       const bool from_img = !live || (mk & 4u) != 0u;
       const float m2f = (mk & 8u) ? 1.f : 0.f;
       // the shortcut: this lane's four channels of every 8-channel group at the output position - out of the input image
