@@ -254,7 +254,7 @@ def e2e_leg(cfg, weights, wl, fsize, records: int = 0, seed: int | None = None):
             t0 = time.perf_counter()
             n_rows = P.run_core(input=str(fa), output=str(out), model_path=str(tmp / "model_root"), fsize=fsize, stride=fsize,
                                 overwrite=True, dustmask=True, verbose=0, batch=96, rc=0.1, pc=3)
-            runs.append((time.perf_counter() - t0, dict(P.LAST_RUN)))
+            runs.append((time.perf_counter() - t0, {k: v for k, v in P.LAST_RUN.items() if k not in ("timeline", "t_start_epoch")}))
         dt, stages = min(runs, key=lambda r: r[0])
         tsv = next(out.rglob("bench.tsv"), None)
         what = (f"{records} records of exactly {fsize} bp as a FASTA (tmpfs)" if records else
@@ -491,7 +491,7 @@ def measure(args, name: str, steps: int, warmup: int, ctx: dict, headline: bool)
     if args.rank_contigs and headline:
         per_rank = [int(x) for x in args.rank_contigs.split(",")]
         n_contigs = per_rank[(rank if args.rank_seed is None else args.rank_seed) % len(per_rank)]
-    l_pad = frame_length(fsize)
+    l_pad = eng.model.row_length(fsize)
     rng = np.random.Generator(np.random.PCG64(wl["seed"] + (rank if args.rank_seed is None else args.rank_seed)))
     lengths, bases = synth_contigs(rng, n_contigs, exact=(fsize if wl["exact"] else None))
     offsets = np.zeros(lengths.size + 1, np.int64)
@@ -671,7 +671,7 @@ def measure(args, name: str, steps: int, warmup: int, ctx: dict, headline: bool)
     del d_bases, d_start, d_len, d_pred, d_rel, d_counts
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and args.timed_dbg is None:
-        if not args.no_e2e:
+        if not args.no_e2e and (headline or name != "pyramid"):      # (pyramid rides along as a kernel figure only)
             try:
                 if headline or wl["model"] != CONFIGS[args.config]["model"]:
                     line["e2e"] = e2e_leg(cfg, weights, wl, fsize)
@@ -684,9 +684,10 @@ def measure(args, name: str, steps: int, warmup: int, ctx: dict, headline: bool)
                 line["e2e"] = {"error": f"run_core exited with {e.code}"}
         if headline and not args.no_also:
             # the other BASELINE configs in the same driver-run line (2 timed steps each): configs[2]'s per-GPU shard
-            # and configs[3]; a failure there must not lose the headline
+            # and configs[3] - and the reference's pyramid ResNet (not a BASELINE config: the width- / stride-general
+            # kernels' figure); a failure there must not lose the headline
             line["also"] = {}
-            for other in ("default", "frag1m", "baseline500"):
+            for other in ("default", "frag1m", "baseline500", "pyramid"):
                 if other == name:
                     continue
                 try:

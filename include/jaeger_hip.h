@@ -52,6 +52,10 @@ typedef enum {
   JG_OP_OODSIG = 7,    /* OODSignalLayer                           layers.py:1632-1667 */
   JG_OP_MAXPOOL1D = 8, /* MaxPooling1D(2) of the legacy tower      v1/layers.py:154-207*/
   JG_OP_FRAMESUM = 9,  /* legacy frame Add                         v1/layers.py:399-423*/
+  JG_OP_EMBED = 11,    /* Embedding lookup of WIDE ids (codon: DICODON - 4 096 codon pairs + the padding id, nnlib/inference.py:
+                          430-451, builder.py:858-867): ids (rows, L) u16 -> out_buf f32 (rows, L, cout) = table[id] (b_off,
+                          vocab x cout floats), out_mask = (id != 0).  Codon ids (one byte) are gathered inside the first
+                          conv instead (in_buf = JG_BUF_IDS); a program with this op takes 16-bit id tensors */
   JG_OP_STRANDS = 10   /* a branched (shared-weight) model over the k strands of a nucleotide input: every strand is a
                           program row of its own (ids (W, k, L), one frame per row); arg = how the strands' predictions
                           merge (jg_merge_kind); the embedding output is their average.  builder.py:1195-1266, :776-791 */
@@ -210,13 +214,17 @@ int jg_model_describe(const jg_model *m, char *buf, int64_t cap);
  *              _map_complement :28-33) - ids (n_win, 2, l_pad) u8, row 0 the window's first min(len, fsize) bases as
  *              A,G,C,T (either case) -> 1,2,3,4, row 1 the reverse complement of those bases, 0 = any other byte /
  *              padding (the all-zero one-hot row); l_pad counts bases; lut65 is not read
+ *              bit 3 (JG_ENC_DICODON): codon = DICODON (ngram_width 6, encode.py:272-284 with the 4 096 pairs of
+ *              seqops/maps.py:544-546) - ids (n_win, 6, l_pad) u16 (TWO bytes per id), entry i of frame j = the 6-gram at
+ *              base j + 6 i of the strand -> 64 * (lut65[first codon] - 1) + (lut65[second codon] - 1) + 1 (lut65 = the
+ *              plain codon table), 0 when either half is invalid; ceil((n - 8 + off) / 6) entries per frame
  *   l_pad      codons per frame row in the output (>= frame length of the longest window when the
  *              window table is on the host, >= frame length of fsize when it is on the device)
  * outputs (device or host per out_loc):
  *   ids        (n_win, 6, l_pad) u8, rows f1,f2,f3,r1,r2,r3, 0 = invalid / padding
  *   counts     (n_win, 4) i32 upper-case G,C,A,T counts of each window
  */
-enum { JG_ENC_PRECASED = 1, JG_ENC_CASE_SENSITIVE = 2, JG_ENC_NUCLEOTIDE = 4 };
+enum { JG_ENC_PRECASED = 1, JG_ENC_CASE_SENSITIVE = 2, JG_ENC_NUCLEOTIDE = 4, JG_ENC_DICODON = 8 };
 int jg_encode(jg_engine *e, const uint8_t *bases, int64_t n_bases, int bases_loc,
               const int64_t *win_start, const int32_t *win_len, int win_loc, int64_t n_win,
               int32_t fsize, const uint8_t *lut65, int32_t soft_mask, int32_t l_pad,
@@ -224,7 +232,7 @@ int jg_encode(jg_engine *e, const uint8_t *bases, int64_t n_bases, int bases_loc
 
 /* Replaces InferModel.predict's per-batch serving_default call
  * (nnlib/inference.py:355-363): ids (n_win, 6, l) u8 - (n_win, 2, l) for a two-strand nucleotide model
- * (JG_OP_STRANDS) - -> per-window outputs.
+ * (JG_OP_STRANDS), (n_win, 6, l) u16 for a dicodon model (a program with JG_OP_EMBED) - -> per-window outputs.
  * Any output pointer may be NULL.  Output widths are those of the program
  * (jg_model_vec_width).  `chunk` = windows per launch group (0 = default). */
 int jg_forward(jg_model *m, const uint8_t *ids, int ids_loc, int64_t n_win, int32_t l,

@@ -28,7 +28,7 @@ JG_STAT_STREAM_GROUPS, JG_STAT_STREAM_BYTES, JG_STAT_PEAK_DEVICE_BASES, JG_STAT_
 JG_MSTAT_CONVS, JG_MSTAT_CONVS_F16X3, JG_MSTAT_LAYOUT_CONVERSIONS, JG_MSTAT_SMALL_FUSED = 0, 1, 2, 3
 
 # jg_op_kind
-OP_CONV, OP_MASK, OP_POOL, OP_DENSE, OP_ELTWISE, OP_NMD_FINAL, OP_OODSIG, OP_MAXPOOL1D, OP_FRAMESUM, OP_STRANDS = range(1, 11)
+OP_CONV, OP_MASK, OP_POOL, OP_DENSE, OP_ELTWISE, OP_NMD_FINAL, OP_OODSIG, OP_MAXPOOL1D, OP_FRAMESUM, OP_STRANDS, OP_EMBED = range(1, 12)
 # jg_stage_kind
 ST_NONE, ST_BIAS, ST_BN, ST_DYT, ST_ADD, ST_ACT, ST_NMD, ST_MASKMUL, ST_LN = range(9)
 # jg_act
@@ -37,7 +37,7 @@ MASK_ANY, MASK_MAJORITY, MASK_STRICT = range(3)
 PAD_VALID, PAD_SAME = 0, 1
 POOL_MAX, POOL_AVG, POOL_MAX_NOMASK = 0, 1, 2
 MERGE_AVERAGE, MERGE_SUM, MERGE_MAX = 0, 1, 2            # jg_merge_kind (OP_STRANDS)
-JG_ENC_PRECASED, JG_ENC_CASE_SENSITIVE, JG_ENC_NUCLEOTIDE = 1, 2, 4   # jg_encode / jg_predict_windows soft_mask bits
+JG_ENC_PRECASED, JG_ENC_CASE_SENSITIVE, JG_ENC_NUCLEOTIDE, JG_ENC_DICODON = 1, 2, 4, 8   # jg_encode / jg_predict_windows soft_mask bits
 # vector slot convention (jg_api.hip: jg_model_vec_width)
 VEC_EMBEDDING, VEC_NMD, VEC_PREDICTION, VEC_RELIABILITY, VEC_SCRATCH0 = 0, 1, 2, 3, 4
 

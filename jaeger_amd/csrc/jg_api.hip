@@ -322,7 +322,7 @@ static int validate_program(const jg_model *m) {
     auto slot_ok = [](int s, bool allow_ids) {
       return (s >= 0 && s < JG_MAX_BUFS) || s == JG_BUF_NONE || (allow_ids && s == JG_BUF_IDS);
     };
-    JG_REQUIRE(op.kind >= JG_OP_CONV && op.kind <= JG_OP_STRANDS, JG_ERR_INVALID,
+    JG_REQUIRE(op.kind >= JG_OP_CONV && op.kind <= JG_OP_EMBED, JG_ERR_INVALID,
                "op %zu: unknown kind %d", i, op.kind);
     if (op.kind == JG_OP_STRANDS)
       JG_REQUIRE(i + 1 == m->ops.size() && op.k >= 2 && op.k <= 8 && op.arg >= JG_MERGE_AVERAGE && op.arg <= JG_MERGE_MAX,
@@ -345,6 +345,14 @@ static int validate_program(const jg_model *m) {
       if (op.in_buf == JG_BUF_IDS)
         JG_REQUIRE(off_ok(op.b_off, (int64_t)m->vocab * op.cin), JG_ERR_INVALID,
                    "op %zu: embedding table outside the weight blob", i);
+    }
+    if (op.kind == JG_OP_EMBED) {
+      JG_REQUIRE(i == 0 && op.out_buf >= 0 && op.out_mask >= 0 && op.cout >= 4 && op.cout % 4 == 0 && m->vocab > 256 &&
+                     m->vocab <= 65536 && off_ok(op.b_off, (int64_t)m->vocab * op.cout),
+                 JG_ERR_INVALID, "op %zu: an embedding op opens the program (16-bit ids, vocabulary 257 .. 65536, table inside the weight blob)", i);
+    } else if (!m->ops.empty() && m->ops[0].kind == JG_OP_EMBED) {
+      JG_REQUIRE(op.in_buf != JG_BUF_IDS && op.in_mask != JG_BUF_IDS, JG_ERR_INVALID,
+                 "op %zu: reads the id tensor directly in a program of 16-bit ids (the embedding op's buffer and mask take its place)", i);
     }
     if (op.kind == JG_OP_DENSE) {
       JG_REQUIRE(off_ok(op.w_off, (int64_t)op.cin * op.cout), JG_ERR_INVALID,
@@ -443,6 +451,13 @@ static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
           if (op.stages[s].kind == JG_ST_NMD)
             nmd_elems[op.stages[s].arg] = std::max<int64_t>(nmd_elems[op.stages[s].arg],
                                                            (int64_t)in.frames * tiles * op.cout);
+      } break;
+      case JG_OP_EMBED: {
+        JG_REQUIRE(op.out_buf >= 0 && op.out_mask >= 0 && op.cout > 0, JG_ERR_INVALID, "op %zu: bad embedding op", i);
+        sh[op.out_buf] = Shape{m->id_frames, l, op.cout};
+        act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)m->id_frames * (l + (l & 1)) * op.cout);
+        mlen[op.out_mask] = m->id_frames * l;
+        msk_elems[op.out_mask] = std::max<int64_t>(msk_elems[op.out_mask], (int64_t)m->id_frames * l);
       } break;
       case JG_OP_MASK: {
         const int L_in = op.in_mask == JG_BUF_IDS ? l : (mlen[op.in_mask] / m->id_frames);
@@ -1116,7 +1131,8 @@ static int prepare_f16(jg_model *m, const float *weights) {
   };
   auto writes = [&](size_t j, int buf) {
     const jg_op &o = m->ops[j];
-    return (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM) &&
+    return (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM ||
+            o.kind == JG_OP_EMBED) &&
            o.out_buf == buf;
   };
   bool cvt_overflow = false;
@@ -1170,6 +1186,9 @@ static int prepare_f16(jg_model *m, const float *weights) {
           }
         }
       } break;
+      case JG_OP_EMBED:
+        is_f32[op.out_buf] = true;                      // the lookup writes f32 rows: the first conv converts if it wants F16S
+        break;
       case JG_OP_ELTWISE:
         need(i, op.in_buf, true);
         for (int q = 0; q < op.n_stages; ++q)
@@ -1225,7 +1244,8 @@ static int plan_phase_split(jg_model *m, const float *weights) {
   };
   auto writes_buf = [&](size_t j, int buf) {
     const jg_op &o = m->ops[j];
-    return (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM) &&
+    return (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM ||
+            o.kind == JG_OP_EMBED) &&
            o.out_buf == buf;
   };
   for (size_t p = 0; p < n; ++p) {
@@ -1327,7 +1347,8 @@ static int plan_resblocks(jg_model *m, const float *weights) {
   };
   auto writes_buf = [&](size_t j, int buf) {
     const jg_op &o = m->ops[j];
-    return (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM) &&
+    return (o.kind == JG_OP_CONV || o.kind == JG_OP_ELTWISE || o.kind == JG_OP_MAXPOOL1D || o.kind == JG_OP_FRAMESUM ||
+            o.kind == JG_OP_EMBED) &&
            o.out_buf == buf;
   };
   // bias / batch-norm stages in front of the first other stage, folded with the weights' un-scale (as prepare_f16 does)
@@ -1507,6 +1528,7 @@ extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const 
   m->vocab = vocab;
   int rc = validate_program(m);
   if (rc != JG_OK) { delete m; return rc; }
+  if (m->ops[0].kind == JG_OP_EMBED) m->id_bytes = 2;
   if (m->ops.back().kind == JG_OP_STRANDS) {
     m->strands = m->ops.back().k;
     m->id_frames = 1;
@@ -1797,6 +1819,13 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
       continue;
     }
     switch (op.kind) {
+      case JG_OP_EMBED: {
+        JG_REQUIRE(m->id_bytes == 2, JG_ERR_INVALID, "embedding op in a program of one-byte ids");
+        rc = jg_launch_embed(reinterpret_cast<const uint16_t *>(d_ids), (int64_t)nw * m->id_frames * l, m->d_w + op.b_off,
+                             m->vocab, op.cout, m->act[op.out_buf], m->msk[op.out_mask], s);
+        sh[op.out_buf] = Shape{m->id_frames, l, op.cout};
+        mlen[op.out_mask] = m->id_frames * l;
+      } break;
       case JG_OP_CONV: {
         Shape in;
         if (op.in_buf == JG_BUF_IDS) { in.frames = m->id_frames; in.L = l; in.C = op.cin; }
@@ -2163,7 +2192,7 @@ static int forward_chunks(jg_model *m, const uint8_t *d_ids, int64_t n_win, int 
   const int w_emb = jg_model_vec_width(m, 2), w_nmd = jg_model_vec_width(m, 3);
   for (int64_t w0 = 0; w0 < n_win; w0 += chunk) {
     const int nw = (int)std::min<int64_t>(chunk, n_win - w0);
-    int rc = run_chunk(m, d_ids + w0 * m->strands * m->id_frames * (int64_t)l, nw * m->strands, l, s);
+    int rc = run_chunk(m, d_ids + w0 * m->strands * m->id_frames * (int64_t)l * m->id_bytes, nw * m->strands, l, s);
     if (rc != JG_OK) return rc;
     if ((rc = copy_out(m, 2, w_pred, prediction, w0, nw, out_loc, s)) != JG_OK) return rc;
     if ((rc = copy_out(m, 3, w_rel, reliability, w0, nw, out_loc, s)) != JG_OK) return rc;
@@ -2208,7 +2237,7 @@ extern "C" int jg_forward(jg_model *m, const uint8_t *ids, int ids_loc, int64_t 
   hipStream_t s = pick_stream(e, stream);
   const uint8_t *d_ids = ids;
   if (ids_loc == JG_PTR_HOST) {
-    const int64_t bytes = n_win * m->strands * m->id_frames * (int64_t)l;
+    const int64_t bytes = n_win * m->strands * m->id_frames * (int64_t)l * m->id_bytes;
     int rc = grow(&m->d_ids, &m->d_ids_cap, bytes);
     if (rc != JG_OK) return rc;
     JG_HIP(hipMemcpyAsync(m->d_ids, ids, (size_t)bytes, hipMemcpyHostToDevice, s));
@@ -2240,13 +2269,19 @@ static int encode_common(jg_engine *e, jg_model *scratch_owner, const uint8_t *b
   // l_pad must hold the longest frame: known exactly for host-side window tables (the short-contig
   // pass pads to the longest window of a batch, commands/predict.py:236-245), fsize-derived otherwise
   const bool nt_ids = (flags & JG_ENC_NUCLEOTIDE) != 0;       // a row holds bases, not codons
-  int need = nt_ids ? fsize : frame_len(fsize);
-  if (win_loc == JG_PTR_HOST && fsize >= 3) {
+  const bool di_ids = (flags & JG_ENC_DICODON) != 0;          // ... or codon pairs (six bases apart)
+  JG_REQUIRE(!(nt_ids && di_ids), JG_ERR_INVALID, "encode: nucleotide and dicodon ids are different encodings");
+  auto row_len = [&](int n) {                                  // entries per frame of a window cropped to n bases
     const int off3 = (fsize % 3 == 0) ? -2 : ((fsize % 3 == 1) ? -1 : 0);
+    if (di_ids) { const int u = n - 8 + off3; return u > 0 ? (u + 5) / 6 : 0; }
+    const int u = n - 5 + off3;
+    return u > 0 ? (u + 2) / 3 : 0;
+  };
+  int need = nt_ids ? fsize : (di_ids ? row_len(fsize) : frame_len(fsize));
+  if (win_loc == JG_PTR_HOST && fsize >= 3) {
     int longest = 0;
     for (int64_t i = 0; i < n_win; ++i) longest = std::max(longest, std::min(win_len[i], fsize));
-    const int usable = longest - 5 + off3;
-    need = nt_ids ? longest : (usable > 0 ? (usable + 2) / 3 : 0);
+    need = nt_ids ? longest : row_len(longest);
   }
   JG_REQUIRE(fsize >= 3 && l_pad >= need && l_pad >= 1, JG_ERR_INVALID,
              "encode: l_pad=%d is smaller than the %d %s the longest window yields (fsize %d)", l_pad,
@@ -2314,7 +2349,7 @@ extern "C" int jg_encode(jg_engine *e, const uint8_t *bases, int64_t n_bases, in
   std::vector<void *> to_free;
   uint8_t *d_ids = ids;
   int32_t *d_counts = counts;
-  const int64_t id_bytes = n_win * ((soft_mask & JG_ENC_NUCLEOTIDE) ? 2 : 6) * (int64_t)l_pad;
+  const int64_t id_bytes = n_win * ((soft_mask & JG_ENC_NUCLEOTIDE) ? 2 : 6) * (int64_t)l_pad * ((soft_mask & JG_ENC_DICODON) ? 2 : 1);
   void *d_lut = nullptr;
   JG_HIP(hipMalloc(&d_lut, 80));
   to_free.push_back(d_lut);
@@ -2470,7 +2505,7 @@ static int predict_streamed(jg_model *m, const uint8_t *bases, int64_t n_bases, 
   io += 64;
   int rc = stream_setup(e, std::max<int64_t>(span_cap, 4096), (io + 4095) / 4096 * 4096);
   if (rc != JG_OK) return rc;
-  if ((rc = grow(&m->d_ids, &m->d_ids_cap, win_cap * 6 * (int64_t)l_pad)) != JG_OK) return rc;
+  if ((rc = grow(&m->d_ids, &m->d_ids_cap, win_cap * 6 * (int64_t)l_pad * m->id_bytes)) != JG_OK) return rc;
   if ((rc = grow(&m->d_win, &m->d_win_cap, win_cap * 12)) != JG_OK) return rc;
   if (counts != nullptr && host_out)
     if ((rc = grow(&m->d_counts, &m->d_counts_cap, win_cap * 16)) != JG_OK) return rc;
@@ -2631,6 +2666,7 @@ extern "C" int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_b
   e->peak_dev_bases = bases_loc == JG_PTR_HOST ? n_bases : 0;
   e->windows_done.store(0, std::memory_order_release);
   if (m->strands > 1) soft_mask |= JG_ENC_NUCLEOTIDE;       // a two-strand model reads nucleotide ids (n_win, 2, l_pad)
+  if (m->id_bytes == 2) soft_mask |= JG_ENC_DICODON;        // a dicodon model reads 16-bit ids of codon pairs
   if (bases_loc == JG_PTR_HOST && win_loc == JG_PTR_HOST && n_bases > e->stream_bytes) {
     // streamed ingest needs a start-sorted window list (the fragmenter's FASTA order is) inside the buffer
     bool sorted = true;
@@ -2644,8 +2680,9 @@ extern "C" int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_b
     }
     if (sorted) {
       const int off3 = (fsize % 3 == 0) ? -2 : ((fsize % 3 == 1) ? -1 : 0);
-      const int usable = longest - 5 + off3;
-      const int need = m->strands > 1 ? longest : (usable > 0 ? (usable + 2) / 3 : 0);
+      const int usable = longest - 5 + off3, usable6 = longest - 8 + off3;
+      const int need = m->strands > 1 ? longest : m->id_bytes == 2 ? (usable6 > 0 ? (usable6 + 5) / 6 : 0)
+                                                                   : (usable > 0 ? (usable + 2) / 3 : 0);
       JG_REQUIRE(fsize >= 3 && l_pad >= need && l_pad >= 1, JG_ERR_INVALID,
                  "encode: l_pad=%d is smaller than the %d %s the longest window yields (fsize %d)", l_pad, need,
                  m->strands > 1 ? "bases" : "codons", fsize);
@@ -2654,7 +2691,7 @@ extern "C" int jg_predict_windows(jg_model *m, const uint8_t *bases, int64_t n_b
     }
   }
   std::vector<void *> to_free;
-  int rc = grow(&m->d_ids, &m->d_ids_cap, n_win * 6 * (int64_t)l_pad);
+  int rc = grow(&m->d_ids, &m->d_ids_cap, n_win * 6 * (int64_t)l_pad * m->id_bytes);
   if (rc != JG_OK) return rc;
   int32_t *d_counts = counts;
   if (counts != nullptr && out_loc == JG_PTR_HOST) {

@@ -300,6 +300,7 @@ struct jg_model {
   // its own with ONE frame; the strands' outputs are merged into the window's behind the last op
   int strands = 1;
   int id_frames = 6;                // frames per program row of the id tensor: 6 codon frames, or 1 (a strand)
+  int id_bytes = 1;                 // bytes per id: 1, or 2 for a dicodon model (the program holds a JG_OP_EMBED)
   int merge_kind = 0;               // jg_merge_kind of the prediction
   float *merged[JG_MAX_VECS] = {};
   int64_t merged_cap[JG_MAX_VECS] = {};
@@ -321,6 +322,8 @@ int jg_usable_cores();
 
 // ---- kernel launchers (defined in jg_kernels.hip) ---------------------------
 int jg_launch_conv(jg_engine *e, const ConvArgs &a, hipStream_t s);
+int jg_launch_embed(const uint16_t *ids, int64_t n_pos, const float *table, int vocab, int c, float *out, uint8_t *mask,
+                    hipStream_t s);
 int jg_launch_mask(const uint8_t *in, int rows, int L_in, int L_out, int k, int stride, int dil,
                    int pad_left, int mode, uint8_t *out, hipStream_t s);
 int jg_launch_pool(const float *x, const uint8_t *mask, int n_win, int positions, int c, int kind,

@@ -268,6 +268,37 @@ __global__ __launch_bounds__(256) void encode_kernel(const uint8_t *__restrict__
   }
   // frame length: ceil((n-5+off)/3), off from crop_size % 3 (encode.py:232-236, :279-284)
   const int off3 = (fsize % 3 == 0) ? -2 : ((fsize % 3 == 1) ? -1 : 0);
+  if (flags & 8) {
+    // codon = DICODON (ngram_width 6): ngrams() leaves n - 5 six-grams, frame j keeps every sixth one from j below the
+    // codon frames' own stop (-3 + j + off): ceil((n - 8 + off) / 6) entries; id = 64 * codon(first half) +
+    // codon(second half) + 1 in the reference's codon order (seqops/maps.py:544-546), 16 bits wide
+    const int usable6 = n - 8 + off3;
+    const int lw6 = usable6 > 0 ? (usable6 + 5) / 6 : 0;
+    uint16_t *out16 = reinterpret_cast<uint16_t *>(ids) + w * 6 * (int64_t)l_pad;
+    for (int idx = tid; idx < 6 * l_pad; idx += 256) {
+      const int f = idx / l_pad, i = idx - f * l_pad;
+      uint16_t v = 0;
+      if (i < lw6) {
+        const int j = f >= 3 ? f - 3 : f;
+        int b[6];
+        if (f < 3) {
+          const int p = j + 6 * i;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) b[q] = code[p + q];
+        } else {
+          const int p = n - 1 - j - 6 * i;              // rev[q] = complement(fwd[n - 1 - q])
+#pragma unroll
+          for (int q = 0; q < 6; ++q) b[q] = code[p - q] ^ 2;
+        }
+        if ((b[0] | b[1] | b[2] | b[3] | b[4] | b[5]) < 4) {
+          const int ca_ = slut[16 * b[0] + 4 * b[1] + b[2]], cb_ = slut[16 * b[3] + 4 * b[4] + b[5]];
+          if (ca_ != 0 && cb_ != 0) v = (uint16_t)(64 * (ca_ - 1) + (cb_ - 1) + 1);
+        }
+      }
+      out16[idx] = v;
+    }
+    return;
+  }
   const int usable = n - 5 + off3;
   const int lw = usable > 0 ? (usable + 2) / 3 : 0;
   uint8_t *out = ids + w * 6 * (int64_t)l_pad;
@@ -302,6 +333,32 @@ int jg_launch_encode(const uint8_t *bases, const int64_t *win_start, const int32
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(encode_kernel, dim3((unsigned)n_win), dim3(256), smem, s, bases, win_start,
                      win_len, fsize, lut, flags, l_pad, ids, counts);
+  JG_HIP(hipGetLastError());
+  return JG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Embedding lookup of 16-bit ids (JG_OP_EMBED: dicodon models) - one thread per (position, 4 channels)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const uint16_t *__restrict__ ids, int64_t n_pos,
+                                                    const float *__restrict__ table, int vocab, int c4,
+                                                    float *__restrict__ out, uint8_t *__restrict__ mask) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n_pos * c4) return;
+  const int64_t pos = q / c4;
+  const int g = (int)(q - pos * c4);
+  const int id = min((int)ids[pos], vocab - 1);
+  reinterpret_cast<float4 *>(out)[q] = reinterpret_cast<const float4 *>(table)[(int64_t)id * c4 + g];
+  if (g == 0 && mask != nullptr) mask[pos] = id != 0;
+}
+
+int jg_launch_embed(const uint16_t *ids, int64_t n_pos, const float *table, int vocab, int c, float *out, uint8_t *mask,
+                    hipStream_t s) {
+  JG_REQUIRE(c > 0 && c % 4 == 0 && vocab > 0, JG_ERR_UNSUPPORTED, "embed: %d channels (multiples of 4), vocabulary %d", c, vocab);
+  if (n_pos == 0) return JG_OK;
+  const int64_t n = n_pos * (c / 4);
+  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ids, n_pos, table, vocab, c / 4, out,
+                     mask);
   JG_HIP(hipGetLastError());
   return JG_OK;
 }

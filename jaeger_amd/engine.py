@@ -40,6 +40,14 @@ def frame_length(nucleotides: int) -> int:
     return 0 if usable <= 0 else -(-usable // 3)
 
 
+def dicodon_frame_length(nucleotides: int) -> int:
+    """Entries per frame of a ``nucleotides``-long crop under ``codon: DICODON`` (6-grams, seqops/encode.py:272-284):
+    ``ngrams`` leaves n - 5 of them, a frame keeps every sixth below the codon frames' own stop."""
+    nt = int(nucleotides)
+    usable = nt - 8 + (-2, -1, 0)[nt % 3]
+    return 0 if usable <= 0 else -(-usable // 6)
+
+
 def codon_lut(codon_id: list[int]) -> np.ndarray:
     """65-byte table for ``jg_encode``: 16*b0+4*b1+b2 over TCAG=0..3 -> codon_id+1."""
     from .maps import CODONS
@@ -209,8 +217,9 @@ class HipDevice:
         wl = np.ascontiguousarray(win_len, np.int32)
         n = ws.size
         nt = bool(int(flags) & L.JG_ENC_NUCLEOTIDE)
-        l_pad = (int(fsize) if nt else frame_length(fsize)) if l_pad is None else int(l_pad)
-        ids = np.zeros((n, 2 if nt else 6, l_pad), np.uint8)
+        di = bool(int(flags) & L.JG_ENC_DICODON)           # codon pairs: 16-bit ids, six bases apart
+        l_pad = (int(fsize) if nt else dicodon_frame_length(fsize) if di else frame_length(fsize)) if l_pad is None else int(l_pad)
+        ids = np.zeros((n, 2 if nt else 6, l_pad), np.uint16 if di else np.uint8)
         counts = np.zeros((n, 4), np.int32)
         lut = np.ascontiguousarray(lut, np.uint8)
         L.check(self.lib.jg_encode(self.handle, _ptr(bases), bases.size, L.JG_PTR_HOST, _ptr(ws), _ptr(wl),
@@ -232,6 +241,7 @@ class HipModel:
         self.widths = {name: self.lib.jg_model_vec_width(self.handle, i)
                        for i, name in enumerate(("prediction", "reliability", "embedding", "nmd"))}
         self.strands = int(getattr(program, "strands", 1))      # > 1: nucleotide ids (W, strands, L), rows count bases
+        self.wide_ids = int(program.vocab) > 256                 # dicodon model: 16-bit ids, rows count codon pairs
         device._models.add(self)
 
     def close(self):
@@ -269,7 +279,9 @@ class HipModel:
 
     def row_length(self, nucleotides: int) -> int:
         """Positions per id row of a window of ``nucleotides`` bases: codons per frame, or the bases themselves."""
-        return int(nucleotides) if self.strands > 1 else frame_length(nucleotides)
+        if self.strands > 1:
+            return int(nucleotides)
+        return dicodon_frame_length(nucleotides) if self.wide_ids else frame_length(nucleotides)
 
     def _host_outputs(self, n: int, want: Iterable[str]):
         outs = {}
@@ -282,7 +294,7 @@ class HipModel:
                 want=("prediction", "reliability", "embedding", "nmd")) -> dict[str, np.ndarray]:
         """ids (W, 6, L) u8 on the host - (W, 2, L) nucleotide ids for a two-strand model - -> dict of host arrays
         (``jg_forward``)."""
-        ids = np.ascontiguousarray(ids, np.uint8)
+        ids = np.ascontiguousarray(ids, np.uint16 if self.wide_ids else np.uint8)
         n, rows, l = ids.shape
         if rows != (self.strands if self.strands > 1 else 6):
             raise ValueError(f"id tensor has {rows} rows per window, the model takes {self.strands if self.strands > 1 else 6}")
@@ -410,8 +422,12 @@ class JaegerHipEngine:
             self.model.set_precision(precision)
         if return_embedding and self.model.widths["embedding"] == 0:
             raise ValueError("The selected model does not expose an 'embedding' output.")
-        self.lut = codon_lut(sp["codon_id"]) if sp.get("codon_id") else np.zeros(65, np.uint8)
-        self.encode_flags = 2 if sp.get("masking") else 0
+        if sp.get("ngram_width", 3) == 6:                  # codon pairs: the plain codon table, combined on the device
+            from .maps import CODON_ID
+            self.lut = codon_lut(CODON_ID)
+        else:
+            self.lut = codon_lut(sp["codon_id"]) if sp.get("codon_id") else np.zeros(65, np.uint8)
+        self.encode_flags = (2 if sp.get("masking") else 0) | (L.JG_ENC_DICODON if sp.get("ngram_width", 3) == 6 else 0)
         if self.plan.strands > 1:
             self.encode_flags |= L.JG_ENC_NUCLEOTIDE
             if sp.get("input_type_note"):

@@ -92,17 +92,21 @@ _PC5_GROUP = {
 }
 PC5_ID: list[int] = _ids_by_first_appearance([_PC5_GROUP[a] for a in AA])
 
+#: the 4 096 ordered codon pairs of ``codon: DICODON`` and their ids (seqops/maps.py:544-546): 6-grams, numbered
+#: 64 * index(first codon) + index(second codon)
+DICODONS = [a + b for a in CODONS for b in CODONS]
+DICODON_ID = list(range(len(DICODONS)))
+
 #: names a ``*_project.yaml`` may use for ``string_processor.codon`` /
-#: ``codon_id`` (nnlib/inference.py:424-432).  Dicodon maps are not supported
-#: by the MI355X encoder (ngram_width 6) and resolve to ``None`` -> loud error.
+#: ``codon_id`` (nnlib/inference.py:424-432).
 NAMED_MAPS: dict[str, list | None] = {
     "CODON": CODONS,
     "CODON_ID": CODON_ID,
     "AA_ID": AA_ID,
     "MURPHY10_ID": MURPHY10_ID,
     "PC5_ID": PC5_ID,
-    "DICODON": None,
-    "DICODON_ID": None,
+    "DICODON": DICODONS,
+    "DICODON_ID": DICODON_ID,
 }
 
 

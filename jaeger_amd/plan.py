@@ -274,8 +274,13 @@ def build_plan(model_cfg: dict) -> ModelPlan:
         raise UnsupportedLayer("positional embeddings are not supported")
     if sp["input_type"] != "translated":
         raise UnsupportedLayer(f"input_type {sp['input_type']!r} on a graph built for translated input")
-    if sp.get("ngram_width", 3) != 3:
-        raise UnsupportedLayer("dicodon (ngram_width 6) encodings are not supported")
+    if sp.get("ngram_width", 3) not in (3, 6):
+        raise UnsupportedLayer(f"n-gram width {sp.get('ngram_width')} (codons: 3, dicodons: 6)")
+    if sp.get("ngram_width", 3) == 6:
+        # codon: DICODON (nnlib/inference.py:430-451 -> ngram_width 6, commands/predict.py:224, seqops/encode.py:272-284): ids
+        # of 4 096 codon pairs, 16-bit on the device; an Embedding lookup runs as an op of its own in front of the first conv
+        if sp["codon_id"] != maps.DICODON_ID or sp["codon"] != maps.DICODONS:
+            raise UnsupportedLayer("6-gram encodings other than DICODON / DICODON_ID")
     if "projection" in model_cfg:
         pass  # training-only head, not part of the serving graph outputs
     use_masking = bool(model_cfg.get("use_masking", True))          # builder.py:259

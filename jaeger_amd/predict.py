@@ -160,6 +160,8 @@ def predict_batch(engine, fa: "frag.FastaBatch", fsize: int, stride: int | None,
             lmax = int(max(0, -(-(int(table.length[sl].max()) - 5 + off3) // 3)))
             if getattr(engine.model, "strands", 1) > 1:                       # nucleotide rows hold bases
                 lmax = int(table.length[sl].max())
+            elif getattr(engine.model, "wide_ids", False):                    # dicodon rows: codon pairs six bases apart
+                lmax = int(max(0, -(-(int(table.length[sl].max()) - 8 + off3) // 6)))
             c0, c1 = int(cstart[i]), int(cstart[sl][-1] + wl[sl][-1])
             s_b, l_b = starts[sl], wl[sl]
             cut = np.nonzero(s_b[1:] != s_b[:-1] + l_b[:-1])[0] + 1          # where a new run of adjacent records starts
@@ -462,6 +464,7 @@ def run_core(**kwargs) -> int:
     LAST_RUN.clear()
     timeline: list = []                     # (event, seconds since run_core was entered): where the wall time of a short run goes
     LAST_RUN["timeline"] = timeline
+    LAST_RUN["t_start_epoch"] = t_start
 
     def mark(name):
         timeline.append((name, round(time.time() - t_start, 4)))
@@ -819,6 +822,16 @@ def run_core(**kwargs) -> int:
     if engine is not None:
         # the engine's buffers (workspace, pinned staging) are released beside the caller: freeing them takes tens of
         # milliseconds - a tenth of a short run - and nothing the caller gets depends on it
+        # ... nor on the large host buffers of the run (bases, window table, per-window outputs: unmapping half a gigabyte
+        # takes another 20 ms): their last references are dropped on that thread too
         import threading
-        threading.Thread(target=engine.close, name="jaeger-engine-close").start()
+        garbage = [engine, locals().get("fa"), locals().get("table"), locals().get("out"), locals().get("agg"),
+                   locals().get("starts"), locals().get("y_pred")]
+
+        def release(objs):
+            objs[0].close()
+            objs.clear()
+
+        threading.Thread(target=release, args=(garbage,), name="jaeger-engine-close").start()
+        del garbage
     return n_written

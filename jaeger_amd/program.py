@@ -255,6 +255,11 @@ class _Compiler:
             table = np.concatenate([np.zeros((1, rows.shape[1]), np.float32), np.asarray(rows, np.float32)])
         self.emb_off = self.blob.add(table)
         buf, mask = L.JG_BUF_IDS, L.JG_BUF_IDS      # Embedding(mask_zero=True), builder.py:858-867
+        if plan.vocab > 256:
+            # codon pairs (codon: DICODON, 4 097 ids): 16-bit ids do not fit the convs' one-byte gather - the lookup runs as
+            # an op of its own that writes the rows and the mask (id != 0); everything behind it reads those
+            buf, mask = self.bufs.take(), self.masks.take()
+            self.ops.append(self._op(L.OP_EMBED, out_buf=buf, out_mask=mask, cout=plan.embedding_dim, b_off=self.emb_off))
         i = 0
         if not layers or not isinstance(layers[0], Conv):
             # A norm / activation / nmd / residual block - or the pool itself - directly on the Embedding output (the

@@ -240,13 +240,16 @@ def onehot_depth(model_cfg: dict) -> int:
     import json
     from pathlib import Path
     name = (model_cfg.get("string_processor", {}) or {}).get("codon_id", "CODON_ID")
+    if name == "DICODON_ID":
+        return 4096
     table = json.loads((Path(__file__).resolve().parents[1] / "tests" / "golden" / "maps.json").read_text())
     return max(table[name]) + 1
 
 
 def vocab_size(model_cfg: dict) -> int:
-    """len(codon_id)+1 (inference.py:449): every id map has 64 entries."""
-    return 65
+    """len(codon_id)+1 (inference.py:449): the codon id maps have 64 entries, DICODON_ID 4 096."""
+    name = (model_cfg.get("string_processor", {}) or {}).get("codon_id", "CODON_ID")
+    return 4097 if name == "DICODON_ID" else 65
 
 
 def _block_specs(prefix: str, layers: list[dict], cin: int, specs: dict,

@@ -28,8 +28,9 @@ import os
 if os.environ.get("JAEGER_SCAN_FIRST"):
     kw["scan_first"] = True
 for r in range(reps):
-    t0 = time.perf_counter(); P.run_core(**kw); dt = time.perf_counter() - t0
-    lr = dict(P.LAST_RUN); tl = lr.pop("timeline")
+    e0 = time.time(); t0 = time.perf_counter(); P.run_core(**kw); dt = time.perf_counter() - t0; e1 = time.time()
+    lr = dict(P.LAST_RUN); tl = lr.pop("timeline"); ts = lr.pop("t_start_epoch")
+    print(f"   before run_core's clock {ts - e0:.4f} s, behind its last mark {e1 - ts - tl[-1][1]:.4f} s")
     print(f"== {which} run {r}: {dt:.3f} s = {bases.size / dt / 1e6:.1f} Mbp/s  {json.dumps(lr)}", flush=True)
     print("   ", "  ".join(f"{n}@{t:.3f}" for n, t in tl), flush=True)
     time.sleep(0.3)

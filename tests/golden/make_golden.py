@@ -99,7 +99,11 @@ def main():
     # ---- tables ------------------------------------------------------------------------
     (HERE / "maps.json").write_text(json.dumps({
         "CODONS": maps.CODONS, "CODON_ID": maps.CODON_ID, "AA_ID": maps.AA_ID,
-        "MURPHY10_ID": maps.MURPHY10_ID, "PC5_ID": maps.PC5_ID}, indent=0))
+        "MURPHY10_ID": maps.MURPHY10_ID, "PC5_ID": maps.PC5_ID,
+        # the 4 096 codon pairs of `codon: DICODON` (maps.py:544-546): digest + ends instead of the whole list
+        "DICODONS_SHA256": hashlib.sha256(",".join(maps.DICODONS).encode()).hexdigest(),
+        "DICODONS_HEAD": maps.DICODONS[:5], "DICODONS_TAIL": maps.DICODONS[-3:], "DICODONS_LEN": len(maps.DICODONS),
+        "DICODON_ID_IS_IDENTITY": maps.DICODON_ID == list(range(len(maps.DICODONS)))}, indent=0))
     (HERE / "crop.json").write_text(json.dumps({
         "tf_frame_length": {str(n): crop.tf_frame_length(n) for n in (2, 3, 5, 6, 7, 8, 9, 500, 1500, 1501,
                                                                         1502, 1505, 2000, 2048)},

@@ -55,3 +55,39 @@ def test_short_window_uses_crop_offset():
         vec = E.encode_windows([w], crop)
         assert vec.shape[2] == lit.shape[1]
         np.testing.assert_array_equal(vec[0], lit.astype(np.uint8))
+
+
+def test_dicodon_maps_are_the_references():
+    """``codon: DICODON`` (nnlib/inference.py:430-451): the 4 096 codon pairs and their identity ids, pinned to the digest /
+    ends dumped from the reference's seqops/maps.py:544-546 (tests/golden/make_golden.py)."""
+    import hashlib
+    import json
+
+    from conftest import GOLDEN
+    from jaeger_amd import maps
+    from oracle import encoder as oenc
+    g = json.loads((GOLDEN / "maps.json").read_text())
+    for table in (maps.DICODONS, oenc.DICODONS):
+        assert len(table) == g["DICODONS_LEN"] == 4096
+        assert table[:5] == g["DICODONS_HEAD"] and table[-3:] == g["DICODONS_TAIL"]
+        assert hashlib.sha256(",".join(table).encode()).hexdigest() == g["DICODONS_SHA256"]
+    assert g["DICODON_ID_IS_IDENTITY"] and maps.DICODON_ID == oenc.DICODON_ID == list(range(4096))
+
+
+def test_dicodon_encoder_literal_equals_vectorised():
+    """The step-by-step restatement of encode.py:228-302 at ``ngram_width = 6`` (all 6-grams, frames ``tri[j : -3 + j + off : 6]``,
+    hash lookup with default -1) against the vectorised form the parity tests use: every crop residue, short and cropped
+    windows, N / lower case with and without ``masking``."""
+    from jaeger_amd.engine import dicodon_frame_length
+    from oracle import encoder as oenc
+    rng = np.random.default_rng(6)
+    for n, crop in ((60, 60), (61, 61), (62, 62), (100, 150), (151, 150), (7, 60), (8, 60), (14, 62), (500, 500), (1500, 1500)):
+        w = "".join(rng.choice(list("ACGTNacgt"), p=[.22, .22, .22, .22, .04, .02, .02, .02, .02], size=n))
+        for masking in (False, True):
+            lit = oenc.encode_window_literal(w, crop, codons=oenc.DICODONS, codon_id=oenc.DICODON_ID, masking=masking)
+            vec = oenc.encode_windows_dicodon([w], crop, masking=masking)[0]
+            assert lit.shape == (6, oenc.dicodon_frame_length(min(n, crop), crop))
+            np.testing.assert_array_equal(vec, lit.astype(np.uint16))
+    assert dicodon_frame_length(1500) == oenc.dicodon_frame_length(1500) == 249
+    assert dicodon_frame_length(2000) == oenc.dicodon_frame_length(2000) == 332
+    assert oenc.encode_windows_dicodon(["ACGTTT", "ACGTTTA" * 3], 60).shape == (2, 6, 2)     # (21 - 8 - 2) / 6 -> 2; a 6-base window yields no entry

@@ -506,6 +506,73 @@ def test_box_calibration_reports_a_plausible_matrix_core_rate(device):
     assert box["launches"] >= 2
 
 
+def _dicodon_cfg(name):
+    import copy
+    cfg = copy.deepcopy(load_model_cfg(name))
+    cfg["string_processor"]["codon"], cfg["string_processor"]["codon_id"] = "DICODON", "DICODON_ID"
+    cfg["embedding"]["embedding_size"] = 16 if name == "baseline500" else 128
+    return cfg
+
+
+@pytest.mark.parametrize("fsize", [500, 1501, 62])
+def test_dicodon_encoder_bit_exact(device, fsize):
+    """``codon: DICODON`` (seqops/encode.py:272-284 at ngram_width 6): 16-bit ids of codon pairs, bit-exact against the
+    oracle - N runs, lower case, ragged windows, both case rules."""
+    from jaeger_amd import _lib as L
+    from jaeger_amd.engine import codon_lut, dicodon_frame_length
+    from jaeger_amd.maps import CODON_ID
+    from oracle import encoder as oenc
+    rng = np.random.Generator(np.random.PCG64(fsize))
+    n_win = 11
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.02, lower_frac=0.1)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    lens[2::4] = rng.integers(6, fsize, lens[2::4].size)
+    windows = [seq[s:s + n].tobytes() for s, n in zip(starts, lens)]
+    for masking in (False, True):
+        flags = L.JG_ENC_DICODON | (3 if masking else 0)
+        ids, counts = device.encode(seq, starts, lens, fsize, codon_lut(CODON_ID), flags=flags)
+        assert ids.dtype == np.uint16 and ids.shape == (n_win, 6, dicodon_frame_length(fsize))
+        ref = oenc.encode_windows_dicodon(windows, fsize, masking=masking, pad_to=dicodon_frame_length(fsize))
+        np.testing.assert_array_equal(ids, ref)
+        if not masking:
+            np.testing.assert_array_equal(counts, np.array([oenc.window_counts(w.upper()) for w in windows], np.int32))
+    lit = oenc.encode_window_literal(windows[1].decode(), fsize, codons=oenc.DICODONS, codon_id=oenc.DICODON_ID)
+    np.testing.assert_array_equal(ids[1][:, :lit.shape[1]], oenc.encode_windows_dicodon([windows[1]], fsize, masking=True)[0])
+
+
+@pytest.mark.parametrize("name,fsize,precision", [("baseline500", 500, "f16x3"), ("baseline500", 500, "f32"),
+                                                  ("brain", 1500, "f16x3")])
+def test_forward_dicodon_model(name, fsize, precision):
+    """A model on codon-pair ids (vocabulary 4 097): fused encode + forward and the id-tensor entry point against the
+    oracle - the Embedding lookup runs as an op of its own, the first conv reads its rows under its mask."""
+    from jaeger_amd.engine import JaegerHipEngine, dicodon_frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = _dicodon_cfg(name)
+    weights = ofwd.random_weights(cfg, seed=38341)
+    rng = np.random.Generator(np.random.PCG64(7 + fsize))
+    n_win = 9
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.02)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    lens[1::3] = rng.integers(fsize // 2, fsize, lens[1::3].size)
+    eng = JaegerHipEngine(model_cfg=cfg, weights=weights, precision=precision)
+    assert eng.model.wide_ids and not eng.model.placement()["small_fused"]
+    got = eng.predict_windows(seq, starts, lens, fsize)
+    ids = oenc.encode_windows_dicodon([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize,
+                                      pad_to=dicodon_frame_length(fsize))
+    got2 = eng.model.forward(ids)
+    eng.close()
+    ref = ofwd.forward(cfg, weights, ids)
+    for k, r in ref.items():
+        np.testing.assert_array_equal(got[k], got2[k])
+        if k in ("prediction", "reliability"):
+            assert float(np.abs(got[k] - r).max()) <= TOL, (k, float(np.abs(got[k] - r).max()))
+        else:
+            check_side_output(k, got[k], r)
+
+
 def test_small_window_model_on_longer_rows_runs_layer_by_layer():
     """Rows beyond the fused kernel's 160 positions (fsize 1000 -> 332 codons) fall back to the per-layer path
     inside the same model, same results contract."""

@@ -167,6 +167,28 @@ def test_keras3_weights_h5_mismatch_lists_what_is_left():
     assert "functional_8/dense [(16, 8), (8,)]" in msg and "functional_8/dense_1 [(8, 3), (3,)]" in msg
 
 
+def test_dicodon_model_compiles_to_an_embedding_op_in_front_of_the_first_conv():
+    """``codon: DICODON`` / ``codon_id: DICODON_ID`` (nnlib/inference.py:430-451, commands/predict.py:224): vocabulary 4 097,
+    6-grams; the 16-bit ids get an EMBED op of their own (rows + mask), and nothing else reads the id tensor."""
+    from jaeger_amd import _lib as L
+    from jaeger_amd import plan as P
+    from jaeger_amd import program as G
+    from oracle import forward as F
+    cfg = copy.deepcopy(load_model_cfg("baseline500"))
+    cfg["string_processor"]["codon"], cfg["string_processor"]["codon_id"] = "DICODON", "DICODON_ID"
+    cfg["embedding"]["embedding_size"] = 16
+    plan = P.build_plan(cfg)
+    assert plan.vocab == 4097 and plan.string_processor["ngram_width"] == 6
+    w = F.random_weights(cfg)
+    assert w["embedding/embeddings"].shape == (4097, 16)
+    prog = G.compile_plan(plan, w)
+    assert prog.ops[0].kind == L.OP_EMBED and prog.ops[0].cout == 16 and prog.vocab == 4097
+    assert not any(op.in_buf == L.JG_BUF_IDS or op.in_mask == L.JG_BUF_IDS for op in prog.ops[1:])
+    cfg["string_processor"]["codon_id"] = "CODON_ID"                 # 6-grams with a 64-entry id map: no such encoding
+    with pytest.raises(P.UnsupportedLayer):
+        P.build_plan(cfg)
+
+
 def test_layernorm_cuts_the_epilogue_into_an_elementwise_op():
     """MaskedLayerNormalization reduces over the channels: the conv keeps the stages in front of it, an element-wise
     op led by the LN stage runs the norm and everything behind it (shortcut add, activation, NMD tap, next norm)."""
