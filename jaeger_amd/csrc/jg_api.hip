@@ -1858,8 +1858,8 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           ra.wfrag = hp.d_rb_wfrag;
           ra.epi = hp.d_rb_epi;
           ra.overflow = m->d_overflow;
-          ra.rows = nw * in.frames; ra.L = in.L; ra.dil = op.dilation;
-          jg_resblock_tiling(in.L, op.dilation, &ra.nb, &ra.tile_out, &ra.tiles_per_row);
+          ra.rows = nw * in.frames; ra.L = in.L; ra.k = op.k; ra.dil = op.dilation;
+          jg_resblock_tiling(in.L, op.k, op.dilation, &ra.nb, &ra.tile_out, &ra.tiles_per_row);
           ra.psplit = hp.ps_store ? 1 : 0;
           if (e->profile) pe.flops *= 2.0;                   // both convs of the block
           pe.cls = JG_PROF_MFMA_F16X3;

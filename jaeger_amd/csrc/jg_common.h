@@ -149,15 +149,15 @@ struct JgResBlockArgs {
   const uint8_t *m0;      // (rows, L) input mask of conv1 (x * m0), or null
   const uint8_t *m1;      // ... of conv2 (= conv1's output mask), or null
   const uint8_t *m2;      // conv2's output mask: only read for a phase-split store, or null
-  const uint4 *wfrag;     // [2 convs][5 taps][2 chunks][2 planes][64 lanes] MFMA A-operand fragments (hi / lo f16, pre-scaled)
+  const uint4 *wfrag;     // [2 convs][k taps][2 chunks][2 planes][64 lanes] MFMA A-operand fragments (hi / lo f16, pre-scaled)
   const float *epi;       // [2 convs][scale | shift][32] folded bias / batch-norm affines (incl. the weights' un-scale)
   int *overflow;
-  int rows, L, dil;
+  int rows, L, k, dil;    // taps (5 or 3), dilation
   int nb, tile_out, tiles_per_row;   // jg_resblock_tiling
   int psplit;
 };
 bool jg_resblock_supports(int c, int k, int dil);
-void jg_resblock_tiling(int L, int dil, int *nb, int *tile_out, int *tiles);
+void jg_resblock_tiling(int L, int k, int dil, int *nb, int *tile_out, int *tiles);
 int jg_launch_resblock(jg_engine *e, const JgResBlockArgs &a, hipStream_t s);
 
 struct EltArgs {

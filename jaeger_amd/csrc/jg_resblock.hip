@@ -1,7 +1,7 @@
 // A whole narrow residual block in one launch (ResidualBlock, nnlib/v2/layers.py:1882-1915, stride 1, no bypass):
 //     h = gelu(bn1(conv1(x * m0)))          y = gelu(bn2(conv2(h * m1)) + x)
 // for 32-channel stages of pyramid-shaped models (train_config/nn_config_baseline.yaml: eight five-tap convs at 659
-// positions).  Layer by layer those convs are bound by their HBM round trips, not by the matrix cores (1.3 - 1.9 GB moved
+// positions) and the three-tap blocks of the small-window family on longer rows (nn_config_500bp_baseline.yaml at 1 500 bp).  Layer by layer those convs are bound by their HBM round trips, not by the matrix cores (1.3 - 1.9 GB moved
 // per launch of 10 GFLOP): here a workgroup keeps a position tile of the block input in LDS (F16S items, brought in by
 // global_load_lds DMA), runs conv1 on the matrix cores, writes the re-split intermediate back to LDS, runs conv2 from
 // there and adds the shortcut out of the SAME input image - the intermediate tensor never exists in HBM, the input is
@@ -26,7 +26,6 @@
 
 namespace {
 
-constexpr int RB_K = 5;
 constexpr int RB_C = 32;
 constexpr int RB_CC = RB_C / 16;          // 16-channel chunks
 constexpr int RB_PL = RB_CC * 4;          // (chunk, plane, half) item rows per position: 8
@@ -38,6 +37,7 @@ __device__ __forceinline__ void rb_swap32(unsigned &lo_half_keeps, unsigned &hi_
   hi_half_keeps = r[1];
 }
 
+template <int RB_K>
 __global__ __launch_bounds__(256, 2) void resblock32_kernel(JgResBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -282,34 +282,38 @@ __global__ __launch_bounds__(256, 2) void resblock32_kernel(JgResBlockArgs a) {
 }  // namespace
 
 // a tile computes RB_NB x 32 intermediate positions; its outputs are the 128 - 4 d positions whose taps stay inside it
-void jg_resblock_tiling(int L, int dil, int *nb, int *tile_out, int *tiles) {
+void jg_resblock_tiling(int L, int k, int dil, int *nb, int *tile_out, int *tiles) {
   *nb = RB_NB;
-  *tile_out = 32 * RB_NB - (RB_K - 1) * dil;
+  *tile_out = 32 * RB_NB - (k - 1) * dil;
   *tiles = (L + *tile_out - 1) / *tile_out;
 }
 
-bool jg_resblock_supports(int c, int k, int dil) { return c == RB_C && k == RB_K && dil >= 1 && (RB_K - 1) * dil <= 32; }
+bool jg_resblock_supports(int c, int k, int dil) { return c == RB_C && (k == 5 || k == 3) && dil >= 1 && (k - 1) * dil <= 32; }
 
 int jg_launch_resblock(jg_engine *e, const JgResBlockArgs &a, hipStream_t s) {
   JG_REQUIRE(a.xh != nullptr && a.y != nullptr && a.wfrag != nullptr && a.epi != nullptr && a.nb == RB_NB &&
-                 a.tile_out == 32 * a.nb - (RB_K - 1) * a.dil && a.tile_out >= 1 && a.tiles_per_row * a.tile_out >= a.L,
+                 (a.k == 5 || a.k == 3) && a.tile_out == 32 * a.nb - (a.k - 1) * a.dil && a.tile_out >= 1 &&
+                 a.tiles_per_row * a.tile_out >= a.L,
              JG_ERR_INVALID, "resblock: bad geometry (nb %d, tile_out %d, tiles %d, L %d, dilation %d)", a.nb, a.tile_out,
              a.tiles_per_row, a.L, a.dil);
   JG_REQUIRE((double)a.rows * RB_PL * a.L * 16.0 < 4.0e9, JG_ERR_UNSUPPORTED,
              "resblock: activation tensor of %d rows exceeds the 32-bit DMA offset range", a.rows);
   if (a.rows == 0 || a.L <= 0) return JG_OK;
-  const int RH = 32 * a.nb, RX = RH + (RB_K - 1) * a.dil;
+  const int RH = 32 * a.nb, RX = RH + (a.k - 1) * a.dil;
   const int x_slot = (RB_PL * RX + 63) & ~63;        // two input images (double buffer), whole 64-item DMA calls each
   const size_t smem = (size_t)(2 * x_slot + RB_PL * RH) * 16 + 4 * RB_C * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(resblock32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(resblock32_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               128 * 1024));
+    JG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(resblock32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                128 * 1024));
     attr_set = true;
   }
   const long units = (long)a.rows * a.tiles_per_row;
   const int grid = (int)std::min<long>(units, 2L * e->n_cu);
-  hipLaunchKernelGGL(resblock32_kernel, dim3((unsigned)grid), dim3(256), smem, s, a);
+  if (a.k == 5) hipLaunchKernelGGL(resblock32_kernel<5>, dim3((unsigned)grid), dim3(256), smem, s, a);
+  else hipLaunchKernelGGL(resblock32_kernel<3>, dim3((unsigned)grid), dim3(256), smem, s, a);
   JG_HIP(hipGetLastError());
   return JG_OK;
 }
