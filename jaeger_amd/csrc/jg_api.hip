@@ -1252,7 +1252,8 @@ static int plan_phase_split(jg_model *m, const float *weights) {
     const jg_op &po = m->ops[p];
     ConvHPrep &pp = m->hprep[p];
     if (po.kind != JG_OP_CONV || !pp.f16_ok || !pp.out_f16s || pp.pool_op >= 0 || po.stride != 1 || po.out_buf < 0 ||
-        po.cout % 16 != 0 || (int)p == m->tab_conv)
+        po.cout % 16 != 0 || (int)p == m->tab_conv || po.in_buf == JG_BUF_IDS ||
+        !jg_conv_f16_has_narrow_pattern(pp.ep))           // (the store is built into the run-time-geometry tiles)
       continue;
     std::vector<size_t> readers;
     bool ok = true, mask_rewritten = false;
@@ -1939,7 +1940,7 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
             const int64_t flat_tiles = ((int64_t)nw * wp + 255) / 256;
             const int64_t row_tiles = (int64_t)a.rows * a.tiles_m;
             if (!no_flat && a.k == 5 && op.in_buf != JG_BUF_IDS && hp.d_lut == nullptr && eff_stride == 1 && eff_lin == lo &&
-                ((op.cout == 128 && !hp.as_k5 && hp.ps_read == 0) ? jg_conv_f16_has_flat_pattern(hp.ep) : jg_conv_f16_has_narrow_pattern(hp.ep)) &&
+                ((op.cout == 128 && !hp.as_k5 && hp.ps_read == 0 && !hp.ps_store) ? jg_conv_f16_has_flat_pattern(hp.ep) : jg_conv_f16_has_narrow_pattern(hp.ep)) &&
                 (int64_t)nw * wp < (1 << 24) && flat_tiles * 100 <= row_tiles * 95) {
               a.flat = 1;
               a.flat_p = fp;

@@ -144,7 +144,8 @@ int jg_launch_conv_f16(jg_engine *e, const ConvHArgs &a, hipStream_t s) {
     if (a.k == 7) return a.cw == 64 ? jg_conv_f16_part_x8(e, a, s) : jg_conv_f16_part_x9(e, a, s);
     return a.cw == 64 ? jg_conv_f16_part_x11(e, a, s) : jg_conv_f16_part_x12(e, a, s);
   }
-  if (a.cout != HN || a.ostride != 1 || a.tap_lo != 0 || a.tap_hi != a.k - 1) {     // (ch0 != 0 implies cout > 128)
+  if (a.cout != HN || a.ostride != 1 || a.tap_lo != 0 || a.tap_hi != a.k - 1 || a.psplit) {     // (ch0 != 0 implies cout > 128; a
+                                                                  // phase-split store is built into the run-time-geometry tiles only)
     if (a.k == 5) return jg_conv_f16_part_g128(e, a, s);
     JG_REQUIRE(!a.flat, JG_ERR_UNSUPPORTED, "conv_f16x3: window-packed tiling is only built for k = 5");
     return a.k == 7 ? jg_conv_f16_part_x10(e, a, s) : jg_conv_f16_part_x13(e, a, s);

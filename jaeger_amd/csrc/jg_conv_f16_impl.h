@@ -934,11 +934,18 @@ void conv_f16x3_kernel(ConvHArgs a) {
       };
       // where an output item goes: as item4, or - phase-split store - position p of chunk cc at chunk (p & 1) * CC + cc,
       // position p >> 1 of rows that hold 2 * CC chunks of (L_out + 1) / 2 positions
-      const int L_st = a.psplit ? ((a.L_out + 1) >> 1) : a.L_out;      // positions per chunk row of the stored tensor
+      // (run-time-geometry variants only: the 128-channel instantiations of the residual stacks stay free of it - a
+      // 128-wide producer of a phase-split tensor is dispatched to the general tile, CW = 129)
+      const bool psplit = GEN && a.psplit != 0;
+      const int L_st = psplit ? ((a.L_out + 1) >> 1) : a.L_out;      // positions per chunk row of the stored tensor
       auto item4_out = [&](int row, int mc, int nb, int j) -> unsigned {
-        if (!a.psplit) return item4(row, mc, nb, j);
-        const int G = ((nb + ch0) >> 3) + 2 * j + h, CC = a.cout_pad >> 4;
-        return (unsigned)(((row * 2 * CC + (mc & 1) * CC + (G >> 1)) * 4 + (G & 1)) * L_st + (mc >> 1));
+        if constexpr (GEN) {
+          if (psplit) {
+            const int G = ((nb + ch0) >> 3) + 2 * j + h, CC = a.cout_pad >> 4;
+            return (unsigned)(((row * 2 * CC + (mc & 1) * CC + (G >> 1)) * 4 + (G & 1)) * L_st + (mc >> 1));
+          }
+        }
+        return item4(row, mc, nb, j);
       };
       // this lane's output position in block tm: row, clamped position, alive
       auto out_pos = [&](const Tile &tile, int tm, int &row, int &mc) -> bool {
@@ -1110,9 +1117,11 @@ void conv_f16x3_kernel(ConvHArgs a) {
           if constexpr (N2 == 2) st_dyt(N1 ? 2 : 1, a.alpha2, a.dytmask2);
           if constexpr (EP & JG_EP_ACT2) st_gelu();
         }
-        if (a.psplit) {            // the stride-2 readers take their input mask from here (they read x * mask)
+        if constexpr (GEN) {
+          if (psplit) {            // the stride-2 readers take their input mask from here (they read x * mask)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) x[r] *= mk;
+            for (int r = 0; r < 16; ++r) x[r] *= mk;
+          }
         }
         // results stay in the block's registers (F16S: re-split, lane-pair swapped and bit-cast,
         // dword 4j..4j+3 = hi item, 8+4j.. = lo item of group 2j+h); stored by store_block() once
@@ -1170,7 +1179,7 @@ void conv_f16x3_kernel(ConvHArgs a) {
               // streamed (nt) rather than write-allocated in L2 (+1.3 % measured)
               __builtin_nontemporal_store(vhi, reinterpret_cast<u32x4 *>(yh + it4));
               __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)L_st));
-              if (a.psplit && (a.L_out & 1) && mc == a.L_out - 1) {
+              if (GEN && psplit && (a.L_out & 1) && mc == a.L_out - 1) {
                 // an odd row length: the odd phase is one position short - its last slot (position L_out) reads as zero
                 const unsigned itz = it4 + (unsigned)((a.cout_pad >> 4) * 4 * L_st);
                 const u32x4 z = {0u, 0u, 0u, 0u};
