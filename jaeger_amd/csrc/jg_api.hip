@@ -11,6 +11,7 @@
 
 #include "jg_common.h"
 #include "jg_small.h"
+#include "jg_resblock64.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -1375,7 +1376,7 @@ static int plan_resblocks(jg_model *m, const float *weights) {
     const jg_op &A = m->ops[ia];
     ConvHPrep &ha = m->hprep[ia];
     if (A.kind != JG_OP_CONV || !ha.f16_ok || ha.rb_second >= 0 || ha.rb_first >= 0 || A.in_buf < 0 || A.stride != 1 ||
-        A.padding != JG_PAD_SAME || A.cin != A.cout || !jg_resblock_supports(A.cout, A.k, A.dilation) || !ha.out_f16s ||
+        A.padding != JG_PAD_SAME || A.cin != A.cout || !(jg_resblock_supports(A.cout, A.k, A.dilation) || jg_resblock64_supports(A.cout, A.k, A.dilation)) || !ha.out_f16s ||
         ha.ep != JG_EP_ACT1 || ha.act_kind != JG_ACT_GELU_TANH || ha.pool_op >= 0 || ha.ps_store || ha.ps_read != 0 ||
         ha.n_cvt != 0 || (int)ia == m->tab_conv)
       continue;
@@ -1401,9 +1402,10 @@ static int plan_resblocks(jg_model *m, const float *weights) {
         B.out_buf == A.in_buf || B.out_buf == A.out_buf || hb.pool_op >= 0 || hb.ps_read != 0 || hb.n_cvt != 0 ||
         hb.nmd_slot >= 0 || ha.nmd_slot >= 0)
       continue;
-    // weight fragments [conv][tap][chunk][plane][lane][8 halfs]: lane = (cin group of 8) x (output channel)
-    const int C = A.cout, K = A.k, cc_n = C / 16;
-    std::vector<uint16_t> frag((size_t)2 * K * cc_n * 2 * 64 * 8, 0);
+    // weight fragments [conv][tap][chunk][plane][32-channel output tile][lane][8 halfs]: lane = (cin group of 8) x (output
+    // channel of the tile)
+    const int C = A.cout, K = A.k, cc_n = C / 16, ct_n = C / 32;
+    std::vector<uint16_t> frag((size_t)2 * K * cc_n * 2 * ct_n * 64 * 8, 0);
     std::vector<float> epi((size_t)4 * C, 0.f);
     bool range_ok = true;
     for (int c = 0; c < 2; ++c) {
@@ -1414,16 +1416,17 @@ static int plan_resblocks(jg_model *m, const float *weights) {
       const float wscale = 1.0f / hp.acc_scale;
       for (int t = 0; t < K; ++t)
         for (int cc = 0; cc < cc_n; ++cc)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 8; ++j) {
-              const int co = lane & 31, ci = cc * 16 + (lane >> 5) * 8 + j;
-              const float v = w[((size_t)t * cin_pad + ci) * cout_pad32 + co] * wscale;
-              const float hi = f16_value(v);
-              if (!(fabsf(v) <= 65000.f)) range_ok = false;
-              const size_t base = ((((size_t)c * K + t) * cc_n + cc) * 2) * 64 * 8;
-              frag[base + (size_t)lane * 8 + j] = f16_bits(hi);
-              frag[base + 64 * 8 + (size_t)lane * 8 + j] = f16_bits(v - hi);
-            }
+          for (int ct = 0; ct < ct_n; ++ct)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j) {
+                const int co = ct * 32 + (lane & 31), ci = cc * 16 + (lane >> 5) * 8 + j;
+                const float v = w[((size_t)t * cin_pad + ci) * cout_pad32 + co] * wscale;
+                const float hi = f16_value(v);
+                if (!(fabsf(v) <= 65000.f)) range_ok = false;
+                const size_t base = ((((size_t)c * K + t) * cc_n + cc) * 2) * ct_n * 64 * 8;
+                frag[base + ((size_t)ct * 64 + lane) * 8 + j] = f16_bits(hi);
+                frag[base + ((size_t)(ct_n + ct) * 64 + lane) * 8 + j] = f16_bits(v - hi);
+              }
       fold(op, hp.acc_scale, epi.data() + (size_t)c * 2 * C, epi.data() + (size_t)c * 2 * C + C);
     }
     if (!range_ok) continue;
@@ -1860,11 +1863,13 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
           ra.epi = hp.d_rb_epi;
           ra.overflow = m->d_overflow;
           ra.rows = nw * in.frames; ra.L = in.L; ra.k = op.k; ra.dil = op.dilation;
-          jg_resblock_tiling(in.L, op.k, op.dilation, &ra.nb, &ra.tile_out, &ra.tiles_per_row);
+          const bool wide = op.cout == 64;                   // jg_resblock64.hip: the waves split into conv1 / conv2 roles
+          if (wide) jg_resblock64_tiling(in.L, op.k, op.dilation, &ra.nb, &ra.tile_out, &ra.tiles_per_row);
+          else jg_resblock_tiling(in.L, op.k, op.dilation, &ra.nb, &ra.tile_out, &ra.tiles_per_row);
           ra.psplit = hp.ps_store ? 1 : 0;
           if (e->profile) pe.flops *= 2.0;                   // both convs of the block
           pe.cls = JG_PROF_MFMA_F16X3;
-          rc = jg_launch_resblock(e, ra, s);
+          rc = wide ? jg_launch_resblock64(e, ra, s) : jg_launch_resblock(e, ra, s);
           if (e->profile && rc == JG_OK) {
             JG_HIP(hipEventRecord(pe.b, s));
             e->pending.push_back(pe);

@@ -237,9 +237,10 @@ def test_pyramid_strided_blocks_read_phase_split_tensors():
 
 
 def test_narrow_residual_blocks_run_fused_and_equal_the_layer_by_layer_path():
-    """Round 5: the pyramid's four 32-channel residual blocks run as ONE launch each (jg_resblock.hip: the intermediate
-    tensor stays in LDS, the shortcut comes out of the same input image).  Same split-f16 arithmetic in the same order as
-    the two conv launches it replaces: logits and side outputs must agree with the layer-by-layer path
+    """Round 5: the pyramid's four 32-channel and three 64-channel stride-1 residual blocks run as ONE launch each
+    (jg_resblock.hip, jg_resblock64.hip: the intermediate tensor stays in LDS, the shortcut comes out of the same input
+    image).  Same split-f16 arithmetic as the two conv launches it replaces (the 64-channel kernel sums even and odd steps
+    in two accumulators): logits and side outputs must agree with the layer-by-layer path
     (JG_OPT_FUSE_RESBLOCK = 0) to rounding, on windows with N runs (masked positions: the shortcut of a masked position is
     read from HBM) and short windows (padding); both paths are inside the oracle gate in the tests above."""
     from jaeger_amd.engine import JaegerHipEngine
@@ -251,9 +252,9 @@ def test_narrow_residual_blocks_run_fused_and_equal_the_layer_by_layer_path():
             weights[key] = weights[key] * np.float32(0.85)
     eng = JaegerHipEngine(model_cfg=cfg, weights=weights, precision="f16x3")
     text = eng.model.describe()
-    assert sum("fused residual block" in ln and "second conv" not in ln for ln in text.splitlines()) == 4, text
-    assert sum("computed by the block's second conv" in ln for ln in text.splitlines()) == 4, text
-    assert sum("fused residual block, phase-split store" in ln for ln in text.splitlines()) == 1, text
+    assert sum("fused residual block" in ln and "second conv" not in ln for ln in text.splitlines()) == 7, text
+    assert sum("computed by the block's second conv" in ln for ln in text.splitlines()) == 7, text
+    assert sum("fused residual block, phase-split store" in ln for ln in text.splitlines()) == 2, text
     rng = np.random.Generator(np.random.PCG64(52))
     fsize, n_win = 2000, 40
     seq = _random_dna(rng, fsize * n_win, n_frac=0.03)
