@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512, 1) void resblock64_kernel(JgResBlockArgs a) {
       if (q0 < x_items) {
         const int pos = min(max(xp0 + j, 0), a.L - 1);
         // (lanes past the image's end fetch some item of the last row again, into the slack behind the image)
-        const unsigned voff = (row_off + (unsigned)(min(cph, R6_PL - 1) * a.L + pos)) * 16u;
+        const unsigned voff = (row_off + __umul24((unsigned)min(cph, R6_PL - 1), (unsigned)a.L) + (unsigned)pos) * 16u;
         glds16_nt(a.xh, voff, __builtin_amdgcn_readfirstlane(ldsX + (unsigned)(buf * x_slot + q0) * 16u));
       }
       cph += step_rows;
@@ -265,6 +265,12 @@ __global__ __launch_bounds__(512, 1) void resblock64_kernel(JgResBlockArgs a) {
     const float m2f = (bits & 2u) ? 1.f : 0.f;
     const char *simg = reinterpret_cast<const char *>(Ximg + min(o + halo, RX - 1)) + 8 * hh;
     const char *sgl = reinterpret_cast<const char *>(a.xh) + 8 * hh;
+    // byte offset of this lane's first output item (the launcher bounds the tensor to 32-bit byte offsets); the lo plane
+    // sits 2 L items behind the hi plane, the next chunk 4 L
+    const unsigned out_step = (unsigned)(4 * L_st) * 16u;
+    const unsigned out_item = a.psplit ? (unsigned)(((row * 2 * R6_CC + (p & 1) * R6_CC + 2 * ct) * 4 + hh) * L_st + (p >> 1))
+                                       : (unsigned)(((row * R6_CC + 2 * ct) * 4 + hh) * a.L + p);
+    const unsigned out_off = out_item * 16u;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       unsigned ph[4], pl[4];
@@ -294,18 +300,17 @@ __global__ __launch_bounds__(512, 1) void resblock64_kernel(JgResBlockArgs a) {
       r6_swap32(ph[0], ph[2]); r6_swap32(ph[1], ph[3]);
       r6_swap32(pl[0], pl[2]); r6_swap32(pl[1], pl[3]);
       if (live) {
-        const int Gq = 2 * j + hh, chunk = 2 * ct + (Gq >> 1);
-        size_t it;
-        if (a.psplit) it = (((size_t)row * 2 * R6_CC + (p & 1) * R6_CC + chunk) * 4 + (Gq & 1)) * L_st + (p >> 1);
-        else it = (((size_t)row * R6_CC + chunk) * 4 + (Gq & 1)) * a.L + p;
+        // group 2j + hh of this wave's channels = item row (chunk 2 ct + j, half hh): 4 L items further per j
+        const unsigned off = out_off + (unsigned)j * out_step;
         const u32x4 vhi = {ph[0], ph[1], ph[2], ph[3]}, vlo = {pl[0], pl[1], pl[2], pl[3]};
-        __builtin_nontemporal_store(vhi, reinterpret_cast<u32x4 *>(a.y + it));
-        __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(a.y + it + 2 * (size_t)L_st));
+        char *yb = reinterpret_cast<char *>(a.y);
+        __builtin_nontemporal_store(vhi, reinterpret_cast<u32x4 *>(yb + (size_t)off));
+        __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yb + (size_t)(off + out_step / 2)));
         if (a.psplit && (a.L & 1) && p == a.L - 1) {               // the odd phase of an odd row is one position short: zero
-          const size_t itz = it + (size_t)R6_CC * 4 * L_st;
+          const unsigned offz = off + (unsigned)(R6_CC * 4 * L_st) * 16u;
           const u32x4 z = {0u, 0u, 0u, 0u};
-          __builtin_nontemporal_store(z, reinterpret_cast<u32x4 *>(a.y + itz));
-          __builtin_nontemporal_store(z, reinterpret_cast<u32x4 *>(a.y + itz + 2 * (size_t)L_st));
+          __builtin_nontemporal_store(z, reinterpret_cast<u32x4 *>(yb + (size_t)offz));
+          __builtin_nontemporal_store(z, reinterpret_cast<u32x4 *>(yb + (size_t)(offz + out_step / 2)));
         }
       }
     }
@@ -447,8 +452,8 @@ int jg_launch_resblock64(jg_engine *e, const JgResBlockArgs &a, hipStream_t s) {
                  a.tiles_per_row * a.tile_out >= a.L,
              JG_ERR_INVALID, "resblock64: bad geometry (nb %d, tile_out %d, tiles %d, L %d, dilation %d)", a.nb, a.tile_out,
              a.tiles_per_row, a.L, a.dil);
-  JG_REQUIRE((double)a.rows * R6_PL * a.L * 16.0 < 4.0e9, JG_ERR_UNSUPPORTED,
-             "resblock64: activation tensor of %d rows exceeds the 32-bit DMA offset range", a.rows);
+  JG_REQUIRE((double)a.rows * R6_PL * (a.L + 1) * 16.0 < 4.2e9, JG_ERR_UNSUPPORTED,
+             "resblock64: activation tensor of %d rows exceeds the 32-bit byte offsets of the DMA and the stores", a.rows);
   if (a.rows == 0 || a.L <= 0) return JG_OK;
   const size_t smem = r6_smem(a.k, a.dil);
   const long units = (long)a.rows * a.tiles_per_row;
