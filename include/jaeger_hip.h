@@ -149,8 +149,9 @@ int jg_engine_sync(jg_engine *e);
  * (beside the previous group's convolutions) or, 0, on the compute stream in front of the span's encoder; same masks.
  * JG_OPT_TABLE_NET_LDS (default 0): a strand branch's conv + pool ("table net") runs on the matrix cores (0) or, 1, as the
  * exact-f32 LDS-table kernel - the form every shape the matrix-core kernel does not cover takes anyway.
- * JG_OPT_FUSE_RESBLOCK (default 1): narrow residual blocks (32 channels, five taps, stride 1, no bypass) run as ONE launch that
- * keeps the block's intermediate tensor in LDS (1), or conv by conv (0: A/B timing and the test that compares the two).
+ * JG_OPT_FUSE_RESBLOCK (default 1): narrow residual blocks (32 channels: three or five taps, any dilation with (k - 1) d <= 32;
+ * 64 channels: dilation 1 or 2; stride 1, no bypass) run as ONE launch that keeps the block's intermediate tensor in LDS (1),
+ * or conv by conv (0: A/B timing and the test that compares the two).
  * JG_OPT_RESET_PROGRESS (value ignored): sets JG_STAT_WINDOWS_DONE back to 0.  A thread that polls the mark of a
  * jg_predict_windows call ANOTHER thread is about to make calls this first (the call resets the mark itself, but only
  * once it has been entered - a poller that starts earlier would read the previous call's final count). */
