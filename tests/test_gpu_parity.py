@@ -272,6 +272,48 @@ def test_narrow_residual_blocks_run_fused_and_equal_the_layer_by_layer_path():
             assert err <= 2e-5, (k, err)
 
 
+@pytest.mark.parametrize("ksize,dil", [(5, 1), (5, 2), (3, 1), (3, 2)])
+def test_fused_64_channel_blocks_every_instantiation(ksize, dil):
+    """jg_resblock64.hip is compiled per (kernel size, dilation): the pyramid with its 64-channel stage set to each of the
+    four - against the oracle, and against the layer-by-layer path, on masked (N runs) and ragged windows; odd and even
+    row lengths (the last fused block stores phase-split for the strided block behind it)."""
+    import copy
+
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("pyramid"))
+    n64 = 0
+    for layer in cfg["representation_learner"]["hidden_layers"]:
+        c = layer["config"]
+        if layer["name"] == "residual_block" and c.get("filters") == 64 and c.get("strides", 1) == 1:
+            c["kernel_size"], c["dilation_rate"] = ksize, dil
+            n64 += c.get("block_size", 1)
+    assert n64 == 3
+    weights = ofwd.random_weights(cfg, seed=977 + 10 * ksize + dil)
+    for key in weights:
+        if key.startswith("rep/") and key.endswith("/kernel"):
+            weights[key] = weights[key] * np.float32(0.85)
+    rng = np.random.Generator(np.random.PCG64(60 + ksize + dil))
+    for fsize, n_win in ((2000, 7), (1988, 5)):                          # 330 / 328 positions on the 64-channel stage
+        seq = _random_dna(rng, fsize * n_win, n_frac=0.04)
+        starts = (np.arange(n_win) * fsize).astype(np.int64)
+        lens = np.full(n_win, fsize, np.int32)
+        lens[1::2] = rng.integers(fsize // 3, fsize, lens[1::2].size)
+        eng = JaegerHipEngine(model_cfg=cfg, weights=weights, precision="f16x3")
+        text = eng.model.describe()
+        assert sum("fused residual block" in ln and "second conv" not in ln for ln in text.splitlines()) == 7, text
+        fused = eng.predict_windows(seq, starts, lens, fsize)
+        eng.device.set_fuse_resblock(False)
+        plain = eng.predict_windows(seq, starts, lens, fsize)
+        eng.close()
+        ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+        ref = ofwd.forward(cfg, weights, ids)
+        for k in ("prediction", "reliability"):
+            assert np.abs(fused[k] - ref[k]).max() <= TOL, (fsize, k, np.abs(fused[k] - ref[k]).max())
+            assert np.abs(fused[k] - plain[k]).max() <= 2e-5, (fsize, k, np.abs(fused[k] - plain[k]).max())
+
+
 def test_forward_pyramid_resnet_short_windows_chunked():
     _forward_case("pyramid", 2000, 9, 22, n_frac=0.03, short=True, chunk=4, precision="f16x3", gain=0.85)
     _forward_case("pyramid", 900, 5, 23, n_frac=0.0, precision="f16x3", gain=0.85)
