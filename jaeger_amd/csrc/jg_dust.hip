@@ -227,7 +227,9 @@ extern "C" int jg_dust_mask(uint8_t *bases, const int64_t *offsets, int64_t n_re
 // read (+ a 1.2x halo from L2) and at most one written per base - 0.8 GB for 400 Mbp, 0.1 ms of HBM time; the kernel
 // is bound by the 62 dependent DP steps (~30 vector / LDS instructions and a barrier each per start: ~30 ms of vector
 // issue for 400 Mbp on 256 CUs).  Measured 39 ms = 10.3 Gbp/s (workgroups of 768 = three waves per SIMD, two per CU;
-// 384 threads: 64 ms, 512: 40, 640: 55, 1 024: 53), the host scan on 16 threads 1.5 Gbp/s.
+// 384 threads: 64 ms, 512: 40, 640: 55, 1 024: 53), the host scan on 16 threads 1.5 Gbp/s.  Round 5: a barrier-free
+// filter in front of the programme (does ANY interval of the tile score above the threshold?) lets the tiles of
+// ordinary sequence leave after the repeat counts alone.
 namespace {
 
 constexpr int DT = 768, DOWN = 640, DHALO = 64;
@@ -288,6 +290,37 @@ __global__ __launch_bounds__(DT) void dust_kernel(uint8_t *bases, int64_t origin
     tri[q] = ok ? (uint8_t)((a & 3) * 16 + (b & 3) * 4 + (c & 3)) : (uint8_t)0xff;
   }
   __syncthreads();
+  // Filter: a perfect interval scores above T / 10, so a tile in which NO interval (any start, any length) does has
+  // nothing to mask - and the repeat counts alone need neither the neighbour exchange nor a barrier per step.  Most
+  // tiles of ordinary sequence stop here; the others clear the count table and run the dynamic programme.
+  {
+    // the thread's counter of a triplet is a byte of the dword it shares with three neighbours: one returning LDS add
+    // per step, nothing in the loop waits for the step before it (a dead start - its triplet chain broken - adds zero)
+    bool hot = false, live = true;
+    int rf = 0;
+    const int sh = 8 * (j & 3);
+    uint32_t *col = cnt32 + (j >> 2);
+#pragma unroll 4
+    for (int l = 1; l <= lmax; ++l) {
+      const unsigned t = tri[j + l - 1];
+      live = live && t != 0xffu;
+      const uint32_t old = atomicAdd(col + (t & 63u) * (DPITCH / 4), live ? 1u << sh : 0u);
+      rf += live ? (int)((old >> sh) & 0xffu) : 0;
+      hot = hot || 10 * rf > T * (l - 1);          // (l = 1: r = 0; a dead start's count no longer grows)
+    }
+    if (__syncthreads_or(hot ? 1 : 0) == 0) {
+      if (j >= DHALO && j < DHALO + DOWN) {        // nothing masked: the owned bases are upper-cased, that is all
+        const int64_t pos = tile0 + j, loc = pos - origin;
+        if (pos >= own0 && pos < own1 && loc >= 0 && loc < span_len) {
+          const uint8_t b = bases[loc];
+          if (b >= 'a' && b <= 'z') bases[loc] = (uint8_t)(b - 32);
+        }
+      }
+      return;
+    }
+    for (int q = j; q < 64 * DPITCH / 4; q += DT) cnt32[q] = 0u;
+    __syncthreads();
+  }
   bool alive = true;
   int r = 0, reach = 0;
   for (int l = 1; l <= lmax; ++l) {

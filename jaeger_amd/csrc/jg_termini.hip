@@ -310,6 +310,70 @@ __global__ void termini_finish_kernel(const uint8_t *__restrict__ bases, const T
   out[idx] = o;
 }
 
+// ---- alignments scoring above 100 that are ONE exact run ---------------------------------------------------------------
+// Under match +2 / mismatch -100 / gap open 100 an alignment is a chain of exact-match runs joined by steps that cost at
+// least 100 each, and a junction only pays when the scores on both sides of it exceed 100: every alignment that scores above
+// 100 contains a run of more than 50 matches ("long run"), and attaching anything to it - shorter runs, a mismatch, a gap -
+// gains at most nothing.  So when the matrix holds EXACTLY ONE long run, the best alignment is that run: score 2 L, L columns,
+// no gap, ending in the run's last cell - which is also the first maximum in (column, row) order (a 50-match run behind a
+// mismatch ties the score only in a later column).  That is the shape of every record shorter than twice its scan length
+// (a 500-bp record scanned over 400: the two ends overlap in one 300-base run on one diagonal), which otherwise sends a
+// million alignments through the length / gap carrying kernel.
+// One wave per alignment.  Every long run covers >= 51 reference positions, hence a whole 32-mer starting at a multiple of
+// 20: the wave compares those sampled 32-mers of the reference with every 32-mer of the query (first differing base ends a
+// comparison: 1.3 bases on random sequence), extends each hit to its maximal run and keeps the smallest and the largest
+// (diagonal, first row) it has seen - equal: one run.  Anything else (two runs, none, a run of <= 50) is left to termini_kernel.
+constexpr int SR_NMAX = TT * RMAX;        // codes per end and wave in LDS (scan <= 4 096)
+
+__global__ __launch_bounds__(256) void termini_single_kernel(const uint8_t *__restrict__ bases, const TermJob *__restrict__ jobs,
+                                                             TermOut *__restrict__ out, int n_jobs) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 4 + wave;
+  const bool live = idx < n_jobs;
+  const TermJob job = jobs[live ? idx : 0];
+  const int n = live ? job.n : 0;
+  uint8_t *qc = smem + (size_t)wave * 2 * SR_NMAX, *rc = qc + SR_NMAX;
+  for (int j = lane; j < n; j += 64) {
+    qc[j] = (uint8_t)base_code(bases[job.q_off + j]);
+    int c = job.itr ? base_code(bases[job.r_off + n - 1 - j]) : base_code(bases[job.r_off + j]);
+    if (job.itr && c < 4) c = 3 - c;
+    rc[j] = (uint8_t)(c < 4 ? c : 7);                               // (a letter that matches nothing, not even another one)
+  }
+  __syncthreads();
+  unsigned lo = 0xffffffffu, hi = 0u;
+  int run_len = 0, run_end_q = -1, run_end_r = -1;
+  for (int p = 0; p + 32 <= n; p += 20) {
+    for (int i = lane; i + 32 <= n; i += 64) {
+      int t = 0;
+      while (t < 32 && qc[i + t] == rc[p + t]) ++t;
+      if (t < 32) continue;
+      int a = 0, b = 32;                                            // the maximal run through this hit: rows i - a .. i + b - 1
+      while (i - a > 0 && p - a > 0 && qc[i - a - 1] == rc[p - a - 1]) ++a;
+      while (i + b < n && p + b < n && qc[i + b] == rc[p + b]) ++b;
+      const unsigned sig = ((unsigned)(i - p + n) << 16) | (unsigned)(i - a);
+      lo = min(lo, sig);
+      hi = max(hi, sig);
+      run_len = a + b;
+      run_end_q = i + b - 1;
+      run_end_r = p + b - 1;
+    }
+  }
+  const unsigned long long hit = __ballot(run_len > 0);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = min(lo, (unsigned)__shfl_xor((int)lo, off, 64));
+    hi = max(hi, (unsigned)__shfl_xor((int)hi, off, 64));
+  }
+  TermOut o{0, -1, 0, -1, -1};                                      // len = -1: not settled here
+  if (hit != 0ull && lo == hi) {
+    const int src = __builtin_ctzll(hit);                           // (every hit of the wave lies in the one run)
+    const int L = __shfl(run_len, src, 64), eq = __shfl(run_end_q, src, 64), er = __shfl(run_end_r, src, 64);
+    if (L > 50) o = TermOut{2 * L, L, 0, eq, er};
+  }
+  if (live && lane == 0) out[idx] = o;
+}
+
 template <int R>
 static int launch_fast(const uint8_t *d_bases, const TermRec *d_recs, TermFast *d_out, int n_recs, hipStream_t s) {
   if (n_recs <= 0) return JG_OK;
@@ -428,17 +492,48 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
   std::vector<TermOut> host(recs.size() * 2);
   JG_HIP(hipMemcpyAsync(host.data(), d_out, host.size() * sizeof(TermOut), hipMemcpyDeviceToHost, s));
   JG_HIP(hipStreamSynchronize(s));
-  // pass 2: the alignments that scored above 100 (real repeats) through the kernel that carries length and gaps
+  // pass 2: the alignments that scored above 100 (real repeats).  First the check for "one exact run, nothing else"
+  // (termini_single_kernel: a wave each); what it does not settle - two long runs, mismatches or gaps inside the repeat -
+  // goes through the kernel that carries length and gaps
   std::vector<TermJob> jobs;
   std::vector<size_t> slot;
-  int max_n2 = 0;
   for (size_t k = 0; k < host.size(); ++k)
     if (host[k].len < 0 || e->termini_exact) {
       const TermRec &rc = recs[k / 2];
       jobs.push_back(TermJob{rc.q_off, rc.r_off, rc.n, (int32_t)(k & 1)});
       slot.push_back(k);
-      max_n2 = std::max(max_n2, rc.n);
     }
+  if (!jobs.empty() && !e->termini_exact) {
+    void *d_j1 = nullptr, *d_o1 = nullptr;
+    struct Cleanup2 {
+      void **p[2];
+      ~Cleanup2() { for (void **q : p) if (*q) (void)hipFree(*q); }
+    } cleanup2{{&d_j1, &d_o1}};
+    JG_HIP(hipMalloc(&d_j1, jobs.size() * sizeof(TermJob)));
+    JG_HIP(hipMalloc(&d_o1, jobs.size() * sizeof(TermOut)));
+    JG_HIP(hipMemcpyAsync(d_j1, jobs.data(), jobs.size() * sizeof(TermJob), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(termini_single_kernel, dim3((unsigned)((jobs.size() + 3) / 4)), dim3(256), (size_t)4 * 2 * SR_NMAX, s,
+                       d_bases, static_cast<const TermJob *>(d_j1), static_cast<TermOut *>(d_o1), (int)jobs.size());
+    JG_HIP(hipGetLastError());
+    std::vector<TermOut> single(jobs.size());
+    JG_HIP(hipMemcpyAsync(single.data(), d_o1, jobs.size() * sizeof(TermOut), hipMemcpyDeviceToHost, s));
+    JG_HIP(hipStreamSynchronize(s));
+    size_t kept = 0;
+    for (size_t k = 0; k < jobs.size(); ++k) {
+      // (the score is the packed pass's: a run that is not the whole story would not match it)
+      if (single[k].len > 0 && single[k].score == host[slot[k]].score) {
+        host[slot[k]] = single[k];
+      } else {
+        jobs[kept] = jobs[k];
+        slot[kept] = slot[k];
+        ++kept;
+      }
+    }
+    jobs.resize(kept);
+    slot.resize(kept);
+  }
+  int max_n2 = 0;
+  for (const TermJob &j : jobs) max_n2 = std::max(max_n2, j.n);
   if (!jobs.empty()) {
     JG_HIP(hipMalloc(&d_jobs, jobs.size() * sizeof(TermJob)));
     JG_HIP(hipMalloc(&d_out2, jobs.size() * sizeof(TermOut)));

@@ -135,3 +135,80 @@ def test_fast_pass_equals_exact_kernel_on_random_records():
     assert (exact[:, 0] > 100).sum() > 30 and ((exact[:, 0] > 24) & (exact[:, 0] <= 100)).sum() > 300
     bad = np.nonzero((fast != exact).any(axis=1))[0]
     assert bad.size == 0, (bad[:5], fast[bad[:5]], exact[bad[:5]])
+
+
+def test_single_run_shortcut_equals_exact_kernel():
+    """Alignments scoring above 100 that are one exact run are settled without the length / gap carrying kernel
+    (termini_single_kernel); everything else still goes through it.  Shapes built to sit on the line between the two:
+    overlapping ends (records shorter than twice their scan length - with N runs, lower case and low-complexity stretches
+    inside the overlap), one planted repeat, two planted repeats, a repeat followed / preceded by exactly 50 (or 49, 51)
+    matching bases behind one mismatch or a short gap, direct and inverted, homopolymer and dinucleotide ends."""
+    from jaeger_amd import fragment as frag
+    from jaeger_amd import _lib as L
+    from jaeger_amd.termini import terminal_repeat_table
+    from jaeger_amd.engine import HipDevice
+    from oracle.termini import reverse_complement
+    rng = np.random.Generator(np.random.PCG64(2025))
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+
+    def rand(n):
+        return acgt[rng.integers(0, 4, n)].copy()
+
+    def other(b):
+        return acgt[(int(np.nonzero(acgt == b)[0][0]) + int(rng.integers(1, 4))) % 4]
+
+    seqs = []
+    for r in range(1500):
+        kind = r % 10
+        if kind < 3:                                   # overlapping ends, 500 - 790 bases
+            n = int(rng.integers(500, 790))
+            s = rand(n)
+            if kind == 1:
+                p = int(rng.integers(0, n - 30))
+                s[p:p + int(rng.integers(1, 30))] = ord("N")
+            if kind == 2:
+                p, k = int(rng.integers(0, n - 120)), int(rng.integers(10, 120))
+                s[p:p + k] = np.tile(rand(int(rng.integers(1, 4))), k)[:k]
+                s[int(rng.integers(0, n - 50)):][:50] |= 0x20
+        else:
+            n = int(rng.integers(1500, 9000))
+            s = rand(n)
+            k = int(rng.integers(51, 200))
+            a, b = int(rng.integers(0, 400 - k)), n - int(rng.integers(k, 400))
+            piece = s[a:a + k].copy()
+            inverted = kind == 9
+            plant = (lambda x: np.frombuffer(reverse_complement(bytes(x).decode()).encode(), np.uint8)) if inverted \
+                else (lambda x: x)
+            s[b:b + k] = plant(piece)
+            if kind == 4:                              # a second repeat elsewhere between the two ends
+                k2 = int(rng.integers(51, 120))
+                a2, b2 = int(rng.integers(0, 400 - k2)), n - int(rng.integers(k2, 400))
+                s[b2:b2 + k2] = s[a2:a2 + k2]
+            if kind in (5, 6) and a + k + 60 < 400 and b + k + 60 < n:        # k matches, one mismatch, m matches
+                m = int(rng.choice([49, 50, 51]))
+                s[a + k] = other(s[a + k - 1]) if s[a + k] == s[b + k] else s[a + k]
+                s[b + k] = other(s[a + k])
+                s[b + k + 1:b + k + 1 + m] = s[a + k + 1:a + k + 1 + m]
+                if b + k + 1 + m < n and a + k + 1 + m < n:
+                    s[b + k + 1 + m] = other(s[a + k + 1 + m])
+            if kind in (7, 8) and a > 60 and b > 460:                          # m matches, a mismatch or a gap, k matches
+                m = int(rng.choice([49, 50, 51]))
+                gap = int(rng.integers(0, 3)) if kind == 8 else 0
+                s[b - 1] = other(s[a - 1])
+                s[b - 1 - gap - m:b - 1 - gap] = s[a - 1 - m:a - 1]
+                s[b - 2 - gap - m] = other(s[a - 2 - m])
+        if r % 97 == 0:
+            s[:] = ord("A")                            # every diagonal of the matrix is one long run
+        if r % 89 == 0:
+            s[:] = np.tile(np.frombuffer(b"AC", np.uint8), n)[:n]
+        seqs.append(bytes(s))
+    bases, offsets = frag.concat_records(seqs)
+    fa = frag.FastaBatch([f"r{i}" for i in range(len(seqs))], bases, offsets)
+    dev = HipDevice(0)
+    fast = terminal_repeat_table(dev, fa, 500)
+    L.check(dev.lib.jg_engine_set_option(dev.handle, L.JG_OPT_TERMINI_EXACT, 1))
+    exact = terminal_repeat_table(dev, fa, 500)
+    dev.close()
+    assert (exact[:, 0] > 100).sum() > 1200 and (exact[:, 2] > 0).sum() > 3         # real repeats, some with gaps
+    bad = np.nonzero((fast != exact).any(axis=1))[0]
+    assert bad.size == 0, (bad[:5], fast[bad[:5]], exact[bad[:5]])
