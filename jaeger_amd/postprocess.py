@@ -423,13 +423,21 @@ def merge_data(parts: list[dict]) -> dict:
 
 
 class _Summaries:
-    """The contigs' run-length strings, already built (``_Runs.summaries`` per aggregation batch, beside the forward)."""
+    """The contigs' run-length strings, already built (``_Runs.summaries`` per aggregation batch, beside the forward): a list
+    of strings, or the library's text as it came (``blob`` = the strings back to back, one NUL behind each) - the table writer
+    hands that straight back to ``jg_table_format``, and Python strings are only made when something asks for ``texts``."""
 
-    def __init__(self, texts: list[str]):
-        self.texts = texts
+    def __init__(self, texts: list[str] | None = None, blob: bytes | None = None, n: int = 0):
+        self._texts, self.blob, self._n = texts, blob, (len(texts) if texts is not None else n)
+
+    @property
+    def texts(self) -> list[str]:
+        if self._texts is None:
+            self._texts = self.blob.decode("ascii").split("\0")[:-1]
+        return self._texts
 
     def __len__(self):
-        return len(self.texts)
+        return self._n
 
 
 def window_letters(class_map: dict) -> dict:
@@ -464,9 +472,16 @@ class _Runs:
         """Every contig's run-length string; rendered by the library (``jg_run_summaries``) when the letters are single
         ASCII characters - a Python string per RUN was the largest single cost of the per-contig aggregation - else by
         :meth:`summaries_py` (same strings, tests/test_postprocess.py)."""
+        blob = self.summaries_blob(letter)
+        if blob is not None:
+            return blob.decode("ascii").split("\0")[:-1]
+        return self.summaries_py(letter) if self.calls.size else []
+
+    def summaries_blob(self, letter: dict) -> bytes | None:
+        """The library's text itself (every contig's string + a NUL), or None where :meth:`summaries_py` has to do it."""
         calls, seg = self.calls, self.seg
         if calls.size == 0:
-            return []
+            return None
         ids = [int(k) for k in letter]
         if all(len(v) == 1 and v.isascii() for v in letter.values()) and (not ids or (min(ids) >= 0 and max(ids) < 256)):
             import ctypes as C
@@ -483,11 +498,10 @@ class _Runs:
             _lib.check(lib.jg_run_summaries(c32.ctypes.data, c32.size, first.ctypes.data, count.ctypes.data, seg.n,
                                             table.ctypes.data, table.size, 0, C.byref(text), C.byref(size)), "jg_run_summaries")
             try:
-                blob = C.string_at(text, size.value)
+                return C.string_at(text, size.value)
             finally:
                 lib.jg_table_free(text)
-            return blob.decode("ascii").split("\0")[:-1]
-        return self.summaries_py(letter)
+        return None
 
     def summaries_py(self, letter: dict) -> list[str]:
         calls, seg = self.calls, self.seg
@@ -530,17 +544,26 @@ def _left_join(df: pd.DataFrame, right: pd.DataFrame, columns: list) -> pd.DataF
     return out
 
 
-def generate_summary(data, **kwargs) -> pd.DataFrame:
-    """Per-contig summary table (collect.py:438-558); column order is part of the surface."""
+def _summary_columns(data, **kwargs) -> dict:
+    """The columns of the per-contig summary table in output order, before the repeat table is joined on
+    (collect.py:438-526); values are arrays, lists or a :class:`_Summaries`."""
     classes_, indices_ = kwargs.get("labels"), kwargs.get("indices")
     class_map = {int(k): v for k, v in zip(indices_, classes_)}
-    reliability = data["ood"] if data.get("has_reliability", True) else ["unavailable"] * len(data["headers"])
+    n = len(data["headers"])
+    reliability = data["ood"] if data.get("has_reliability", True) else ["unavailable"] * n
     mean_of = lambda x: x.means if isinstance(x, _Means) else [np.mean(v) for v in x]          # noqa: E731
     counts = data["per_class_counts"]
+    consensus = np.asarray(data["consensus"])
+    if n and consensus.dtype.kind in "iu" and consensus.min() >= 0 and all(k in class_map for k in range(int(consensus.max()) + 1)):
+        names = np.empty(int(consensus.max()) + 1, dtype=object)          # one label object per class, shared by the rows
+        names[:] = [class_map[k] for k in range(len(names))]
+        prediction = names[consensus]
+    else:
+        prediction = [class_map[x] for x in consensus.tolist()]
     columns = {
         "contig_id": data["headers"],
         "length": data["length"],
-        "prediction": [class_map[x] for x in np.asarray(data["consensus"]).tolist()],
+        "prediction": prediction,
         "entropy": data["entropy"],
         "energy": data["energy"],
         "reliability_score": reliability,
@@ -560,12 +583,20 @@ def generate_summary(data, **kwargs) -> pd.DataFrame:
         columns["var"] = data["pred_var"]
     frag = data["frag_pred"]
     if isinstance(frag, _Summaries):
-        columns["window_summary"] = frag.texts
+        columns["window_summary"] = frag
     elif isinstance(frag, _Runs):
         letter = {k: (v[0].upper() if v.lower() in ("virus", "phage") else v[0].lower()) for k, v in class_map.items()}
         columns["window_summary"] = frag.summaries(letter)
     else:
         columns["window_summary"] = [get_window_summary(x, class_map=class_map, classes=["virus", "phage"]) for x in frag]
+    return columns
+
+
+def generate_summary(data, **kwargs) -> pd.DataFrame:
+    """Per-contig summary table (collect.py:438-558); column order is part of the surface."""
+    columns = _summary_columns(data, **kwargs)
+    if isinstance(columns["window_summary"], _Summaries):
+        columns["window_summary"] = columns["window_summary"].texts
     df = pd.DataFrame(columns)
     repeats = data.get("repeats")
     if repeats is None:
@@ -626,54 +657,90 @@ def _string_column(values):
     return blob, starts
 
 
-def _tsv_bytes(df: pd.DataFrame, header: bool = True) -> bytes:
-    """The same text as UTF-8 bytes, rendered by the library's ``jg_table_format`` (include/jaeger_hip.h) on every usable
-    core: floats by an exact ``"%.3f"``, integers, booleans and strings as pandas prints them.  A table with a column
-    it does not know, or with a string the csv writer would quote, goes through ``_tsv_text``."""
+def _blob_column(blob: bytes, n: int):
+    """(bytes, starts) of ``n`` strings laid end to end with a NUL behind each, or None when the csv writer would quote one."""
+    if any(c in blob for c in _CSV_SPECIAL):
+        return None
+    seps = np.flatnonzero(np.frombuffer(blob, dtype=np.uint8) == 0)
+    if seps.size != n:
+        return None
+    starts = np.zeros(n + 1, dtype=np.int64)
+    starts[1:] = seps + 1
+    return blob, starts
+
+
+def _columns_text(names: list, values: list, rows: np.ndarray | None, header: bool) -> bytes | None:
+    """Rows ``rows`` (None: all) of a table given as columns - arrays, lists of strings, :class:`_Summaries` - rendered by
+    the library's ``jg_table_format`` as ``to_csv(sep="\t", index=False, float_format="%.3f")`` would print the frame made of
+    them; None when a column is of a kind the library does not print (the caller goes through pandas then)."""
     import ctypes as C
 
     from . import _lib
-    n, cols = len(df), list(df.columns)
+    n = len(values[0]) if values else 0
+    if not (len(names) > 1 and n > 0 and all(isinstance(c, str) and not any(ch in c for ch in '\t"\n\r') for c in names)):
+        return None
     kinds, keep, ptrs, starts = [], [], [], []
-    native = len(cols) > 1 and n > 0 and all(isinstance(c, str) and not any(ch in c for ch in '\t"\n\r') for c in cols)
-    for col in cols if native else ():
-        v = df[col].to_numpy()
-        kind = v.dtype.kind
-        if kind == "f":
-            arr, k = np.ascontiguousarray(v, dtype=np.float64), _lib.JG_COL_FLOAT
-        elif kind in "iu" and v.dtype != np.uint64:
-            arr, k = np.ascontiguousarray(v, dtype=np.int64), _lib.JG_COL_INT
-        elif kind == "b":
-            arr, k = np.ascontiguousarray(v).view(np.uint8), _lib.JG_COL_BOOL
-        elif kind == "O":
-            got = _string_column(v)
+    for v in values:
+        st = None
+        if isinstance(v, _Summaries) and v.blob is not None:
+            got = _blob_column(v.blob, len(v))
+        elif isinstance(v, _Summaries):
+            got = _string_column(np.asarray(v.texts, dtype=object))
+        else:
+            v = np.asarray(v) if not isinstance(v, np.ndarray) else v
+            kind = v.dtype.kind
+            got = None
+            if kind == "f":
+                arr, k = np.ascontiguousarray(v, dtype=np.float64), _lib.JG_COL_FLOAT
+            elif kind in "iu" and v.dtype != np.uint64:
+                arr, k = np.ascontiguousarray(v, dtype=np.int64), _lib.JG_COL_INT
+            elif kind == "b":
+                arr, k = np.ascontiguousarray(v).view(np.uint8), _lib.JG_COL_BOOL
+            elif kind in "OU":
+                got = _string_column(v)
+                if got is None:
+                    return None
+            else:
+                return None
+        if got is not None or isinstance(v, _Summaries):
             if got is None:
-                native = False
-                break
+                return None
             blob, st = got
             arr, k = np.frombuffer(blob, dtype=np.uint8), _lib.JG_COL_STRING
             keep.append(blob)
-        else:
-            native = False
-            break
-        starts.append(st if k == _lib.JG_COL_STRING else None)
+        if (len(st) - 1 if st is not None else len(arr)) != n:
+            return None
+        starts.append(st)
         kinds.append(k)
         keep.append(arr)
         ptrs.append(arr.ctypes.data)
-    if not native:
-        return _tsv_text(df, header).encode("utf-8")
     lib = _lib.load()
-    nc = len(cols)
+    nc = len(names)
     kind_arr = np.asarray(kinds, dtype=np.int32)
     col_ptrs = (C.c_void_p * nc)(*ptrs)
     start_ptrs = (C.c_void_p * nc)(*[None if st is None else st.ctypes.data for st in starts])
     text, size = C.c_void_p(), C.c_int64()
-    _lib.check(lib.jg_table_format(nc, kind_arr.ctypes.data, col_ptrs, start_ptrs, None, n, 0, C.byref(text), C.byref(size)))
-    try:
-        body = C.string_at(text, size.value)
-    finally:
-        lib.jg_table_free(text)
-    return ("\t".join(cols) + "\n").encode("utf-8") + body if header else body
+    if rows is not None:
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+    n_out = n if rows is None else len(rows)
+    body = b""
+    if n_out:
+        _lib.check(lib.jg_table_format(nc, kind_arr.ctypes.data, col_ptrs, start_ptrs, None if rows is None else rows.ctypes.data,
+                                       n_out, 0, C.byref(text), C.byref(size)))
+        try:
+            body = C.string_at(text, size.value)
+        finally:
+            lib.jg_table_free(text)
+    return ("\t".join(names) + "\n").encode("utf-8") + body if header else body
+
+
+def _tsv_bytes(df: pd.DataFrame, header: bool = True) -> bytes:
+    """The same text as UTF-8 bytes, rendered by the library's ``jg_table_format`` (include/jaeger_hip.h) on every usable
+    core: floats by an exact ``"%.3f"``, integers, booleans and strings as pandas prints them.  A table with a column
+    it does not know, or with a string the csv writer would quote, goes through ``_tsv_text``."""
+    cols = list(df.columns)
+    text = _columns_text(cols, [df[c].to_numpy() for c in cols], None, header) if len(df) else None
+    return text if text is not None else _tsv_text(df, header).encode("utf-8")
 
 
 def _to_tsv(df: pd.DataFrame, path) -> None:
@@ -691,8 +758,9 @@ class TableWriter:
     a later batch) leaves no truncated table at the final path - ``abort()`` closes and removes the partial files."""
 
     def __init__(self, labels, indices, output_table_path, output_phage_table_path, reliability_cutoff=0.5, phage_score=1,
-                 refined_contig=None):
+                 refined_contig=None, columns_path: bool = True):
         self.kw = dict(labels=labels, indices=indices, refined_contig=refined_contig)
+        self.columns_path = columns_path          # False: every batch through the DataFrame (what the tests compare with)
         self.table_path, self.phage_path = output_table_path, output_phage_table_path
         self.rc, self.pc = reliability_cutoff, phage_score
         lower = [label.lower() for label in labels]
@@ -703,19 +771,83 @@ class TableWriter:
         self.header_written = False
 
     def append(self, data: dict) -> None:
+        if self.columns_path and self.kw.get("refined_contig") is None and self._append_columns(data):
+            return
         df = generate_summary(data, **self.kw).query("`N%` < 0.3")
-        if self.fh is None:
-            self.fh = open(f"{self.table_path}.partial", "wb")
-        self.fh.write(_tsv_bytes(df, header=not self.header_written))
-        self.header_written = True
+        self._write(_tsv_bytes(df, header=not self.header_written), len(df))
         clause = f" and (reliability_score > {self.rc})" if data.get("has_reliability", True) else ""
         phage_df = df.query(f'(prediction == "{self.viral}") and ({self.viral}_score > {self.pc}){clause}')
         if not phage_df.empty:
-            first = self.fh_phage is None
-            if first:
-                self.fh_phage = open(f"{self.phage_path}.partial", "wb")
-            self.fh_phage.write(_tsv_bytes(phage_df, header=first))
-        self.rows += len(df)
+            self._write_phage(_tsv_bytes(phage_df, header=self.fh_phage is None))
+
+    def _write(self, text: bytes, n_rows: int) -> None:
+        if self.fh is None:
+            self.fh = open(f"{self.table_path}.partial", "wb")
+        self.fh.write(text)
+        self.header_written = True
+        self.rows += n_rows
+
+    def _write_phage(self, text: bytes) -> None:
+        if self.fh_phage is None:
+            self.fh_phage = open(f"{self.phage_path}.partial", "wb")
+        self.fh_phage.write(text)
+
+    def _append_columns(self, data: dict) -> bool:
+        """The same rows without a DataFrame: the columns as ``_summary_columns`` makes them, the repeat table joined on by
+        row number (``data["repeat_rows"]``, set by the pipeline: row of every contig in the repeat table or -1) or by one
+        hash lookup per name, the ``N% < 0.3`` filter and the phage query as masks over the column arrays, the text of the
+        surviving rows straight from ``jg_table_format``.  False (nothing written) where that is not the frame pandas would
+        build: repeated names in the repeat table, a column the library does not print."""
+        n = len(data["headers"])
+        if n == 0:
+            return False
+        cols = _summary_columns(data, **self.kw)
+        repeats = data.get("repeats")
+        at = data.get("repeat_rows")
+        kinds_col = np.full(n, np.nan, dtype=object)
+        length_col = np.full(n, np.nan, dtype=np.float64)
+        if repeats is not None and len(repeats):
+            index = repeats.attrs.get("_contig_index")
+            if index is None:
+                index = repeats.attrs["_contig_index"] = pd.Index(repeats["contig_id"].to_numpy(dtype=object))
+            if not index.is_unique:
+                return False
+            if at is None:
+                at = index.get_indexer(np.asarray(cols["contig_id"], dtype=object))
+            at = np.asarray(at, dtype=np.int64)
+            hit = at >= 0
+            rk, rl = repeats["terminal_repeats"].to_numpy(dtype=object), repeats["repeat_length"].to_numpy()
+            if rl.dtype.kind not in "fiu":
+                return False
+            kinds_col[hit] = rk[at[hit]]
+            length_col[hit] = rl[at[hit]]
+            if rl.dtype.kind in "iu" and hit.all():
+                length_col = rl[at]                                     # (merge keeps integers that get no holes)
+        elif repeats is not None and not {"terminal_repeats", "repeat_length"} <= set(repeats.columns):
+            return False
+        cols["terminal_repeats"], cols["repeat_length"] = kinds_col, length_col
+        ids = np.asarray(cols["contig_id"]).tolist()
+        if "___" in "\0".join(ids):                                 # (io.py:109 wrote commas as ___; collect.py:556 turns them back)
+            cols["contig_id"] = np.array([x.replace("___", ",") for x in ids], dtype=object)
+        with np.errstate(invalid="ignore"):
+            keep = np.asarray(cols["N%"]) < 0.3
+        rows = None if keep.all() else np.flatnonzero(keep)
+        names = list(cols)
+        text = _columns_text(names, [cols[c] for c in names], rows, header=not self.header_written)
+        if text is None:
+            return False
+        score_name = f"{self.viral}_score"
+        if score_name not in cols or not isinstance(cols["prediction"], np.ndarray):
+            return False
+        with np.errstate(invalid="ignore"):
+            phage = keep & (cols["prediction"] == self.viral) & (np.asarray(cols[score_name]) > self.pc)
+            if data.get("has_reliability", True):
+                phage &= np.asarray(cols["reliability_score"]) > self.rc
+        self._write(text, int(keep.sum()))
+        if phage.any():
+            ptext = _columns_text(names, [cols[c] for c in names], np.flatnonzero(phage), header=self.fh_phage is None)
+            self._write_phage(ptext)
+        return True
 
     def close(self) -> int:
         import os

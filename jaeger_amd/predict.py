@@ -244,7 +244,10 @@ class _Aggregator:
         if w1 <= self.w_done or (not final and w1 - self.w_done < self.min_batch):
             return
         t0 = time.time()
-        self.add(self.slice(self.w_done, w1))
+        rec = self.table.contig[self.w_done:w1]
+        first = np.ones(len(rec), dtype=bool)
+        first[1:] = rec[1:] != rec[:-1]
+        self.add(self.slice(self.w_done, w1), records=np.asarray(rec[first], dtype=np.int64))
         self.w_done = w1
         self.busy_s += time.time() - t0
 
@@ -256,12 +259,16 @@ class _Aggregator:
         y.update(frag.window_metadata(sub, self.hdr, self.out["counts"][w0:w1], normalised=True))
         return y
 
-    def add(self, y_pred: dict) -> None:
+    def add(self, y_pred: dict, records: np.ndarray | None = None) -> None:
         from .postprocess import _Summaries, pred_to_dict, window_letters
         if y_pred and len(y_pred["meta_2"]):
             data, full = pred_to_dict(y_pred, **self.kw)
-            # the run-length strings of the batch's contigs (a Python string per run) belong beside the forward too
-            data["frag_pred"] = _Summaries(data["frag_pred"].summaries(window_letters(self.kw["class_map"])))
+            # the run-length strings of the batch's contigs belong beside the forward too: the library's text as it comes
+            runs, letters = data["frag_pred"], window_letters(self.kw["class_map"])
+            blob = runs.summaries_blob(letters)
+            data["frag_pred"] = _Summaries(blob=blob, n=len(runs)) if blob is not None else _Summaries(runs.summaries(letters))
+            if records is not None and len(records) == len(data["headers"]):
+                data["record_index"] = records        # FASTA record of every contig of the batch: the repeat table joins by it
             self.parts.append((data, full))
 
     def flush(self, writer, term_repeats) -> None:
@@ -271,6 +278,9 @@ class _Aggregator:
         while self.flushed < len(self.parts):
             data = self.parts[self.flushed][0]
             data["repeats"] = term_repeats
+            row_of = term_repeats.attrs.get("_row_of_record") if term_repeats is not None else None
+            if row_of is not None and "record_index" in data and len(row_of) == len(self.hdr):
+                data["repeat_rows"] = row_of[data["record_index"]]
             writer.append(data)
             self.flushed += 1
         self.busy_s += time.time() - t0
@@ -597,7 +607,10 @@ def run_core(**kwargs) -> int:
         from .termini import scan_for_terminal_repeats
         t_term = time.time()
         mark("repeat_scan_begin")
-        rep = scan_for_terminal_repeats(device, fa, fsize)
+        from .termini import repeats_frame, terminal_repeat_table
+        table = terminal_repeat_table(device, fa, fsize)
+        mark("repeat_table_done")
+        rep = repeats_frame(table, fa.names, fa.lengths)
         LAST_RUN["terminal_repeats_s"] = round(time.time() - t_term, 3)
         mark("repeat_scan_done")
         lg.info(f"terminal repeats: {int(rep['terminal_repeats'].notna().sum())} of {len(rep)} "
@@ -708,6 +721,8 @@ def run_core(**kwargs) -> int:
                         agg.flush(writer, scan["frame"])
                     time.sleep(0.004)
                 t_forward = f_pred.result()
+                agg.advance(n_long, final=True)       # the last contigs: needs no repeat column, runs while the scan finishes
+                mark("aggregated")
                 th.join()
                 if "error" in scan:
                     raise scan["error"]

@@ -46,11 +46,22 @@ def repeats_frame(res: np.ndarray, names: list[str], lengths: np.ndarray) -> pd.
     score = np.where(is_itr, i_score, d_score).astype(np.float64)
     score[~found] = np.nan
     lengths = np.asarray(lengths)
-    return pd.DataFrame({
-        "contig_id": [names[i].strip().replace(",", "___") for i in keep.tolist()],
+    from .fragment import normalise_headers
+    ids = normalise_headers(names)[keep] if keep.size * 2 > len(names) else \
+        np.array([names[i].strip().replace(",", "___") for i in keep.tolist()], dtype=object)
+    df = pd.DataFrame({
+        "contig_id": ids,
         "repeat_length": length, "score": score, "terminal_repeats": kind,
         "seq_len": lengths[keep] if keep.size else np.array([], np.int64),
     })
+    # what the table writer's join needs, made here (the scan runs beside the forward, the join behind it): the name index
+    # with its uniqueness known, and the row of every record (-1: not scanned) for a join by record number
+    index = df.attrs["_contig_index"] = pd.Index(ids)
+    _ = index.is_unique
+    row_of = np.full(len(names), -1, dtype=np.int64)
+    row_of[keep] = np.arange(keep.size)
+    df.attrs["_row_of_record"] = row_of
+    return df
 
 
 def scan_for_terminal_repeats(device, fa, fsize: int) -> pd.DataFrame:

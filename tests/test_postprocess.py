@@ -1,6 +1,7 @@
 """pred_to_dict / write_output vs TSVs written by the reference itself on the same seeded
 logits (tests/golden/make_golden.py; postprocess/collect.py:247-608)."""
 import json
+from pathlib import Path
 
 import numpy as np
 import pandas as pd
@@ -273,3 +274,62 @@ def test_native_segment_reductions_equal_numpy_bit_for_bit():
         np.testing.assert_array_equal(seg.mean_flat(m), seg.mean_flat_numpy(m))
     m64 = rng.standard_normal((n, 2))
     np.testing.assert_array_equal(seg.mean_flat(m64), seg.mean_flat_numpy(m64))
+
+
+@pytest.mark.parametrize("n_cls,with_rel", [(6, True), (3, False), (4, True)])
+def test_table_writer_column_path_equals_the_dataframe_path(n_cls, with_rel, tmp_path):
+    """``TableWriter`` renders a batch from its column arrays (join by row number or one hash lookup per name, filters as
+    masks, text by ``jg_table_format`` for the surviving rows) - byte for byte what the DataFrame path
+    (``generate_summary`` -> ``query`` -> ``to_csv``) writes: with and without a repeat table, a repeat table that misses
+    contigs or has integer lengths, contigs dropped by the ``N%`` filter, commas in names, NaN scores, the library's
+    summary text handed through, ``repeat_rows`` given or not; a repeat table with a repeated name takes the DataFrame."""
+    from jaeger_amd import postprocess as P
+    rng = np.random.default_rng(31 * n_cls + with_rel)
+    names = (CLASSES + ["x", "y"])[:max(n_cls, 2)]
+    idx = list(range(len(names)))
+    cm = {"num_classes": len(names), "class": names, "index": idx}
+    n_contigs = 300
+    y, rep = _random_case(rng, n_contigs, n_cls, with_rel)
+    hdr = np.asarray(y["meta_0"]).astype(object)
+    plain = np.array([h.replace("___z", "") for h in hdr.tolist()], dtype=object)            # names without commas
+    ends = np.nonzero(np.asarray(y["meta_2"]) == 1)[0] + 1
+    # a few windows of contig 5 mostly N: dropped by the filter in the middle of a batch
+    first5 = int(ends[4])
+    y["meta_5"][first5:int(ends[5])] = 3
+    y["meta_6"][first5:int(ends[5])] = 3
+    if n_cls > 1:                                     # (a binary head has no class for a NaN mean: both paths raise)
+        y["prediction"][int(ends[9]):int(ends[10])] = np.nan                                  # NaN scores print as nothing
+    variants = {
+        "none": (hdr, None, False),
+        "full": (hdr, rep, False),
+        "rows": (hdr, rep, True),
+        "holes": (plain, pd.DataFrame({"contig_id": [f"ctg_{i}" for i in range(0, n_contigs, 3)],
+                                       "terminal_repeats": ["ITR"] * len(range(0, n_contigs, 3)),
+                                       "repeat_length": np.arange(len(range(0, n_contigs, 3)), dtype=np.int64) + 13}), False),
+        "repeated": (plain, pd.DataFrame({"contig_id": ["ctg_1", "ctg_1", "ctg_2"], "terminal_repeats": ["DTR", "ITR", None],
+                                          "repeat_length": [20.0, 30.0, np.nan]}), False),
+    }
+    for tag, (headers, repeats, by_row) in variants.items():
+        y["meta_0"] = headers
+        outs = []
+        for columns_path in (True, False):
+            base = tmp_path / f"{tag}_{int(columns_path)}"
+            w = P.TableWriter(names, idx, f"{base}.tsv", f"{base}_ph.tsv", reliability_cutoff=0.1, phage_score=0.5,
+                              columns_path=columns_path)
+            for a, b in ((0, int(ends[120])), (int(ends[120]), int(ends[121])), (int(ends[121]), int(ends[-1]))):
+                data, _ = P.pred_to_dict({k: v[a:b] for k, v in y.items()}, class_map=cm, fsize=1500, term_repeats=None)
+                if columns_path:                       # as the pipeline hands it over: the library's text, rows of the join
+                    blob = data["frag_pred"].summaries_blob(P.window_letters(cm))
+                    assert blob is not None
+                    data["frag_pred"] = P._Summaries(blob=blob, n=len(data["headers"]))
+                data["repeats"] = repeats
+                if by_row and columns_path:
+                    lookup = {c: i for i, c in enumerate(repeats["contig_id"])}
+                    data["repeat_rows"] = np.array([lookup.get(h, -1) for h in data["headers"]], dtype=np.int64)
+                w.append(data)
+            n = w.close()
+            outs.append((n, Path(f"{base}.tsv").read_bytes(),
+                         Path(f"{base}_ph.tsv").read_bytes() if Path(f"{base}_ph.tsv").exists() else None))
+        assert outs[0][0] == outs[1][0] and 0 < outs[0][0] < n_contigs, tag
+        assert outs[0][1] == outs[1][1], tag
+        assert outs[0][2] == outs[1][2] and outs[0][2] is not None, tag
