@@ -599,6 +599,8 @@ def generate_summary(data, **kwargs) -> pd.DataFrame:
         columns["window_summary"] = columns["window_summary"].texts
     df = pd.DataFrame(columns)
     repeats = data.get("repeats")
+    if repeats is not None and hasattr(repeats, "frame"):            # termini.RepeatColumns
+        repeats = repeats.frame()
     if repeats is None:
         repeats = pd.DataFrame({"contig_id": [], "terminal_repeats": [], "repeat_length": []})
     df = _left_join(df, repeats, ["terminal_repeats", "repeat_length"])
@@ -806,6 +808,15 @@ class TableWriter:
         at = data.get("repeat_rows")
         kinds_col = np.full(n, np.nan, dtype=object)
         length_col = np.full(n, np.nan, dtype=np.float64)
+        if repeats is not None and hasattr(repeats, "frame"):        # termini.RepeatColumns: arrays, no DataFrame yet
+            if at is not None and data.get("names_unique") and len(repeats):
+                at = np.asarray(at, dtype=np.int64)
+                hit = at >= 0
+                kinds_col[hit] = repeats.kind[at[hit]]
+                length_col[hit] = repeats.length[at[hit]]
+                repeats = None
+            else:
+                repeats = repeats.frame()
         if repeats is not None and len(repeats):
             index = repeats.attrs.get("_contig_index")
             if index is None:

@@ -235,6 +235,7 @@ class _Aggregator:
         self.parts: list = []
         self.busy_s = 0.0
         self.flushed = 0                                          # parts already handed to the table writer
+        self._unique = None
 
     def advance(self, done: int, final: bool = False) -> None:
         if len(self.ends) == 0:
@@ -250,6 +251,14 @@ class _Aggregator:
         self.add(self.slice(self.w_done, w1), records=np.asarray(rec[first], dtype=np.int64))
         self.w_done = w1
         self.busy_s += time.time() - t0
+
+    def names_unique(self) -> bool:
+        """No record name twice (then a join by record number IS the reference's merge on the name).  One hash pass over
+        the names, made once - the polling loop calls it beside the forward."""
+        if self._unique is None:
+            import pandas as pd
+            self._unique = bool(pd.Index(self.hdr).is_unique)
+        return self._unique
 
     def slice(self, w0: int, w1: int) -> dict:
         """Engine outputs + window metadata of windows [w0, w1) in ``InferModel.predict``'s dict form."""
@@ -278,9 +287,12 @@ class _Aggregator:
         while self.flushed < len(self.parts):
             data = self.parts[self.flushed][0]
             data["repeats"] = term_repeats
-            row_of = term_repeats.attrs.get("_row_of_record") if term_repeats is not None else None
+            row_of = getattr(term_repeats, "row_of_record", None)
+            if row_of is None and term_repeats is not None and hasattr(term_repeats, "attrs"):
+                row_of = term_repeats.attrs.get("_row_of_record")
             if row_of is not None and "record_index" in data and len(row_of) == len(self.hdr):
                 data["repeat_rows"] = row_of[data["record_index"]]
+                data["names_unique"] = self.names_unique()
             writer.append(data)
             self.flushed += 1
         self.busy_s += time.time() - t0
@@ -604,17 +616,15 @@ def run_core(**kwargs) -> int:
             lg.warning(msg)
 
     def scan_repeats(device):
-        from .termini import scan_for_terminal_repeats
         t_term = time.time()
         mark("repeat_scan_begin")
-        from .termini import repeats_frame, terminal_repeat_table
+        from .termini import RepeatColumns, terminal_repeat_table
         table = terminal_repeat_table(device, fa, fsize)
         mark("repeat_table_done")
-        rep = repeats_frame(table, fa.names, fa.lengths)
+        rep = RepeatColumns(table, fa.names, fa.lengths)       # (the DataFrame form only where something asks for it)
         LAST_RUN["terminal_repeats_s"] = round(time.time() - t_term, 3)
         mark("repeat_scan_done")
-        lg.info(f"terminal repeats: {int(rep['terminal_repeats'].notna().sum())} of {len(rep)} "
-                f"contigs in {time.time() - t_term:.2f} s")
+        lg.info(f"terminal repeats: {rep.n_found} of {len(rep)} contigs in {time.time() - t_term:.2f} s")
         return rep
 
     # DUST soft-masking (on by default like the reference): on the GPU, on the uploaded copy of the bases inside the
@@ -716,6 +726,7 @@ def run_core(**kwargs) -> int:
             log_setup(engine)
             if piped:
                 while not f_pred.done():
+                    agg.names_unique()
                     agg.advance(engine.device.windows_done())
                     if "frame" in scan:                       # rows of finished batches go to the table beside the forward
                         agg.flush(writer, scan["frame"])

@@ -29,39 +29,57 @@ def terminal_repeat_table(device, fa, fsize: int) -> np.ndarray:
     return res[:n]
 
 
+class RepeatColumns:
+    """The decision rule's columns (termini.py:137-154, :58-63) for the scanned records, as arrays: what the table writer's
+    join by record number reads (``kind``, ``length``, ``row_of_record``).  The DataFrame the reference passes around
+    (:meth:`frame`: names, a pandas index over them) is only built when something asks for it - on a million records it
+    costs more than the scan's kernels."""
+
+    def __init__(self, res: np.ndarray, names: list[str], lengths: np.ndarray):
+        keep = np.nonzero(res[:, 0] >= 0)[0] if len(res) else np.zeros(0, np.int64)
+        d_score, d_len, d_fg = res[keep, 0], res[keep, 1], res[keep, 2]
+        i_score, i_len = res[keep, 5], res[keep, 6]
+        found = (i_len > 12) | (d_len > 12)
+        is_itr = found & (i_score > d_score)
+        is_dtr = found & ~is_itr
+        kind = np.full(keep.size, None, dtype=object)
+        kind[is_itr] = "ITR"
+        kind[is_dtr] = "DTR"
+        kind[is_dtr & ((d_len - d_fg) >= 250)] = "LTR_DTR"
+        length = np.where(is_itr, i_len, d_len).astype(np.float64)
+        length[~found] = np.nan
+        score = np.where(is_itr, i_score, d_score).astype(np.float64)
+        score[~found] = np.nan
+        lengths = np.asarray(lengths)
+        self.keep, self.kind, self.length, self.score, self.n_found = keep, kind, length, score, int(found.sum())
+        self.seq_len = lengths[keep] if keep.size else np.array([], np.int64)
+        self.row_of_record = np.full(len(names), -1, dtype=np.int64)      # row of every record (-1: not scanned)
+        self.row_of_record[keep] = np.arange(keep.size)
+        self._names, self._frame = names, None
+
+    def __len__(self) -> int:
+        return int(self.keep.size)
+
+    def frame(self) -> pd.DataFrame:
+        """One row per scanned record: contig_id, repeat_length, score, terminal_repeats, seq_len."""
+        if self._frame is None:
+            from .fragment import normalise_headers
+            names, keep = self._names, self.keep
+            ids = normalise_headers(names)[keep] if keep.size * 2 > len(names) else \
+                np.array([names[i].strip().replace(",", "___") for i in keep.tolist()], dtype=object)
+            df = pd.DataFrame({"contig_id": ids, "repeat_length": self.length, "score": self.score,
+                               "terminal_repeats": self.kind, "seq_len": self.seq_len})
+            # what the table writer's joins need: the name index with its uniqueness known, the row of every record
+            index = df.attrs["_contig_index"] = pd.Index(ids)
+            _ = index.is_unique
+            df.attrs["_row_of_record"] = self.row_of_record
+            self._frame = df
+        return self._frame
+
+
 def repeats_frame(res: np.ndarray, names: list[str], lengths: np.ndarray) -> pd.DataFrame:
     """Decision rule (termini.py:137-154, :58-63) over a :func:`terminal_repeat_table`; one row per scanned record."""
-    keep = np.nonzero(res[:, 0] >= 0)[0] if len(res) else np.zeros(0, np.int64)
-    d_score, d_len, d_fg = res[keep, 0], res[keep, 1], res[keep, 2]
-    i_score, i_len = res[keep, 5], res[keep, 6]
-    found = (i_len > 12) | (d_len > 12)
-    is_itr = found & (i_score > d_score)
-    is_dtr = found & ~is_itr
-    kind = np.full(keep.size, None, dtype=object)
-    kind[is_itr] = "ITR"
-    kind[is_dtr] = "DTR"
-    kind[is_dtr & ((d_len - d_fg) >= 250)] = "LTR_DTR"
-    length = np.where(is_itr, i_len, d_len).astype(np.float64)
-    length[~found] = np.nan
-    score = np.where(is_itr, i_score, d_score).astype(np.float64)
-    score[~found] = np.nan
-    lengths = np.asarray(lengths)
-    from .fragment import normalise_headers
-    ids = normalise_headers(names)[keep] if keep.size * 2 > len(names) else \
-        np.array([names[i].strip().replace(",", "___") for i in keep.tolist()], dtype=object)
-    df = pd.DataFrame({
-        "contig_id": ids,
-        "repeat_length": length, "score": score, "terminal_repeats": kind,
-        "seq_len": lengths[keep] if keep.size else np.array([], np.int64),
-    })
-    # what the table writer's join needs, made here (the scan runs beside the forward, the join behind it): the name index
-    # with its uniqueness known, and the row of every record (-1: not scanned) for a join by record number
-    index = df.attrs["_contig_index"] = pd.Index(ids)
-    _ = index.is_unique
-    row_of = np.full(len(names), -1, dtype=np.int64)
-    row_of[keep] = np.arange(keep.size)
-    df.attrs["_row_of_record"] = row_of
-    return df
+    return RepeatColumns(res, names, lengths).frame()
 
 
 def scan_for_terminal_repeats(device, fa, fsize: int) -> pd.DataFrame:

@@ -309,6 +309,14 @@ def test_table_writer_column_path_equals_the_dataframe_path(n_cls, with_rel, tmp
         "repeated": (plain, pd.DataFrame({"contig_id": ["ctg_1", "ctg_1", "ctg_2"], "terminal_repeats": ["DTR", "ITR", None],
                                           "repeat_length": [20.0, 30.0, np.nan]}), False),
     }
+    from jaeger_amd.termini import RepeatColumns
+    res = np.full((n_contigs, 10), 0, np.int64)
+    res[::7, 1] = 40 + np.arange(0, n_contigs, 7)                       # a direct repeat on every seventh contig
+    res[::7, 0] = 2 * res[::7, 1]
+    res[5::11, 6] = 300                                               # an inverted one on some others
+    res[5::11, 5] = 600
+    res[3::50, 0] = -1                                                # not scanned
+    variants["columns"] = (hdr, RepeatColumns(res, [f"ctg_{i}___z" for i in range(n_contigs)], np.full(n_contigs, 9000)), True)
     for tag, (headers, repeats, by_row) in variants.items():
         y["meta_0"] = headers
         outs = []
@@ -324,8 +332,10 @@ def test_table_writer_column_path_equals_the_dataframe_path(n_cls, with_rel, tmp
                     data["frag_pred"] = P._Summaries(blob=blob, n=len(data["headers"]))
                 data["repeats"] = repeats
                 if by_row and columns_path:
-                    lookup = {c: i for i, c in enumerate(repeats["contig_id"])}
+                    frame = repeats.frame() if hasattr(repeats, "frame") else repeats
+                    lookup = {c: i for i, c in enumerate(frame["contig_id"])}
                     data["repeat_rows"] = np.array([lookup.get(h, -1) for h in data["headers"]], dtype=np.int64)
+                    data["names_unique"] = True
                 w.append(data)
             n = w.close()
             outs.append((n, Path(f"{base}.tsv").read_bytes(),
