@@ -28,7 +28,7 @@ JG_STAT_STREAM_GROUPS, JG_STAT_STREAM_BYTES, JG_STAT_PEAK_DEVICE_BASES, JG_STAT_
 JG_MSTAT_CONVS, JG_MSTAT_CONVS_F16X3, JG_MSTAT_LAYOUT_CONVERSIONS, JG_MSTAT_SMALL_FUSED = 0, 1, 2, 3
 
 # jg_op_kind
-OP_CONV, OP_MASK, OP_POOL, OP_DENSE, OP_ELTWISE, OP_NMD_FINAL, OP_OODSIG, OP_MAXPOOL1D, OP_FRAMESUM, OP_STRANDS, OP_EMBED = range(1, 12)
+OP_CONV, OP_MASK, OP_POOL, OP_DENSE, OP_ELTWISE, OP_NMD_FINAL, OP_OODSIG, OP_MAXPOOL1D, OP_FRAMESUM, OP_STRANDS, OP_EMBED, OP_VECMAX = range(1, 13)
 # jg_stage_kind
 ST_NONE, ST_BIAS, ST_BN, ST_DYT, ST_ADD, ST_ACT, ST_NMD, ST_MASKMUL, ST_LN = range(9)
 # jg_act

@@ -12,6 +12,7 @@
 #include "jg_common.h"
 #include "jg_small.h"
 #include "jg_resblock64.h"
+#include "jg_vecmax.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -323,8 +324,11 @@ static int validate_program(const jg_model *m) {
     auto slot_ok = [](int s, bool allow_ids) {
       return (s >= 0 && s < JG_MAX_BUFS) || s == JG_BUF_NONE || (allow_ids && s == JG_BUF_IDS);
     };
-    JG_REQUIRE(op.kind >= JG_OP_CONV && op.kind <= JG_OP_EMBED, JG_ERR_INVALID,
+    JG_REQUIRE(op.kind >= JG_OP_CONV && op.kind <= JG_OP_VECMAX, JG_ERR_INVALID,
                "op %zu: unknown kind %d", i, op.kind);
+    if (op.kind == JG_OP_VECMAX)
+      JG_REQUIRE(op.in_vec >= 0 && op.out_vec >= 0 && op.in_vec != op.out_vec && op.k >= 1 && op.cout >= 1 && op.vec_off >= 0,
+                 JG_ERR_INVALID, "op %zu: vecmax takes k >= 1 groups of cout values from one vector into another", i);
     if (op.kind == JG_OP_STRANDS)
       JG_REQUIRE(i + 1 == m->ops.size() && op.k >= 2 && op.k <= 8 && op.arg >= JG_MERGE_AVERAGE && op.arg <= JG_MERGE_MAX,
                  JG_ERR_INVALID, "op %zu: a strands op closes the program, merges 2 - 8 strands by average / sum / max", i);
@@ -509,6 +513,11 @@ static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
         break;
       case JG_OP_OODSIG:
         JG_REQUIRE(op.out_vec >= 0, JG_ERR_INVALID, "op %zu: oodsig needs an output vector", i);
+        vec_w[op.out_vec] = std::max(vec_w[op.out_vec], op.vec_off + op.cout);
+        break;
+      case JG_OP_VECMAX:
+        JG_REQUIRE(vec_w[op.in_vec] >= op.k * op.cout, JG_ERR_INVALID, "op %zu: vecmax expects %d x %d inputs, vector %d has %d", i,
+                   op.k, op.cout, op.in_vec, vec_w[op.in_vec]);
         vec_w[op.out_vec] = std::max(vec_w[op.out_vec], op.vec_off + op.cout);
         break;
       default:
@@ -2111,6 +2120,10 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
                               nw, (unsigned)op.arg, op.f0, m->vec[op.out_vec], m->vec_w[op.out_vec],
                               op.vec_off, s);
         break;
+      case JG_OP_VECMAX:
+        rc = jg_launch_vecmax(m->vec[op.in_vec], m->vec_w[op.in_vec], op.k, op.cout, nw, m->vec[op.out_vec], m->vec_w[op.out_vec],
+                              op.vec_off, s);
+        break;
       case JG_OP_STRANDS:      // the strands' rows are merged into the window's behind the program (forward_chunks)
         break;
       default:
@@ -2134,7 +2147,7 @@ extern "C" int jg_model_vec_width(const jg_model *m, int which) {
   for (const jg_op &op : m->ops) {
     if (op.out_vec != slot) continue;
     int wd = 0;
-    if (op.kind == JG_OP_DENSE || op.kind == JG_OP_NMD_FINAL)
+    if (op.kind == JG_OP_DENSE || op.kind == JG_OP_NMD_FINAL || op.kind == JG_OP_VECMAX)
       wd = op.vec_off + op.cout;
     else if (op.kind == JG_OP_POOL)
       wd = op.vec_off + op.cout;

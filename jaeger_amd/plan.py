@@ -117,10 +117,21 @@ class ModelPlan:
     # (builder.py:488-494, :563-590, :1195-1266).  strands > 1 marks such a plan; merge = the classifier's merge method
     strands: int = 1
     merge: str = "average"
+    # NMDMerge (nnlib/v2/nmd.py:93-170) over two or more NMD vectors: None / "concat" = the vectors side by side; "sum" /
+    # "mean" / "max" / "weighted" = every vector through its own bias-free Dense(nmd_merge_dim) first
+    # (rep/nmd_merge/proj_<i>/kernel; "weighted": + rep/nmd_merge/layer_weights, softmax-ed), then combined
+    nmd_merge_mode: str = "concat"
+    nmd_merge_dim: int = 0
+
+    @property
+    def nmd_raw_dim(self) -> int:
+        """Width of the NMD vectors side by side (what the taps write)."""
+        return sum(self.nmd_dims)
 
     @property
     def nmd_dim(self) -> int:
-        return sum(self.nmd_dims)
+        """Width of the model's ``nmd`` output (what the reliability head reads)."""
+        return self.nmd_merge_dim if self.nmd_merge_mode != "concat" else sum(self.nmd_dims)
 
 
 def _norm(name: str, kind: str, channels: int, cfg: dict, use_masking: bool) -> Norm:
@@ -307,13 +318,30 @@ def build_plan(model_cfg: dict) -> ModelPlan:
     rel = model_cfg.get("reliability_model")
     if rel is not None and nmd_dims:
         merge = rel.get("merge") or {}
-        if len(nmd_dims) > 1 and merge.get("mode", "concat") != "concat":
-            raise UnsupportedLayer("NMDMerge modes other than concat are not supported")
+        if len(nmd_dims) > 1 and merge:                        # builder.py:1176-1180: NMDMerge(**merge) over the list
+            mmode = merge.get("mode", "concat")
+            if mmode not in ("concat", "sum", "mean", "max", "weighted"):
+                raise ValueError(f"Unsupported NMD merge mode: {mmode}")          # nmd.py:110-111
+            if merge.get("axis", -1) != -1:
+                raise UnsupportedLayer("NMDMerge: only axis = -1 is supported")
+            if mmode != "concat":
+                target = merge.get("target_dim")
+                if target is None:
+                    if len(set(nmd_dims)) != 1:
+                        raise ValueError(f"target_dim is required for merge mode '{mmode}' when NMD channel "
+                                         f"dimensions differ.")                 # nmd.py:128-132
+                    target = nmd_dims[0]
+                pk = {k: v for k, v in (merge.get("projection_kwargs") or {}).items()
+                      if not k.startswith("kernel_")}          # (initialisers / regularisers / constraints: training only)
+                if pk.get("activation") not in (None, "linear") or set(pk) - {"activation"}:
+                    raise UnsupportedLayer(f"NMDMerge projection_kwargs {sorted(pk)} are not supported (linear, bias-free "
+                                           f"projections only)")
+                plan.nmd_merge_mode, plan.nmd_merge_dim = mmode, int(target)
         mode = rel.get("mode", "nmd")
         if mode not in ("nmd", "nmd_plus_signals"):
             raise ValueError(f"Unsupported reliability_model.mode: {mode!r}")   # builder.py:628-632
         sig = list(rel.get("signals", _DEFAULT_SIGNALS)) if mode == "nmd_plus_signals" else []
-        rin = sum(nmd_dims) + len(sig)
+        rin = plan.nmd_dim + len(sig)
         expected = rel.get("input_shape")
         if expected is not None and expected != rin:
             raise ValueError(f"reliability_model.input_shape ({expected}) does not match computed "
@@ -422,6 +450,11 @@ def weight_shapes(plan: ModelPlan) -> dict[str, tuple]:
                 out[f"{layer.name}/kernel"] = (layer.cin, layer.units)
                 if layer.use_bias:
                     out[f"{layer.name}/bias"] = (layer.units,)
+        if seq is plan.rep and plan.nmd_merge_mode != "concat":                 # NMDMerge is built behind the rep block's layers
+            for i, d in enumerate(plan.nmd_dims):
+                out[f"rep/nmd_merge/proj_{i}/kernel"] = (d, plan.nmd_merge_dim)
+            if plan.nmd_merge_mode == "weighted":
+                out["rep/nmd_merge/layer_weights"] = (len(plan.nmd_dims),)
     return out
 
 

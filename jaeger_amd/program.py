@@ -124,6 +124,9 @@ class _Compiler:
         self.masks = _Slots(L.JG_MAX_BUFS, "mask")
         self.parts = _Slots(L.JG_MAX_BUFS, "nmd partial")
         self.nmd_off = 0
+        # the taps write the model's nmd output itself - or, under an NMDMerge that projects (sum / mean / max / weighted),
+        # a scratch vector the merge reads (the two last vector slots: the heads use the ones from VEC_SCRATCH0 up)
+        self.nmd_vec = L.VEC_NMD if plan.nmd_merge_mode == "concat" else L.JG_MAX_VECS - 1
 
     # ---- helpers -----------------------------------------------------------
     def _op(self, kind, **kw):
@@ -237,7 +240,7 @@ class _Compiler:
     def _flush_nmd(self, pending: list, buf: int):
         for nmd, slot, mask in pending:
             self.ops.append(self._op(L.OP_NMD_FINAL, in_buf=buf, in_mask=mask, cout=nmd.channels, arg=slot,
-                                     out_vec=L.VEC_NMD, vec_off=self.nmd_off, f0=nmd.epsilon,
+                                     out_vec=self.nmd_vec, vec_off=self.nmd_off, f0=nmd.epsilon,
                                      b_off=self.blob.add(self.w[f"{nmd.name}/moving_mean"])))
             self.nmd_off += nmd.channels
             self.parts.give(slot)
@@ -400,9 +403,42 @@ class _Compiler:
             cur = dst
             j += 1
 
+    def _nmd_merge(self) -> None:
+        """NMDMerge(mode != "concat") (nnlib/v2/nmd.py:141-155) behind the representation learner.  Every tap's vector goes
+        through its own bias-free projection and the results are added (sum), averaged (mean), weighted by
+        softmax(layer_weights) (weighted) - all three ONE dense layer over the vectors side by side, its kernel the
+        projections stacked and scaled - or maximised element by element (max: the projections as one block-diagonal
+        dense layer, then JG_OP_VECMAX over the blocks)."""
+        plan = self.plan
+        n, t = len(plan.nmd_dims), plan.nmd_merge_dim
+        proj = [np.asarray(self.w[f"rep/nmd_merge/proj_{i}/kernel"], np.float32) for i in range(n)]
+        raw = plan.nmd_raw_dim
+        if plan.nmd_merge_mode == "max":
+            kernel = np.zeros((raw, n * t), np.float32)
+            at = 0
+            for i, (d, p) in enumerate(zip(plan.nmd_dims, proj)):
+                kernel[at:at + d, i * t:(i + 1) * t] = p
+                at += d
+            blocks = L.JG_MAX_VECS - 2
+            self.ops.append(self._op(L.OP_DENSE, in_vec=self.nmd_vec, out_vec=blocks, vec_off=0, cin=raw, cout=n * t,
+                                     arg=act_code(None), w_off=self.blob.add(kernel), b_off=-1))
+            self.ops.append(self._op(L.OP_VECMAX, in_vec=blocks, out_vec=L.VEC_NMD, vec_off=0, k=n, cout=t))
+            return
+        if plan.nmd_merge_mode == "weighted":
+            lw = np.asarray(self.w["rep/nmd_merge/layer_weights"], np.float32)
+            e = np.exp(lw - lw.max())
+            scale = (e / e.sum()).astype(np.float32)            # tf.nn.softmax(layer_weights), nmd.py:153-155
+        else:
+            scale = np.full(n, 1.0 if plan.nmd_merge_mode == "sum" else 1.0 / n, np.float32)
+        kernel = np.concatenate([p * s for p, s in zip(proj, scale)], axis=0).astype(np.float32)
+        self.ops.append(self._op(L.OP_DENSE, in_vec=self.nmd_vec, out_vec=L.VEC_NMD, vec_off=0, cin=raw, cout=t,
+                                 arg=act_code(None), w_off=self.blob.add(kernel), b_off=-1))
+
     def compile(self) -> Program:
         plan = self.plan
         self._rep()
+        if plan.nmd_merge_mode != "concat":
+            self._nmd_merge()
         self._head(plan.classifier, L.VEC_EMBEDDING, L.VEC_PREDICTION, L.VEC_SCRATCH0)
         if plan.reliability is not None:
             if plan.reliability_signals:

@@ -198,6 +198,37 @@ def masked_global_max(x, mask):
     return torch.where(has_valid > 0, pooled, torch.zeros_like(pooled))
 
 
+def nmd_merge_dim(merge: dict | None, nmd_dims: list) -> int:
+    """Width of NMDMerge's output (nmd.py:120-134): the vectors side by side, or ``target_dim`` (default: the common width)."""
+    if len(nmd_dims) < 2 or not merge or merge.get("mode", "concat") == "concat":
+        return sum(nmd_dims)
+    if merge.get("target_dim") is not None:
+        return int(merge["target_dim"])
+    if len(set(nmd_dims)) != 1:
+        raise ValueError(f"target_dim is required for merge mode '{merge.get('mode')}' when NMD channel dimensions differ.")
+    return int(nmd_dims[0])
+
+
+def nmd_merge(nmds: list, merge: dict | None, weights: dict, dtype):
+    """NMDMerge.call (nmd.py:141-155): concat; or every vector through its own bias-free Dense, then add_n / mean / max /
+    softmax(layer_weights)-weighted sum - in that order of operations.  builder.py:1176-1184: no merge config = Concatenate."""
+    mode = (merge or {}).get("mode", "concat")
+    if mode == "concat":
+        return torch.cat(nmds, dim=-1)
+    if mode not in ("sum", "mean", "max", "weighted"):
+        raise ValueError(f"Unsupported NMD merge mode: {mode}")
+    projected = [v @ torch.as_tensor(weights[f"rep/nmd_merge/proj_{i}/kernel"]).to(dtype) for i, v in enumerate(nmds)]
+    if mode == "sum":
+        return sum(projected[1:], projected[0])
+    if mode == "mean":
+        return sum(projected[1:], projected[0]) / len(projected)
+    stacked = torch.stack(projected, dim=0)
+    if mode == "max":
+        return stacked.max(dim=0).values
+    w = torch.softmax(torch.as_tensor(weights["rep/nmd_merge/layer_weights"]).to(dtype), dim=0).reshape(-1, 1, 1)
+    return (stacked * w).sum(dim=0)
+
+
 def ood_signals(logits, nmd, signals, eps=1e-10):
     """layers.py:1632-1667."""
     probs = torch.softmax(logits, dim=-1)
@@ -334,7 +365,14 @@ def weight_specs(model_cfg: dict) -> dict[str, tuple]:
         n_sig = 0
         if rel.get("mode", "nmd") == "nmd_plus_signals":
             n_sig = len(rel.get("signals", ["max_prob", "entropy", "energy", "margin", "nmd_norm"]))
-        _block_specs("reliability", rel["hidden_layers"], sum(nmd_dims) + n_sig, specs)
+        merge = rel.get("merge")
+        merged = nmd_merge_dim(merge, nmd_dims)
+        if len(nmd_dims) > 1 and merge and merge.get("mode", "concat") != "concat":
+            for i, d in enumerate(nmd_dims):
+                specs[f"rep/nmd_merge/proj_{i}/kernel"] = (d, merged)
+            if merge["mode"] == "weighted":
+                specs["rep/nmd_merge/layer_weights"] = (len(nmd_dims),)
+        _block_specs("reliability", rel["hidden_layers"], merged + n_sig, specs)
     return specs
 
 
@@ -494,10 +532,7 @@ def forward(model_cfg: dict, weights: dict[str, Any], ids: np.ndarray,
                            weights, model_cfg, dtype)
     out["prediction"] = logits
     if nmds:
-        nmd = nmds[0] if len(nmds) == 1 else torch.cat(nmds, dim=-1)  # NMDMerge concat
-        merge = (model_cfg.get("reliability_model", {}) or {}).get("merge")
-        if len(nmds) > 1 and merge is not None and merge.get("mode", "concat") != "concat":
-            raise ValueError("oracle: only NMDMerge mode=concat is restated")
+        nmd = nmds[0] if len(nmds) == 1 else nmd_merge(nmds, (model_cfg.get("reliability_model") or {}).get("merge"), weights, dtype)
         out["nmd"] = nmd
         rel_cfg = model_cfg.get("reliability_model")
         if rel_cfg is not None:

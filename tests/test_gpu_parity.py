@@ -314,6 +314,42 @@ def test_fused_64_channel_blocks_every_instantiation(ksize, dil):
             assert np.abs(fused[k] - plain[k]).max() <= 2e-5, (fsize, k, np.abs(fused[k] - plain[k]).max())
 
 
+@pytest.mark.parametrize("mode,target", [("sum", None), ("mean", 24), ("max", 24), ("weighted", 40)])
+def test_forward_nmd_merge_modes(mode, target):
+    """NMDMerge modes other than concat (nnlib/v2/nmd.py:141-155) on the nmdmerge500 family - both precisions, the fused
+    small-window kernel and the layer-by-layer path - against the oracle's restatement (projection per vector, then
+    add_n / mean / reduce_max / softmax-weighted sum); with the OOD signals appended behind the merged vector."""
+    import copy
+
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("nmdmerge500"))
+    rel = cfg["reliability_model"]
+    rel["merge"] = {"mode": mode, "axis": -1}
+    width = 32
+    if target is not None:
+        rel["merge"]["target_dim"] = width = target
+    rel["mode"] = "nmd_plus_signals"
+    rel["input_shape"] = width + 5
+    weights = ofwd.random_weights(cfg, seed=4242)
+    rng = np.random.Generator(np.random.PCG64(9))
+    for fsize, n_win, precision in ((500, 40, "f16x3"), (500, 11, "f32"), (1500, 6, "f16x3")):
+        seq = _random_dna(rng, fsize * n_win, n_frac=0.02)
+        starts = (np.arange(n_win) * fsize).astype(np.int64)
+        lens = np.full(n_win, fsize, np.int32)
+        lens[1::3] = rng.integers(fsize // 2, fsize, lens[1::3].size)
+        eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, precision=precision)
+        got = eng.predict_windows(seq, starts, lens, fsize)
+        eng.close()
+        ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+        ref = ofwd.forward(cfg, weights, ids)
+        assert got["nmd"].shape == ref["nmd"].shape == (n_win, width)
+        for k in ("prediction", "reliability"):
+            assert np.abs(got[k] - ref[k]).max() <= TOL, (mode, fsize, precision, k, np.abs(got[k] - ref[k]).max())
+        check_side_output("nmd", got["nmd"], ref["nmd"])
+
+
 def test_forward_pyramid_resnet_short_windows_chunked():
     _forward_case("pyramid", 2000, 9, 22, n_frac=0.03, short=True, chunk=4, precision="f16x3", gain=0.85)
     _forward_case("pyramid", 900, 5, 23, n_frac=0.0, precision="f16x3", gain=0.85)

@@ -337,3 +337,47 @@ def test_layers_directly_on_the_embedding_get_an_identity_conv():
         conv = next(op for op in prog.ops if op.kind == L.OP_CONV)
         assert [conv.stages[j].kind for j in range(conv.n_stages)] == [L.ST_NMD, L.ST_BN]
         assert prog.nmd_dim == 8
+
+
+@pytest.mark.parametrize("mode", ["sum", "mean", "max", "weighted"])
+def test_nmd_merge_modes_compile_to_one_dense_layer_or_a_block_diagonal_one_and_a_maximum(mode):
+    """NMDMerge (nnlib/v2/nmd.py:93-170) over the two NMD taps of the nmdmerge500 family: every vector through its own
+    bias-free projection, then added / averaged / softmax-weighted - ONE dense op over the vectors side by side, its kernel
+    the projections stacked and scaled - or maximised (a block-diagonal dense op + JG_OP_VECMAX).  The taps write a scratch
+    vector, the model's nmd output is the merged one (target_dim wide) and feeds the reliability head."""
+    import copy
+
+    from jaeger_amd import _lib as L
+    from jaeger_amd.plan import UnsupportedLayer, build_plan, weight_shapes
+    from jaeger_amd.program import compile_plan
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("nmdmerge500"))
+    rel = cfg["reliability_model"]
+    rel["merge"] = {"mode": mode, "target_dim": 24}
+    rel["input_shape"] = 24
+    plan = build_plan(cfg)
+    assert plan.nmd_merge_mode == mode and plan.nmd_dim == 24 and plan.nmd_raw_dim == 64 and len(plan.nmd_dims) == 2
+    shapes = weight_shapes(plan)
+    assert shapes["rep/nmd_merge/proj_0/kernel"] == (plan.nmd_dims[0], 24)
+    assert ("rep/nmd_merge/layer_weights" in shapes) == (mode == "weighted")
+    assert shapes == ofwd.weight_specs(cfg)
+    weights = ofwd.random_weights(cfg, seed=5)
+    prog = compile_plan(plan, weights)
+    kinds = [op.kind for op in prog.ops]
+    finals = [op for op in prog.ops if op.kind == L.OP_NMD_FINAL]
+    assert len(finals) == 2 and all(op.out_vec == L.JG_MAX_VECS - 1 for op in finals)
+    merged = [op for op in prog.ops if op.out_vec == L.VEC_NMD]
+    if mode == "max":
+        assert [op.kind for op in merged] == [L.OP_VECMAX] and merged[0].k == 2 and merged[0].cout == 24
+        dense = prog.ops[kinds.index(L.OP_VECMAX) - 1]
+        assert dense.kind == L.OP_DENSE and dense.cin == 64 and dense.cout == 48 and dense.b_off < 0
+    else:
+        assert [op.kind for op in merged] == [L.OP_DENSE] and merged[0].cin == 64 and merged[0].cout == 24 and merged[0].b_off < 0
+    assert prog.nmd_dim == 24
+    # what stays rejected, loudly: a projection with an activation; differing widths without a target_dim
+    rel["merge"] = {"mode": mode, "target_dim": 24, "projection_kwargs": {"activation": "relu"}}
+    with pytest.raises(UnsupportedLayer):
+        build_plan(cfg)
+    rel["merge"] = {"mode": "bogus"}
+    with pytest.raises(ValueError):
+        build_plan(cfg)
