@@ -55,7 +55,9 @@ typedef enum {
   JG_OP_EMBED = 11,    /* Embedding lookup of WIDE ids (codon: DICODON - 4 096 codon pairs + the padding id, nnlib/inference.py:
                           430-451, builder.py:858-867): ids (rows, L) u16 -> out_buf f32 (rows, L, cout) = table[id] (b_off,
                           vocab x cout floats), out_mask = (id != 0).  Codon ids (one byte) are gathered inside the first
-                          conv instead (in_buf = JG_BUF_IDS); a program with this op takes 16-bit id tensors */
+                          conv instead (in_buf = JG_BUF_IDS); a program with this op takes 16-bit id tensors when its vocabulary
+                          exceeds 256.  w_off >= 0: + postab[position in the row] (k rows x cout floats: the rows of
+                          SinusoidalPositionEmbedding, use_positional_embeddings, builder.py:886-892) - then also for one-byte ids */
   JG_OP_VECMAX = 12,   /* NMDMerge(mode="max") (nnlib/v2/nmd.py:150-152): out_vec[vec_off + c] = max over g < k of in_vec[g * cout + c] */
   JG_OP_STRANDS = 10   /* a branched (shared-weight) model over the k strands of a nucleotide input: every strand is a
                           program row of its own (ids (W, k, L), one frame per row); arg = how the strands' predictions

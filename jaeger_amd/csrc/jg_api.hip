@@ -352,12 +352,15 @@ static int validate_program(const jg_model *m) {
                    "op %zu: embedding table outside the weight blob", i);
     }
     if (op.kind == JG_OP_EMBED) {
-      JG_REQUIRE(i == 0 && op.out_buf >= 0 && op.out_mask >= 0 && op.cout >= 4 && op.cout % 4 == 0 && m->vocab > 256 &&
+      JG_REQUIRE(i == 0 && op.out_buf >= 0 && op.out_mask >= 0 && op.cout >= 4 && op.cout % 4 == 0 && m->vocab >= 2 &&
                      m->vocab <= 65536 && off_ok(op.b_off, (int64_t)m->vocab * op.cout),
-                 JG_ERR_INVALID, "op %zu: an embedding op opens the program (16-bit ids, vocabulary 257 .. 65536, table inside the weight blob)", i);
+                 JG_ERR_INVALID, "op %zu: an embedding op opens the program (vocabulary 2 .. 65536 - 16-bit ids above 256 -, table inside the weight blob)", i);
+      // w_off >= 0: rows of a position table (k positions x cout floats) added to the looked-up rows
+      JG_REQUIRE(op.w_off < 0 || (op.k >= 1 && off_ok(op.w_off, (int64_t)op.k * op.cout)), JG_ERR_INVALID,
+                 "op %zu: position table outside the weight blob", i);
     } else if (!m->ops.empty() && m->ops[0].kind == JG_OP_EMBED) {
       JG_REQUIRE(op.in_buf != JG_BUF_IDS && op.in_mask != JG_BUF_IDS, JG_ERR_INVALID,
-                 "op %zu: reads the id tensor directly in a program of 16-bit ids (the embedding op's buffer and mask take its place)", i);
+                 "op %zu: reads the id tensor directly in a program that opens with an embedding op (its buffer and mask take the tensor's place)", i);
     }
     if (op.kind == JG_OP_DENSE) {
       JG_REQUIRE(off_ok(op.w_off, (int64_t)op.cin * op.cout), JG_ERR_INVALID,
@@ -459,6 +462,8 @@ static int plan_shapes(jg_model *m, int l, int64_t act_elems[JG_MAX_BUFS],
       } break;
       case JG_OP_EMBED: {
         JG_REQUIRE(op.out_buf >= 0 && op.out_mask >= 0 && op.cout > 0, JG_ERR_INVALID, "op %zu: bad embedding op", i);
+        JG_REQUIRE(op.w_off < 0 || l <= op.k, JG_ERR_UNSUPPORTED,
+                   "op %zu: rows of %d positions, the model's position table holds %d", i, l, op.k);
         sh[op.out_buf] = Shape{m->id_frames, l, op.cout};
         act_elems[op.out_buf] = std::max<int64_t>(act_elems[op.out_buf], (int64_t)m->id_frames * (l + (l & 1)) * op.cout);
         mlen[op.out_mask] = m->id_frames * l;
@@ -1541,7 +1546,7 @@ extern "C" int jg_model_create(jg_engine *e, const jg_op *ops, int n_ops, const 
   m->vocab = vocab;
   int rc = validate_program(m);
   if (rc != JG_OK) { delete m; return rc; }
-  if (m->ops[0].kind == JG_OP_EMBED) m->id_bytes = 2;
+  if (m->ops[0].kind == JG_OP_EMBED && m->vocab > 256) m->id_bytes = 2;
   if (m->ops.back().kind == JG_OP_STRANDS) {
     m->strands = m->ops.back().k;
     m->id_frames = 1;
@@ -1833,9 +1838,8 @@ static int run_chunk(jg_model *m, const uint8_t *d_ids, int nw, int l, hipStream
     }
     switch (op.kind) {
       case JG_OP_EMBED: {
-        JG_REQUIRE(m->id_bytes == 2, JG_ERR_INVALID, "embedding op in a program of one-byte ids");
-        rc = jg_launch_embed(reinterpret_cast<const uint16_t *>(d_ids), (int64_t)nw * m->id_frames * l, m->d_w + op.b_off,
-                             m->vocab, op.cout, m->act[op.out_buf], m->msk[op.out_mask], s);
+        rc = jg_launch_embed_pos(d_ids, m->id_bytes, (int64_t)nw * m->id_frames * l, l, m->d_w + op.b_off, m->vocab, op.cout,
+                                 op.w_off >= 0 ? m->d_w + op.w_off : nullptr, m->act[op.out_buf], m->msk[op.out_mask], s);
         sh[op.out_buf] = Shape{m->id_frames, l, op.cout};
         mlen[op.out_mask] = m->id_frames * l;
       } break;

@@ -122,6 +122,9 @@ class ModelPlan:
     # (rep/nmd_merge/proj_<i>/kernel; "weighted": + rep/nmd_merge/layer_weights, softmax-ed), then combined
     nmd_merge_mode: str = "concat"
     nmd_merge_dim: int = 0
+    # use_positional_embeddings (builder.py:886-892): SinusoidalPositionEmbedding(max_wavelength) rows (layers.py:2149-2195)
+    # added to the embedded input; None = none
+    positional_wavelength: float | None = None
 
     @property
     def nmd_raw_dim(self) -> int:
@@ -281,8 +284,13 @@ def build_plan(model_cfg: dict) -> ModelPlan:
     if use_emb == bool(sp.get("seq_onehot")):
         # Embedding needs ids, the Dense / pass-through branch needs one-hot rows (builder.py:856-880)
         raise UnsupportedLayer("use_embedding_layer and seq_onehot must be opposite (ids -> Embedding, one-hot -> Dense)")
+    positional = None
     if emb.get("use_positional_embeddings", False):
-        raise UnsupportedLayer("positional embeddings are not supported")
+        # builder.py:886-892: x = Add()([x, SinusoidalPositionEmbedding(max_wavelength=positional_embedding_length)(x)])
+        positional = emb.get("positional_embedding_length")
+        if not positional or float(positional) <= 0:
+            raise ValueError("use_positional_embeddings needs embedding.positional_embedding_length (the max_wavelength)")
+        positional = float(positional)
     if sp["input_type"] != "translated":
         raise UnsupportedLayer(f"input_type {sp['input_type']!r} on a graph built for translated input")
     if sp.get("ngram_width", 3) not in (3, 6):
@@ -314,7 +322,8 @@ def build_plan(model_cfg: dict) -> ModelPlan:
     plan = ModelPlan(vocab=sp["vocab_size"], embedding_dim=e, rep=rep, pooling=pooling,
                      rep_channels=rep_c, classifier=cls, n_classes=n_cls, nmd_dims=nmd_dims,
                      use_masking=use_masking, string_processor=sp,
-                     class_label_map=list(model_cfg.get("class_label_map", []) or []), embedding_kind=kind)
+                     class_label_map=list(model_cfg.get("class_label_map", []) or []), embedding_kind=kind,
+                     positional_wavelength=positional)
     rel = model_cfg.get("reliability_model")
     if rel is not None and nmd_dims:
         merge = rel.get("merge") or {}

@@ -258,11 +258,19 @@ class _Compiler:
             table = np.concatenate([np.zeros((1, rows.shape[1]), np.float32), np.asarray(rows, np.float32)])
         self.emb_off = self.blob.add(table)
         buf, mask = L.JG_BUF_IDS, L.JG_BUF_IDS      # Embedding(mask_zero=True), builder.py:858-867
-        if plan.vocab > 256:
+        if plan.vocab > 256 or plan.positional_wavelength is not None:
             # codon pairs (codon: DICODON, 4 097 ids): 16-bit ids do not fit the convs' one-byte gather - the lookup runs as
-            # an op of its own that writes the rows and the mask (id != 0); everything behind it reads those
+            # an op of its own that writes the rows and the mask (id != 0); everything behind it reads those.  The same op
+            # adds the rows of SinusoidalPositionEmbedding (use_positional_embeddings): a table of POSITION_ROWS positions
+            # computed here once - the sum depends on the position, so it cannot live in the convs' id -> row gather
             buf, mask = self.bufs.take(), self.masks.take()
-            self.ops.append(self._op(L.OP_EMBED, out_buf=buf, out_mask=mask, cout=plan.embedding_dim, b_off=self.emb_off))
+            pos = {}
+            if plan.positional_wavelength is not None:
+                if plan.embedding_dim % 4:
+                    raise UnsupportedLayer("positional embeddings need an embedding width that is a multiple of 4")
+                pe = sinusoidal_position_rows(POSITION_ROWS, plan.embedding_dim, plan.positional_wavelength)
+                pos = dict(w_off=self.blob.add(pe), k=POSITION_ROWS)
+            self.ops.append(self._op(L.OP_EMBED, out_buf=buf, out_mask=mask, cout=plan.embedding_dim, b_off=self.emb_off, **pos))
         i = 0
         if not layers or not isinstance(layers[0], Conv):
             # A norm / activation / nmd / residual block - or the pool itself - directly on the Embedding output (the
@@ -458,6 +466,23 @@ class _Compiler:
                                      arg={"average": L.MERGE_AVERAGE, "sum": L.MERGE_SUM, "max": L.MERGE_MAX}[plan.merge]))
         return Program(self.ops, self.blob.finish(), plan.vocab, plan.n_classes,
                        plan.reliability is not None, plan.nmd_dim, plan.rep_channels, plan.strands)
+
+
+POSITION_ROWS = 8192        # rows of the position table a program carries: windows of up to 24 576 bases (a row = one frame's codons)
+
+
+def sinusoidal_position_rows(n_pos: int, hidden: int, max_wavelength: float) -> np.ndarray:
+    """SinusoidalPositionEmbedding.call (nnlib/v2/layers.py:2155-2195) for positions 0 .. n_pos - 1, in float32 like the
+    layer's compute dtype: timescale_i = (1 / max_wavelength) ** (2 floor(i / 2) / hidden), row[p, i] = sin(p timescale_i) for
+    even i, cos(p timescale_i) for odd i."""
+    f = np.float32
+    positions = np.arange(n_pos, dtype=f)
+    dims = np.arange(hidden, dtype=f)
+    even = np.floor(dims / f(2)) * f(2)
+    timescales = np.power(f(1.0) / f(max_wavelength), even / f(hidden)).astype(f)
+    angles = (positions[:, None] * timescales[None, :]).astype(f)
+    sin_mask = (np.arange(hidden) % 2 == 0).astype(f)
+    return (np.sin(angles) * sin_mask + np.cos(angles) * (f(1.0) - sin_mask)).astype(f)
 
 
 def compile_plan(plan: ModelPlan, weights: dict[str, np.ndarray]) -> Program:

@@ -198,6 +198,27 @@ def masked_global_max(x, mask):
     return torch.where(has_valid > 0, pooled, torch.zeros_like(pooled))
 
 
+def sinusoidal_position_embedding(x, max_wavelength):
+    """SinusoidalPositionEmbedding.call (nnlib/v2/layers.py:2155-2195) for an input [..., seq_length, hidden]: positions
+    0 .. seq_length - 1, timescales min_freq ** (2 floor(i / 2) / hidden), sine on the even dims, cosine on the odd ones,
+    broadcast over the leading axes (the Add layer that follows keeps the input's mask).  Evaluated in float32 with numpy's
+    powf / sinf / cosf, operation by operation as the layer does in its compute dtype: at angles of hundreds of radians
+    the LAST BIT of a float32 timescale moves the sine by 1e-5, so the rows are only defined up to the libm in use
+    (TensorFlow's Eigen kernels are not available here: this part of the oracle is unpinned like the rest of it)."""
+    import numpy as np
+    f = np.float32
+    seq, hidden = int(x.shape[-2]), int(x.shape[-1])
+    positions = np.arange(seq).astype(f)
+    min_freq = f(1.0) / f(max_wavelength)
+    dims = np.arange(hidden).astype(f)
+    even = np.floor(dims / f(2)) * f(2)
+    timescales = np.power(min_freq, even / f(hidden), dtype=f)
+    angles = np.expand_dims(positions, -1) * np.expand_dims(timescales, 0)
+    sin_mask = (dims % f(2) == 0).astype(f)
+    enc = np.sin(angles, dtype=f) * sin_mask + np.cos(angles, dtype=f) * (f(1.0) - sin_mask)
+    return torch.as_tensor(enc).to(x.dtype).expand(x.shape)
+
+
 def nmd_merge_dim(merge: dict | None, nmd_dims: list) -> int:
     """Width of NMDMerge's output (nmd.py:120-134): the vectors side by side, or ``target_dim`` (default: the common width)."""
     if len(nmd_dims) < 2 or not merge or merge.get("mode", "concat") == "concat":
@@ -524,6 +545,8 @@ def forward(model_cfg: dict, weights: dict[str, Any], ids: np.ndarray,
         onehot = torch.nn.functional.one_hot(torch.clamp(idt - 1, min=0), depth).to(dtype) * (idt != 0).unsqueeze(-1)
         mask = (onehot != 0).any(dim=-1).to(dtype)
         x = onehot @ torch.as_tensor(weights["embedding/kernel"]).to(dtype) if "embedding/kernel" in weights else onehot
+    if model_cfg["embedding"].get("use_positional_embeddings", False):            # builder.py:886-892
+        x = x + sinusoidal_position_embedding(x, model_cfg["embedding"].get("positional_embedding_length"))
     rep = model_cfg["representation_learner"]
     emb, nmds = _run_block(x, mask, rep["hidden_layers"], "rep", weights, model_cfg, dtype,
                            pooling=rep.get("pooling"))

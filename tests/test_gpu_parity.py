@@ -350,6 +350,42 @@ def test_forward_nmd_merge_modes(mode, target):
         check_side_output("nmd", got["nmd"], ref["nmd"])
 
 
+@pytest.mark.parametrize("name,fsize", [("baseline500", 500), ("brain", 1500)])
+def test_forward_positional_embeddings(name, fsize):
+    """use_positional_embeddings (builder.py:886-892; SinusoidalPositionEmbedding, nnlib/v2/layers.py:2149-2195): the embedded
+    input plus sine / cosine position rows - both precisions against the oracle, ragged windows and N runs (masked positions
+    carry row 0 + the position row; the masked convs ignore them)."""
+    import copy
+
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg(name))
+    cfg["embedding"]["use_positional_embeddings"] = True
+    cfg["embedding"]["positional_embedding_length"] = 10000
+    weights = ofwd.random_weights(cfg, seed=77)
+    if name == "brain":                # He-uniform stand-in kernels + position rows of norm 5.7 drive the logits to +-125
+        for key in weights:
+            if key.startswith("rep/") and key.endswith("/kernel"):
+                weights[key] = weights[key] * np.float32(0.8)
+    rng = np.random.Generator(np.random.PCG64(19))
+    for precision, n_win in (("f16x3", 9), ("f32", 5)):
+        seq = _random_dna(rng, fsize * n_win, n_frac=0.03)
+        starts = (np.arange(n_win) * fsize).astype(np.int64)
+        lens = np.full(n_win, fsize, np.int32)
+        lens[1::3] = rng.integers(fsize // 2, fsize, lens[1::3].size)
+        eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, precision=precision)
+        got = eng.predict_windows(seq, starts, lens, fsize)
+        eng.close()
+        ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+        ref = ofwd.forward(cfg, weights, ids)
+        plain = ofwd.forward(load_model_cfg(name), weights, ids)
+        assert np.abs(ref["prediction"] - plain["prediction"]).max() > 1e-2          # the position rows matter
+        for k in ("prediction", "reliability"):
+            if k in ref:
+                assert np.abs(got[k] - ref[k]).max() <= TOL, (name, precision, k, np.abs(got[k] - ref[k]).max())
+
+
 def test_forward_pyramid_resnet_short_windows_chunked():
     _forward_case("pyramid", 2000, 9, 22, n_frac=0.03, short=True, chunk=4, precision="f16x3", gain=0.85)
     _forward_case("pyramid", 900, 5, 23, n_frac=0.0, precision="f16x3", gain=0.85)

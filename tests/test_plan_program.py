@@ -381,3 +381,35 @@ def test_nmd_merge_modes_compile_to_one_dense_layer_or_a_block_diagonal_one_and_
     rel["merge"] = {"mode": "bogus"}
     with pytest.raises(ValueError):
         build_plan(cfg)
+
+
+def test_positional_embeddings_compile_to_an_embedding_op_with_a_position_table():
+    """use_positional_embeddings (builder.py:886-892): the embedded input + SinusoidalPositionEmbedding rows.  The sum
+    depends on the position, so the lookup leaves the first conv's id gather: JG_OP_EMBED opens the program (one-byte ids -
+    the vocabulary is the codons'), its position table holds program.POSITION_ROWS rows equal to the oracle's restatement
+    of the layer; without the wavelength the plan fails like the reference's 1 / None."""
+    import copy
+
+    import torch
+
+    from jaeger_amd import _lib as L
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.program import POSITION_ROWS, compile_plan, sinusoidal_position_rows
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("baseline500"))
+    cfg["embedding"]["use_positional_embeddings"] = True
+    with pytest.raises(ValueError):
+        build_plan(cfg)
+    cfg["embedding"]["positional_embedding_length"] = 1000
+    plan = build_plan(cfg)
+    assert plan.positional_wavelength == 1000.0 and plan.vocab <= 256
+    prog = compile_plan(plan, ofwd.random_weights(cfg, seed=3))
+    first = prog.ops[0]
+    assert first.kind == L.OP_EMBED and first.k == POSITION_ROWS and first.w_off >= 0 and first.cout == plan.embedding_dim
+    assert all(op.in_buf != L.JG_BUF_IDS and op.in_mask != L.JG_BUF_IDS for op in prog.ops[1:])
+    rows = sinusoidal_position_rows(700, plan.embedding_dim, 1000.0)
+    ref = ofwd.sinusoidal_position_embedding(torch.zeros(2, 6, 700, plan.embedding_dim), 1000.0)[0, 0].numpy()
+    assert rows.dtype == np.float32 and np.abs(rows - ref).max() <= 2e-6          # (same libm: equal; see the oracle's note)
+    assert np.allclose(rows[0, 0::2], 0.0) and np.allclose(rows[0, 1::2], 1.0)
+    table = np.asarray(prog.blob[first.w_off:first.w_off + 700 * plan.embedding_dim]).reshape(700, -1)
+    np.testing.assert_array_equal(table, rows)
