@@ -148,6 +148,12 @@ int jg_engine_sync(jg_engine *e);
  * JG_OPT_TERMINI_EXACT (default 0): 1 = jg_terminal_repeats runs every alignment through the kernel that carries length and
  * gap count through the dynamic programme, instead of only those the packed score-only pass leaves open (score > 100);
  * same table either way (tests/test_gpu_termini.py).
+ * JG_OPT_TERMINI_REPORT_MIN (default 0; 2 .. 15): jg_terminal_repeats may report an alignment of FEWER than this many columns
+ * as no alignment (score 0, length 0, ends -1) instead of scoring it.  The reference's decision rule only looks at alignments
+ * longer than 12 columns (utils/termini.py:137-154), and under its scoring an alignment of L <= 50 columns is an exact run of
+ * L matches: with the value 13 a record whose ends share no 13 matching bases in either orientation skips the dynamic
+ * programme altogether (a hash probe of the 13-mers decides), and one whose only shared run is a single long one is settled
+ * by the one-run check alone; every alignment of at least that many columns is reported exactly as with 0.
  * JG_OPT_DUST_ON_COPY_STREAM (default 1): the DUST pass of a streamed span runs on the copy stream behind the span's upload
  * (beside the previous group's convolutions) or, 0, on the compute stream in front of the span's encoder; same masks.
  * JG_OPT_TABLE_NET_LDS (default 0): a strand branch's conv + pool ("table net") runs on the matrix cores (0) or, 1, as the
@@ -159,7 +165,7 @@ int jg_engine_sync(jg_engine *e);
  * jg_predict_windows call ANOTHER thread is about to make calls this first (the call resets the mark itself, but only
  * once it has been entered - a poller that starts earlier would read the previous call's final count). */
 enum { JG_OPT_STREAM_BYTES = 1, JG_OPT_CONV_PC = 2, JG_OPT_TERMINI_EXACT = 3, JG_OPT_DUST_ON_COPY_STREAM = 4,
-       JG_OPT_TABLE_NET_LDS = 5, JG_OPT_RESET_PROGRESS = 6, JG_OPT_FUSE_RESBLOCK = 7 };
+       JG_OPT_TABLE_NET_LDS = 5, JG_OPT_RESET_PROGRESS = 6, JG_OPT_FUSE_RESBLOCK = 7, JG_OPT_TERMINI_REPORT_MIN = 8 };
 int jg_engine_set_option(jg_engine *e, int key, int64_t value);
 /* statistics of the engine's last jg_predict_windows call: number of streamed groups (0 = not streamed), bytes sent
  * through the staging buffers, peak bytes of bases resident on the device.  JG_STAT_WINDOWS_DONE may be read from

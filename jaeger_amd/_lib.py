@@ -19,6 +19,7 @@ JG_BUF_NONE, JG_BUF_IDS = -1, -2
 JG_OPT_STREAM_BYTES = 1
 JG_OPT_CONV_PC = 2
 JG_OPT_TERMINI_EXACT = 3
+JG_OPT_TERMINI_REPORT_MIN = 8
 JG_OPT_DUST_ON_COPY_STREAM = 4
 JG_OPT_TABLE_NET_LDS = 5
 JG_OPT_RESET_PROGRESS = 6

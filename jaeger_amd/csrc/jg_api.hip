@@ -104,6 +104,11 @@ extern "C" int jg_engine_set_option(jg_engine *e, int key, int64_t value) {
     case JG_OPT_TERMINI_EXACT:
       e->termini_exact = value != 0;
       return JG_OK;
+    case JG_OPT_TERMINI_REPORT_MIN:
+      JG_REQUIRE(value == 0 || (value >= 2 && value <= 15), JG_ERR_INVALID,
+                 "jg_engine_set_option: JG_OPT_TERMINI_REPORT_MIN = %lld (0, or 2 .. 15 columns)", (long long)value);
+      e->termini_report_min = (int)value;
+      return JG_OK;
     case JG_OPT_DUST_ON_COPY_STREAM:
       e->dust_on_copy = value != 0;
       return JG_OK;

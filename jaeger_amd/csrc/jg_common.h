@@ -190,6 +190,7 @@ struct jg_engine {
   int n_cu = 256;
   int dust_on_copy = 1;           // JG_OPT_DUST_ON_COPY_STREAM: streamed spans are soft-masked on the copy stream (1) or in front of their encoder (0)
   int termini_exact = 0;          // JG_OPT_TERMINI_EXACT: every terminal-repeat alignment through the length / gap carrying kernel
+  int termini_report_min = 0;     // JG_OPT_TERMINI_REPORT_MIN: alignments of fewer columns are reported as none (0 = every alignment exactly)
   int tab_lds_only = 0;           // JG_OPT_TABLE_NET_LDS: keep the table net on the LDS-table kernel
   int fuse_resblock = 1;          // JG_OPT_FUSE_RESBLOCK: narrow residual blocks as one launch (jg_resblock.hip)
   int conv_pc = 0;                // JG_OPT_CONV_PC: producer / consumer kernel for the 128-channel five-tap convs

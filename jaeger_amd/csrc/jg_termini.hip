@@ -374,6 +374,76 @@ __global__ __launch_bounds__(256) void termini_single_kernel(const uint8_t *__re
   if (live && lane == 0) out[idx] = o;
 }
 
+// ---- records whose ends share no K matching bases ------------------------------------------------------------------------
+// JG_OPT_TERMINI_REPORT_MIN = K: an alignment of fewer than K columns may be reported as none.  Under this scoring an
+// alignment of L <= 50 columns is an exact run of L matches (and a longer one contains such a run), so an alignment of at
+// least K columns exists exactly when the two ends share K consecutive matching bases - directly (DTR) or with the
+// reverse complement (ITR: q[i ..] matches rc(ref) exactly when the reverse complement of the query K-mer occurs in the
+// reference as it lies in the record).  One workgroup per record: the reference's K-mers go into an LDS hash set (open
+// addressing, 2-bit codes, K <= 15), every query K-mer and its reverse complement is looked up; bit 0 / bit 1 of the
+// record's flag = a direct / an inverted alignment of >= K columns exists.  4 000-base scans: 8 000 inserts and probes instead
+// of 16 million cells; random sequence shares 13 bases in a quarter of them, 400-base scans in 0.3 %.
+constexpr unsigned SEED_EMPTY = 0xffffffffu;
+
+__global__ __launch_bounds__(256) void termini_seed_kernel(const uint8_t *__restrict__ bases, const TermRec *__restrict__ recs,
+                                                           int K, uint8_t *__restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const TermRec job = recs[blockIdx.x];
+  const int n = job.n, tid = threadIdx.x;
+  uint8_t *qc = smem, *rc = smem + SR_NMAX;
+  unsigned *table = reinterpret_cast<unsigned *>(smem + 2 * SR_NMAX);
+  __shared__ unsigned found;
+  int bits = 4;                                                     // slots = the power of two >= 2 n (<= 8 192)
+  while ((1 << bits) < 2 * n) ++bits;
+  const unsigned mask = (1u << bits) - 1u;
+  for (int j = tid; j < n; j += 256) {
+    qc[j] = (uint8_t)base_code(bases[job.q_off + j]);
+    rc[j] = (uint8_t)base_code(bases[job.r_off + j]);
+  }
+  for (unsigned q = tid; q <= mask; q += 256) table[q] = SEED_EMPTY;
+  if (tid == 0) found = 0u;
+  __syncthreads();
+  for (int j = tid; j + K <= n; j += 256) {
+    unsigned code = 0;
+    bool ok = true;
+    for (int t = 0; t < K; ++t) { const unsigned c = rc[j + t]; ok = ok && c < 4; code = (code << 2) | (c & 3u); }
+    if (!ok) continue;
+    unsigned h = (code * 2654435761u) >> (32 - bits);
+    for (;;) {
+      const unsigned old = atomicCAS(&table[h], SEED_EMPTY, code);
+      if (old == SEED_EMPTY || old == code) break;
+      h = (h + 1u) & mask;
+    }
+  }
+  __syncthreads();
+  unsigned mine = 0;
+  auto present = [&](unsigned code) {
+    unsigned h = (code * 2654435761u) >> (32 - bits);
+    for (;;) {
+      const unsigned v = table[h];
+      if (v == code) return true;
+      if (v == SEED_EMPTY) return false;
+      h = (h + 1u) & mask;
+    }
+  };
+  for (int i = tid; i + K <= n; i += 256) {
+    unsigned fwd = 0, rev = 0;
+    bool ok = true;
+    for (int t = 0; t < K; ++t) {
+      const unsigned c = qc[i + t];
+      ok = ok && c < 4;
+      fwd = (fwd << 2) | (c & 3u);
+      rev |= (3u - (c & 3u)) << (2 * t);                            // complement, first base last
+    }
+    if (!ok) continue;
+    if (!(mine & 1u) && present(fwd)) mine |= 1u;
+    if (!(mine & 2u) && present(rev)) mine |= 2u;
+  }
+  if (mine) atomicOr(&found, mine);
+  __syncthreads();
+  if (tid == 0) flags[blockIdx.x] = (uint8_t)found;
+}
+
 template <int R>
 static int launch_fast(const uint8_t *d_bases, const TermRec *d_recs, TermFast *d_out, int n_recs, hipStream_t s) {
   if (n_recs <= 0) return JG_OK;
@@ -460,18 +530,88 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
     d_bases = static_cast<const uint8_t *>(tmp_bases);
   }
   JG_HIP(hipMalloc(&d_recs, recs.size() * sizeof(TermRec)));
-  JG_HIP(hipMalloc(&d_fast, recs.size() * sizeof(TermFast)));
-  JG_HIP(hipMalloc(&d_out, recs.size() * 2 * sizeof(TermOut)));
   JG_HIP(hipMemcpyAsync(d_recs, recs.data(), recs.size() * sizeof(TermRec), hipMemcpyHostToDevice, s));
-  // pass 1: both scores of every record, one wave each; records sorted by scan length, one launch per strip height
-  {
+  std::vector<TermOut> host(recs.size() * 2);
+  std::vector<uint8_t> settled(host.size(), 0);          // 1: host[k] is final
+  std::vector<int> todo;                                 // records whose alignments go through the packed pass
+  todo.reserve(recs.size());
+  const int seed_k = e->termini_exact ? 0 : e->termini_report_min;
+  if (seed_k >= 2) {
+    // JG_OPT_TERMINI_REPORT_MIN: (1) which alignments have >= seed_k columns at all (termini_seed_kernel) - the others are
+    // reported as none; (2) of those, the ones that are one exact run (termini_single_kernel) are settled; the packed pass
+    // only sees records with an alignment that is neither
+    JG_REQUIRE(seed_k <= 15, JG_ERR_INVALID, "jg_terminal_repeats: JG_OPT_TERMINI_REPORT_MIN = %d (2 .. 15)", seed_k);
+    void *d_flags = nullptr, *d_j0 = nullptr, *d_o0 = nullptr;
+    struct Cleanup0 {
+      void **p[3];
+      ~Cleanup0() { for (void **q : p) if (*q) (void)hipFree(*q); }
+    } cleanup0{{&d_flags, &d_j0, &d_o0}};
+    JG_HIP(hipMalloc(&d_flags, recs.size()));
+    hipLaunchKernelGGL(termini_seed_kernel, dim3((unsigned)n_recs), dim3(256), (size_t)2 * SR_NMAX + 8192 * sizeof(unsigned), s,
+                       d_bases, static_cast<const TermRec *>(d_recs), seed_k, static_cast<uint8_t *>(d_flags));
+    JG_HIP(hipGetLastError());
+    std::vector<uint8_t> flags(recs.size());
+    JG_HIP(hipMemcpyAsync(flags.data(), d_flags, flags.size(), hipMemcpyDeviceToHost, s));
+    JG_HIP(hipStreamSynchronize(s));
+    std::vector<TermJob> jobs0;
+    std::vector<size_t> slot0;
+    for (size_t k = 0; k < host.size(); ++k) {
+      if ((flags[k / 2] >> (k & 1)) & 1) {
+        const TermRec &rc = recs[k / 2];
+        jobs0.push_back(TermJob{rc.q_off, rc.r_off, rc.n, (int32_t)(k & 1)});
+        slot0.push_back(k);
+      } else {
+        host[k] = TermOut{0, 0, 0, -1, -1};
+        settled[k] = 1;
+      }
+    }
+    if (!jobs0.empty()) {
+      JG_HIP(hipMalloc(&d_j0, jobs0.size() * sizeof(TermJob)));
+      JG_HIP(hipMalloc(&d_o0, jobs0.size() * sizeof(TermOut)));
+      JG_HIP(hipMemcpyAsync(d_j0, jobs0.data(), jobs0.size() * sizeof(TermJob), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(termini_single_kernel, dim3((unsigned)((jobs0.size() + 3) / 4)), dim3(256), (size_t)4 * 2 * SR_NMAX, s,
+                         d_bases, static_cast<const TermJob *>(d_j0), static_cast<TermOut *>(d_o0), (int)jobs0.size());
+      JG_HIP(hipGetLastError());
+      std::vector<TermOut> single(jobs0.size());
+      JG_HIP(hipMemcpyAsync(single.data(), d_o0, jobs0.size() * sizeof(TermOut), hipMemcpyDeviceToHost, s));
+      JG_HIP(hipStreamSynchronize(s));
+      for (size_t k = 0; k < jobs0.size(); ++k)
+        if (single[k].len > 0) {
+          host[slot0[k]] = single[k];
+          settled[slot0[k]] = 1;
+        }
+    }
+    for (int r = 0; r < n_recs; ++r)
+      if (!settled[(size_t)2 * r] || !settled[(size_t)2 * r + 1]) todo.push_back(r);
+  } else {
+    for (int r = 0; r < n_recs; ++r) todo.push_back(r);
+  }
+  // pass 1: both scores of the records left, one wave each; records sorted by scan length, one launch per strip height
+  if (!todo.empty()) {
+    const int n_todo = (int)todo.size();
+    std::vector<TermRec> sub;
     const TermRec *dr = static_cast<const TermRec *>(d_recs);
+    void *d_sub = nullptr;
+    struct Cleanup1 {
+      void **p;
+      ~Cleanup1() { if (*p) (void)hipFree(*p); }
+    } cleanup1{&d_sub};
+    if (n_todo != n_recs) {                      // (the subset keeps the order: still runs of one strip height)
+      sub.reserve(todo.size());
+      for (int r : todo) sub.push_back(recs[(size_t)r]);
+      JG_HIP(hipMalloc(&d_sub, sub.size() * sizeof(TermRec)));
+      JG_HIP(hipMemcpyAsync(d_sub, sub.data(), sub.size() * sizeof(TermRec), hipMemcpyHostToDevice, s));
+      dr = static_cast<const TermRec *>(d_sub);
+    }
+    const std::vector<TermRec> &rs = n_todo != n_recs ? sub : recs;
+    JG_HIP(hipMalloc(&d_fast, rs.size() * sizeof(TermFast)));
+    JG_HIP(hipMalloc(&d_out, rs.size() * 2 * sizeof(TermOut)));
     TermFast *df = static_cast<TermFast *>(d_fast);
     int a = 0, rc = JG_OK;
-    while (a < n_recs && rc == JG_OK) {          // records are sorted by scan length: one launch per run of a strip height
-      const int rows = fast_rows(recs[(size_t)a].n);
+    while (a < n_todo && rc == JG_OK) {          // one launch per run of a strip height
+      const int rows = fast_rows(rs[(size_t)a].n);
       int b = a;
-      while (b < n_recs && fast_rows(recs[(size_t)b].n) == rows) ++b;
+      while (b < n_todo && fast_rows(rs[(size_t)b].n) == rows) ++b;
       switch (rows) {
         case 7: rc = launch_fast<7>(d_bases, dr + a, df + a, b - a, s); break;
         case 8: rc = launch_fast<8>(d_bases, dr + a, df + a, b - a, s); break;
@@ -485,25 +625,30 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
       a = b;
     }
     if (rc != JG_OK) return rc;
-    hipLaunchKernelGGL(termini_finish_kernel, dim3((unsigned)((2 * n_recs + 255) / 256)), dim3(256), 0, s, d_bases, dr, df,
-                       static_cast<TermOut *>(d_out), n_recs);
+    hipLaunchKernelGGL(termini_finish_kernel, dim3((unsigned)((2 * n_todo + 255) / 256)), dim3(256), 0, s, d_bases, dr, df,
+                       static_cast<TermOut *>(d_out), n_todo);
     JG_HIP(hipGetLastError());
+    std::vector<TermOut> part((size_t)n_todo * 2);
+    JG_HIP(hipMemcpyAsync(part.data(), d_out, part.size() * sizeof(TermOut), hipMemcpyDeviceToHost, s));
+    JG_HIP(hipStreamSynchronize(s));
+    for (int q = 0; q < n_todo; ++q)
+      for (int h = 0; h < 2; ++h) {
+        const size_t k = (size_t)2 * todo[(size_t)q] + h;
+        if (!settled[k]) host[k] = part[(size_t)2 * q + h];
+      }
   }
-  std::vector<TermOut> host(recs.size() * 2);
-  JG_HIP(hipMemcpyAsync(host.data(), d_out, host.size() * sizeof(TermOut), hipMemcpyDeviceToHost, s));
-  JG_HIP(hipStreamSynchronize(s));
   // pass 2: the alignments that scored above 100 (real repeats).  First the check for "one exact run, nothing else"
   // (termini_single_kernel: a wave each); what it does not settle - two long runs, mismatches or gaps inside the repeat -
   // goes through the kernel that carries length and gaps
   std::vector<TermJob> jobs;
   std::vector<size_t> slot;
   for (size_t k = 0; k < host.size(); ++k)
-    if (host[k].len < 0 || e->termini_exact) {
+    if (!settled[k] && (host[k].len < 0 || e->termini_exact)) {
       const TermRec &rc = recs[k / 2];
       jobs.push_back(TermJob{rc.q_off, rc.r_off, rc.n, (int32_t)(k & 1)});
       slot.push_back(k);
     }
-  if (!jobs.empty() && !e->termini_exact) {
+  if (!jobs.empty() && !e->termini_exact && seed_k < 2) {        // (with a seed length the one-run check has already run)
     void *d_j1 = nullptr, *d_o1 = nullptr;
     struct Cleanup2 {
       void **p[2];

@@ -618,8 +618,9 @@ def run_core(**kwargs) -> int:
     def scan_repeats(device):
         t_term = time.time()
         mark("repeat_scan_begin")
-        from .termini import RepeatColumns, terminal_repeat_table
-        table = terminal_repeat_table(device, fa, fsize)
+        from .termini import REPORT_MIN_COLUMNS, RepeatColumns, terminal_repeat_table
+        # (alignments of at most 12 columns never reach the table: the scan may skip them - same repeat columns)
+        table = terminal_repeat_table(device, fa, fsize, report_min=REPORT_MIN_COLUMNS)
         mark("repeat_table_done")
         rep = RepeatColumns(table, fa.names, fa.lengths)       # (the DataFrame form only where something asks for it)
         LAST_RUN["terminal_repeats_s"] = round(time.time() - t_term, 3)

@@ -16,10 +16,17 @@ import pandas as pd
 from . import _lib as L
 
 
-def terminal_repeat_table(device, fa, fsize: int) -> np.ndarray:
+REPORT_MIN_COLUMNS = 13       # the decision rule reads alignments of MORE than 12 columns (termini.py:137-154)
+
+
+def terminal_repeat_table(device, fa, fsize: int, report_min: int = 0) -> np.ndarray:
     """(n_records, 10) int32 from ``jg_terminal_repeats``: per record DTR then ITR (score, alignment length, query gaps,
-    end in the query, end in the reference); -1 rows for records shorter than ``fsize``."""
+    end in the query, end in the reference); -1 rows for records shorter than ``fsize``.  ``report_min`` (0, or 2 .. 15):
+    alignments of fewer columns may come back as none (``JG_OPT_TERMINI_REPORT_MIN``) - ``REPORT_MIN_COLUMNS`` leaves
+    every row of :class:`RepeatColumns` as it is and skips the dynamic programme for most records."""
     n = len(fa)
+    L.check(device.lib.jg_engine_set_option(device.handle, L.JG_OPT_TERMINI_REPORT_MIN, int(report_min)),
+            "jg_engine_set_option")
     res = np.full((max(n, 1), 10), -1, np.int32)
     bases = np.ascontiguousarray(fa.bases, np.uint8)
     offsets = np.ascontiguousarray(fa.offsets, np.int64)

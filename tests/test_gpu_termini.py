@@ -212,3 +212,63 @@ def test_single_run_shortcut_equals_exact_kernel():
     assert (exact[:, 0] > 100).sum() > 1200 and (exact[:, 2] > 0).sum() > 3         # real repeats, some with gaps
     bad = np.nonzero((fast != exact).any(axis=1))[0]
     assert bad.size == 0, (bad[:5], fast[bad[:5]], exact[bad[:5]])
+
+
+def test_report_min_leaves_the_decision_rule_as_it_is():
+    """JG_OPT_TERMINI_REPORT_MIN = 13 (what run_core sets): records whose ends share no 13 matching bases skip the dynamic
+    programme, one-run repeats are settled by the 32-mer check alone - the decision rule's columns (kind, length, score of
+    every record: termini.RepeatColumns) equal the exact scan's, and every alignment of at least 13 columns comes back with
+    the same five numbers.  Random records of every strip-height class, planted repeats of 8 - 45 bases (both sides of the
+    13-column line), real repeats, overlapping ends, N runs, the adversarial shapes of the one-run test."""
+    from jaeger_amd import fragment as frag
+    from jaeger_amd.termini import REPORT_MIN_COLUMNS, RepeatColumns, terminal_repeat_table
+    from jaeger_amd.engine import HipDevice
+    from oracle.termini import reverse_complement
+    rng = np.random.Generator(np.random.PCG64(99))
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    seqs = []
+    for r in range(2500):
+        n = int(np.exp(rng.uniform(np.log(500), np.log(160_000))))
+        s = acgt[rng.integers(0, 4, n)].copy()
+        u = rng.random()
+        if u < 0.5 and n > 1200:                       # a short repeat between the two scanned ends (direct or inverted)
+            k = int(rng.integers(8, 46))
+            a, b = int(rng.integers(0, 350 - k)), n - int(rng.integers(k, 350))
+            piece = bytes(s[a:a + k])
+            s[b:b + k] = np.frombuffer(piece if u < 0.25 else reverse_complement(piece.decode()).encode(), np.uint8)
+        elif u < 0.56 and n > 3000:                    # a real one, now and then with a mismatch inside
+            k = int(rng.integers(60, 300))
+            s[n - k:] = s[:k]
+            if rng.random() < 0.4:
+                s[n - k + k // 2] = acgt[(int(np.nonzero(acgt == s[k // 2])[0][0]) + 1) % 4]
+        if rng.random() < 0.2:
+            p = int(rng.integers(0, n - 20))
+            s[p:p + int(rng.integers(1, 20))] = ord("N")
+        if rng.random() < 0.2:
+            p = int(rng.integers(0, n - 50))
+            s[p:p + 50] |= 0x20
+        if r % 211 == 0:
+            s[:] = ord("A")
+        seqs.append(bytes(s))
+    bases, offsets = frag.concat_records(seqs)
+    names = [f"r{i}" for i in range(len(seqs))]
+    fa = frag.FastaBatch(names, bases, offsets)
+    dev = HipDevice(0)
+    exact = terminal_repeat_table(dev, fa, 500)
+    quick = terminal_repeat_table(dev, fa, 500, report_min=REPORT_MIN_COLUMNS)
+    again = terminal_repeat_table(dev, fa, 500)            # (the option is set per call: back to the exact table)
+    dev.close()
+    np.testing.assert_array_equal(again, exact)
+    skipped = int(((quick[:, 1] == 0) & (quick[:, 6] == 0)).sum())
+    assert skipped > 1000, skipped                        # most records never reach the dynamic programme
+    for col in (0, 5):                                    # every alignment of >= 13 columns: the same five numbers
+        long_enough = exact[:, col + 1] >= REPORT_MIN_COLUMNS
+        assert long_enough.sum() > 300
+        np.testing.assert_array_equal(quick[long_enough, col:col + 5], exact[long_enough, col:col + 5])
+        assert (quick[~long_enough, col + 1] < REPORT_MIN_COLUMNS).all()
+    a, b = RepeatColumns(exact, names, fa.lengths), RepeatColumns(quick, names, fa.lengths)
+    np.testing.assert_array_equal(a.keep, b.keep)
+    assert a.n_found == b.n_found > 300
+    assert (a.kind == b.kind).all()
+    np.testing.assert_array_equal(a.length, b.length)
+    np.testing.assert_array_equal(a.score, b.score)
