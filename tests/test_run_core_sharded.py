@@ -111,7 +111,7 @@ def _run(out_dir, fasta, model_root, min_len, no_pipeline=True, dust_host=False)
     T.scan_for_terminal_repeats = lambda device, fa, fsize: pd.DataFrame(
         {"contig_id": [n.strip().replace(",", "___") for n, ln in zip(fa.names, fa.lengths.tolist()) if ln >= fsize],
          "terminal_repeats": None, "repeat_length": np.nan})
-    T.terminal_repeat_table = lambda device, fa, fsize: np.where(
+    T.terminal_repeat_table = lambda device, fa, fsize, report_min=0: np.where(
         (fa.lengths >= fsize)[:, None], np.zeros((len(fa), 10), np.int32), np.int32(-1)).astype(np.int32)
     return run_core(input=str(fasta), output=str(out_dir), model_path=str(model_root), fsize=1500, stride=1500,
                     min_len=min_len, batch=2, dustmask=True, rc=0.1, pc=1, overwrite=True, verbose=1,
