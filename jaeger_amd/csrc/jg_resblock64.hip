@@ -25,8 +25,8 @@
 // geometry known at compile time every LDS operand address is one register + an immediate offset - the run-time form needed
 // 35 registers more than the 256 a wave of a 512-thread workgroup has.
 //
-// Measured (MI355X, pyramid bench, 7 644 rows x 330 positions, k 5, d 2): 714 us per launch against 951 us for the two
-// conv launches it replaces.  Per step of 56 output positions the SIMD's matrix pipe is busy 3 840 of ~7 200 cycles: the
+// Measured (MI355X, pyramid bench, 7 644 rows x 330 positions, k 5, d 2): 676 - 683 us per launch against 951 us for the two
+// conv launches it replaces.  Per step of 56 output positions the SIMD's matrix pipe is busy 3 840 of ~6 900 cycles: the
 // epilogues' vector work (two transcendentals and ~25 other instructions per value pair, SGPR-spill traffic) only partly
 // hides beside the partner's dependency-paced MFMAs (phase stamps: -DR6_STAMP).
 #include <math.h>
