@@ -407,9 +407,70 @@ def test_positional_embeddings_compile_to_an_embedding_op_with_a_position_table(
     first = prog.ops[0]
     assert first.kind == L.OP_EMBED and first.k == POSITION_ROWS and first.w_off >= 0 and first.cout == plan.embedding_dim
     assert all(op.in_buf != L.JG_BUF_IDS and op.in_mask != L.JG_BUF_IDS for op in prog.ops[1:])
+    # the reference's own assertion (tests/unit/test_nnlib_v2_layers.py:187-192): the layer's output has its input's shape
+    assert tuple(ofwd.sinusoidal_position_embedding(torch.zeros(2, 6, 32, 8), 1000).shape) == (2, 6, 32, 8)
     rows = sinusoidal_position_rows(700, plan.embedding_dim, 1000.0)
     ref = ofwd.sinusoidal_position_embedding(torch.zeros(2, 6, 700, plan.embedding_dim), 1000.0)[0, 0].numpy()
     assert rows.dtype == np.float32 and np.abs(rows - ref).max() <= 2e-6          # (same libm: equal; see the oracle's note)
     assert np.allclose(rows[0, 0::2], 0.0) and np.allclose(rows[0, 1::2], 1.0)
     table = np.asarray(prog.blob[first.w_off:first.w_off + 700 * plan.embedding_dim]).reshape(700, -1)
     np.testing.assert_array_equal(table, rows)
+
+
+def _nmd_merge_builder_config():
+    """The model of the reference's ``tests/integration/test_builder_nmd_merge.py:13-90`` (data only): two convs with an
+    ``nmd`` layer each (16 and 8 channels), max pool, a three-class head."""
+    return {
+        "name": "test_nmd_merge", "classifier_out_dim": 3, "reliability_out_dim": 0,
+        "class_label_map": [{"class": "chromosome", "label": 0}, {"class": "virus", "label": 1}, {"class": "plasmid", "label": 2}],
+        "embedding": {"use_embedding_layer": True, "input_type": "translated", "strands": 2, "frames": 6,
+                      "input_shape": [6, None], "embedding_size": 64},
+        "string_processor": {"data_format": "numpy", "seq_onehot": False, "codon": "CODON", "codon_id": "CODON_ID", "crop_size": 100},
+        "representation_learner": {"hidden_layers": [
+            {"name": "masked_conv1d", "config": {"filters": 16, "kernel_size": 3}}, {"name": "nmd", "config": {}},
+            {"name": "activation", "config": {"activation": "gelu"}},
+            {"name": "masked_conv1d", "config": {"filters": 8, "kernel_size": 3}}, {"name": "nmd", "config": {}},
+            {"name": "activation", "config": {"activation": "gelu"}}], "pooling": "max"},
+        "classifier": {"input_shape": 8, "hidden_layers": [{"name": "dense", "config": {"units": 3, "activation": None}}]},
+    }
+
+
+def test_reference_builder_kats_for_nmd_merge():
+    """The reference's builder-level assertions for several NMD layers and their merge
+    (``tests/integration/test_builder_nmd_merge.py:93-185``, ``tests/unit/test_nnlib_v2_nmd.py:66-97``) on the plan and the
+    oracle's forward: concat -> a 24-wide nmd output and reliability input; sum / mean / max / weighted with target_dim 8 ->
+    8 wide; a reliability ``input_shape`` that disagrees raises "does not match"; no NMD tensor under a configured
+    reliability head raises "no NMD tensor"; an unknown mode raises ValueError."""
+    import copy
+
+    from jaeger_amd.plan import build_plan
+    from oracle import forward as ofwd
+    head = [{"name": "dense", "config": {"units": 1, "activation": None}}]
+    ids = np.random.default_rng(1).integers(1, 60, (4, 6, 40))
+    for merge, width in (({"mode": "concat"}, 24), ({"mode": "sum", "target_dim": 8}, 8), ({"mode": "mean", "target_dim": 8}, 8),
+                         ({"mode": "max", "target_dim": 8}, 8), ({"mode": "weighted", "target_dim": 8}, 8)):
+        cfg = _nmd_merge_builder_config()
+        cfg["reliability_model"] = {"merge": merge, "input_shape": width, "hidden_layers": copy.deepcopy(head)}
+        plan = build_plan(cfg)
+        assert plan.nmd_dims == [16, 8] and plan.nmd_dim == width and plan.reliability[0].cin == width
+        out = ofwd.forward(cfg, ofwd.random_weights(cfg, seed=2), ids)
+        assert out["nmd"].shape == (4, width) and out["reliability"].shape == (4, 1)
+    cfg = _nmd_merge_builder_config()
+    cfg["reliability_model"] = {"merge": {"mode": "sum", "target_dim": 8}, "input_shape": 999, "hidden_layers": head}
+    with pytest.raises(ValueError, match="does not match"):
+        build_plan(cfg)
+    cfg = _nmd_merge_builder_config()
+    cfg["representation_learner"]["hidden_layers"] = [{"name": "masked_conv1d", "config": {"filters": 16, "kernel_size": 3}},
+                                                      {"name": "activation", "config": {"activation": "gelu"}}]
+    cfg["classifier"]["input_shape"] = 16
+    cfg["reliability_model"] = {"merge": {"mode": "concat"}, "input_shape": 16, "hidden_layers": head}
+    with pytest.raises(ValueError, match="no NMD tensor"):
+        build_plan(cfg)
+    cfg = _nmd_merge_builder_config()
+    cfg["reliability_model"] = {"merge": {"mode": "unsupported"}, "hidden_layers": head}
+    with pytest.raises(ValueError):
+        build_plan(cfg)
+    cfg = _nmd_merge_builder_config()                      # differing widths need a target_dim (nmd.py:128-132)
+    cfg["reliability_model"] = {"merge": {"mode": "mean"}, "hidden_layers": head}
+    with pytest.raises(ValueError, match="target_dim is required"):
+        build_plan(cfg)
