@@ -453,6 +453,106 @@ static int launch_fast(const uint8_t *d_bases, const TermRec *d_recs, TermFast *
   return JG_OK;
 }
 
+// ---- the host side's four device stages: upload what the stage reads, launch, bring its results back ------------------
+struct DevBuf {                       // device allocation released with its scope
+  void *p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) {
+    JG_HIP(hipMalloc(&p, std::max<size_t>(bytes, 1)));
+    return JG_OK;
+  }
+  template <typename T>
+  T *as() const { return static_cast<T *>(p); }
+};
+
+template <typename T>
+static int upload(DevBuf &d, const std::vector<T> &v, hipStream_t s) {
+  int rc = d.alloc(v.size() * sizeof(T));
+  if (rc != JG_OK) return rc;
+  JG_HIP(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  return JG_OK;
+}
+
+template <typename T>
+static int download(std::vector<T> &v, const DevBuf &d, hipStream_t s) {
+  JG_HIP(hipMemcpyAsync(v.data(), d.p, v.size() * sizeof(T), hipMemcpyDeviceToHost, s));
+  JG_HIP(hipStreamSynchronize(s));
+  return JG_OK;
+}
+
+// which alignments of the records have at least k columns at all: bit 0 direct, bit 1 inverted (termini_seed_kernel)
+static int run_seeds(const uint8_t *d_bases, const TermRec *d_recs, int n_recs, int k, std::vector<uint8_t> &flags, hipStream_t s) {
+  DevBuf d_flags;
+  int rc = d_flags.alloc((size_t)n_recs);
+  if (rc != JG_OK) return rc;
+  hipLaunchKernelGGL(termini_seed_kernel, dim3((unsigned)n_recs), dim3(256), (size_t)2 * SR_NMAX + 8192 * sizeof(unsigned), s, d_bases,
+                     d_recs, k, d_flags.as<uint8_t>());
+  JG_HIP(hipGetLastError());
+  flags.resize((size_t)n_recs);
+  return download(flags, d_flags, s);
+}
+
+// alignments above 100 through the one-run check (exact = false: len = -1 where it settles nothing) or through the kernel
+// that carries length and gaps (exact = true)
+static int run_jobs(const uint8_t *d_bases, const std::vector<TermJob> &jobs, bool exact, std::vector<TermOut> &out, hipStream_t s) {
+  out.resize(jobs.size());
+  if (jobs.empty()) return JG_OK;
+  DevBuf d_jobs, d_out;
+  int rc = upload(d_jobs, jobs, s);
+  if (rc == JG_OK) rc = d_out.alloc(jobs.size() * sizeof(TermOut));
+  if (rc != JG_OK) return rc;
+  if (exact) {
+    int max_n = 0;
+    for (const TermJob &j : jobs) max_n = std::max(max_n, j.n);
+    const size_t smem = (size_t)((max_n + 15) & ~15) + 2 * TT * sizeof(int4) + TT * 12;
+    hipLaunchKernelGGL(termini_kernel, dim3((unsigned)jobs.size()), dim3(TT), smem, s, d_bases, d_jobs.as<const TermJob>(),
+                       d_out.as<TermOut>());
+  } else {
+    hipLaunchKernelGGL(termini_single_kernel, dim3((unsigned)((jobs.size() + 3) / 4)), dim3(256), (size_t)4 * 2 * SR_NMAX, s, d_bases,
+                       d_jobs.as<const TermJob>(), d_out.as<TermOut>(), (int)jobs.size());
+  }
+  JG_HIP(hipGetLastError());
+  return download(out, d_out, s);
+}
+
+// the packed pass + its finish kernel over records sorted by scan length (d_recs: their device copy): both alignments of
+// every record, out[2 r + {0, 1}]; one launch per run of a strip height
+static int run_packed(const uint8_t *d_bases, const std::vector<TermRec> &recs, const TermRec *d_recs, std::vector<TermOut> &out,
+                      hipStream_t s) {
+  const int n = (int)recs.size();
+  out.resize((size_t)2 * n);
+  if (n == 0) return JG_OK;
+  DevBuf d_fast, d_out;
+  int rc = d_fast.alloc((size_t)n * sizeof(TermFast));
+  if (rc == JG_OK) rc = d_out.alloc((size_t)2 * n * sizeof(TermOut));
+  TermFast *df = d_fast.as<TermFast>();
+  int a = 0;
+  while (a < n && rc == JG_OK) {
+    const int rows = fast_rows(recs[(size_t)a].n);
+    int b = a;
+    while (b < n && fast_rows(recs[(size_t)b].n) == rows) ++b;
+    switch (rows) {
+      case 7: rc = launch_fast<7>(d_bases, d_recs + a, df + a, b - a, s); break;
+      case 8: rc = launch_fast<8>(d_bases, d_recs + a, df + a, b - a, s); break;
+      case 12: rc = launch_fast<12>(d_bases, d_recs + a, df + a, b - a, s); break;
+      case 16: rc = launch_fast<16>(d_bases, d_recs + a, df + a, b - a, s); break;
+      case 24: rc = launch_fast<24>(d_bases, d_recs + a, df + a, b - a, s); break;
+      case 32: rc = launch_fast<32>(d_bases, d_recs + a, df + a, b - a, s); break;
+      case 48: rc = launch_fast<48>(d_bases, d_recs + a, df + a, b - a, s); break;
+      default: rc = launch_fast<64>(d_bases, d_recs + a, df + a, b - a, s); break;
+    }
+    a = b;
+  }
+  if (rc != JG_OK) return rc;
+  hipLaunchKernelGGL(termini_finish_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, s, d_bases, d_recs, df,
+                     d_out.as<TermOut>(), n);
+  JG_HIP(hipGetLastError());
+  return download(out, d_out, s);
+}
+
 }  // namespace
 
 // results: (n_records, 10) int32 rows = DTR(score, len, fgaps, end_q, end_r), ITR(score, len, fgaps, end_q, end_r);
@@ -517,152 +617,80 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
   }
   const int n_recs = (int)recs.size();
   const uint8_t *d_bases = bases;
-  void *tmp_bases = nullptr, *d_recs = nullptr, *d_fast = nullptr, *d_out = nullptr, *d_jobs = nullptr, *d_out2 = nullptr;
-  struct Cleanup {
-    void **p[6];
-    ~Cleanup() { for (void **q : p) if (*q) (void)hipFree(*q); }
-  } cleanup{{&tmp_bases, &d_recs, &d_fast, &d_out, &d_jobs, &d_out2}};
+  DevBuf tmp_bases, d_recs;
+  int rc = JG_OK;
   if (bases_loc == JG_PTR_HOST) {
     const uint8_t *src = whole ? bases : ends.data();
     const size_t nb = whole ? (size_t)n_bases : ends.size();
-    JG_HIP(hipMalloc(&tmp_bases, std::max<size_t>(nb, 1)));
-    JG_HIP(hipMemcpyAsync(tmp_bases, src, nb, hipMemcpyHostToDevice, s));
-    d_bases = static_cast<const uint8_t *>(tmp_bases);
+    if ((rc = tmp_bases.alloc(nb)) != JG_OK) return rc;
+    JG_HIP(hipMemcpyAsync(tmp_bases.p, src, nb, hipMemcpyHostToDevice, s));
+    d_bases = tmp_bases.as<const uint8_t>();
   }
-  JG_HIP(hipMalloc(&d_recs, recs.size() * sizeof(TermRec)));
-  JG_HIP(hipMemcpyAsync(d_recs, recs.data(), recs.size() * sizeof(TermRec), hipMemcpyHostToDevice, s));
-  std::vector<TermOut> host(recs.size() * 2);
+  if ((rc = upload(d_recs, recs, s)) != JG_OK) return rc;
+  auto job_of = [&](size_t k) { return TermJob{recs[k / 2].q_off, recs[k / 2].r_off, recs[k / 2].n, (int32_t)(k & 1)}; };
+  std::vector<TermOut> host(recs.size() * 2);            // alignment k = 2 record + (0 direct | 1 inverted)
   std::vector<uint8_t> settled(host.size(), 0);          // 1: host[k] is final
-  std::vector<int> todo;                                 // records whose alignments go through the packed pass
-  todo.reserve(recs.size());
   const int seed_k = e->termini_exact ? 0 : e->termini_report_min;
   if (seed_k >= 2) {
-    // JG_OPT_TERMINI_REPORT_MIN: (1) which alignments have >= seed_k columns at all (termini_seed_kernel) - the others are
-    // reported as none; (2) of those, the ones that are one exact run (termini_single_kernel) are settled; the packed pass
-    // only sees records with an alignment that is neither
+    // JG_OPT_TERMINI_REPORT_MIN: (1) which alignments have >= seed_k columns at all - the others are reported as none;
+    // (2) of those, the ones that are one exact run are settled; the packed pass only sees records with an alignment
+    // that is neither
     JG_REQUIRE(seed_k <= 15, JG_ERR_INVALID, "jg_terminal_repeats: JG_OPT_TERMINI_REPORT_MIN = %d (2 .. 15)", seed_k);
-    void *d_flags = nullptr, *d_j0 = nullptr, *d_o0 = nullptr;
-    struct Cleanup0 {
-      void **p[3];
-      ~Cleanup0() { for (void **q : p) if (*q) (void)hipFree(*q); }
-    } cleanup0{{&d_flags, &d_j0, &d_o0}};
-    JG_HIP(hipMalloc(&d_flags, recs.size()));
-    hipLaunchKernelGGL(termini_seed_kernel, dim3((unsigned)n_recs), dim3(256), (size_t)2 * SR_NMAX + 8192 * sizeof(unsigned), s,
-                       d_bases, static_cast<const TermRec *>(d_recs), seed_k, static_cast<uint8_t *>(d_flags));
-    JG_HIP(hipGetLastError());
-    std::vector<uint8_t> flags(recs.size());
-    JG_HIP(hipMemcpyAsync(flags.data(), d_flags, flags.size(), hipMemcpyDeviceToHost, s));
-    JG_HIP(hipStreamSynchronize(s));
-    std::vector<TermJob> jobs0;
-    std::vector<size_t> slot0;
+    std::vector<uint8_t> flags;
+    if ((rc = run_seeds(d_bases, d_recs.as<const TermRec>(), n_recs, seed_k, flags, s)) != JG_OK) return rc;
+    std::vector<TermJob> jobs;
+    std::vector<size_t> slot;
     for (size_t k = 0; k < host.size(); ++k) {
       if ((flags[k / 2] >> (k & 1)) & 1) {
-        const TermRec &rc = recs[k / 2];
-        jobs0.push_back(TermJob{rc.q_off, rc.r_off, rc.n, (int32_t)(k & 1)});
-        slot0.push_back(k);
+        jobs.push_back(job_of(k));
+        slot.push_back(k);
       } else {
         host[k] = TermOut{0, 0, 0, -1, -1};
         settled[k] = 1;
       }
     }
-    if (!jobs0.empty()) {
-      JG_HIP(hipMalloc(&d_j0, jobs0.size() * sizeof(TermJob)));
-      JG_HIP(hipMalloc(&d_o0, jobs0.size() * sizeof(TermOut)));
-      JG_HIP(hipMemcpyAsync(d_j0, jobs0.data(), jobs0.size() * sizeof(TermJob), hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(termini_single_kernel, dim3((unsigned)((jobs0.size() + 3) / 4)), dim3(256), (size_t)4 * 2 * SR_NMAX, s,
-                         d_bases, static_cast<const TermJob *>(d_j0), static_cast<TermOut *>(d_o0), (int)jobs0.size());
-      JG_HIP(hipGetLastError());
-      std::vector<TermOut> single(jobs0.size());
-      JG_HIP(hipMemcpyAsync(single.data(), d_o0, jobs0.size() * sizeof(TermOut), hipMemcpyDeviceToHost, s));
-      JG_HIP(hipStreamSynchronize(s));
-      for (size_t k = 0; k < jobs0.size(); ++k)
-        if (single[k].len > 0) {
-          host[slot0[k]] = single[k];
-          settled[slot0[k]] = 1;
-        }
-    }
+    std::vector<TermOut> single;
+    if ((rc = run_jobs(d_bases, jobs, false, single, s)) != JG_OK) return rc;
+    for (size_t k = 0; k < jobs.size(); ++k)
+      if (single[k].len > 0) {
+        host[slot[k]] = single[k];
+        settled[slot[k]] = 1;
+      }
+  }
+  // pass 1: both scores of the records that still have an open alignment, one wave each
+  {
+    std::vector<int> todo;
     for (int r = 0; r < n_recs; ++r)
       if (!settled[(size_t)2 * r] || !settled[(size_t)2 * r + 1]) todo.push_back(r);
-  } else {
-    for (int r = 0; r < n_recs; ++r) todo.push_back(r);
-  }
-  // pass 1: both scores of the records left, one wave each; records sorted by scan length, one launch per strip height
-  if (!todo.empty()) {
-    const int n_todo = (int)todo.size();
-    std::vector<TermRec> sub;
-    const TermRec *dr = static_cast<const TermRec *>(d_recs);
-    void *d_sub = nullptr;
-    struct Cleanup1 {
-      void **p;
-      ~Cleanup1() { if (*p) (void)hipFree(*p); }
-    } cleanup1{&d_sub};
-    if (n_todo != n_recs) {                      // (the subset keeps the order: still runs of one strip height)
+    std::vector<TermRec> sub;                  // (a subset keeps the order: still runs of one strip height)
+    DevBuf d_sub;
+    const bool all = (int)todo.size() == n_recs;
+    if (!all) {
       sub.reserve(todo.size());
       for (int r : todo) sub.push_back(recs[(size_t)r]);
-      JG_HIP(hipMalloc(&d_sub, sub.size() * sizeof(TermRec)));
-      JG_HIP(hipMemcpyAsync(d_sub, sub.data(), sub.size() * sizeof(TermRec), hipMemcpyHostToDevice, s));
-      dr = static_cast<const TermRec *>(d_sub);
+      if ((rc = upload(d_sub, sub, s)) != JG_OK) return rc;
     }
-    const std::vector<TermRec> &rs = n_todo != n_recs ? sub : recs;
-    JG_HIP(hipMalloc(&d_fast, rs.size() * sizeof(TermFast)));
-    JG_HIP(hipMalloc(&d_out, rs.size() * 2 * sizeof(TermOut)));
-    TermFast *df = static_cast<TermFast *>(d_fast);
-    int a = 0, rc = JG_OK;
-    while (a < n_todo && rc == JG_OK) {          // one launch per run of a strip height
-      const int rows = fast_rows(rs[(size_t)a].n);
-      int b = a;
-      while (b < n_todo && fast_rows(rs[(size_t)b].n) == rows) ++b;
-      switch (rows) {
-        case 7: rc = launch_fast<7>(d_bases, dr + a, df + a, b - a, s); break;
-        case 8: rc = launch_fast<8>(d_bases, dr + a, df + a, b - a, s); break;
-        case 12: rc = launch_fast<12>(d_bases, dr + a, df + a, b - a, s); break;
-        case 16: rc = launch_fast<16>(d_bases, dr + a, df + a, b - a, s); break;
-        case 24: rc = launch_fast<24>(d_bases, dr + a, df + a, b - a, s); break;
-        case 32: rc = launch_fast<32>(d_bases, dr + a, df + a, b - a, s); break;
-        case 48: rc = launch_fast<48>(d_bases, dr + a, df + a, b - a, s); break;
-        default: rc = launch_fast<64>(d_bases, dr + a, df + a, b - a, s); break;
-      }
-      a = b;
-    }
-    if (rc != JG_OK) return rc;
-    hipLaunchKernelGGL(termini_finish_kernel, dim3((unsigned)((2 * n_todo + 255) / 256)), dim3(256), 0, s, d_bases, dr, df,
-                       static_cast<TermOut *>(d_out), n_todo);
-    JG_HIP(hipGetLastError());
-    std::vector<TermOut> part((size_t)n_todo * 2);
-    JG_HIP(hipMemcpyAsync(part.data(), d_out, part.size() * sizeof(TermOut), hipMemcpyDeviceToHost, s));
-    JG_HIP(hipStreamSynchronize(s));
-    for (int q = 0; q < n_todo; ++q)
+    std::vector<TermOut> part;
+    if ((rc = run_packed(d_bases, all ? recs : sub, (all ? d_recs : d_sub).as<const TermRec>(), part, s)) != JG_OK) return rc;
+    for (size_t q = 0; q < todo.size(); ++q)
       for (int h = 0; h < 2; ++h) {
-        const size_t k = (size_t)2 * todo[(size_t)q] + h;
-        if (!settled[k]) host[k] = part[(size_t)2 * q + h];
+        const size_t k = (size_t)2 * todo[q] + h;
+        if (!settled[k]) host[k] = part[2 * q + h];
       }
   }
-  // pass 2: the alignments that scored above 100 (real repeats).  First the check for "one exact run, nothing else"
-  // (termini_single_kernel: a wave each); what it does not settle - two long runs, mismatches or gaps inside the repeat -
-  // goes through the kernel that carries length and gaps
+  // pass 2: the alignments that scored above 100 (real repeats).  First the check for "one exact run, nothing else" (a wave
+  // each; with a seed length it has already run); what it does not settle - two long runs, mismatches or gaps inside the
+  // repeat - goes through the kernel that carries length and gaps
   std::vector<TermJob> jobs;
   std::vector<size_t> slot;
   for (size_t k = 0; k < host.size(); ++k)
     if (!settled[k] && (host[k].len < 0 || e->termini_exact)) {
-      const TermRec &rc = recs[k / 2];
-      jobs.push_back(TermJob{rc.q_off, rc.r_off, rc.n, (int32_t)(k & 1)});
+      jobs.push_back(job_of(k));
       slot.push_back(k);
     }
-  if (!jobs.empty() && !e->termini_exact && seed_k < 2) {        // (with a seed length the one-run check has already run)
-    void *d_j1 = nullptr, *d_o1 = nullptr;
-    struct Cleanup2 {
-      void **p[2];
-      ~Cleanup2() { for (void **q : p) if (*q) (void)hipFree(*q); }
-    } cleanup2{{&d_j1, &d_o1}};
-    JG_HIP(hipMalloc(&d_j1, jobs.size() * sizeof(TermJob)));
-    JG_HIP(hipMalloc(&d_o1, jobs.size() * sizeof(TermOut)));
-    JG_HIP(hipMemcpyAsync(d_j1, jobs.data(), jobs.size() * sizeof(TermJob), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(termini_single_kernel, dim3((unsigned)((jobs.size() + 3) / 4)), dim3(256), (size_t)4 * 2 * SR_NMAX, s,
-                       d_bases, static_cast<const TermJob *>(d_j1), static_cast<TermOut *>(d_o1), (int)jobs.size());
-    JG_HIP(hipGetLastError());
-    std::vector<TermOut> single(jobs.size());
-    JG_HIP(hipMemcpyAsync(single.data(), d_o1, jobs.size() * sizeof(TermOut), hipMemcpyDeviceToHost, s));
-    JG_HIP(hipStreamSynchronize(s));
+  if (!jobs.empty() && !e->termini_exact && seed_k < 2) {
+    std::vector<TermOut> single;
+    if ((rc = run_jobs(d_bases, jobs, false, single, s)) != JG_OK) return rc;
     size_t kept = 0;
     for (size_t k = 0; k < jobs.size(); ++k) {
       // (the score is the packed pass's: a run that is not the whole story would not match it)
@@ -677,21 +705,9 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
     jobs.resize(kept);
     slot.resize(kept);
   }
-  int max_n2 = 0;
-  for (const TermJob &j : jobs) max_n2 = std::max(max_n2, j.n);
-  if (!jobs.empty()) {
-    JG_HIP(hipMalloc(&d_jobs, jobs.size() * sizeof(TermJob)));
-    JG_HIP(hipMalloc(&d_out2, jobs.size() * sizeof(TermOut)));
-    JG_HIP(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(TermJob), hipMemcpyHostToDevice, s));
-    const size_t smem = (size_t)((max_n2 + 15) & ~15) + 2 * TT * sizeof(int4) + TT * 12;
-    hipLaunchKernelGGL(termini_kernel, dim3((unsigned)jobs.size()), dim3(TT), smem, s, d_bases,
-                       static_cast<const TermJob *>(d_jobs), static_cast<TermOut *>(d_out2));
-    JG_HIP(hipGetLastError());
-    std::vector<TermOut> exact(jobs.size());
-    JG_HIP(hipMemcpyAsync(exact.data(), d_out2, jobs.size() * sizeof(TermOut), hipMemcpyDeviceToHost, s));
-    JG_HIP(hipStreamSynchronize(s));
-    for (size_t k = 0; k < jobs.size(); ++k) host[slot[k]] = exact[k];
-  }
+  std::vector<TermOut> exact;
+  if ((rc = run_jobs(d_bases, jobs, true, exact, s)) != JG_OK) return rc;
+  for (size_t k = 0; k < jobs.size(); ++k) host[slot[k]] = exact[k];
   for (size_t k = 0; k < host.size(); ++k) {
     int32_t *dst = results + owner[k / 2] * 10 + (k % 2) * 5;
     dst[0] = host[k].score; dst[1] = host[k].len; dst[2] = host[k].fgaps; dst[3] = host[k].end_q; dst[4] = host[k].end_r;
