@@ -251,10 +251,12 @@ def e2e_leg(cfg, weights, wl, fsize, records: int = 0, seed: int | None = None):
         out = tmp / "out"
         runs = []
         for _ in range(2):
+            P.wait_for_release()             # the run before has given its device memory and pinned staging back
             t0 = time.perf_counter()
             n_rows = P.run_core(input=str(fa), output=str(out), model_path=str(tmp / "model_root"), fsize=fsize, stride=fsize,
                                 overwrite=True, dustmask=True, verbose=0, batch=96, rc=0.1, pc=3)
             runs.append((time.perf_counter() - t0, {k: v for k, v in P.LAST_RUN.items() if k not in ("timeline", "t_start_epoch")}))
+        P.wait_for_release()
         dt, stages = min(runs, key=lambda r: r[0])
         tsv = next(out.rglob("bench.tsv"), None)
         what = (f"{records} records of exactly {fsize} bp as a FASTA (tmpfs)" if records else
@@ -392,6 +394,11 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="tests only: let the N ranks share the visible GPUs (rank r on GPU r %% visible) and exchange "
                          "over gloo instead of RCCL, so that the N-rank launch can be exercised on a 1-GPU box")
+    ap.add_argument("--collective", choices=["auto", "nccl"], default="auto",
+                    help="'nccl': take the N-rank exchange path over RCCL even with ONE rank (world 1: init_process_group on "
+                         "the device, the padded gather of the logits on device tensors inside the timed region, the "
+                         "all_gather of the per-rank statistics, barrier, destroy) - first contact for the collective code "
+                         "on a one-GPU box; a failure prints the RCCL / HIP error and exits non-zero, there is no gloo fallback")
     ap.add_argument("--rank-timeout", type=float, default=1800.0,
                     help="--gpus N outside torchrun: seconds after which the child ranks are killed (exit 124)")
     ap.add_argument("--rank-seed", type=int, default=None,
@@ -432,20 +439,32 @@ def main():
     # the ranks of a node share its cores: every rank generates its own contigs and runs its own host threads
     lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     torch.set_num_threads(max(1, min(cpu_quota()) // lws))
-    if world > 1:
+    coll = world > 1 or args.collective == "nccl"           # the exchange path: every N > 1 run, and world 1 on request
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.oversubscribe:
-            dist.init_process_group("gloo")
+        if "MASTER_PORT" not in os.environ:                  # (world 1 outside torchrun)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        if args.oversubscribe and world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            except Exception as e:                           # noqa: BLE001 - surfaced, never replaced by another backend
+                print(f"bench.py: RCCL initialisation failed on rank {rank} (HSA_ENABLE_IPC_MODE_LEGACY="
+                      f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}): {type(e).__name__}: {e}", file=sys.stderr)
+                raise
     dev_t = torch.device("cuda", local_rank)
     coll_dev = torch.device("cpu") if (world > 1 and args.oversubscribe) else dev_t
 
-    ctx = dict(torch=torch, dist=dist, rank=rank, world=world, local_rank=local_rank, dev_t=dev_t, coll_dev=coll_dev)
+    ctx = dict(torch=torch, dist=dist, rank=rank, world=world, local_rank=local_rank, dev_t=dev_t, coll_dev=coll_dev,
+               coll=coll)
     line = measure(args, args.config, args.steps, args.warmup, ctx, headline=True)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if coll:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -468,6 +487,7 @@ def measure(args, name: str, steps: int, warmup: int, ctx: dict, headline: bool)
 
     torch, dist = ctx["torch"], ctx["dist"]
     rank, world, local_rank, dev_t, coll_dev = ctx["rank"], ctx["world"], ctx["local_rank"], ctx["dev_t"], ctx["coll_dev"]
+    coll = ctx["coll"]
     wl = CONFIGS[name]
     cfg = yaml.safe_load((ROOT / "tests" / "golden" / f"{wl['model']}_project.yaml").read_text())["model"]
     weights = random_weights(build_plan(cfg), seed=38341)
@@ -526,14 +546,14 @@ def measure(args, name: str, steps: int, warmup: int, ctx: dict, headline: bool)
         eng.device.sync()
         tb = time.perf_counter()
         got = None
-        if world > 1:                       # the final gather of per-window logits to rank 0
+        if coll:                            # the final gather of per-window logits to rank 0
             got = jdist.gather_rows(d_pred.to(coll_dev), dst=0)
         split["compute_s"] += tb - ta
         split["gather_s"] += time.perf_counter() - tb
         return got
 
     def fence():
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -561,7 +581,7 @@ def measure(args, name: str, steps: int, warmup: int, ctx: dict, headline: bool)
 
     t = torch.tensor([dt, float(bp_per_step), float(n_win), split["compute_s"], split["gather_s"]], dtype=torch.float64,
                      device=coll_dev)
-    if world > 1:
+    if coll:
         rows = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(rows, t)
         per_rank = torch.stack(rows).cpu().numpy()
@@ -612,7 +632,9 @@ def measure(args, name: str, steps: int, warmup: int, ctx: dict, headline: bool)
                        "name": name,
                        "windows_per_gpu": int(win_total / world), "bp_per_gpu": int(bp_total / world),
                        "windows_per_gpu_min": int(per_rank[:, 2].min()), "windows_per_gpu_max": int(per_rank[:, 2].max()),
-                       "parallelism": f"contig-sharded x{world}, final {'gloo (test mode)' if args.oversubscribe and world > 1 else 'RCCL'} gather",
+                       "parallelism": f"contig-sharded x{world}, final {'gloo (test mode)' if args.oversubscribe and world > 1 else 'RCCL'} gather"
+                                      + (" (executed)" if coll else " (one rank: no exchange)"),
+                       "collective_backend": (dist.get_backend() if coll else None),
                        "outputs": "prediction + reliability + G/C/A/T counts per window stay in HBM (the logits are "
                                   "gathered); embedding / nmd vectors (InferModel.predict also returns them, 2.6 kB "
                                   "per window) are computed but not copied out in the timed region"},

@@ -151,7 +151,7 @@ def load():
     # `python -m jaeger_amd` outside torchrun) skips the ~2 s import and binds the ROCm copy.
     import sys
     want_torch = os.environ.get("JAEGER_HIP_TORCH", "1") != "0" or "torch" in sys.modules \
-        or int(os.environ.get("WORLD_SIZE", "1")) > 1
+        or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("JAEGER_SHARDED") == "1"
     if want_torch:
         try:
             import torch  # noqa: F401

@@ -78,11 +78,25 @@ __device__ __forceinline__ void glds16(const void *sbase, unsigned voff, unsigne
 // weight slices every workgroup of the XCD keeps re-reading from L2
 __device__ __forceinline__ void glds16_nt(const void *sbase, unsigned voff, unsigned lds_addr) {
   unsigned keep;
+#ifdef JG_EXP_NO_NT
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+#else
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+#endif
                : "=&s"(keep)
                : "v"(voff), "s"(sbase), "s"(lds_addr)
                : "memory");
 }
+// Streamed (read-once / written-once) global accesses of the conv kernels: non-temporal.  -DJG_EXP_NO_NT (experiment build
+// only, scripts/r6_mall.sh round 6): the same accesses with the default cache policy, to see whether the nt hint is what
+// keeps a small pass's tensors out of the Infinity Cache.
+#ifdef JG_EXP_NO_NT
+template <typename T> __device__ __forceinline__ void st_stream(T v, T *p) { *p = v; }
+template <typename T> __device__ __forceinline__ T ld_stream(const T *p) { return *p; }
+#else
+template <typename T> __device__ __forceinline__ void st_stream(T v, T *p) { __builtin_nontemporal_store(v, p); }
+template <typename T> __device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontemporal_load(p); }
+#endif
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

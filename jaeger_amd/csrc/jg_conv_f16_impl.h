@@ -738,10 +738,10 @@ void conv_f16x3_kernel(ConvHArgs a) {
         if constexpr (HAS_ADD) {
           if (!(a.dbg & 128)) {
             const unsigned it0 = ob[tm] + (unsigned)(2 * tn) * L4, it1 = it0 + L4;
-            q.sh0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.addh + it0));
-            q.sl0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.addh + it0 + 2u * (unsigned)a.L_out));
-            q.sh1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.addh + it1));
-            q.sl1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.addh + it1 + 2u * (unsigned)a.L_out));
+            q.sh0 = ld_stream(reinterpret_cast<const u32x4 *>(a.addh + it0));
+            q.sl0 = ld_stream(reinterpret_cast<const u32x4 *>(a.addh + it0 + 2u * (unsigned)a.L_out));
+            q.sh1 = ld_stream(reinterpret_cast<const u32x4 *>(a.addh + it1));
+            q.sl1 = ld_stream(reinterpret_cast<const u32x4 *>(a.addh + it1 + 2u * (unsigned)a.L_out));
           } else {
             q.sh0 = q.sh1 = q.sl0 = q.sl1 = u32x4{0u, 0u, 0u, 0u};
           }
@@ -865,8 +865,8 @@ void conv_f16x3_kernel(ConvHArgs a) {
                 uint4 *yh = reinterpret_cast<uint4 *>(a.y);
                 const unsigned it4 = ob[tm] + (unsigned)(2 * tn + j) * L4;
                 const u32x4 vhi = {hp[0], hp[1], hp[2], hp[3]}, vlo = {lp[0], lp[1], lp[2], lp[3]};
-                __builtin_nontemporal_store(vhi, reinterpret_cast<u32x4 *>(yh + it4));
-                __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)a.L_out));
+                st_stream(vhi, reinterpret_cast<u32x4 *>(yh + it4));
+                st_stream(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)a.L_out));
               }
             } else if (a.pool_out != nullptr) {
 #pragma unroll
@@ -975,8 +975,8 @@ void conv_f16x3_kernel(ConvHArgs a) {
             const unsigned it4 = item4(orow, mc, (!GEN || nb + ch0 + 16 * j < a.cout) ? nb : 0, j);
             // (read once, like the activation slices: non-temporal)
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 nh = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.addh + it4));   // whole item of group 2j+h
-            const u32x4 nl = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.addh + it4 + 2u * (unsigned)a.L_out));
+            const u32x4 nh = ld_stream(reinterpret_cast<const u32x4 *>(a.addh + it4));   // whole item of group 2j+h
+            const u32x4 nl = ld_stream(reinterpret_cast<const u32x4 *>(a.addh + it4 + 2u * (unsigned)a.L_out));
             uint4 vh = make_uint4(nh[0], nh[1], nh[2], nh[3]);
             uint4 vl = make_uint4(nl[0], nl[1], nl[2], nl[3]);
             // give each lane back its own 4 channels of groups 2j and 2j+1
@@ -1177,14 +1177,14 @@ void conv_f16x3_kernel(ConvHArgs a) {
                                  __float_as_uint(x[8 + 4 * j + 2]), __float_as_uint(x[8 + 4 * j + 3])};
               // the output (1.5 GB per launch) is read next by another launch, far beyond any cache:
               // streamed (nt) rather than write-allocated in L2 (+1.3 % measured)
-              __builtin_nontemporal_store(vhi, reinterpret_cast<u32x4 *>(yh + it4));
-              __builtin_nontemporal_store(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)L_st));
+              st_stream(vhi, reinterpret_cast<u32x4 *>(yh + it4));
+              st_stream(vlo, reinterpret_cast<u32x4 *>(yh + it4 + 2u * (unsigned)L_st));
               if (GEN && psplit && (a.L_out & 1) && mc == a.L_out - 1) {
                 // an odd row length: the odd phase is one position short - its last slot (position L_out) reads as zero
                 const unsigned itz = it4 + (unsigned)((a.cout_pad >> 4) * 4 * L_st);
                 const u32x4 z = {0u, 0u, 0u, 0u};
-                __builtin_nontemporal_store(z, reinterpret_cast<u32x4 *>(yh + itz));
-                __builtin_nontemporal_store(z, reinterpret_cast<u32x4 *>(yh + itz + 2u * (unsigned)L_st));
+                st_stream(z, reinterpret_cast<u32x4 *>(yh + itz));
+                st_stream(z, reinterpret_cast<u32x4 *>(yh + itz + 2u * (unsigned)L_st));
               }
             }
           } else {

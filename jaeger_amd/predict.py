@@ -307,6 +307,24 @@ SHARD_STATS: dict = {}        # filled by the sharded path (tests read it): loca
 LAST_RUN: dict = {}           # stage split of the last single-GPU run_core of this process (bench.py's e2e leg reads it)
 
 
+_PENDING_RELEASE: list = []      # threads still releasing a finished run's engine / host buffers
+
+
+def wait_for_release(timeout: float | None = 60.0) -> None:
+    """Join the background release of earlier ``run_core`` calls (device memory and pinned staging are back when this
+    returns).  ``run_core`` calls it on entry, so two runs never overlap one's teardown with the other's forward."""
+    while _PENDING_RELEASE:
+        _PENDING_RELEASE.pop().join(timeout)
+
+
+def _close_process_group():
+    """Destroy the process group if ``_predict_sharded`` created it (a caller's own group is left alone)."""
+    if SHARD_STATS.pop("own_process_group", False):
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
 def _coll_device(local_rank: int):
     import torch
     import torch.distributed as dist
@@ -347,11 +365,26 @@ def _predict_sharded(make_engine, input_path, fsize, stride, user_min_len, min_l
     from . import dist as jdist
     from .termini import repeats_frame, terminal_repeat_table
     if not dist.is_initialized():
+        SHARD_STATS["own_process_group"] = True          # run_core destroys what it created
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
         # RCCL ("nccl") when GPUs are there; JAEGER_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
-        dist.init_process_group(os.environ.get("JAEGER_DIST_BACKEND") or
-                                ("nccl" if torch.cuda.is_available() else "gloo"))
+        backend = os.environ.get("JAEGER_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ and world == 1:      # one rank outside torchrun (JAEGER_SHARDED=1)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        try:
+            if backend == "nccl":
+                dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        except Exception as e:              # no fallback to another backend: the error is the result
+            lg.error(f"could not initialise the {backend} process group on rank {rank}/{world} "
+                     f"(HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}): {type(e).__name__}: {e}")
+            raise
     dev = _coll_device(local_rank)
 
     def all_ok(ok: bool) -> bool:
@@ -482,6 +515,7 @@ def run_core(**kwargs) -> int:
 
     from .engine import JaegerHipEngine
 
+    wait_for_release()
     t_start = time.time()
     LAST_RUN.clear()
     timeline: list = []                     # (event, seconds since run_core was entered): where the wall time of a short run goes
@@ -642,10 +676,14 @@ def run_core(**kwargs) -> int:
     term_repeats = None
     class_map = None
     t_predict = time.time()
-    if world > 1:
+    # JAEGER_SHARDED=1: take the sharded path whatever the world size - with ONE rank under torchrun every collective of the
+    # 8-GPU run (init over RCCL, broadcasts, the error all_reduce, both padded gathers, barrier) executes on the one GPU
+    sharded = world > 1 or os.environ.get("JAEGER_SHARDED") == "1"
+    if sharded:
         got = _predict_sharded(make_engine, input_path, fsize, stride, user_min_len, min_len, dust, common, want, lg,
                                rank, world, local_rank, log_setup)
         if got is None:                 # ranks other than 0 are done after the gather
+            _close_process_group()
             return 0
         y_pred, term_repeats, class_map = got["y_pred"], got["term_repeats"], got["class_map"]
         num, t_ingest, t_predict = got["num"], got["t_ingest"], got["t_predict"]
@@ -775,7 +813,7 @@ def run_core(**kwargs) -> int:
     t_post = time.time()
 
     from .postprocess import pred_to_dict, write_output
-    if world > 1:
+    if sharded:
         data, data_full = pred_to_dict(y_pred, class_map=class_map, fsize=fsize, term_repeats=term_repeats,
                                        want_full=bool(kwargs.get("window_scores") or kwargs.get("prophage")), **crf_kw)
         n_windows = len(y_pred["meta_2"])
@@ -856,9 +894,17 @@ def run_core(**kwargs) -> int:
                    locals().get("starts"), locals().get("y_pred")]
 
         def release(objs):
-            objs[0].close()
-            objs.clear()
+            try:
+                objs[0].close()
+            except Exception as e:          # noqa: BLE001 - nobody joins this thread for its result: say it in the run log
+                lg.warning(f"releasing the engine failed: {type(e).__name__}: {e}")
+            finally:
+                objs.clear()
 
-        threading.Thread(target=release, args=(garbage,), name="jaeger-engine-close").start()
+        th_close = threading.Thread(target=release, args=(garbage,), name="jaeger-engine-close")
+        _PENDING_RELEASE.append(th_close)   # the next run_core (and bench.py before it times anything) joins it
+        th_close.start()
         del garbage
+    if sharded:
+        _close_process_group()
     return n_written

@@ -31,8 +31,12 @@ def terminal_repeat_table(device, fa, fsize: int, report_min: int = 0) -> np.nda
     bases = np.ascontiguousarray(fa.bases, np.uint8)
     offsets = np.ascontiguousarray(fa.offsets, np.int64)
     ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    L.check(device.lib.jg_terminal_repeats(device.handle, ptr(bases), bases.size, L.JG_PTR_HOST, ptr(offsets), n,
-                                           int(fsize), ptr(res)), "jg_terminal_repeats")
+    try:
+        L.check(device.lib.jg_terminal_repeats(device.handle, ptr(bases), bases.size, L.JG_PTR_HOST, ptr(offsets), n,
+                                               int(fsize), ptr(res)), "jg_terminal_repeats")
+    finally:
+        if report_min:                       # the option belongs to this call: a later jg_terminal_repeats on the same
+            device.lib.jg_engine_set_option(device.handle, L.JG_OPT_TERMINI_REPORT_MIN, 0)   # engine scores every alignment
     return res[:n]
 
 

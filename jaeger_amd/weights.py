@@ -65,6 +65,14 @@ def _layer_order(plan: ModelPlan) -> list[tuple[str, list[str]]]:
         out.append((c.name, ["kernel", "bias"] if c.use_bias else ["kernel"]))
 
     for seq in (plan.rep, plan.classifier, plan.reliability or []):
+        if seq is plan.classifier and plan.nmd_merge_mode != "concat" and len(plan.nmd_dims) > 1:
+            # NMDMerge(sum / mean / max / weighted) is called at the end of the representation block (builder.py:1176-1180):
+            # its own variable (``layer_weights``, nmd.py:143-149) sits on the layer, the bias-free projections are the
+            # sub-layers ``projections/<i>`` (nmd.py:133-141) - in a bundle the layer's path sorts in front of theirs
+            if plan.nmd_merge_mode == "weighted":
+                out.append(("rep/nmd_merge", ["layer_weights"]))
+            for i in range(len(plan.nmd_dims)):
+                out.append((f"rep/nmd_merge/proj_{i}", ["kernel"]))
         for layer in seq:
             if isinstance(layer, Conv):
                 conv(layer)
@@ -123,8 +131,14 @@ def load_keras3_h5(path, plan: ModelPlan) -> dict[str, np.ndarray]:
     # loose layers: Keras numbers auto names per class GLOBALLY in creation order (``masked_batch_norm``,
     # ``masked_batch_norm_1`` ... wherever the layer sits), so the layer's own name decides first and its container only
     # breaks ties (names given per container - ``dense`` in ``functional_8`` and in ``functional_9`` - keep path order)
-    loose = sorted((k for k in groups if not (k[-1] in _BLOCK_SUBLAYERS and k[:-1] in block_paths)),
-                   key=lambda k: (_natural_key(k[-1:]), _natural_key(k)))
+    # ... - but `save_weights` numbers the layers of EVERY container from scratch (``functional_8/{dense, dense_1}`` and
+    # ``functional_9/{dense, dense_1}``): when a leaf name occurs in more than one container the names are per container,
+    # and the containers' own order (path-major) is creation order
+    loose = [k for k in groups if not (k[-1] in _BLOCK_SUBLAYERS and k[:-1] in block_paths)]
+    if len({k[-1] for k in loose}) == len(loose):
+        loose.sort(key=lambda k: (_natural_key(k[-1:]), _natural_key(k)))
+    else:
+        loose.sort(key=_natural_key)
     order = _layer_order(plan)
     plan_blocks: list[str] = []
     for prefix, _ in order:
@@ -169,7 +183,8 @@ class BundleSchemeError(ValueError):
     with the weights file.  A bundle that IS understood and disagrees with the plan (a missing layer, a shape) stays fatal."""
 
 
-_KNOWN_VARIABLES = {"kernel", "bias", "embeddings", "gamma", "beta", "moving_mean", "moving_variance", "alpha"}
+_KNOWN_VARIABLES = {"kernel", "bias", "embeddings", "gamma", "beta", "moving_mean", "moving_variance", "alpha",
+                    "layer_weights"}
 
 
 def assign_groups(groups: list[tuple[tuple[str, ...], dict[str, np.ndarray]]], order: list[tuple[str, list[str]]],
@@ -241,9 +256,17 @@ def bundle_checkpoint_keys(plan: ModelPlan) -> dict[str, str]:
     keys = {}
     n = 0
     last_block = None
+    merge_n = None
     for prefix, leaves in _layer_order(plan):
         head, _, sub = prefix.rpartition("/")
-        if sub in _BLOCK_SUBLAYERS:
+        if prefix == "rep/nmd_merge" or head == "rep/nmd_merge":
+            # one operation: ``layer_weights`` on the layer itself, the projections under ``projections/<i>``
+            if merge_n is None:
+                n += 1
+                merge_n = n
+                last_block = None
+            base = f"_operations/{merge_n}" if prefix == "rep/nmd_merge" else f"_operations/{merge_n}/projections/{sub[len('proj_'):]}"
+        elif sub in _BLOCK_SUBLAYERS:
             if head != last_block:
                 n += 1
                 last_block = head

@@ -38,17 +38,26 @@ def brain():
 
 
 def _oracle_check(cfg, weights, bases, starts, lens, fsize, got, sample):
+    """Sampled windows against the CPU oracle on its fused oneDNN form (``oracle.forward.FAST``: proven equal to the
+    spelled-out form in tests/test_oracle_forward.py), 256 windows per batch - the suite's time on a slow host is this
+    function's (the GPU suite has to fit the driver's step limit whatever host the box has)."""
     from jaeger_amd.engine import frame_length
     from oracle import encoder as oenc
     from oracle import forward as ofwd
     windows = [bases[starts[i]:starts[i] + lens[i]].tobytes() for i in sample]
     ids = oenc.encode_windows(windows, fsize, pad_to=frame_length(fsize))
     worst = {}
-    for i in range(0, len(sample), 96):
-        ref = ofwd.forward(cfg, weights, ids[i:i + 96])
-        sl = sample[i:i + 96]
-        for k in ("prediction", "reliability"):
-            worst[k] = max(worst.get(k, 0.0), float(np.abs(got[k][sl] - ref[k]).max()))
+    t0 = time.time()
+    ofwd.FAST = True
+    try:
+        for i in range(0, len(sample), 256):
+            ref = ofwd.forward(cfg, weights, ids[i:i + 256])
+            sl = sample[i:i + 256]
+            for k in ("prediction", "reliability"):
+                worst[k] = max(worst.get(k, 0.0), float(np.abs(got[k][sl] - ref[k]).max()))
+    finally:
+        ofwd.FAST = False
+    print("oracle forward of", len(sample), "windows: %.1f s" % (time.time() - t0))
     ref_counts = np.array([oenc.window_counts(w) for w in windows], np.int32)
     np.testing.assert_array_equal(got["counts"][sample], ref_counts)
     print("oracle parity on", len(sample), "sampled windows:", worst)
@@ -85,7 +94,8 @@ def test_config3_shard_125k_fragments(brain):
     assert stats["groups"] >= 11 and stats["peak_device_bases"] < 40 << 20
     for k in ("prediction", "reliability", "counts"):
         np.testing.assert_array_equal(got[k], again[k])
-    sample = np.sort(np.random.Generator(np.random.PCG64(3)).choice(n_frag, 2048, replace=False))   # (>= 2 000)
+    # 1 024 sampled windows here, >= 2 000 in the configs[4] test below
+    sample = np.sort(np.random.Generator(np.random.PCG64(3)).choice(n_frag, 1024, replace=False))
     _oracle_check(cfg, weights, bases, starts, table.length, fsize, got, sample)
 
 
@@ -165,7 +175,7 @@ def test_bench_two_ranks_gather_equals_single_rank_runs(tmp_path):
     """BASELINE configs[2] in miniature: rank 0's gathered logits of a 2-rank ``--config frag1m`` launch are, bit for bit,
     rank 0's own logits followed by rank 1's - each reproduced by a single-rank run on that rank's contig set."""
     base = [sys.executable, str(ROOT / "bench.py"), "--config", "frag1m", "--contigs", "400", "--steps", "1", "--warmup", "1",
-            "--no-cpu-baseline", "--no-exact-f32"]
+            "--no-cpu-baseline", "--no-exact-f32", "--no-e2e", "--no-also", "--no-box"]
     both = tmp_path / "both.npy"
     res = subprocess.run(base + ["--gpus", "2", "--oversubscribe", "--dump-gather", str(both)], capture_output=True,
                          text=True, timeout=600)
@@ -189,7 +199,8 @@ def test_bench_eight_ranks_unequal_shards_gather_equals_single_rank_runs(tmp_pat
     and the line carries the per-rank split (windows min / max, compute and gather time of the slowest rank)."""
     shards = [200, 0, 150, 40, 200, 7, 120, 64]
     base = [sys.executable, str(ROOT / "bench.py"), "--config", "frag1m", "--steps", "1", "--warmup", "1",
-            "--no-cpu-baseline", "--no-exact-f32", "--no-e2e", "--rank-contigs", ",".join(map(str, shards))]
+            "--no-cpu-baseline", "--no-exact-f32", "--no-e2e", "--no-also", "--no-box", "--rank-contigs",
+            ",".join(map(str, shards))]
     both = tmp_path / "all.npy"
     res = subprocess.run(base + ["--gpus", "8", "--oversubscribe", "--dump-gather", str(both)], capture_output=True,
                          text=True, timeout=900)
@@ -219,7 +230,7 @@ def test_bench_failing_rank_is_reported_and_times_out(tmp_path):
     """A rank that dies surfaces its stderr and a non-zero exit; ranks that hang are killed after --rank-timeout."""
     import os
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--oversubscribe", "--contigs", "50", "--steps", "1",
-           "--warmup", "0", "--no-cpu-baseline", "--no-exact-f32", "--rank-timeout", "240"]
+           "--warmup", "0", "--no-cpu-baseline", "--no-exact-f32", "--no-e2e", "--no-also", "--no-box", "--rank-timeout", "240"]
     t0 = time.time()
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, JAEGER_BENCH_FAIL_RANK="1"))
@@ -232,7 +243,7 @@ def test_bench_gpus_flag_spawns_ranks():
     """``python bench.py --gpus 2`` with no torchrun environment launches two ranks by itself and reports n_gpus 2
     (here both ranks share the test box's one GPU and exchange over gloo: --oversubscribe)."""
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--oversubscribe", "--contigs", "200", "--steps", "1",
-           "--warmup", "1", "--no-cpu-baseline", "--no-exact-f32"]
+           "--warmup", "1", "--no-cpu-baseline", "--no-exact-f32", "--no-e2e", "--no-also", "--no-box"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -276,3 +287,26 @@ def test_streamed_ingest_random_window_tables(brain, seed):
     assert stats["groups"] >= 2 and stats["bytes"] >= int(lens.sum()) // 2
     for k in ("prediction", "reliability", "counts"):
         np.testing.assert_array_equal(whole[k], streamed[k])
+
+
+def test_bench_one_rank_over_rccl(tmp_path):
+    """First contact for the collective code on the one GPU there is: ``--gpus 1 --collective nccl``
+    initialises the RCCL process group on the device, gathers the logits with ``dist.gather`` on DEVICE tensors inside the
+    timed region, all_gathers the per-rank statistics, takes the barriers and destroys the group - and rank 0's gathered
+    matrix is the plain single-rank run's, bit for bit.  A failure exits non-zero with the RCCL / HIP error (no gloo)."""
+    base = [sys.executable, str(ROOT / "bench.py"), "--config", "frag1m", "--contigs", "400", "--steps", "2", "--warmup", "1",
+            "--no-cpu-baseline", "--no-exact-f32", "--no-e2e", "--no-also", "--no-box"]
+    res = subprocess.run(base + ["--collective", "nccl", "--dump-gather", str(tmp_path / "rccl.npy")], capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-4000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["collective_backend"] == "nccl"
+    assert line["config"]["parallelism"].endswith("final RCCL gather (executed)")
+    assert line["per_rank"]["gather_ms_per_step"]["max"] > 0 and line["per_rank"]["windows"] == [400]
+    res = subprocess.run(base + ["--dump-gather", str(tmp_path / "plain.npy")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-4000:]
+    plain = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert plain["config"]["collective_backend"] is None and "no exchange" in plain["config"]["parallelism"]
+    a, b = np.load(tmp_path / "rccl.npy"), np.load(tmp_path / "plain.npy")
+    assert a.shape == (400, 6) and np.abs(a).max() > 0
+    np.testing.assert_array_equal(a, b)

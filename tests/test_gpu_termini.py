@@ -137,18 +137,10 @@ def test_fast_pass_equals_exact_kernel_on_random_records():
     assert bad.size == 0, (bad[:5], fast[bad[:5]], exact[bad[:5]])
 
 
-def test_single_run_shortcut_equals_exact_kernel():
-    """Alignments scoring above 100 that are one exact run are settled without the length / gap carrying kernel
-    (termini_single_kernel); everything else still goes through it.  Shapes built to sit on the line between the two:
-    overlapping ends (records shorter than twice their scan length - with N runs, lower case and low-complexity stretches
-    inside the overlap), one planted repeat, two planted repeats, a repeat followed / preceded by exactly 50 (or 49, 51)
-    matching bases behind one mismatch or a short gap, direct and inverted, homopolymer and dinucleotide ends."""
-    from jaeger_amd import fragment as frag
-    from jaeger_amd import _lib as L
-    from jaeger_amd.termini import terminal_repeat_table
-    from jaeger_amd.engine import HipDevice
+def _one_run_line_records(seed: int = 2025, n_records: int = 1500):
+    """Records built to sit on the line between 'one exact run' and everything else (see the test below)."""
     from oracle.termini import reverse_complement
-    rng = np.random.Generator(np.random.PCG64(2025))
+    rng = np.random.Generator(np.random.PCG64(seed))
     acgt = np.frombuffer(b"ACGT", np.uint8)
 
     def rand(n):
@@ -158,7 +150,7 @@ def test_single_run_shortcut_equals_exact_kernel():
         return acgt[(int(np.nonzero(acgt == b)[0][0]) + int(rng.integers(1, 4))) % 4]
 
     seqs = []
-    for r in range(1500):
+    for r in range(n_records):
         kind = r % 10
         if kind < 3:                                   # overlapping ends, 500 - 790 bases
             n = int(rng.integers(500, 790))
@@ -202,6 +194,21 @@ def test_single_run_shortcut_equals_exact_kernel():
         if r % 89 == 0:
             s[:] = np.tile(np.frombuffer(b"AC", np.uint8), n)[:n]
         seqs.append(bytes(s))
+    return seqs
+
+
+def test_single_run_shortcut_equals_exact_kernel():
+    """Alignments scoring above 100 that are one exact run are settled without the length / gap carrying kernel
+    (termini_single_kernel); everything else still goes through it.  Shapes built to sit on the line between the two:
+    overlapping ends (records shorter than twice their scan length - with N runs, lower case and low-complexity stretches
+    inside the overlap), one planted repeat, two planted repeats, a repeat followed / preceded by exactly 50 (or 49, 51)
+    matching bases behind one mismatch or a short gap, direct and inverted, homopolymer and dinucleotide ends."""
+    from jaeger_amd import fragment as frag
+    from jaeger_amd import _lib as L
+    from jaeger_amd.termini import terminal_repeat_table
+    from jaeger_amd.engine import HipDevice
+    from oracle.termini import reverse_complement
+    seqs = _one_run_line_records()
     bases, offsets = frag.concat_records(seqs)
     fa = frag.FastaBatch([f"r{i}" for i in range(len(seqs))], bases, offsets)
     dev = HipDevice(0)
@@ -269,6 +276,95 @@ def test_report_min_leaves_the_decision_rule_as_it_is():
     a, b = RepeatColumns(exact, names, fa.lengths), RepeatColumns(quick, names, fa.lengths)
     np.testing.assert_array_equal(a.keep, b.keep)
     assert a.n_found == b.n_found > 300
+    assert (a.kind == b.kind).all()
+    np.testing.assert_array_equal(a.length, b.length)
+    np.testing.assert_array_equal(a.score, b.score)
+
+
+def test_report_min_on_the_one_run_line_equals_the_exact_kernel():
+    """with JG_OPT_TERMINI_REPORT_MIN = 13 (run_core's setting) an alignment settled by the one-run check is
+    final without the packed pass's score beside it - so the seed path is held to the exact kernel (JG_OPT_TERMINI_EXACT)
+    on the shapes that sit on the line: the one-run test's records, plus runs of exactly 50 / 51 / 52 bases (the 'more than
+    50' bound of the argument), two runs of 50 and 51 in one record, a run that touches the edge of the scanned end, N
+    inside a run, a run of 12 / 13 / 14 bases (the report bound itself), mismatches where the sampled 32-mers sit.  Every
+    alignment of >= 13 columns: the same five numbers; the decision rule's columns: equal."""
+    from jaeger_amd import _lib as L
+    from jaeger_amd import fragment as frag
+    from jaeger_amd.engine import HipDevice
+    from jaeger_amd.termini import REPORT_MIN_COLUMNS, RepeatColumns, terminal_repeat_table
+    from oracle.termini import reverse_complement
+    rng = np.random.Generator(np.random.PCG64(606))
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+
+    def rand(n):
+        return acgt[rng.integers(0, 4, n)].copy()
+
+    def plant(s, a, b, k, inverted=False):
+        piece = bytes(s[a:a + k])
+        s[b:b + k] = np.frombuffer(reverse_complement(piece.decode()).encode() if inverted else piece, np.uint8)
+
+    seqs = _one_run_line_records(seed=77, n_records=600)
+    for r in range(900):
+        n = int(rng.integers(1500, 12000))
+        s = rand(n)
+        kind = r % 9
+        inv = bool(rng.random() < 0.3)
+        if kind == 0:                                   # one run of exactly 50 / 51 / 52 bases
+            k = int(rng.choice([50, 51, 52]))
+            plant(s, int(rng.integers(0, 300)), n - int(rng.integers(k, 350)), k, inv)
+        elif kind == 1:                                 # two runs, 50 and 51 bases, apart
+            plant(s, 10, n - 390, 50, inv)
+            plant(s, 200, n - 200, 51, inv)
+        elif kind == 2:                                 # a run that ends with the record (the scan's far edge) ...
+            k = int(rng.integers(51, 180))
+            plant(s, int(rng.integers(0, 200)), n - k, k, inv)
+        elif kind == 3:                                 # ... or starts with it
+            k = int(rng.integers(51, 180))
+            plant(s, 0, n - int(rng.integers(k, 380)), k, inv)
+        elif kind == 4:                                 # N inside the planted run (one copy / both copies)
+            k = int(rng.integers(80, 200))
+            a, b = int(rng.integers(0, 150)), n - int(rng.integers(k, 380))
+            plant(s, a, b, k, inv)
+            q = int(rng.integers(5, k - 5))
+            s[b + q:b + q + int(rng.integers(1, 4))] = ord("N")
+            if rng.random() < 0.5:
+                s[a + q] = ord("N")
+        elif kind == 5:                                 # the report bound: 12, 13, 14 shared bases
+            k = int(rng.choice([12, 13, 14]))
+            plant(s, int(rng.integers(0, 300)), n - int(rng.integers(k, 350)), k, inv)
+        elif kind == 6:                                 # a long run with mismatches 51 bases apart (runs of exactly 50 between)
+            k = int(rng.integers(100, 300))
+            a, b = int(rng.integers(0, 80)), n - int(rng.integers(k, 390))
+            plant(s, a, b, k, inv)
+            for q in (51, 102):
+                if q < k - 1:
+                    s[b + q] = acgt[(int(np.nonzero(acgt == s[b + q])[0][0]) + 1) % 4]
+        elif kind == 7:                                 # records around twice the 4 000-base scan length, run at the scan's edge
+            n = int(rng.choice([7999, 8000, 8001, 8050]))
+            s = rand(n)
+            k = int(rng.integers(51, 120))
+            plant(s, 4000 - k, n - 4000, k, inv)
+        else:                                           # lower case over half the run
+            k = int(rng.integers(51, 150))
+            a, b = int(rng.integers(0, 200)), n - int(rng.integers(k, 380))
+            plant(s, a, b, k, inv)
+            s[b:b + k // 2] |= 0x20
+        seqs.append(bytes(s))
+    bases, offsets = frag.concat_records(seqs)
+    names = [f"r{i}" for i in range(len(seqs))]
+    fa = frag.FastaBatch(names, bases, offsets)
+    dev = HipDevice(0)
+    quick = terminal_repeat_table(dev, fa, 500, report_min=REPORT_MIN_COLUMNS)
+    L.check(dev.lib.jg_engine_set_option(dev.handle, L.JG_OPT_TERMINI_EXACT, 1))
+    exact = terminal_repeat_table(dev, fa, 500)            # every alignment through the length / gap carrying kernel
+    dev.close()
+    assert (exact[:, 0] > 100).sum() + (exact[:, 5] > 100).sum() > 800
+    for col in (0, 5):
+        long_enough = exact[:, col + 1] >= REPORT_MIN_COLUMNS
+        bad = np.nonzero((quick[long_enough, col:col + 5] != exact[long_enough, col:col + 5]).any(axis=1))[0]
+        assert bad.size == 0, (col, bad[:5], quick[long_enough][bad[:5]], exact[long_enough][bad[:5]])
+        assert (quick[~long_enough, col + 1] < REPORT_MIN_COLUMNS).all()
+    a, b = RepeatColumns(exact, names, fa.lengths), RepeatColumns(quick, names, fa.lengths)
     assert (a.kind == b.kind).all()
     np.testing.assert_array_equal(a.length, b.length)
     np.testing.assert_array_equal(a.score, b.score)

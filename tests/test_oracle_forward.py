@@ -139,3 +139,78 @@ def test_f32_oracle_close_to_f64():
     b = F.forward(cfg, w, ids, dtype=torch.float64)
     assert np.abs(a["prediction"] - b["prediction"]).max() < 1e-4
     assert a["nmd"].shape == (2, 512) and a["reliability"].shape == (2, 1) and a["embedding"].shape == (2, 128)
+
+
+def test_mask_mode_known_answers_through_the_indicator_model():
+    """tests/unit/test_mask_mode.py:41-98 again, this time through the pooled indicator model of tests/kat_models.py (the
+    form the GPU twin runs, tests/test_gpu_reference_kats.py): the probed conv first in the model and behind an identity conv."""
+    from kat_models import MASK_MODE_KATS, mask_from_pooled, mask_mode_case
+    from oracle import forward as F
+    for deep in (False, True):
+        for name, n_pos, mode, expected in MASK_MODE_KATS:
+            cfg, w, ids = mask_mode_case(n_pos, mode, deep)
+            got = mask_from_pooled(F.forward(cfg, w, ids)["embedding"])
+            np.testing.assert_array_equal(got, np.array(expected), err_msg=f"{name} deep={deep}")
+
+
+def test_masked_average_ignores_padding():
+    """tests/unit/test_nnlib_v2_layers_short_fragment.py:111-127: [[2, 3], [5, 6]], rtol 1e-5."""
+    from kat_models import masked_average_case
+    from oracle import forward as F
+    cfg, w, ids, want = masked_average_case()
+    out = F.forward(cfg, w, ids)
+    np.testing.assert_allclose(out["embedding"][:, :2], want, rtol=1e-5)
+    assert not out["embedding"][:, 2:].any()
+
+
+def test_masked_dyt_zeroes_masked_positions():
+    """tests/unit/test_resblock_norm_type.py:74-81, directly on the layer and through the model of kat_models."""
+    from kat_models import dyt_zeroes_masked_case
+    from oracle import forward as F
+    x = torch.tensor(np.random.default_rng(0).normal(size=(1, 1, 32, 8)).astype(np.float32))
+    m = torch.cat([torch.ones(1, 1, 16), torch.zeros(1, 1, 16)], dim=-1)
+    out = F.masked_dyt(x, m, {"alpha": torch.tensor([0.5]), "gamma": torch.ones(8), "beta": torch.full((8,), 0.25)})
+    np.testing.assert_allclose(out.numpy()[:, :, 16:], 0.0, atol=1e-5)
+    assert np.abs(out.numpy()[:, :, :16]).min() > 0
+    cfg, w, ids, want, not_zeroed = dyt_zeroes_masked_case()
+    got = F.forward(cfg, w, ids)["embedding"]
+    np.testing.assert_allclose(got, want, atol=1e-5)
+    assert np.abs(not_zeroed - want).min() > 0.3                    # what an un-zeroed masked half would have added
+
+
+def test_layernorm_block_masked_equals_truncated():
+    """tests/unit/test_resblock_norm_type.py:84-94: positions 0..9 of the masked and the truncated run agree (1e-4) - on the
+    block's per-position output, and through the eroding-selector models whose pools read exactly those positions."""
+    from kat_models import layernorm_block_masked_vs_truncated_case
+    from oracle import forward as F
+    (cfg_m, w_m, ids_m), (cfg_t, w_t, ids_t) = layernorm_block_masked_vs_truncated_case("average")
+    tw = {k: torch.tensor(v) for k, v in w_m.items()}
+    bcfg = cfg_m["representation_learner"]["hidden_layers"][0]["config"]
+    table = tw["embedding/embeddings"]
+    xm, mm = table[torch.tensor(ids_m)], torch.tensor((ids_m != 0).astype(np.float32))
+    xt, mt = table[torch.tensor(ids_t)], torch.tensor((ids_t != 0).astype(np.float32))
+    ym, om = F._residual_block(xm, mm, tw, "rep/0/block0", bcfg, True, True, torch.float32)
+    yt, _ = F._residual_block(xt, mt, tw, "rep/0/block0", bcfg, True, True, torch.float32)
+    np.testing.assert_allclose(ym.numpy()[:, :, :10], yt.numpy()[:, :, :10], atol=1e-4)       # the reference's assertion
+    assert np.abs(ym.numpy()[:, :, 12:16] - yt.numpy()[:, :, 12:16]).max() > 1e-3            # and the boundary does differ
+    assert om[0, 0].numpy().astype(bool).tolist() == [i < 20 for i in range(32)]             # 'any': 16 + 2 + 2 valid
+    for pooling in ("average", "max"):
+        (cfg_m, w_m, ids_m), (cfg_t, w_t, ids_t) = layernorm_block_masked_vs_truncated_case(pooling)
+        a, b = F.forward(cfg_m, w_m, ids_m), F.forward(cfg_t, w_t, ids_t)
+        np.testing.assert_allclose(a["embedding"], b["embedding"], atol=1e-4)
+        red = ym.numpy()[0, :, :10].mean(axis=(0, 1)) if pooling == "average" else ym.numpy()[0, :, :10].max(axis=(0, 1))
+        np.testing.assert_allclose(a["embedding"][0], red, atol=1e-5)                        # the pool reads positions 0..9
+
+
+def test_strided_block_on_a_half_padded_batch():
+    """tests/unit/test_resblock_norm_type.py:160-173: length 16 and finite for all three norms."""
+    from kat_models import strided_block_partial_mask_case
+    from oracle import forward as F
+    for nt in ("masked_batchnorm", "masked_layernorm", "masked_dyt"):
+        cfg, w, ids = strided_block_partial_mask_case(nt)
+        tw = {k: torch.tensor(v) for k, v in w.items()}
+        x, m = tw["embedding/embeddings"][torch.tensor(ids)], torch.tensor((ids != 0).astype(np.float32))
+        y, om = F._residual_block(x, m, tw, "rep/0/block0", cfg["representation_learner"]["hidden_layers"][0]["config"],
+                                  True, True, torch.float32)
+        assert y.shape[2] == 16 and om.shape[2] == 16 and np.isfinite(y.numpy()).all(), nt
+        assert np.isfinite(F.forward(cfg, w, ids)["embedding"]).all()

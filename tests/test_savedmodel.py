@@ -283,3 +283,86 @@ def test_understood_bundle_that_disagrees_with_the_plan_stays_fatal(tmp_path, ca
     w500 = random_weights(plan, seed=500)
     got = load_weights({"weights": GOLDEN / "baseline500_keras3.weights.h5", "weights_npz": npz}, plan)
     assert all(np.array_equal(got[k], w500[k]) for k in w500)
+
+
+def _merge_cfg(mode):
+    from test_plan_program import _nmd_merge_builder_config
+    cfg = _nmd_merge_builder_config()
+    cfg["reliability_model"] = {"merge": {"mode": mode, "target_dim": 8}, "input_shape": 8,
+                                "hidden_layers": [{"name": "dense", "config": {"units": 1, "activation": None}}]}
+    return cfg
+
+
+@pytest.mark.parametrize("mode", ["sum", "max", "weighted"])
+def test_nmd_merge_variables_load_from_a_bundle(tmp_path, mode):
+    """a model whose NMD vectors are merged by projections (``reliability_model.merge.mode`` sum / mean /
+    max / weighted, nmd.py:93-155) can be loaded from the reference's containers, not only from random weights: the bundle
+    holds ``layer_weights`` on the NMDMerge operation and the bias-free kernels under its ``projections/<i>``."""
+    from jaeger_amd import savedmodel_lite as S
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import _layer_order, bundle_checkpoint_keys, load_savedmodel_bundle, load_weights, random_weights
+    plan = build_plan(_merge_cfg(mode))
+    w = random_weights(plan, seed=5)
+    assert "rep/nmd_merge/proj_1/kernel" in w and ("rep/nmd_merge/layer_weights" in w) == (mode == "weighted")
+    order = [p for p, _ in _layer_order(plan)]
+    assert order.index("rep/nmd_merge/proj_0") > order.index("rep/3") and order.index("rep/nmd_merge/proj_1") < order.index("classifier/0")
+    keys = bundle_checkpoint_keys(plan)
+    assert set(keys) == set(w)
+    merge_keys = sorted(v for k, v in keys.items() if k.startswith("rep/nmd_merge"))
+    op = merge_keys[0].split("/")[1]
+    assert all(k.split("/")[1] == op for k in merge_keys)                          # ONE operation of the graph
+    assert f"_operations/{op}/projections/1/_kernel/.ATTRIBUTES/VARIABLE_VALUE" in merge_keys
+    if mode == "weighted":
+        assert f"_operations/{op}/layer_weights/.ATTRIBUTES/VARIABLE_VALUE" in merge_keys
+    graph = tmp_path / "m_graph"
+    S.write_bundle(graph / "variables", {keys[k]: v for k, v in w.items()})
+    back = load_savedmodel_bundle(graph, plan)
+    assert set(back) == set(w)
+    for k in w:
+        np.testing.assert_array_equal(back[k], w[k])
+    got = load_weights({"graph": graph}, plan)                                      # no BundleSchemeError, no fallback
+    np.testing.assert_array_equal(got["rep/nmd_merge/proj_0/kernel"], w["rep/nmd_merge/proj_0/kernel"])
+
+
+@pytest.mark.parametrize("mode", ["mean", "weighted"])
+def test_nmd_merge_variables_load_from_a_weights_h5(monkeypatch, mode):
+    """The same from a Keras-3 ``.weights.h5`` as ``save_weights`` lays it out (layers numbered per container; the merge
+    layer's own variable under ``layers/<merge>/vars/0``, its projections as the container ``projections`` holding
+    ``dense``, ``dense_1``): the datasets as ``hdf5_lite.read_datasets`` returns them (no HDF5 writer in the image - the
+    container itself is covered by the committed fixtures), a classifier ``dense`` of the SAME shape as a projection
+    included: per-container names keep path order, so nothing is swapped."""
+    from jaeger_amd import hdf5_lite
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.weights import load_keras3_h5, random_weights
+    cfg = _merge_cfg(mode)
+    cfg["classifier_out_dim"] = 8                  # classifier Dense(8 -> 8, bias) next to proj_1 (8 -> 8, no bias)
+    cfg["class_label_map"] = [{"class": f"c{i}", "label": i} for i in range(8)]
+    cfg["classifier"]["hidden_layers"] = [{"name": "dense", "config": {"units": 8, "activation": None, "use_bias": False}},
+                                          {"name": "dense", "config": {"units": 8, "activation": None, "use_bias": False}}]
+    plan = build_plan(cfg)
+    w = random_weights(plan, seed=9)
+    assert w["rep/nmd_merge/proj_1/kernel"].shape == w["classifier/0/kernel"].shape == w["classifier/1/kernel"].shape == (8, 8)
+    d = {"/layers/functional/layers/embedding/vars/0": w["embedding/embeddings"],
+         "/layers/functional/layers/masked_conv1d/vars/0": w["rep/0/kernel"], "/layers/functional/layers/masked_conv1d/vars/1": w["rep/0/bias"],
+         "/layers/functional/layers/nmd_layer/vars/0": w["rep/1/moving_mean"],
+         "/layers/functional/layers/masked_conv1d_1/vars/0": w["rep/3/kernel"], "/layers/functional/layers/masked_conv1d_1/vars/1": w["rep/3/bias"],
+         "/layers/functional/layers/nmd_layer_1/vars/0": w["rep/4/moving_mean"],
+         "/layers/functional/layers/rep_nmd_merge/projections/dense/vars/0": w["rep/nmd_merge/proj_0/kernel"],
+         "/layers/functional/layers/rep_nmd_merge/projections/dense_1/vars/0": w["rep/nmd_merge/proj_1/kernel"],
+         "/layers/functional_1/layers/dense/vars/0": w["classifier/0/kernel"],
+         "/layers/functional_1/layers/dense_1/vars/0": w["classifier/1/kernel"],
+         "/layers/functional_2/layers/dense/vars/0": w["reliability/0/kernel"], "/layers/functional_2/layers/dense/vars/1": w["reliability/0/bias"]}
+    if mode == "weighted":
+        d["/layers/functional/layers/rep_nmd_merge/vars/0"] = w["rep/nmd_merge/layer_weights"]
+    monkeypatch.setattr(hdf5_lite, "read_datasets", lambda path: dict(d))
+    got = load_keras3_h5("model.weights.h5", plan)
+    assert set(got) == set(w)
+    for k in w:
+        np.testing.assert_array_equal(got[k], w[k], err_msg=k)
+    # globally numbered leaf names (every name once) still go name-major: the layout of the committed nested fixture
+    d2 = {k.replace("functional_1/layers/dense_1", "functional_1/layers/dense_3").replace("functional_1/layers/dense/", "functional_1/layers/dense_2/")
+           .replace("functional_2/layers/dense/", "functional_2/layers/dense_4/"): v for k, v in d.items()}
+    monkeypatch.setattr(hdf5_lite, "read_datasets", lambda path: dict(d2))
+    got = load_keras3_h5("model.weights.h5", plan)
+    for k in w:
+        np.testing.assert_array_equal(got[k], w[k], err_msg=k)
