@@ -36,7 +36,8 @@ typedef enum {
   JG_ERR_INVALID = -1,      /* bad argument / malformed program */
   JG_ERR_HIP = -2,          /* a HIP runtime call failed */
   JG_ERR_UNSUPPORTED = -3,  /* op or geometry the kernels do not implement */
-  JG_ERR_NOMEM = -4
+  JG_ERR_NOMEM = -4,
+  JG_ERR_IO = -5            /* writing to a caller-supplied file descriptor failed (jg_table_write) */
 } jg_status;
 
 enum { JG_PTR_HOST = 0, JG_PTR_DEVICE = 1 };
@@ -163,9 +164,14 @@ int jg_engine_sync(jg_engine *e);
  * or conv by conv (0: A/B timing and the test that compares the two).
  * JG_OPT_RESET_PROGRESS (value ignored): sets JG_STAT_WINDOWS_DONE back to 0.  A thread that polls the mark of a
  * jg_predict_windows call ANOTHER thread is about to make calls this first (the call resets the mark itself, but only
- * once it has been entered - a poller that starts earlier would read the previous call's final count). */
+ * once it has been entered - a poller that starts earlier would read the previous call's final count).
+ * JG_OPT_STREAM_PRIORITY (default 0; round 6): 1 = the engine's stream is re-created at the device's HIGHEST stream priority (0: the
+ *   default one again); set it on an idle engine, before its first launch.  run_core gives it to the side engine of the
+ *   terminal-repeat scan: its short kernels then take the CUs the network's launches free between each other instead of
+ *   queueing behind them, the repeat table exists long before the forward ends, and finished batches' rows are written beside it. */
 enum { JG_OPT_STREAM_BYTES = 1, JG_OPT_CONV_PC = 2, JG_OPT_TERMINI_EXACT = 3, JG_OPT_DUST_ON_COPY_STREAM = 4,
-       JG_OPT_TABLE_NET_LDS = 5, JG_OPT_RESET_PROGRESS = 6, JG_OPT_FUSE_RESBLOCK = 7, JG_OPT_TERMINI_REPORT_MIN = 8 };
+       JG_OPT_TABLE_NET_LDS = 5, JG_OPT_RESET_PROGRESS = 6, JG_OPT_FUSE_RESBLOCK = 7, JG_OPT_TERMINI_REPORT_MIN = 8,
+       JG_OPT_STREAM_PRIORITY = 9 };
 int jg_engine_set_option(jg_engine *e, int key, int64_t value);
 /* statistics of the engine's last jg_predict_windows call: number of streamed groups (0 = not streamed), bytes sent
  * through the staging buffers, peak bytes of bases resident on the device.  JG_STAT_WINDOWS_DONE may be read from
@@ -341,10 +347,20 @@ int jg_dust_mask_device(jg_engine *e, uint8_t *d_bases, int64_t n_bases, const i
  * quote - tab, double quote, line break - away from this call); JG_COL_INT = int64; JG_COL_FLOAT = float64, printed as
  * CPython's "%.3f" % v (exact value, round-half-even) and as nothing for NaN; JG_COL_BOOL = uint8, "True" / "False".
  * *text (n_bytes bytes, no terminator) is released by jg_table_free.  n_threads <= 0: every usable core. */
-enum { JG_COL_STRING = 0, JG_COL_INT = 1, JG_COL_FLOAT = 2, JG_COL_BOOL = 3 };
+enum { JG_COL_STRING = 0, JG_COL_INT = 1, JG_COL_FLOAT = 2, JG_COL_BOOL = 3, JG_COL_SPANS = 4 };
 int jg_table_format(int32_t n_cols, const int32_t *kinds, const void *const *cols, const int64_t *const *starts,
                     const int64_t *rows, int64_t n_rows, int32_t n_threads, char **text, int64_t *n_bytes);
 void jg_table_free(char *text);
+/* (round 6) JG_COL_SPANS = strings as explicit spans of a byte buffer: string r = bytes [starts[c][2 r], starts[c][2 r + 1])
+ * of cols[c] - record names straight out of the FASTA parser's name buffer (contig_id, collect.py:441), class labels and
+ * repeat kinds as spans of a short label blob (collect.py:443, termini.py:137-154): no per-row string objects on the host.
+ * jg_table_write renders the same rows and writes them to the open file descriptor fd (at its position, in row order)
+ * instead of returning them. */
+int jg_table_write(int32_t n_cols, const int32_t *kinds, const void *const *cols, const int64_t *const *starts,
+                   const int64_t *rows, int64_t n_rows, int32_t n_threads, int32_t fd, int64_t *n_bytes);
+/* *unique = 1 when the n strings buf[off[i] .. off[i + 1]) are pairwise different (host only).  Replaces the uniqueness test of
+ * pandas' merge on contig_id (postprocess/collect.py:527-532): with unique record names the repeat table joins by record number. */
+int jg_names_unique(const uint8_t *buf, const int64_t *off, int64_t n, int32_t n_threads, int32_t *unique);
 /* window_summary strings (replaces get_window_summary of postprocess/helpers.py:73-108 over the run lengths of :8-40, one
  * Python call per contig in postprocess/collect.py:520-523): contig c owns calls[first[c] .. first[c] + count[c]); every run of
  * equal calls prints as its length followed by letters[class] (0 = no letter).  *text holds one NUL-terminated string per

@@ -24,7 +24,8 @@ JG_OPT_DUST_ON_COPY_STREAM = 4
 JG_OPT_TABLE_NET_LDS = 5
 JG_OPT_RESET_PROGRESS = 6
 JG_OPT_FUSE_RESBLOCK = 7
-JG_COL_STRING, JG_COL_INT, JG_COL_FLOAT, JG_COL_BOOL = 0, 1, 2, 3     # jg_table_format column kinds
+JG_OPT_STREAM_PRIORITY = 9
+JG_COL_STRING, JG_COL_INT, JG_COL_FLOAT, JG_COL_BOOL, JG_COL_SPANS = 0, 1, 2, 3, 4     # jg_table_format column kinds
 JG_STAT_STREAM_GROUPS, JG_STAT_STREAM_BYTES, JG_STAT_PEAK_DEVICE_BASES, JG_STAT_DUST_MASKED, JG_STAT_WINDOWS_DONE = 1, 2, 3, 4, 5
 JG_MSTAT_CONVS, JG_MSTAT_CONVS_F16X3, JG_MSTAT_LAYOUT_CONVERSIONS, JG_MSTAT_SMALL_FUSED = 0, 1, 2, 3
 
@@ -125,6 +126,8 @@ SYMBOLS = {
     "jg_fasta_fill": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "jg_fasta_scan_free": (None, [_vp]),
     "jg_table_format": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, C.c_int64, C.c_int32, C.POINTER(_vp), C.POINTER(C.c_int64)]),
+    "jg_table_write": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "jg_names_unique": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]),
     "jg_table_free": (None, [_vp]),
     "jg_segment_mean_var": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp, C.c_int64, _vp, _vp, C.c_int32]),
     "jg_segment_mean_1d": (C.c_int, [_vp, C.c_int32, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int32]),

@@ -121,6 +121,19 @@ extern "C" int jg_engine_set_option(jg_engine *e, int key, int64_t value) {
     case JG_OPT_RESET_PROGRESS:
       e->windows_done.store(0, std::memory_order_release);
       return JG_OK;
+    case JG_OPT_STREAM_PRIORITY: {
+      JG_REQUIRE(value == 0 || value == 1, JG_ERR_INVALID, "jg_engine_set_option: JG_OPT_STREAM_PRIORITY takes 0 or 1, got %lld",
+                 (long long)value);
+      JG_HIP(hipSetDevice(e->dev));
+      JG_HIP(hipStreamSynchronize(e->stream));                   // (an idle engine: nothing is waited for)
+      int least = 0, greatest = 0;                               // numerically lower = more urgent
+      JG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      hipStream_t fresh = nullptr;
+      JG_HIP(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, value ? greatest : least));
+      (void)hipStreamDestroy(e->stream);
+      e->stream = fresh;
+      return JG_OK;
+    }
     default:
       jg_set_error("jg_engine_set_option: unknown key %d", key);
       return JG_ERR_INVALID;

@@ -5,6 +5,7 @@
 // rendered here: floats by an exact "%.3f" (below), integers, booleans ("True" / "False"), strings copied as they are.
 // What the csv writer would QUOTE (a tab, a quote, a line break inside a string) is the caller's to detect - it then
 // formats that batch with pandas (jaeger_amd/postprocess.py: _tsv_bytes).
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@
 #include <exception>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "jg_common.h"
@@ -52,14 +54,14 @@ inline char *put_f3(char *p, double v) {
 
 }  // namespace
 
-extern "C" int jg_table_format(int32_t n_cols, const int32_t *kinds, const void *const *cols, const int64_t *const *starts,
-                               const int64_t *rows, int64_t n_rows, int32_t n_threads, char **text, int64_t *n_bytes) {
-  JG_REQUIRE(n_cols > 0 && kinds != nullptr && cols != nullptr && starts != nullptr && n_rows >= 0 && text != nullptr &&
-                 n_bytes != nullptr,
+static int table_render(int32_t n_cols, const int32_t *kinds, const void *const *cols, const int64_t *const *starts,
+                        const int64_t *rows, int64_t n_rows, int32_t n_threads, char **text, int fd, int64_t *n_bytes) {
+  JG_REQUIRE(n_cols > 0 && kinds != nullptr && cols != nullptr && starts != nullptr && n_rows >= 0 &&
+                 (text != nullptr || fd >= 0) && n_bytes != nullptr,
              JG_ERR_INVALID, "jg_table_format: bad arguments");
   for (int c = 0; c < n_cols; ++c)
-    JG_REQUIRE(kinds[c] >= JG_COL_STRING && kinds[c] <= JG_COL_BOOL && cols[c] != nullptr &&
-                   (kinds[c] != JG_COL_STRING || starts[c] != nullptr),
+    JG_REQUIRE(kinds[c] >= JG_COL_STRING && kinds[c] <= JG_COL_SPANS && cols[c] != nullptr &&
+                   ((kinds[c] != JG_COL_STRING && kinds[c] != JG_COL_SPANS) || starts[c] != nullptr),
                JG_ERR_INVALID, "jg_table_format: column %d: kind %d / missing data", c, kinds[c]);
   int nt = n_threads > 0 ? n_threads : jg_usable_cores();
   nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(nt, 256), n_rows / 2048 + 1));
@@ -71,13 +73,15 @@ extern "C" int jg_table_format(int32_t n_cols, const int32_t *kinds, const void 
     std::string &out = part[(size_t)tix];
     // rows are short (a few hundred bytes); strings may be long (a window summary), so size each row before it is written
     size_t fixed = 0;
-    for (int c = 0; c < n_cols; ++c) fixed += kinds[c] == JG_COL_STRING ? 1 : (kinds[c] == JG_COL_FLOAT ? 400 : 24);
+    for (int c = 0; c < n_cols; ++c)
+      fixed += (kinds[c] == JG_COL_STRING || kinds[c] == JG_COL_SPANS) ? 1 : (kinds[c] == JG_COL_FLOAT ? 400 : 24);
     size_t used = 0;
     for (int64_t i = r0; i < r1; ++i) {
       const int64_t r = rows ? rows[i] : i;
       size_t need = fixed;
       for (int c = 0; c < n_cols; ++c)
         if (kinds[c] == JG_COL_STRING) need += (size_t)(starts[c][r + 1] - 1 - starts[c][r]);
+        else if (kinds[c] == JG_COL_SPANS) need += (size_t)(starts[c][2 * r + 1] - starts[c][2 * r]);
       if (out.size() < used + need) out.resize(std::max(out.size() * 2, used + need + (size_t)(r1 - i) * 64));
       char *p = &out[used];
       for (int c = 0; c < n_cols; ++c) {
@@ -85,6 +89,12 @@ extern "C" int jg_table_format(int32_t n_cols, const int32_t *kinds, const void 
         switch (kinds[c]) {
           case JG_COL_STRING: {
             const int64_t a = starts[c][r], b = starts[c][r + 1] - 1;        // one separator byte behind every string
+            memcpy(p, (const char *)cols[c] + a, (size_t)(b - a));
+            p += b - a;
+            break;
+          }
+          case JG_COL_SPANS: {
+            const int64_t a = starts[c][2 * r], b = starts[c][2 * r + 1];    // an explicit [begin, end) per row
             memcpy(p, (const char *)cols[c] + a, (size_t)(b - a));
             p += b - a;
             break;
@@ -121,6 +131,18 @@ extern "C" int jg_table_format(int32_t n_cols, const int32_t *kinds, const void 
   for (char f : failed) JG_REQUIRE(!f, JG_ERR_NOMEM, "jg_table_format: out of memory while rendering %lld rows", (long long)n_rows);
   size_t total = 0;
   for (const auto &s : part) total += s.size();
+  if (text == nullptr) {                          // straight to the file: the threads' pieces in row order
+    for (const auto &s : part) {
+      size_t done = 0;
+      while (done < s.size()) {
+        const ssize_t w = write(fd, s.data() + done, s.size() - done);
+        JG_REQUIRE(w > 0 || (w < 0 && errno == EINTR), JG_ERR_IO, "jg_table_write: write failed (%s)", strerror(errno));
+        if (w > 0) done += (size_t)w;
+      }
+    }
+    *n_bytes = (int64_t)total;
+    return JG_OK;
+  }
   char *buf = (char *)malloc(total ? total : 1);
   JG_REQUIRE(buf != nullptr, JG_ERR_NOMEM, "jg_table_format: out of memory (%zu bytes)", total);
   size_t at = 0;
@@ -130,7 +152,69 @@ extern "C" int jg_table_format(int32_t n_cols, const int32_t *kinds, const void 
   return JG_OK;
 }
 
+extern "C" int jg_table_format(int32_t n_cols, const int32_t *kinds, const void *const *cols, const int64_t *const *starts,
+                               const int64_t *rows, int64_t n_rows, int32_t n_threads, char **text, int64_t *n_bytes) {
+  JG_REQUIRE(text != nullptr, JG_ERR_INVALID, "jg_table_format: bad arguments");
+  return table_render(n_cols, kinds, cols, starts, rows, n_rows, n_threads, text, -1, n_bytes);
+}
+
+extern "C" int jg_table_write(int32_t n_cols, const int32_t *kinds, const void *const *cols, const int64_t *const *starts,
+                              const int64_t *rows, int64_t n_rows, int32_t n_threads, int32_t fd, int64_t *n_bytes) {
+  JG_REQUIRE(fd >= 0, JG_ERR_INVALID, "jg_table_write: bad file descriptor");
+  return table_render(n_cols, kinds, cols, starts, rows, n_rows, n_threads, nullptr, fd, n_bytes);
+}
+
 extern "C" void jg_table_free(char *text) { free(text); }
+
+// Are the n strings buf[off[i] .. off[i + 1]) pairwise different?  (The repeat table is joined to the result rows by record
+// NUMBER, which is the reference's merge on the record NAME exactly when no name occurs twice - postprocess/collect.py:527-532;
+// a hash set of a million Python strings costs more than the forward of a million short records.)  64-bit hashes on every
+// core, then one open-addressing pass; equal hashes are settled by comparing the bytes.
+extern "C" int jg_names_unique(const uint8_t *buf, const int64_t *off, int64_t n, int32_t n_threads, int32_t *unique) {
+  JG_REQUIRE(off != nullptr && unique != nullptr && n >= 0 && (buf != nullptr || n == 0 || off[n] == off[0]), JG_ERR_INVALID,
+             "jg_names_unique: bad arguments");
+  *unique = 1;
+  if (n < 2) return JG_OK;
+  JG_REQUIRE(n < ((int64_t)1 << 31), JG_ERR_UNSUPPORTED, "jg_names_unique: %lld names", (long long)n);
+  try {
+    std::vector<uint64_t> hash((size_t)n);
+    int nt = n_threads > 0 ? n_threads : jg_usable_cores();
+    nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(nt, 64), n / 65536 + 1));
+    auto work = [&](int tix) {
+      for (int64_t i = n * tix / nt, e = n * (tix + 1) / nt; i < e; ++i) {
+        uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)(off[i + 1] - off[i]);
+        for (int64_t j = off[i]; j < off[i + 1]; ++j) h = (h ^ buf[j]) * 0x100000001b3ull;
+        h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ull; h ^= h >> 32;
+        hash[(size_t)i] = h;
+      }
+    };
+    if (nt == 1) work(0);
+    else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+      for (auto &t : th) t.join();
+    }
+    size_t cap = 1;
+    while (cap < (size_t)n * 2) cap <<= 1;
+    std::vector<uint32_t> slot(cap, 0u);
+    for (int64_t i = 0; i < n; ++i) {
+      size_t at = (size_t)hash[(size_t)i] & (cap - 1);
+      while (slot[at]) {
+        const int64_t j = (int64_t)slot[at] - 1;
+        if (hash[(size_t)j] == hash[(size_t)i] && off[j + 1] - off[j] == off[i + 1] - off[i] &&
+            memcmp(buf + off[j], buf + off[i], (size_t)(off[i + 1] - off[i])) == 0) {
+          *unique = 0;
+          return JG_OK;
+        }
+        at = (at + 1) & (cap - 1);
+      }
+      slot[at] = (uint32_t)(i + 1);
+    }
+  } catch (const std::exception &) {
+    JG_REQUIRE(false, JG_ERR_NOMEM, "jg_names_unique: out of memory (%lld names)", (long long)n);
+  }
+  return JG_OK;
+}
 
 // window_summary of every contig (postprocess/helpers.py:8-40 run lengths, :73-108 letters): the per-window calls of contig c
 // are calls[first[c] .. first[c] + count[c]); each run of equal calls prints as its length followed by the class's letter

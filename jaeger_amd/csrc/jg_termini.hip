@@ -341,36 +341,59 @@ __global__ __launch_bounds__(256) void termini_single_kernel(const uint8_t *__re
     rc[j] = (uint8_t)(c < 4 ? c : 7);                               // (a letter that matches nothing, not even another one)
   }
   __syncthreads();
-  unsigned lo = 0xffffffffu, hi = 0u;
-  int run_len = 0, run_end_q = -1, run_end_r = -1;
-  for (int p = 0; p + 32 <= n; p += 20) {
-    for (int i = lane; i + 32 <= n; i += 64) {
-      int t = 0;
-      while (t < 32 && qc[i + t] == rc[p + t]) ++t;
-      if (t < 32) continue;
-      int a = 0, b = 32;                                            // the maximal run through this hit: rows i - a .. i + b - 1
-      while (i - a > 0 && p - a > 0 && qc[i - a - 1] == rc[p - a - 1]) ++a;
-      while (i + b < n && p + b < n && qc[i + b] == rc[p + b]) ++b;
-      const unsigned sig = ((unsigned)(i - p + n) << 16) | (unsigned)(i - a);
-      lo = min(lo, sig);
-      hi = max(hi, sig);
-      run_len = a + b;
-      run_end_q = i + b - 1;
-      run_end_r = p + b - 1;
+  // (round 6) Hits are handled wave-wide, one at a time: a hit inside the run already known is that run again (nothing to
+  // do - the form before extended EVERY hit base by base in its one lane: a 300-base overlap run was walked fifteen times
+  // by single lanes, 122 ms per million records); a hit outside it is extended by the whole wave, 64 bases per step, and
+  // either becomes the known run or proves a second one - the alignment then is not settled here and the wave leaves.
+  bool known = false, second = false;
+  int k_diag = 0, k_r0 = 0, k_r1 = -1, k_len = 0, k_end_r = -1;        // the known run: diagonal, first / last query row
+  const int n_iter = (n - 32 + 64) / 64;                               // query 32-mers: i = 64 it + lane, i + 32 <= n
+  for (int p = 0; p + 32 <= n && !second; p += 20) {
+    for (int it = 0; it < n_iter && !second; ++it) {
+      const int i = it * 64 + lane;
+      bool hit = false;
+      if (i + 32 <= n) {
+        int t = 0;
+        while (t < 32 && qc[i + t] == rc[p + t]) ++t;
+        hit = t == 32;
+      }
+      unsigned long long hits = __ballot(hit);
+      while (hits != 0ull) {
+        const int hq = it * 64 + __builtin_ctzll(hits);                // query row of this hit (wave-uniform)
+        hits &= hits - 1ull;
+        if (known && hq - p + n == k_diag && hq >= k_r0 && hq <= k_r1) continue;
+        // the maximal run through (hq .. hq + 31, p .. p + 31): left of it, then right of it, 64 cells per step
+        int a = 0, bnd = min(hq, p);
+        for (int base = 0; base < bnd; base += 64) {
+          const int t = base + lane;
+          const bool same = t < bnd && qc[hq - 1 - t] == rc[p - 1 - t];
+          const unsigned long long diff = ~__ballot(same);
+          if (diff != 0ull) { a = base + __builtin_ctzll(diff); break; }
+          a = base + 64;
+        }
+        a = min(a, bnd);
+        int bext = 0;
+        bnd = n - 32 - max(hq, p);
+        for (int base = 0; base < bnd; base += 64) {
+          const int t = base + lane;
+          const bool same = t < bnd && qc[hq + 32 + t] == rc[p + 32 + t];
+          const unsigned long long diff = ~__ballot(same);
+          if (diff != 0ull) { bext = base + __builtin_ctzll(diff); break; }
+          bext = base + 64;
+        }
+        bext = min(bext, max(bnd, 0));
+        if (known) { second = true; break; }                           // a run that is not the known one
+        known = true;
+        k_diag = hq - p + n;
+        k_r0 = hq - a;
+        k_r1 = hq + 31 + bext;
+        k_len = a + 32 + bext;
+        k_end_r = p + 31 + bext;
+      }
     }
   }
-  const unsigned long long hit = __ballot(run_len > 0);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    lo = min(lo, (unsigned)__shfl_xor((int)lo, off, 64));
-    hi = max(hi, (unsigned)__shfl_xor((int)hi, off, 64));
-  }
   TermOut o{0, -1, 0, -1, -1};                                      // len = -1: not settled here
-  if (hit != 0ull && lo == hi) {
-    const int src = __builtin_ctzll(hit);                           // (every hit of the wave lies in the one run)
-    const int L = __shfl(run_len, src, 64), eq = __shfl(run_end_q, src, 64), er = __shfl(run_end_r, src, 64);
-    if (L > 50) o = TermOut{2 * L, L, 0, eq, er};
-  }
+  if (known && !second && k_len > 50) o = TermOut{2 * k_len, k_len, 0, k_r1, k_end_r};
   if (live && lane == 0) out[idx] = o;
 }
 
@@ -454,14 +477,20 @@ static int launch_fast(const uint8_t *d_bases, const TermRec *d_recs, TermFast *
 }
 
 // ---- the host side's four device stages: upload what the stage reads, launch, bring its results back ------------------
-struct DevBuf {                       // device allocation released with its scope
+// Device allocation released with its scope - STREAM-ORDERED (hipMallocAsync / hipFreeAsync on the scan's stream): hipFree
+// waits for every stream of the device, so the scan - which runs beside the network's forward on a stream of its own - used
+// to return only when the forward's whole queue had drained (round 6: the repeat table of a million records arrived with the
+// forward's last launch, 0.2 s after the scan's own kernels had ended, and no result row could be written beside the forward).
+struct DevBuf {
   void *p = nullptr;
+  hipStream_t st = nullptr;
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  int alloc(size_t bytes) {
-    JG_HIP(hipMalloc(&p, std::max<size_t>(bytes, 1)));
+  ~DevBuf() { if (p) (void)hipFreeAsync(p, st); }
+  int alloc(size_t bytes, hipStream_t s) {
+    st = s;
+    JG_HIP(hipMallocAsync(&p, std::max<size_t>(bytes, 1), s));
     return JG_OK;
   }
   template <typename T>
@@ -470,7 +499,7 @@ struct DevBuf {                       // device allocation released with its sco
 
 template <typename T>
 static int upload(DevBuf &d, const std::vector<T> &v, hipStream_t s) {
-  int rc = d.alloc(v.size() * sizeof(T));
+  int rc = d.alloc(v.size() * sizeof(T), s);
   if (rc != JG_OK) return rc;
   JG_HIP(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
   return JG_OK;
@@ -486,7 +515,7 @@ static int download(std::vector<T> &v, const DevBuf &d, hipStream_t s) {
 // which alignments of the records have at least k columns at all: bit 0 direct, bit 1 inverted (termini_seed_kernel)
 static int run_seeds(const uint8_t *d_bases, const TermRec *d_recs, int n_recs, int k, std::vector<uint8_t> &flags, hipStream_t s) {
   DevBuf d_flags;
-  int rc = d_flags.alloc((size_t)n_recs);
+  int rc = d_flags.alloc((size_t)n_recs, s);
   if (rc != JG_OK) return rc;
   hipLaunchKernelGGL(termini_seed_kernel, dim3((unsigned)n_recs), dim3(256), (size_t)2 * SR_NMAX + 8192 * sizeof(unsigned), s, d_bases,
                      d_recs, k, d_flags.as<uint8_t>());
@@ -502,7 +531,7 @@ static int run_jobs(const uint8_t *d_bases, const std::vector<TermJob> &jobs, bo
   if (jobs.empty()) return JG_OK;
   DevBuf d_jobs, d_out;
   int rc = upload(d_jobs, jobs, s);
-  if (rc == JG_OK) rc = d_out.alloc(jobs.size() * sizeof(TermOut));
+  if (rc == JG_OK) rc = d_out.alloc(jobs.size() * sizeof(TermOut), s);
   if (rc != JG_OK) return rc;
   if (exact) {
     int max_n = 0;
@@ -526,8 +555,8 @@ static int run_packed(const uint8_t *d_bases, const std::vector<TermRec> &recs, 
   out.resize((size_t)2 * n);
   if (n == 0) return JG_OK;
   DevBuf d_fast, d_out;
-  int rc = d_fast.alloc((size_t)n * sizeof(TermFast));
-  if (rc == JG_OK) rc = d_out.alloc((size_t)2 * n * sizeof(TermOut));
+  int rc = d_fast.alloc((size_t)n * sizeof(TermFast), s);
+  if (rc == JG_OK) rc = d_out.alloc((size_t)2 * n * sizeof(TermOut), s);
   TermFast *df = d_fast.as<TermFast>();
   int a = 0;
   while (a < n && rc == JG_OK) {
@@ -622,7 +651,7 @@ extern "C" int jg_terminal_repeats(jg_engine *e, const uint8_t *bases, int64_t n
   if (bases_loc == JG_PTR_HOST) {
     const uint8_t *src = whole ? bases : ends.data();
     const size_t nb = whole ? (size_t)n_bases : ends.size();
-    if ((rc = tmp_bases.alloc(nb)) != JG_OK) return rc;
+    if ((rc = tmp_bases.alloc(nb, s)) != JG_OK) return rc;
     JG_HIP(hipMemcpyAsync(tmp_bases.p, src, nb, hipMemcpyHostToDevice, s));
     d_bases = tmp_bases.as<const uint8_t>();
   }

@@ -96,6 +96,10 @@ class HipDevice:
         """Host base buffers above ``nbytes`` are streamed through pinned staging buffers (JG_OPT_STREAM_BYTES)."""
         L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_STREAM_BYTES, int(nbytes)), "jg_engine_set_option")
 
+    def set_stream_priority(self, high: bool):
+        """Re-create this (idle) engine's stream at the device's highest / default stream priority (JG_OPT_STREAM_PRIORITY)."""
+        L.check(self.lib.jg_engine_set_option(self.handle, L.JG_OPT_STREAM_PRIORITY, int(bool(high))), "jg_engine_set_option")
+
     def set_table_net_lds(self, on: bool):
         """A strand branch's conv + pool on the exact-f32 LDS-table kernel (True) instead of the matrix cores
         (JG_OPT_TABLE_NET_LDS; tests and A/B timing)."""

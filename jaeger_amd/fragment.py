@@ -42,7 +42,7 @@ def read_fasta(path: str) -> Iterator[tuple[str, bytes]]:
 @dataclass
 class FastaBatch:
     """All records of a FASTA file in the layout the encoder scans."""
-    names: list[str]
+    names: "list[str] | Names"     # (the native ingest hands out Names: the strings are made on demand)
     bases: np.ndarray          # uint8, all sequences back to back
     offsets: np.ndarray        # int64, len = n_records + 1
 
@@ -57,9 +57,93 @@ class FastaBatch:
         return self.bases[self.offsets[i]:self.offsets[i + 1]].tobytes()
 
 
-def _decode_names(names_buf: np.ndarray, name_off: np.ndarray) -> list[str]:
-    raw, no = names_buf.tobytes(), name_off.tolist()
-    return [raw[no[i]:no[i + 1]].decode() for i in range(len(no) - 1)]
+_NOT_PLAIN = bytes(range(33)) + b",\x85\xa0"
+
+
+class Names:
+    """Record names as the native FASTA parser hands them out: ONE byte buffer + offsets (``name i`` = ``buf[off[i]:off[i+1]]``,
+    UTF-8).  Behaves like the ``list[str]`` it stands for - ``len``, indexing, iteration, ``==`` with a list - but the
+    Python strings are only made when something asks for them: a million short records' names cost 0.3 s as objects, and the
+    table writer takes them as bytes (:meth:`take_bytes`), the repeat join by record number needs only :meth:`is_unique`."""
+
+    def __init__(self, buf: np.ndarray, off: np.ndarray):
+        self.buf = np.ascontiguousarray(buf, np.uint8)
+        self.off = np.ascontiguousarray(off, np.int64)
+        self._list: list[str] | None = None
+        self._plain: bool | None = None
+        self._unique: bool | None = None
+        self.facts: dict = {}              # what the table writer has found out about ``buf`` (postprocess.SpanColumn.facts)
+
+    def __len__(self) -> int:
+        return max(len(self.off) - 1, 0)
+
+    def tolist(self) -> list[str]:
+        if self._list is None:
+            raw, no = self.buf.tobytes(), self.off.tolist()
+            self._list = [raw[no[i]:no[i + 1]].decode() for i in range(len(no) - 1)]
+        return self._list
+
+    def __getitem__(self, i):
+        if isinstance(i, (int, np.integer)):
+            if self._list is not None:
+                return self._list[i]
+            n = len(self)
+            j = int(i) + n if i < 0 else int(i)
+            if not 0 <= j < n:
+                raise IndexError(i)
+            return self.buf[self.off[j]:self.off[j + 1]].tobytes().decode()
+        return self.tolist()[i]
+
+    def __iter__(self):
+        return iter(self.tolist())
+
+    def __eq__(self, other):
+        if isinstance(other, Names):
+            return np.array_equal(self.off - self.off[:1], other.off - other.off[:1]) and \
+                np.array_equal(self.buf[self.off[0]:self.off[-1]], other.buf[other.off[0]:other.off[-1]])
+        try:
+            return self.tolist() == list(other)
+        except TypeError:
+            return NotImplemented
+
+    def __repr__(self) -> str:
+        return f"Names({len(self)} records, {int(self.off[-1] - self.off[0]) if len(self.off) else 0} bytes)"
+
+    def plain(self) -> bool:
+        """No comma, no white space, no NUL in any name: ``name.strip().replace(",", "___")`` (io.py:109) leaves them as they
+        are, and NUL can separate them in a blob."""
+        if self._plain is None:
+            b = self.buf[self.off[0]:self.off[-1]] if len(self) else self.buf[:0]
+            # one pass (bytes.translate): comma, NUL / controls / space, and the bytes 0x85 / 0xA0 (the tails of the two-byte
+            # white-space characters str.strip() also removes; conservative: other characters end in them too)
+            raw = b.tobytes()
+            self._plain = len(raw.translate(None, _NOT_PLAIN)) == len(raw)
+        return self._plain
+
+    def spans(self, idx=None) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(buf, begin, end): the name of record ``idx[r]`` (None: every record) is ``buf[begin[r]:end[r]]`` - the form the
+        table writer hands to ``jg_table_format`` as a JG_COL_SPANS column (no copy of the names, no Python strings)."""
+        if idx is None:
+            return self.buf, self.off[:-1], self.off[1:]
+        idx = np.asarray(idx, np.int64)
+        return self.buf, self.off[idx], self.off[idx + 1]
+
+    def is_unique(self) -> bool:
+        """No name twice (``jg_names_unique``: 64-bit hashes on every core, one open-addressing pass, equal hashes settled by
+        comparing the bytes)."""
+        if self._unique is None:
+            import ctypes as C
+
+            from . import _lib as L
+            flag = C.c_int32(1)
+            L.check(L.load().jg_names_unique(C.c_void_p(self.buf.ctypes.data), C.c_void_p(self.off.ctypes.data), len(self), 0,
+                                             C.byref(flag)), "jg_names_unique")
+            self._unique = bool(flag.value)
+        return self._unique
+
+
+def _decode_names(names_buf: np.ndarray, name_off: np.ndarray) -> Names:
+    return Names(names_buf, name_off)
 
 
 def _scan_fill(text: np.ndarray, threads: int = 0, want_bases: bool = True, want_rec_off: bool = False):
@@ -268,6 +352,10 @@ def normalise_headers(headers: list[str]) -> np.ndarray:
     """io.py:109: ``name.strip().replace(",", "___")`` for every record, as an object array.  Names that hold neither a comma
     nor white space (every name the FASTA parser hands out: a header up to its first white space) are taken as they are -
     one scan of the joined names instead of two string calls per record (0.5 s per million records)."""
+    if isinstance(headers, Names) and headers.plain():
+        out = np.empty(len(headers), dtype=object)
+        out[:] = headers.tolist()
+        return out
     if len(headers) > 64:
         blob = "\x00".join(headers)
         if "," not in blob and len(blob.split()) <= 1:
@@ -282,11 +370,12 @@ def window_metadata(table: WindowTable, headers, counts: np.ndarray, normalised:
     header, index, contig_end, i, seqlen, g, c, a, t, gc_skew (io.py:128-133).  ``meta_0`` is an object array that
     shares the per-record strings (a fixed-width copy per window would cost more than every other field together);
     ``normalised``: ``headers`` already is :func:`normalise_headers`' array."""
-    hdr = headers if normalised else normalise_headers(headers)
+    hdr = headers if (normalised or headers is None) else normalise_headers(headers)
     g, c, a, t = (counts[:, i].astype(np.int64) for i in range(4))
     skew = safe_divide(g - c, g + c)
     return {
-        "meta_0": hdr[table.contig] if len(table) else np.array([], dtype=object),
+        # (``headers`` None: the caller carries the contigs' names as bytes - no per-window header array is built)
+        "meta_0": None if hdr is None else (hdr[table.contig] if len(table) else np.array([], dtype=object)),
         "meta_1": table.start.astype(np.int64),
         "meta_2": table.is_last.astype(np.int32),
         "meta_3": table.ordinal.astype(np.int64),

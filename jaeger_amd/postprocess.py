@@ -317,7 +317,11 @@ def pred_to_dict(y_pred: dict, **kwargs) -> tuple[dict, dict]:
     chain_first = np.append(seg.first, n_win)
     has_reliability = "reliability" in y_pred
 
-    headers = np.asarray(y_pred["meta_0"])[seg.first].astype(str)      # (one string per contig, not per window)
+    headers = kwargs.get("headers")                                    # a SpanColumn of the contigs' names (the pipeline's)
+    if headers is None:
+        headers = np.asarray(y_pred["meta_0"])[seg.first].astype(str)  # (one string per contig, not per window)
+    elif len(headers) != seg.n:
+        raise ValueError(f"pred_to_dict: {len(headers)} headers for {seg.n} contigs")
     lengths = np.array(y_pred["meta_4"], dtype=np.int32)[seg.first]
     # nucleotide content; the reference labels the columns a,t,g,c = meta_7,8,6,5 and only
     # uses their sums (collect.py:319-324)
@@ -401,7 +405,9 @@ def merge_data(parts: list[dict]) -> dict:
     out = {}
     for key, v0 in parts[0].items():
         vals = [p[key] for p in parts]
-        if isinstance(v0, _Summaries):
+        if any(isinstance(v, SpanColumn) for v in vals):                      # (names as bytes in some batches, strings in others)
+            out[key] = SpanColumn.concat(vals)
+        elif isinstance(v0, _Summaries):
             out[key] = _Summaries([t for v in vals for t in v.texts])
         elif isinstance(v0, _Runs):
             offs = np.cumsum([0] + [len(v.calls) for v in vals[:-1]])
@@ -410,6 +416,7 @@ def merge_data(parts: list[dict]) -> dict:
                                       np.concatenate([v.seg.count for v in vals])))
         elif isinstance(v0, _Means):
             out[key] = _Means(np.concatenate([v.means for v in vals]))
+
         elif isinstance(v0, np.ndarray):
             if v0.ndim == 2 and len({v.shape[1] for v in vals}) > 1:          # per-class counts of differing widths
                 width = max(v.shape[1] for v in vals)
@@ -420,6 +427,109 @@ def merge_data(parts: list[dict]) -> dict:
         else:                                                                 # has_reliability, repeats, ood = None
             out[key] = v0
     return out
+
+
+class SpanColumn:
+    """A column of strings kept as BYTES: string r = ``buf[begin[r]:end[r]]`` (UTF-8).  Record names come this way straight out
+    of the FASTA parser's name buffer (``fragment.Names.spans``) and go this way into ``jg_table_format`` (JG_COL_SPANS): a
+    million rows never become a million Python strings.  ``to_objects`` / ``tolist`` make them where a DataFrame is asked for."""
+
+    def __init__(self, buf: np.ndarray, begin: np.ndarray, end: np.ndarray, facts: dict | None = None):
+        self.buf = np.ascontiguousarray(buf, np.uint8)
+        self.begin, self.end = np.ascontiguousarray(begin, np.int64), np.ascontiguousarray(end, np.int64)
+        self.facts = facts if facts is not None else {}      # what is known about ``buf`` (shared by the columns cut from it)
+
+    def __len__(self) -> int:
+        return len(self.begin)
+
+    def tolist(self) -> list[str]:
+        raw = self.buf.tobytes()
+        return [raw[a:b].decode() for a, b in zip(self.begin.tolist(), self.end.tolist())]
+
+    def to_objects(self) -> np.ndarray:
+        out = np.empty(len(self), dtype=object)
+        out[:] = self.tolist()
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.to_objects()
+        return out if dtype is None else out.astype(dtype)
+
+    def spans(self) -> np.ndarray:
+        """[begin_0, end_0, begin_1, end_1, ...] as ``jg_table_format`` reads a JG_COL_SPANS column."""
+        st = np.empty(2 * len(self), np.int64)
+        st[0::2], st[1::2] = self.begin, self.end
+        return st
+
+    def contains(self, sub: bytes) -> bool:
+        """Conservative: ``sub`` occurs somewhere in the buffer (possibly outside this column's spans)."""
+        key = ("contains", sub)
+        if key not in self.facts:
+            self.facts[key] = sub in self.buf.tobytes()
+        return self.facts[key]
+
+    def csv_safe(self) -> bool:
+        if "csv_safe" not in self.facts:
+            raw = self.buf.tobytes()
+            self.facts["csv_safe"] = not any(c in raw for c in _CSV_SPECIAL)
+        return self.facts["csv_safe"]
+
+    @staticmethod
+    def from_strings(values) -> "SpanColumn":
+        raw = [str(v).encode("utf-8") for v in (values.tolist() if isinstance(values, np.ndarray) else values)]
+        ln = np.array([len(r) for r in raw], np.int64)
+        end = np.cumsum(ln)
+        return SpanColumn(np.frombuffer(b"".join(raw) or b"\0", np.uint8), end - ln, end)
+
+    @staticmethod
+    def concat(cols: list) -> "SpanColumn":
+        cols = [c if isinstance(c, SpanColumn) else SpanColumn.from_strings(c) for c in cols]
+        if all(c.buf is cols[0].buf for c in cols):
+            return SpanColumn(cols[0].buf, np.concatenate([c.begin for c in cols]), np.concatenate([c.end for c in cols]),
+                              cols[0].facts)
+        shift = np.cumsum([0] + [c.buf.size for c in cols[:-1]])
+        return SpanColumn(np.concatenate([c.buf for c in cols]), np.concatenate([c.begin + o for c, o in zip(cols, shift)]),
+                          np.concatenate([c.end + o for c, o in zip(cols, shift)]))
+
+
+def header_strings(headers) -> np.ndarray:
+    """Contig names as the fixed-width string array ``pred_to_dict`` used to hand out (the npz writers store it)."""
+    return np.asarray(headers.tolist() if isinstance(headers, SpanColumn) else headers).astype(str)
+
+
+class EnumColumn:
+    """A column with a handful of distinct strings: integer ``codes`` into ``labels`` (None = missing: printed as nothing,
+    NaN in the object form).  The class label of every contig, the kind of its terminal repeat."""
+
+    def __init__(self, codes: np.ndarray, labels: list):
+        self.codes, self.labels = np.asarray(codes), list(labels)
+
+    def __len__(self) -> int:
+        return len(self.codes)
+
+    def to_objects(self) -> np.ndarray:
+        table = np.empty(len(self.labels), dtype=object)
+        table[:] = [np.nan if v is None else v for v in self.labels]
+        return table[self.codes]
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.to_objects()
+        return out if dtype is None else out.astype(dtype)
+
+    def __eq__(self, other):                          # (the phage query: prediction == "phage")
+        if isinstance(other, str):
+            hits = [i for i, v in enumerate(self.labels) if v == other]
+            return np.isin(self.codes, hits) if hits else np.zeros(len(self), dtype=bool)
+        return NotImplemented
+
+    __hash__ = None
+
+    def as_spans(self) -> SpanColumn:
+        raw = [b"" if v is None else str(v).encode("utf-8") for v in self.labels]
+        ends = np.cumsum([len(r) for r in raw]).astype(np.int64)
+        begins = ends - np.array([len(r) for r in raw], np.int64)
+        codes = self.codes.astype(np.int64)
+        return SpanColumn(np.frombuffer(b"".join(raw) or b"\0", np.uint8), begins[codes], ends[codes])
 
 
 class _Summaries:
@@ -555,9 +665,7 @@ def _summary_columns(data, **kwargs) -> dict:
     counts = data["per_class_counts"]
     consensus = np.asarray(data["consensus"])
     if n and consensus.dtype.kind in "iu" and consensus.min() >= 0 and all(k in class_map for k in range(int(consensus.max()) + 1)):
-        names = np.empty(int(consensus.max()) + 1, dtype=object)          # one label object per class, shared by the rows
-        names[:] = [class_map[k] for k in range(len(names))]
-        prediction = names[consensus]
+        prediction = EnumColumn(consensus, [class_map[k] for k in range(int(consensus.max()) + 1)])
     else:
         prediction = [class_map[x] for x in consensus.tolist()]
     columns = {
@@ -597,6 +705,9 @@ def generate_summary(data, **kwargs) -> pd.DataFrame:
     columns = _summary_columns(data, **kwargs)
     if isinstance(columns["window_summary"], _Summaries):
         columns["window_summary"] = columns["window_summary"].texts
+    for key, v in columns.items():
+        if isinstance(v, (SpanColumn, EnumColumn)):
+            columns[key] = v.to_objects()
     df = pd.DataFrame(columns)
     repeats = data.get("repeats")
     if repeats is not None and hasattr(repeats, "frame"):            # termini.RepeatColumns
@@ -671,12 +782,54 @@ def _blob_column(blob: bytes, n: int):
     return blob, starts
 
 
-def _columns_text(names: list, values: list, rows: np.ndarray | None, header: bool) -> bytes | None:
-    """Rows ``rows`` (None: all) of a table given as columns - arrays, lists of strings, :class:`_Summaries` - rendered by
-    the library's ``jg_table_format`` as ``to_csv(sep="\t", index=False, float_format="%.3f")`` would print the frame made of
-    them; None when a column is of a kind the library does not print (the caller goes through pandas then)."""
-    import ctypes as C
+class _Prepared:
+    """Columns of a table in the form ``jg_table_format`` reads them (:func:`_prepare_columns`)."""
 
+    def __init__(self, names, n, kinds, ptrs, starts, keep):
+        self.names, self.n, self.kinds, self.ptrs, self.starts, self.keep = names, n, kinds, ptrs, starts, keep
+
+    def render(self, rows: np.ndarray | None, header: bool, fd: int | None = None):
+        """The text of rows ``rows`` (None: all) - returned as bytes, or written to the open file descriptor ``fd``
+        (``jg_table_write``: the library's buffers go straight to the file; returns the number of bytes)."""
+        import ctypes as C
+        import os
+
+        from . import _lib
+        lib = _lib.load()
+        nc = len(self.names)
+        kind_arr = np.asarray(self.kinds, dtype=np.int32)
+        col_ptrs = (C.c_void_p * nc)(*self.ptrs)
+        start_ptrs = (C.c_void_p * nc)(*[None if st is None else st.ctypes.data for st in self.starts])
+        if rows is not None:
+            rows = np.ascontiguousarray(rows, dtype=np.int64)
+        n_out = self.n if rows is None else len(rows)
+        head = ("\t".join(self.names) + "\n").encode("utf-8") if header else b""
+        rows_ptr = None if rows is None else rows.ctypes.data
+        if fd is not None:
+            done = 0
+            while done < len(head):
+                done += os.write(fd, head[done:])
+            size = C.c_int64(0)
+            if n_out:
+                _lib.check(lib.jg_table_write(nc, kind_arr.ctypes.data, col_ptrs, start_ptrs, rows_ptr, n_out, 0, int(fd),
+                                              C.byref(size)), "jg_table_write")
+            return len(head) + size.value
+        body = b""
+        if n_out:
+            text, size = C.c_void_p(), C.c_int64()
+            _lib.check(lib.jg_table_format(nc, kind_arr.ctypes.data, col_ptrs, start_ptrs, rows_ptr, n_out, 0, C.byref(text),
+                                           C.byref(size)), "jg_table_format")
+            try:
+                body = C.string_at(text, size.value)
+            finally:
+                lib.jg_table_free(text)
+        return head + body
+
+
+def _prepare_columns(names: list, values: list) -> _Prepared | None:
+    """A table given as columns - arrays, lists of strings, :class:`_Summaries`, :class:`SpanColumn`, :class:`EnumColumn` - in
+    the form the library's ``jg_table_format`` prints as ``to_csv(sep="\t", index=False, float_format="%.3f")`` would print the
+    frame made of them; None when a column is of a kind the library does not print (the caller goes through pandas then)."""
     from . import _lib
     n = len(values[0]) if values else 0
     if not (len(names) > 1 and n > 0 and all(isinstance(c, str) and not any(ch in c for ch in '\t"\n\r') for c in names)):
@@ -684,6 +837,19 @@ def _columns_text(names: list, values: list, rows: np.ndarray | None, header: bo
     kinds, keep, ptrs, starts = [], [], [], []
     for v in values:
         st = None
+        if isinstance(v, EnumColumn):
+            v = v.as_spans()
+        if isinstance(v, SpanColumn):
+            if not v.csv_safe():
+                return None
+            st = v.spans()
+            if len(v) != n:
+                return None
+            starts.append(st)
+            kinds.append(_lib.JG_COL_SPANS)
+            keep.append(v)
+            ptrs.append(v.buf.ctypes.data)
+            continue
         if isinstance(v, _Summaries) and v.blob is not None:
             got = _blob_column(v.blob, len(v))
         elif isinstance(v, _Summaries):
@@ -716,24 +882,14 @@ def _columns_text(names: list, values: list, rows: np.ndarray | None, header: bo
         kinds.append(k)
         keep.append(arr)
         ptrs.append(arr.ctypes.data)
-    lib = _lib.load()
-    nc = len(names)
-    kind_arr = np.asarray(kinds, dtype=np.int32)
-    col_ptrs = (C.c_void_p * nc)(*ptrs)
-    start_ptrs = (C.c_void_p * nc)(*[None if st is None else st.ctypes.data for st in starts])
-    text, size = C.c_void_p(), C.c_int64()
-    if rows is not None:
-        rows = np.ascontiguousarray(rows, dtype=np.int64)
-    n_out = n if rows is None else len(rows)
-    body = b""
-    if n_out:
-        _lib.check(lib.jg_table_format(nc, kind_arr.ctypes.data, col_ptrs, start_ptrs, None if rows is None else rows.ctypes.data,
-                                       n_out, 0, C.byref(text), C.byref(size)))
-        try:
-            body = C.string_at(text, size.value)
-        finally:
-            lib.jg_table_free(text)
-    return ("\t".join(names) + "\n").encode("utf-8") + body if header else body
+    return _Prepared(list(names), n, kinds, ptrs, starts, keep)
+
+
+def _columns_text(names: list, values: list, rows: np.ndarray | None, header: bool) -> bytes | None:
+    """Rows ``rows`` (None: all) of a table given as columns, rendered by the library; None when a column is of a kind the
+    library does not print."""
+    prep = _prepare_columns(names, values)
+    return None if prep is None else prep.render(rows, header)
 
 
 def _tsv_bytes(df: pd.DataFrame, header: bool = True) -> bytes:
@@ -782,17 +938,30 @@ class TableWriter:
         if not phage_df.empty:
             self._write_phage(_tsv_bytes(phage_df, header=self.fh_phage is None))
 
-    def _write(self, text: bytes, n_rows: int) -> None:
+    # (unbuffered files: the library writes a batch's rows through the descriptor itself, ``jg_table_write``)
+    def _open(self) -> None:
         if self.fh is None:
-            self.fh = open(f"{self.table_path}.partial", "wb")
-        self.fh.write(text)
+            self.fh = open(f"{self.table_path}.partial", "wb", buffering=0)
+
+    def _open_phage(self) -> None:
+        if self.fh_phage is None:
+            self.fh_phage = open(f"{self.phage_path}.partial", "wb", buffering=0)
+
+    @staticmethod
+    def _write_all(fh, text: bytes) -> None:
+        view = memoryview(text)
+        while len(view):
+            view = view[fh.write(view):]
+
+    def _write(self, text: bytes, n_rows: int) -> None:
+        self._open()
+        self._write_all(self.fh, text)
         self.header_written = True
         self.rows += n_rows
 
     def _write_phage(self, text: bytes) -> None:
-        if self.fh_phage is None:
-            self.fh_phage = open(f"{self.phage_path}.partial", "wb")
-        self.fh_phage.write(text)
+        self._open_phage()
+        self._write_all(self.fh_phage, text)
 
     def _append_columns(self, data: dict) -> bool:
         """The same rows without a DataFrame: the columns as ``_summary_columns`` makes them, the repeat table joined on by
@@ -806,17 +975,21 @@ class TableWriter:
         cols = _summary_columns(data, **self.kw)
         repeats = data.get("repeats")
         at = data.get("repeat_rows")
-        kinds_col = np.full(n, np.nan, dtype=object)
+        kinds_col = None                                              # (an object array only where a DataFrame's column is joined)
         length_col = np.full(n, np.nan, dtype=np.float64)
         if repeats is not None and hasattr(repeats, "frame"):        # termini.RepeatColumns: arrays, no DataFrame yet
             if at is not None and data.get("names_unique") and len(repeats):
                 at = np.asarray(at, dtype=np.int64)
                 hit = at >= 0
-                kinds_col[hit] = repeats.kind[at[hit]]
+                codes = np.zeros(n, np.int8)
+                codes[hit] = repeats.kind_code[at[hit]]
+                kinds_col = EnumColumn(codes, repeats.KIND_LABELS)
                 length_col[hit] = repeats.length[at[hit]]
                 repeats = None
             else:
                 repeats = repeats.frame()
+        if kinds_col is None:
+            kinds_col = np.full(n, np.nan, dtype=object)
         if repeats is not None and len(repeats):
             index = repeats.attrs.get("_contig_index")
             if index is None:
@@ -837,27 +1010,35 @@ class TableWriter:
         elif repeats is not None and not {"terminal_repeats", "repeat_length"} <= set(repeats.columns):
             return False
         cols["terminal_repeats"], cols["repeat_length"] = kinds_col, length_col
-        ids = np.asarray(cols["contig_id"]).tolist()
-        if "___" in "\0".join(ids):                                 # (io.py:109 wrote commas as ___; collect.py:556 turns them back)
-            cols["contig_id"] = np.array([x.replace("___", ",") for x in ids], dtype=object)
+        if isinstance(cols["contig_id"], SpanColumn):
+            if cols["contig_id"].contains(b"___"):                    # (rare: the object path below turns ___ back into commas)
+                cols["contig_id"] = cols["contig_id"].to_objects()
+        if not isinstance(cols["contig_id"], SpanColumn):
+            ids = np.asarray(cols["contig_id"]).tolist()
+            if "___" in "\0".join(ids):                             # (io.py:109 wrote commas as ___; collect.py:556 turns them back)
+                cols["contig_id"] = np.array([x.replace("___", ",") for x in ids], dtype=object)
         with np.errstate(invalid="ignore"):
             keep = np.asarray(cols["N%"]) < 0.3
         rows = None if keep.all() else np.flatnonzero(keep)
         names = list(cols)
-        text = _columns_text(names, [cols[c] for c in names], rows, header=not self.header_written)
-        if text is None:
-            return False
         score_name = f"{self.viral}_score"
-        if score_name not in cols or not isinstance(cols["prediction"], np.ndarray):
+        if score_name not in cols or not isinstance(cols["prediction"], (np.ndarray, EnumColumn)):
+            return False
+        prep = _prepare_columns(names, [cols[c] for c in names])
+        if prep is None:
             return False
         with np.errstate(invalid="ignore"):
             phage = keep & (cols["prediction"] == self.viral) & (np.asarray(cols[score_name]) > self.pc)
             if data.get("has_reliability", True):
                 phage &= np.asarray(cols["reliability_score"]) > self.rc
-        self._write(text, int(keep.sum()))
+        self._open()
+        prep.render(rows, header=not self.header_written, fd=self.fh.fileno())
+        self.header_written = True
+        self.rows += int(keep.sum())
         if phage.any():
-            ptext = _columns_text(names, [cols[c] for c in names], np.flatnonzero(phage), header=self.fh_phage is None)
-            self._write_phage(ptext)
+            first = self.fh_phage is None
+            self._open_phage()
+            prep.render(np.flatnonzero(phage), header=first, fd=self.fh_phage.fileno())
         return True
 
     def close(self) -> int:

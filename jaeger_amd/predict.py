@@ -14,6 +14,7 @@ import json
 import logging
 import os
 import sys
+import threading
 import time
 import traceback
 from collections import defaultdict
@@ -226,7 +227,11 @@ class _Aggregator:
 
     def __init__(self, table: "frag.WindowTable", names: list[str], out: dict, pred_kw: dict, min_batch: int):
         self.table, self.out, self.kw = table, out, pred_kw
-        self.hdr = frag.normalise_headers(names)
+        # names straight from the native parser (fragment.Names) that io.py:109's normalisation leaves as they are stay BYTES
+        # from the FASTA image to the table rows; anything else goes through the per-record strings as before
+        self._names = names
+        self.names_bytes = names if isinstance(names, frag.Names) and names.plain() else None
+        self._hdr = None
         n_rec = len(names)
         per_rec = np.bincount(table.contig, minlength=n_rec).astype(np.int64) if len(table) else np.zeros(n_rec, np.int64)
         self.ends = np.cumsum(per_rec[per_rec > 0])              # window index one past each contig's last window
@@ -236,6 +241,13 @@ class _Aggregator:
         self.busy_s = 0.0
         self.flushed = 0                                          # parts already handed to the table writer
         self._unique = None
+
+    @property
+    def hdr(self) -> np.ndarray:
+        """The records' normalised names as an object array of Python strings (made when something needs them)."""
+        if self._hdr is None:
+            self._hdr = frag.normalise_headers(self._names)
+        return self._hdr
 
     def advance(self, done: int, final: bool = False) -> None:
         if len(self.ends) == 0:
@@ -248,7 +260,7 @@ class _Aggregator:
         rec = self.table.contig[self.w_done:w1]
         first = np.ones(len(rec), dtype=bool)
         first[1:] = rec[1:] != rec[:-1]
-        self.add(self.slice(self.w_done, w1), records=np.asarray(rec[first], dtype=np.int64))
+        self.add(self.slice(self.w_done, w1, with_names=self.names_bytes is None), records=np.asarray(rec[first], dtype=np.int64))
         self.w_done = w1
         self.busy_s += time.time() - t0
 
@@ -256,22 +268,29 @@ class _Aggregator:
         """No record name twice (then a join by record number IS the reference's merge on the name).  One hash pass over
         the names, made once - the polling loop calls it beside the forward."""
         if self._unique is None:
-            import pandas as pd
-            self._unique = bool(pd.Index(self.hdr).is_unique)
+            if self.names_bytes is not None:
+                self._unique = self.names_bytes.is_unique()          # (jg_names_unique: no Python strings)
+            else:
+                import pandas as pd
+                self._unique = bool(pd.Index(self.hdr).is_unique)
         return self._unique
 
-    def slice(self, w0: int, w1: int) -> dict:
-        """Engine outputs + window metadata of windows [w0, w1) in ``InferModel.predict``'s dict form."""
+    def slice(self, w0: int, w1: int, with_names: bool = True) -> dict:
+        """Engine outputs + window metadata of windows [w0, w1) in ``InferModel.predict``'s dict form (``with_names`` False:
+        without the per-window header array ``meta_0`` - the batch's contig names travel as bytes)."""
         t = self.table
         sub = frag.WindowTable(*(getattr(t, f)[w0:w1] for f in ("contig", "start", "length", "is_last", "ordinal", "seqlen")))
         y = {k: v[w0:w1] for k, v in self.out.items() if k != "counts"}
-        y.update(frag.window_metadata(sub, self.hdr, self.out["counts"][w0:w1], normalised=True))
+        y.update(frag.window_metadata(sub, self.hdr if with_names else None, self.out["counts"][w0:w1], normalised=True))
         return y
 
     def add(self, y_pred: dict, records: np.ndarray | None = None) -> None:
-        from .postprocess import _Summaries, pred_to_dict, window_letters
+        from .postprocess import SpanColumn, _Summaries, pred_to_dict, window_letters
         if y_pred and len(y_pred["meta_2"]):
-            data, full = pred_to_dict(y_pred, **self.kw)
+            kw = self.kw
+            if y_pred.get("meta_0") is None:                       # names as bytes: one span per contig of the batch
+                kw = dict(kw, headers=SpanColumn(*self.names_bytes.spans(records), facts=self.names_bytes.facts))
+            data, full = pred_to_dict(y_pred, **kw)
             # the run-length strings of the batch's contigs belong beside the forward too: the library's text as it comes
             runs, letters = data["frag_pred"], window_letters(self.kw["class_map"])
             blob = runs.summaries_blob(letters)
@@ -290,7 +309,7 @@ class _Aggregator:
             row_of = getattr(term_repeats, "row_of_record", None)
             if row_of is None and term_repeats is not None and hasattr(term_repeats, "attrs"):
                 row_of = term_repeats.attrs.get("_row_of_record")
-            if row_of is not None and "record_index" in data and len(row_of) == len(self.hdr):
+            if row_of is not None and "record_index" in data and len(row_of) == len(self._names):
                 data["repeat_rows"] = row_of[data["record_index"]]
                 data["names_unique"] = self.names_unique()
             writer.append(data)
@@ -707,12 +726,15 @@ def run_core(**kwargs) -> int:
             # of it runs while the model is still being set up: beside the forward its workgroups only get the CUs in the gaps
             # between the network's launches (the conv and small-window kernels take a CU's whole LDS), and the rows of
             # finished batches cannot go to the table before the repeat columns exist
-            import threading
 
             def scan_side():
                 try:
                     from .engine import HipDevice
                     side = HipDevice(local_rank)
+                    # the scan's short kernels go in front of the network's launches (stream priority): the repeat table is
+                    # there long before the forward ends, and finished batches' rows are written beside it, not behind it
+                    if not kwargs.get("scan_low_priority") and hasattr(side, "set_stream_priority"):   # (duck-typed devices)
+                        side.set_stream_priority(True)
                     try:
                         scan["frame"] = scan_repeats(side)
                     finally:
@@ -760,20 +782,43 @@ def run_core(**kwargs) -> int:
 
         if piped and th is not None and kwargs.get("scan_first"):
             th.join()                       # A/B: the repeat scan alone on the GPU, the forward behind it
+        flusher, flush_stop, flush_err = None, None, {}
         try:
             f_pred = pool.submit(classify) if piped else None
             log_setup(engine)
             if piped:
+                # rows of finished batches go to the table beside the forward, on a thread of their own (the calling thread
+                # aggregates; formatting a batch's rows is native code and numpy: both run without the interpreter lock)
+                flush_stop = threading.Event()
+
+                def flush_side():
+                    try:
+                        while True:
+                            stopping = flush_stop.is_set()
+                            if "frame" in scan:
+                                agg.flush(writer, scan["frame"])
+                            if stopping:
+                                break
+                            time.sleep(0.002)
+                    except BaseException as e:          # noqa: BLE001 - handed to the calling thread
+                        flush_err["error"] = e
+
+                flusher = threading.Thread(target=flush_side, name="jaeger-rows", daemon=True)
+                flusher.start()
                 while not f_pred.done():
                     agg.names_unique()
                     agg.advance(engine.device.windows_done())
-                    if "frame" in scan:                       # rows of finished batches go to the table beside the forward
-                        agg.flush(writer, scan["frame"])
                     time.sleep(0.004)
                 t_forward = f_pred.result()
                 agg.advance(n_long, final=True)       # the last contigs: needs no repeat column, runs while the scan finishes
                 mark("aggregated")
                 th.join()
+                flush_stop.set()
+                flusher.join()
+                flusher = None
+                mark("rows_beside_forward_done")
+                if "error" in flush_err:
+                    raise flush_err["error"]
                 if "error" in scan:
                     raise scan["error"]
                 term_repeats = scan["frame"]
@@ -791,6 +836,9 @@ def run_core(**kwargs) -> int:
             lg.error(f"an error {e} occured during inference on MI355X #{local_rank}!")
             sys.exit(1)
         finally:
+            if flusher is not None:             # (an error path: the row thread must not outlive the writer it uses)
+                flush_stop.set()
+                flusher.join()
             if pool is not None:
                 pool.shutdown(wait=True)
         t_predict = time.time() - t_predict
@@ -812,7 +860,7 @@ def run_core(**kwargs) -> int:
                 f"fused calls")
     t_post = time.time()
 
-    from .postprocess import pred_to_dict, write_output
+    from .postprocess import header_strings, pred_to_dict, write_output
     if sharded:
         data, data_full = pred_to_dict(y_pred, class_map=class_map, fsize=fsize, term_repeats=term_repeats,
                                        want_full=bool(kwargs.get("window_scores") or kwargs.get("prophage")), **crf_kw)
@@ -836,7 +884,7 @@ def run_core(**kwargs) -> int:
     LAST_RUN["tsv_s"] = round(time.time() - t_post - LAST_RUN["merge_s"], 3)
     lg.info(f"processed {n_written}/{num} sequences")
     if kwargs.get("window_scores"):
-        np.savez(out_dir / f"{file_base}_window_scores.npz", headers=data_full["headers"],
+        np.savez(out_dir / f"{file_base}_window_scores.npz", headers=header_strings(data_full["headers"]),
                  lengths=data_full["lengths"], predictions=np.array(data_full["predictions"], dtype=object),
                  gc_skews=np.array(data_full["gc_skews"], dtype=object),
                  gcs=np.array(data_full["gcs"], dtype=object))
@@ -846,7 +894,7 @@ def run_core(**kwargs) -> int:
         # (ruptures / kneed / pycirclize) are not part of this path; the frames are written for them.
         try:
             from .prophage_inputs import logits_to_df_v2
-            frames = logits_to_df_v2(class_map=class_map, cmdline_kwargs=kwargs, headers=data_full["headers"],
+            frames = logits_to_df_v2(class_map=class_map, cmdline_kwargs=kwargs, headers=header_strings(data_full["headers"]),
                                      predictions=data_full["predictions"], lengths=data_full["lengths"],
                                      gc_skews=data_full["gc_skews"], gcs=data_full["gcs"])
             if frames:
@@ -889,7 +937,6 @@ def run_core(**kwargs) -> int:
         # milliseconds - a tenth of a short run - and nothing the caller gets depends on it
         # ... nor on the large host buffers of the run (bases, window table, per-window outputs: unmapping half a gigabyte
         # takes another 20 ms): their last references are dropped on that thread too
-        import threading
         garbage = [engine, locals().get("fa"), locals().get("table"), locals().get("out"), locals().get("agg"),
                    locals().get("starts"), locals().get("y_pred")]
 

@@ -46,6 +46,8 @@ class RepeatColumns:
     (:meth:`frame`: names, a pandas index over them) is only built when something asks for it - on a million records it
     costs more than the scan's kernels."""
 
+    KIND_LABELS = [None, "DTR", "ITR", "LTR_DTR"]
+
     def __init__(self, res: np.ndarray, names: list[str], lengths: np.ndarray):
         keep = np.nonzero(res[:, 0] >= 0)[0] if len(res) else np.zeros(0, np.int64)
         d_score, d_len, d_fg = res[keep, 0], res[keep, 1], res[keep, 2]
@@ -53,10 +55,14 @@ class RepeatColumns:
         found = (i_len > 12) | (d_len > 12)
         is_itr = found & (i_score > d_score)
         is_dtr = found & ~is_itr
-        kind = np.full(keep.size, None, dtype=object)
-        kind[is_itr] = "ITR"
-        kind[is_dtr] = "DTR"
-        kind[is_dtr & ((d_len - d_fg) >= 250)] = "LTR_DTR"
+        kind_code = np.zeros(keep.size, np.int8)                  # index into KIND_LABELS: what the table writer prints from
+        kind_code[is_itr] = 2
+        kind_code[is_dtr] = 1
+        kind_code[is_dtr & ((d_len - d_fg) >= 250)] = 3
+        labels = np.empty(4, dtype=object)
+        labels[:] = self.KIND_LABELS
+        kind = labels[kind_code]
+        self.kind_code = kind_code
         length = np.where(is_itr, i_len, d_len).astype(np.float64)
         length[~found] = np.nan
         score = np.where(is_itr, i_score, d_score).astype(np.float64)

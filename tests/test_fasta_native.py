@@ -133,3 +133,33 @@ def test_parallel_ingest_equals_the_serial_parser(seed):
         assert all(data[o:o + 1] == b">" for o in rec_off[:-1].tolist()) and rec_off[-1] == len(data)
     names, bases, offsets, _ = frag._scan_fill(text, 0)          # automatic thread count
     assert names == want[0] and np.array_equal(bases, want[1]) and np.array_equal(offsets, want[2])
+
+
+def test_names_container_stands_for_the_list_of_names(tmp_path):
+    """``load_fasta`` hands the record names out as ``fragment.Names`` (one byte buffer + offsets; round 6): it compares, indexes
+    and iterates like the list of strings it stands for, knows natively whether a name occurs twice (``jg_names_unique``) and
+    whether io.py:109's normalisation would change anything, and gives the table writer spans instead of strings."""
+    from jaeger_amd import fragment as frag
+    names = ["r1", "", "r3", "r4,with,commas", "caf\u00e9", "r1x", "z" * 300]
+    p = tmp_path / "n.fa"
+    p.write_text("".join((f">{n} some description\nACGT\n" if n else ">\nACGT\n") for n in names))
+    got = frag.load_fasta(str(p)).names
+    assert isinstance(got, frag.Names) and got == names and list(got) == names and len(got) == 7
+    assert got[3] == "r4,with,commas" and got[-1] == "z" * 300 and got[1:3] == ["", "r3"]
+    with pytest.raises(IndexError):
+        got[7]
+    assert got.is_unique() and not got.plain()                       # (a comma: normalisation rewrites it)
+    buf, b, e = got.spans([4, 0, 6])
+    assert [buf[x:y].tobytes().decode() for x, y in zip(b.tolist(), e.tolist())] == ["caf\u00e9", "r1", "z" * 300]
+    assert frag.normalise_headers(got).tolist() == [n.strip().replace(",", "___") for n in names]
+    p.write_text("".join(f">{n}\nACGT\n" for n in ["a", "b", "c", "b"]))
+    dup = frag.load_fasta(str(p)).names
+    assert dup.plain() and not dup.is_unique() and frag.normalise_headers(dup).tolist() == ["a", "b", "c", "b"]
+    # a few hundred thousand names: hashes on every core, still exact
+    n = 300_000
+    raw = "".join(f"r{i:07d}" for i in range(n)).encode()
+    big = frag.Names(np.frombuffer(raw, np.uint8), np.arange(n + 1, dtype=np.int64) * 8)
+    assert big.is_unique() and big.plain() and big[n - 1] == f"r{n - 1:07d}"
+    raw2 = bytearray(raw)
+    raw2[8 * 777:8 * 778] = raw[8 * 299_000:8 * 299_001]
+    assert not frag.Names(np.frombuffer(bytes(raw2), np.uint8), np.arange(n + 1, dtype=np.int64) * 8).is_unique()

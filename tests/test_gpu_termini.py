@@ -368,3 +368,27 @@ def test_report_min_on_the_one_run_line_equals_the_exact_kernel():
     assert (a.kind == b.kind).all()
     np.testing.assert_array_equal(a.length, b.length)
     np.testing.assert_array_equal(a.score, b.score)
+
+
+def test_high_priority_stream_gives_the_same_table():
+    """JG_OPT_STREAM_PRIORITY (run_core sets it on the repeat scan's side engine so that its kernels are not queued behind
+    the network's): the engine's stream is re-created at the device's highest priority - same table; 0 switches back; any
+    other value is refused."""
+    from jaeger_amd import _lib as L
+    from jaeger_amd import fragment as frag
+    from jaeger_amd.engine import HipDevice
+    from jaeger_amd.termini import terminal_repeat_table
+    seqs = _one_run_line_records(seed=5, n_records=300)
+    bases, offsets = frag.concat_records(seqs)
+    fa = frag.FastaBatch([f"r{i}" for i in range(len(seqs))], bases, offsets)
+    dev = HipDevice(0)
+    plain = terminal_repeat_table(dev, fa, 500)
+    dev.set_stream_priority(True)
+    high = terminal_repeat_table(dev, fa, 500)
+    dev.set_stream_priority(False)
+    again = terminal_repeat_table(dev, fa, 500)
+    assert dev.lib.jg_engine_set_option(dev.handle, L.JG_OPT_STREAM_PRIORITY, 7) != 0
+    dev.close()
+    np.testing.assert_array_equal(plain, high)
+    np.testing.assert_array_equal(plain, again)
+    assert (plain[:, 0] > 100).sum() > 100

@@ -320,12 +320,20 @@ def test_table_writer_column_path_equals_the_dataframe_path(n_cls, with_rel, tmp
     for tag, (headers, repeats, by_row) in variants.items():
         y["meta_0"] = headers
         outs = []
-        for columns_path in (True, False):
-            base = tmp_path / f"{tag}_{int(columns_path)}"
+        # (columns path, names as bytes): round 6 - the pipeline hands the contigs' names over as spans of the FASTA parser's
+        # name buffer (SpanColumn), the class labels and repeat kinds go to the library as codes (EnumColumn)
+        for columns_path, as_bytes in ((True, False), (False, False), (True, True)):
+            base = tmp_path / f"{tag}_{int(columns_path)}{int(as_bytes)}"
             w = P.TableWriter(names, idx, f"{base}.tsv", f"{base}_ph.tsv", reliability_cutoff=0.1, phage_score=0.5,
                               columns_path=columns_path)
             for a, b in ((0, int(ends[120])), (int(ends[120]), int(ends[121])), (int(ends[121]), int(ends[-1]))):
-                data, _ = P.pred_to_dict({k: v[a:b] for k, v in y.items()}, class_map=cm, fsize=1500, term_repeats=None)
+                extra = {}
+                if as_bytes:
+                    firsts = np.concatenate(([a], ends[(ends > a) & (ends < b)]))
+                    extra["headers"] = P.SpanColumn.from_strings(headers[firsts])
+                data, _ = P.pred_to_dict({k: (v[a:b] if not (as_bytes and k == "meta_0") else None) for k, v in y.items()},
+                                         class_map=cm, fsize=1500, term_repeats=None, **extra)
+                assert isinstance(data["headers"], P.SpanColumn) == as_bytes
                 if columns_path:                       # as the pipeline hands it over: the library's text, rows of the join
                     blob = data["frag_pred"].summaries_blob(P.window_letters(cm))
                     assert blob is not None
@@ -334,12 +342,72 @@ def test_table_writer_column_path_equals_the_dataframe_path(n_cls, with_rel, tmp
                 if by_row and columns_path:
                     frame = repeats.frame() if hasattr(repeats, "frame") else repeats
                     lookup = {c: i for i, c in enumerate(frame["contig_id"])}
-                    data["repeat_rows"] = np.array([lookup.get(h, -1) for h in data["headers"]], dtype=np.int64)
+                    data["repeat_rows"] = np.array([lookup.get(h, -1) for h in data["headers"].tolist()], dtype=np.int64)
                     data["names_unique"] = True
                 w.append(data)
             n = w.close()
             outs.append((n, Path(f"{base}.tsv").read_bytes(),
                          Path(f"{base}_ph.tsv").read_bytes() if Path(f"{base}_ph.tsv").exists() else None))
-        assert outs[0][0] == outs[1][0] and 0 < outs[0][0] < n_contigs, tag
-        assert outs[0][1] == outs[1][1], tag
-        assert outs[0][2] == outs[1][2] and outs[0][2] is not None, tag
+        assert outs[0][0] == outs[1][0] == outs[2][0] and 0 < outs[0][0] < n_contigs, tag
+        assert outs[0][1] == outs[1][1] == outs[2][1], tag
+        assert outs[0][2] == outs[1][2] == outs[2][2] and outs[0][2] is not None, tag
+
+
+def test_table_format_span_columns_and_the_file_writer(tmp_path):
+    """``jg_table_format`` with JG_COL_SPANS columns (strings as [begin, end) spans of a byte buffer: record names out of the
+    parser's name buffer, labels out of a label blob) prints what the same strings print as a JG_COL_STRING column, for all
+    rows and for a row selection; ``jg_table_write`` puts the same bytes into an open file."""
+    import ctypes as C
+    import os
+
+    from jaeger_amd import _lib
+    from jaeger_amd import postprocess as P
+    rng = np.random.default_rng(8)
+    n = 5000
+    names = [f"contig_{i}_" + "x" * int(rng.integers(0, 9)) for i in range(n)]
+    names[17] = ""                                                    # an empty name
+    names[18] = "caf\u00e9_\u00e0"                                  # UTF-8
+    codes = rng.integers(0, 4, n)
+    labels = [None, "DTR", "ITR", "LTR_DTR"]
+    vals = rng.normal(size=n)
+    obj_names = np.array(names, dtype=object)
+    obj_kinds = np.array([np.nan if labels[c] is None else labels[c] for c in codes], dtype=object)
+    span_names = P.SpanColumn.from_strings(names)
+    # spans of a LARGER buffer in another order (as fragment.Names.spans(records) hands them out)
+    order = rng.permutation(n)
+    inv = np.argsort(order)
+    shuffled = P.SpanColumn.from_strings([names[i] for i in order.tolist()])
+    picked = P.SpanColumn(shuffled.buf, shuffled.begin[inv], shuffled.end[inv])
+    assert picked.tolist() == names and span_names.tolist() == names and np.asarray(picked).tolist() == names
+    cols = ["contig_id", "score", "terminal_repeats", "n"]
+    rows = np.sort(rng.choice(n, 700, replace=False))
+    for sel in (None, rows):
+        ref = P._columns_text(cols, [obj_names, vals, obj_kinds, np.arange(n)], sel, header=True)
+        for nm in (span_names, picked):
+            got = P._columns_text(cols, [nm, vals, P.EnumColumn(codes, labels), np.arange(n)], sel, header=True)
+            assert got == ref and got is not None
+    assert (P.EnumColumn(codes, labels) == "ITR").tolist() == (codes == 2).tolist()
+    assert not (P.EnumColumn(codes, labels) == "phage").any()
+    # a name the csv writer would quote: the library is not asked (the caller goes through pandas)
+    assert P._columns_text(cols, [P.SpanColumn.from_strings(["a\tb"] + names[1:]), vals, obj_kinds, np.arange(n)], None, True) is None
+    # the file writer: same bytes
+    lib = _lib.load()
+    st = span_names.spans()
+    v64 = np.ascontiguousarray(vals, np.float64)
+    kinds = np.array([_lib.JG_COL_SPANS, _lib.JG_COL_FLOAT], np.int32)
+    col_ptrs = (C.c_void_p * 2)(span_names.buf.ctypes.data, v64.ctypes.data)
+    start_ptrs = (C.c_void_p * 2)(st.ctypes.data, None)
+    text, size = C.c_void_p(), C.c_int64()
+    _lib.check(lib.jg_table_format(2, kinds.ctypes.data, col_ptrs, start_ptrs, None, n, 3, C.byref(text), C.byref(size)))
+    body = C.string_at(text, size.value)
+    lib.jg_table_free(text)
+    fd = os.open(tmp_path / "t.tsv", os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    try:
+        os.write(fd, b"head\n")
+        written = C.c_int64()
+        _lib.check(lib.jg_table_write(2, kinds.ctypes.data, col_ptrs, start_ptrs, None, n, 3, fd, C.byref(written)))
+    finally:
+        os.close(fd)
+    assert written.value == len(body) and (tmp_path / "t.tsv").read_bytes() == b"head\n" + body
+    assert body.split(b"\n")[17] == b"\t%.3f" % vals[17] and body.count(b"\n") == n
+    assert lib.jg_table_write(2, kinds.ctypes.data, col_ptrs, start_ptrs, None, n, 3, -1, C.byref(written)) != 0   # a bad descriptor
