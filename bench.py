@@ -640,6 +640,10 @@ def measure(args, name: str, steps: int, warmup: int, ctx: dict, headline: bool)
                                   "per window) are computed but not copied out in the timed region"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1),
                          "unit": "TFLOP/s", "frac": round(ach / peak, 4) if peak else 0.0, "traffic": pmc["traffic"],
+                         "traffic_what": ("HBM bytes per full-size launch from rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, "
+                                          "profiles/pmc_traffic.json) of THIS kernel build collected on ANOTHER device - a "
+                                          "byte count, the same on every device; hbm_gbs divides it by this run's launch time"
+                                          if pmc["traffic"] else None),
                          "hbm_gbs": pmc["hbm_gbs"], "kernel_hash": kernel_hash(mode),
                          "pmc_kernel_hash": pmc["pmc_kernel_hash"], "pmc_stale": pmc["pmc_stale"],
                          "pmc_other_device": pmc["other_device"],

@@ -75,3 +75,20 @@ def test_oracle_forward_shapes_and_merge_methods():
     cs = copy.deepcopy(cfg)
     cs["classifier"]["branch"]["hidden_layers"][-1]["config"]["method"] = "sum"
     np.testing.assert_allclose(ost.forward(cs, w, ids)["prediction"], 2 * out["prediction"], rtol=1e-6, atol=1e-6)
+
+
+def test_branched_model_with_an_nmd_merge_is_refused():
+    """the reference hands ``nmd_merge`` only to the non-branched representation learner (builder.py:486-502; its
+    parallel_branches path builds the blocks with ``nmd_merge=None``, :1121) - a branched plan with a reliability head / merge
+    config must not compile to some other graph: it is refused."""
+    import copy
+
+    import pytest
+    from conftest import load_model_cfg
+    from jaeger_amd.plan import UnsupportedLayer, build_plan
+    cfg = copy.deepcopy(load_model_cfg("dvf500"))
+    build_plan(cfg)                                                    # as it ships: fine
+    cfg["reliability_model"] = {"merge": {"mode": "sum", "target_dim": 8},
+                                "hidden_layers": [{"name": "dense", "config": {"units": 1, "activation": None}}]}
+    with pytest.raises(UnsupportedLayer, match="reliability head on a branched model"):
+        build_plan(cfg)
