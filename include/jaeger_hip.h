@@ -89,7 +89,7 @@ typedef enum {
 typedef enum { JG_MASK_ANY = 0, JG_MASK_MAJORITY = 1, JG_MASK_STRICT = 2 } jg_mask_mode;
 typedef enum { JG_PAD_VALID = 0, JG_PAD_SAME = 1 } jg_padding;
 typedef enum { JG_POOL_MAX = 0, JG_POOL_AVG = 1, JG_POOL_MAX_NOMASK = 2 } jg_pool_kind;
-typedef enum { JG_MERGE_AVERAGE = 0, JG_MERGE_SUM = 1, JG_MERGE_MAX = 2 } jg_merge_kind;
+typedef enum { JG_MERGE_AVERAGE = 0, JG_MERGE_SUM = 1, JG_MERGE_MAX = 2, JG_MERGE_CONCAT = 3 } jg_merge_kind;   /* CONCAT (round 6): builder.py:1262-1265 */
 
 /* buffer slot constants */
 #define JG_BUF_NONE (-1)

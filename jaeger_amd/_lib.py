@@ -38,7 +38,7 @@ ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_RELU, ACT_TANH, ACT_SIGMOID = range(6
 MASK_ANY, MASK_MAJORITY, MASK_STRICT = range(3)
 PAD_VALID, PAD_SAME = 0, 1
 POOL_MAX, POOL_AVG, POOL_MAX_NOMASK = 0, 1, 2
-MERGE_AVERAGE, MERGE_SUM, MERGE_MAX = 0, 1, 2            # jg_merge_kind (OP_STRANDS)
+MERGE_AVERAGE, MERGE_SUM, MERGE_MAX, MERGE_CONCAT = 0, 1, 2, 3            # jg_merge_kind (OP_STRANDS)
 JG_ENC_PRECASED, JG_ENC_CASE_SENSITIVE, JG_ENC_NUCLEOTIDE, JG_ENC_DICODON = 1, 2, 4, 8   # jg_encode / jg_predict_windows soft_mask bits
 # vector slot convention (jg_api.hip: jg_model_vec_width)
 VEC_EMBEDDING, VEC_NMD, VEC_PREDICTION, VEC_RELIABILITY, VEC_SCRATCH0 = 0, 1, 2, 3, 4

@@ -348,7 +348,7 @@ static int validate_program(const jg_model *m) {
       JG_REQUIRE(op.in_vec >= 0 && op.out_vec >= 0 && op.in_vec != op.out_vec && op.k >= 1 && op.cout >= 1 && op.vec_off >= 0,
                  JG_ERR_INVALID, "op %zu: vecmax takes k >= 1 groups of cout values from one vector into another", i);
     if (op.kind == JG_OP_STRANDS)
-      JG_REQUIRE(i + 1 == m->ops.size() && op.k >= 2 && op.k <= 8 && op.arg >= JG_MERGE_AVERAGE && op.arg <= JG_MERGE_MAX,
+      JG_REQUIRE(i + 1 == m->ops.size() && op.k >= 2 && op.k <= 8 && op.arg >= JG_MERGE_AVERAGE && op.arg <= JG_MERGE_CONCAT,
                  JG_ERR_INVALID, "op %zu: a strands op closes the program, merges 2 - 8 strands by average / sum / max", i);
     JG_REQUIRE(slot_ok(op.in_buf, true) && slot_ok(op.out_buf, false) && slot_ok(op.in_mask, true) &&
                    slot_ok(op.out_mask, false),
@@ -2176,6 +2176,9 @@ extern "C" int jg_model_vec_width(const jg_model *m, int which) {
     width = std::max(width, wd);
   }
   (void)a; (void)b; (void)c; (void)vw;
+  // a branched model whose classifier's merge layer is Concatenate (builder.py:1262-1265): the window's prediction is the
+  // strands' head outputs side by side
+  if (which == 0 && m->strands > 1 && m->merge_kind == JG_MERGE_CONCAT) width *= m->strands;
   return width;
 }
 
@@ -2201,7 +2204,9 @@ static int copy_out(jg_model *m, int slot, int width, float *dst, int64_t row0, 
     // classifier's merge layer, every other output by Average - builder.py:776-791)
     const int rc = grow(&m->merged[slot], &m->merged_cap[slot], (int64_t)nw * width * (int64_t)sizeof(float));
     if (rc != JG_OK) return rc;
-    const int mrc = jg_launch_strand_merge(src, (int)src_ld, nw, m->strands, width, slot == 2 ? m->merge_kind : JG_MERGE_AVERAGE,
+    const int kind = slot == 2 ? m->merge_kind : JG_MERGE_AVERAGE;
+    // (`width` is the OUTPUT's: a concatenated prediction is `strands` head vectors wide)
+    const int mrc = jg_launch_strand_merge(src, (int)src_ld, nw, m->strands, kind == JG_MERGE_CONCAT ? width / m->strands : width, kind,
                                            m->merged[slot], s);
     if (mrc != JG_OK) return mrc;
     src = m->merged[slot];

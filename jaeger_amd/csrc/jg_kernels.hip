@@ -1492,12 +1492,17 @@ int jg_launch_tab_conv_pool(jg_engine *e, const JgTabArgs &a, hipStream_t s) {
   return JG_OK;
 }
 
-// Merge of a branched model's strand outputs (tf.keras.layers.Average / Add / Maximum over the branch outputs,
-// builder.py:1251-1262; the embedding output is always their Average, :779-780): x (n_win * strands, x_ld) -> y (n_win, width)
+// Merge of a branched model's strand outputs (tf.keras.layers.Average / Add / Maximum / Concatenate over the branch outputs,
+// builder.py:1251-1265; the embedding output is always their Average, :779-780): x (n_win * strands, x_ld) -> y (n_win, width)
 __global__ __launch_bounds__(256) void strand_merge_kernel(const float *__restrict__ x, int x_ld, int64_t total, int strands,
                                                            int width, int kind, float *__restrict__ y) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
+  if (kind == JG_MERGE_CONCAT) {                        // y (n_win, strands * width): strand q's vector at columns q width ..
+    const int64_t row = i / width;                      // = window * strands + strand
+    y[i] = x[row * (int64_t)x_ld + (i - row * width)];
+    return;
+  }
   const int64_t w = i / width;
   const int c = (int)(i - w * width);
   const float *src = x + w * strands * (int64_t)x_ld + c;
@@ -1511,7 +1516,7 @@ __global__ __launch_bounds__(256) void strand_merge_kernel(const float *__restri
 }
 
 int jg_launch_strand_merge(const float *x, int x_ld, int n_win, int strands, int width, int kind, float *y, hipStream_t s) {
-  const int64_t total = (int64_t)n_win * width;
+  const int64_t total = (int64_t)n_win * width * (kind == JG_MERGE_CONCAT ? strands : 1);
   if (total == 0) return JG_OK;
   hipLaunchKernelGGL(strand_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x_ld, total, strands,
                      width, kind, y);

@@ -122,6 +122,7 @@ class ModelPlan:
     # (rep/nmd_merge/proj_<i>/kernel; "weighted": + rep/nmd_merge/layer_weights, softmax-ed), then combined
     nmd_merge_mode: str = "concat"
     nmd_merge_dim: int = 0
+    nmd_merge_act: str | None = None        # projection_kwargs.activation of the projections (round 6), None = linear
     # use_positional_embeddings (builder.py:886-892): SinusoidalPositionEmbedding(max_wavelength) rows (layers.py:2149-2195)
     # added to the embedded input; None = none
     positional_wavelength: float | None = None
@@ -342,9 +343,15 @@ def build_plan(model_cfg: dict) -> ModelPlan:
                     target = nmd_dims[0]
                 pk = {k: v for k, v in (merge.get("projection_kwargs") or {}).items()
                       if not k.startswith("kernel_")}          # (initialisers / regularisers / constraints: training only)
-                if pk.get("activation") not in (None, "linear") or set(pk) - {"activation"}:
-                    raise UnsupportedLayer(f"NMDMerge projection_kwargs {sorted(pk)} are not supported (linear, bias-free "
-                                           f"projections only)")
+                # Dense(target_dim, use_bias=False, name=..., **projection_kwargs) (nmd.py:133-141): `use_bias` or `units` here
+                # would be a duplicate keyword in the reference; what is left that changes the graph is `activation`
+                if set(pk) - {"activation"}:
+                    raise UnsupportedLayer(f"NMDMerge projection_kwargs {sorted(set(pk) - {'activation'})} are not supported "
+                                           f"(bias-free projections, optionally with an activation)")
+                act = pk.get("activation")
+                if act is not None and str(act).lower() not in (set(_ACT_ALIASES) | {"linear"}):
+                    raise UnsupportedLayer(f"NMDMerge projection activation {act!r}")
+                plan.nmd_merge_act = None if act is None or str(act).lower() == "linear" else str(act).lower()
                 plan.nmd_merge_mode, plan.nmd_merge_dim = mmode, int(target)
         mode = rel.get("mode", "nmd")
         if mode not in ("nmd", "nmd_plus_signals"):
@@ -411,8 +418,8 @@ def _build_strand_plan(model_cfg: dict, sp: dict, graph_input: str, branched: li
     if not hidden or str(hidden[-1].get("name", "")).lower() != "merge":
         raise ValueError("Branched classifier must end with a 'merge' layer")           # builder.py:565-568
     merge = str((hidden[-1].get("config") or {}).get("method", "average")).lower()    # builder.py:569-570
-    if merge not in ("average", "sum", "max"):
-        raise UnsupportedLayer(f"merge method {merge!r} (average / sum / max)")
+    if merge not in ("average", "sum", "max", "concat"):
+        raise ValueError(f"Unknown merge method: {merge}")                               # builder.py:1266
     cls, n_cls = _block(hidden[:-1], "classifier", rep_c, False, None)
     return ModelPlan(vocab=5, embedding_dim=4, rep=rep, pooling=pooling, rep_channels=rep_c, classifier=cls,
                      n_classes=n_cls, use_masking=False, string_processor=sp,

@@ -421,7 +421,9 @@ class _Compiler:
         n, t = len(plan.nmd_dims), plan.nmd_merge_dim
         proj = [np.asarray(self.w[f"rep/nmd_merge/proj_{i}/kernel"], np.float32) for i in range(n)]
         raw = plan.nmd_raw_dim
-        if plan.nmd_merge_mode == "max":
+        act = getattr(plan, "nmd_merge_act", None)
+        if plan.nmd_merge_mode == "max" or act is not None:
+            # the projections as ONE block-diagonal dense layer (with the projections' activation, projection_kwargs: round 6)
             kernel = np.zeros((raw, n * t), np.float32)
             at = 0
             for i, (d, p) in enumerate(zip(plan.nmd_dims, proj)):
@@ -429,15 +431,23 @@ class _Compiler:
                 at += d
             blocks = L.JG_MAX_VECS - 2
             self.ops.append(self._op(L.OP_DENSE, in_vec=self.nmd_vec, out_vec=blocks, vec_off=0, cin=raw, cout=n * t,
-                                     arg=act_code(None), w_off=self.blob.add(kernel), b_off=-1))
-            self.ops.append(self._op(L.OP_VECMAX, in_vec=blocks, out_vec=L.VEC_NMD, vec_off=0, k=n, cout=t))
-            return
+                                     arg=act_code(act), w_off=self.blob.add(kernel), b_off=-1))
+            if plan.nmd_merge_mode == "max":
+                self.ops.append(self._op(L.OP_VECMAX, in_vec=blocks, out_vec=L.VEC_NMD, vec_off=0, k=n, cout=t))
+                return
         if plan.nmd_merge_mode == "weighted":
             lw = np.asarray(self.w["rep/nmd_merge/layer_weights"], np.float32)
             e = np.exp(lw - lw.max())
             scale = (e / e.sum()).astype(np.float32)            # tf.nn.softmax(layer_weights), nmd.py:153-155
         else:
             scale = np.full(n, 1.0 if plan.nmd_merge_mode == "sum" else 1.0 / n, np.float32)
+        if act is not None:
+            # sum / mean / weighted of ACTIVATED projections: a second, linear dense layer over the blocks whose kernel is the
+            # scaled identity matrices stacked (every product with a zero is exact: the sum is the weighted sum of the blocks)
+            kernel = np.concatenate([np.eye(t, dtype=np.float32) * s for s in scale], axis=0).astype(np.float32)
+            self.ops.append(self._op(L.OP_DENSE, in_vec=L.JG_MAX_VECS - 2, out_vec=L.VEC_NMD, vec_off=0, cin=n * t, cout=t,
+                                     arg=act_code(None), w_off=self.blob.add(kernel), b_off=-1))
+            return
         kernel = np.concatenate([p * s for p, s in zip(proj, scale)], axis=0).astype(np.float32)
         self.ops.append(self._op(L.OP_DENSE, in_vec=self.nmd_vec, out_vec=L.VEC_NMD, vec_off=0, cin=raw, cout=t,
                                  arg=act_code(None), w_off=self.blob.add(kernel), b_off=-1))
@@ -463,7 +473,8 @@ class _Compiler:
             # the heads above ran per strand (shared weights); the window's outputs are the strands' merged
             # (tf.keras.layers.Average / Add / Maximum, builder.py:1251-1262; embedding: Average, :779-780)
             self.ops.append(self._op(L.OP_STRANDS, k=plan.strands,
-                                     arg={"average": L.MERGE_AVERAGE, "sum": L.MERGE_SUM, "max": L.MERGE_MAX}[plan.merge]))
+                                     arg={"average": L.MERGE_AVERAGE, "sum": L.MERGE_SUM, "max": L.MERGE_MAX,
+                                          "concat": L.MERGE_CONCAT}[plan.merge]))
         return Program(self.ops, self.blob.finish(), plan.vocab, plan.n_classes,
                        plan.reliability is not None, plan.nmd_dim, plan.rep_channels, plan.strands)
 

@@ -238,7 +238,9 @@ def nmd_merge(nmds: list, merge: dict | None, weights: dict, dtype):
         return torch.cat(nmds, dim=-1)
     if mode not in ("sum", "mean", "max", "weighted"):
         raise ValueError(f"Unsupported NMD merge mode: {mode}")
-    projected = [v @ torch.as_tensor(weights[f"rep/nmd_merge/proj_{i}/kernel"]).to(dtype) for i, v in enumerate(nmds)]
+    # Dense(target_dim, use_bias=False, **projection_kwargs) (nmd.py:133-141): the only graph-changing keyword is `activation`
+    act = ((merge or {}).get("projection_kwargs") or {}).get("activation")
+    projected = [activation(act, v @ torch.as_tensor(weights[f"rep/nmd_merge/proj_{i}/kernel"]).to(dtype)) for i, v in enumerate(nmds)]
     if mode == "sum":
         return sum(projected[1:], projected[0])
     if mode == "mean":

@@ -157,6 +157,9 @@ def forward(model_cfg: dict, weights: dict, ids: np.ndarray, dtype=torch.float32
         reps.append(r)
         heads.append(_run_branch(r, hidden[:-1], "classifier", weights, dtype))
     stack = torch.stack(heads)
-    pred = {"average": stack.mean(dim=0), "sum": stack.sum(dim=0), "max": stack.max(dim=0).values}[method]
+    if method not in ("average", "sum", "max", "concat"):
+        raise ValueError(f"Unknown merge method: {method}")                             # builder.py:1266
+    pred = {"average": stack.mean(dim=0), "sum": stack.sum(dim=0), "max": stack.max(dim=0).values,
+            "concat": torch.cat(heads, dim=-1)}[method]                                 # builder.py:1251-1265
     out = {"prediction": pred, "embedding": torch.stack(reps).mean(dim=0)}
     return {k: v.detach().to(torch.float32).numpy() for k, v in out.items()}

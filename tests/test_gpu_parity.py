@@ -350,6 +350,43 @@ def test_forward_nmd_merge_modes(mode, target):
         check_side_output("nmd", got["nmd"], ref["nmd"])
 
 
+@pytest.mark.parametrize("mode,act", [("sum", "gelu"), ("mean", "relu"), ("weighted", "tanh"), ("max", "gelu")])
+def test_forward_nmd_merge_projection_activation(mode, act):
+    """NMDMerge ``projection_kwargs: {activation: ...}`` (nnlib/v2/nmd.py:133-141: ``Dense(target_dim, use_bias=False,
+    **projection_kwargs)``; round 6): every NMD vector through its own ACTIVATED projection, then the merge - the projections as
+    one block-diagonal dense op with the activation, the sum / mean / weighted merge as a second, linear one over the blocks
+    (max: JG_OP_VECMAX).  Both precisions against the oracle; the linear form gives other values."""
+    import copy
+
+    from jaeger_amd.engine import JaegerHipEngine, frame_length
+    from oracle import encoder as oenc
+    from oracle import forward as ofwd
+    cfg = copy.deepcopy(load_model_cfg("nmdmerge500"))
+    rel = cfg["reliability_model"]
+    rel["merge"] = {"mode": mode, "axis": -1, "target_dim": 24, "projection_kwargs": {"activation": act, "kernel_initializer": "glorot_uniform"}}
+    rel["input_shape"] = 24
+    weights = ofwd.random_weights(cfg, seed=77)
+    rng = np.random.Generator(np.random.PCG64(10))
+    fsize, n_win = 500, 24
+    seq = _random_dna(rng, fsize * n_win, n_frac=0.02)
+    starts = (np.arange(n_win) * fsize).astype(np.int64)
+    lens = np.full(n_win, fsize, np.int32)
+    lens[2::5] = rng.integers(fsize // 2, fsize, lens[2::5].size)
+    ids = oenc.encode_windows([seq[s:s + n].tobytes() for s, n in zip(starts, lens)], fsize, pad_to=frame_length(fsize))
+    ref = ofwd.forward(cfg, weights, ids)
+    linear = copy.deepcopy(cfg)
+    linear["reliability_model"]["merge"].pop("projection_kwargs")
+    assert np.abs(ofwd.forward(linear, weights, ids)["nmd"] - ref["nmd"]).max() > 1e-3      # the activation is not a no-op
+    for precision in ("f16x3", "f32"):
+        eng = JaegerHipEngine(model_cfg=cfg, weights=weights, device_id=0, precision=precision)
+        got = eng.predict_windows(seq, starts, lens, fsize)
+        eng.close()
+        assert got["nmd"].shape == ref["nmd"].shape == (n_win, 24)
+        for k in ("prediction", "reliability"):
+            assert np.abs(got[k] - ref[k]).max() <= TOL, (mode, act, precision, k, np.abs(got[k] - ref[k]).max())
+        check_side_output("nmd", got["nmd"], ref["nmd"])
+
+
 @pytest.mark.parametrize("name,fsize", [("baseline500", 500), ("brain", 1500)])
 def test_forward_positional_embeddings(name, fsize):
     """use_positional_embeddings (builder.py:886-892; SinusoidalPositionEmbedding, nnlib/v2/layers.py:2149-2195): the embedded

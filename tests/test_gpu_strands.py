@@ -101,7 +101,7 @@ def test_forward_dvf500_long_rows_take_the_lds_form():
     _case(load_model_cfg("dvf500"), 12, 1200, seed=10, short=True)
 
 
-@pytest.mark.parametrize("method", ["sum", "max"])
+@pytest.mark.parametrize("method", ["sum", "max", "concat"])
 def test_forward_dvf500_merge_methods(method):
     cfg = copy.deepcopy(load_model_cfg("dvf500"))
     cfg["classifier"]["branch"]["hidden_layers"][-1]["config"]["method"] = method

@@ -374,8 +374,42 @@ def test_nmd_merge_modes_compile_to_one_dense_layer_or_a_block_diagonal_one_and_
     else:
         assert [op.kind for op in merged] == [L.OP_DENSE] and merged[0].cin == 64 and merged[0].cout == 24 and merged[0].b_off < 0
     assert prog.nmd_dim == 24
-    # what stays rejected, loudly: a projection with an activation; differing widths without a target_dim
-    rel["merge"] = {"mode": mode, "target_dim": 24, "projection_kwargs": {"activation": "relu"}}
+    # round 6: projections with an activation (projection_kwargs, nmd.py:133-141) = the block-diagonal dense op with the
+    # activation + a linear dense op over the blocks (scaled identities stacked), or + JG_OP_VECMAX; against numpy on the oracle
+    rel["merge"] = {"mode": mode, "target_dim": 24, "projection_kwargs": {"activation": "relu", "kernel_regularizer": None}}
+    plan_a = build_plan(cfg)
+    assert plan_a.nmd_merge_act == "relu"
+    prog_a = compile_plan(plan_a, weights)
+    merged = [op for op in prog_a.ops if op.out_vec == L.VEC_NMD]
+    blocks = [op for op in prog_a.ops if op.out_vec == L.JG_MAX_VECS - 2]
+    assert len(blocks) == 1 and blocks[0].kind == L.OP_DENSE and (blocks[0].cin, blocks[0].cout) == (64, 48)
+    assert blocks[0].arg == __import__("jaeger_amd.program", fromlist=["act_code"]).act_code("relu")
+    if mode == "max":
+        assert [op.kind for op in merged] == [L.OP_VECMAX]
+    else:
+        assert [op.kind for op in merged] == [L.OP_DENSE] and (merged[0].cin, merged[0].cout) == (48, 24)
+    ids = np.random.default_rng(3).integers(1, 65, (5, 6, 165))
+    out = ofwd.forward(cfg, weights, ids)
+    lin = copy.deepcopy(cfg)
+    lin["reliability_model"]["merge"] = {"mode": "concat"}
+    lin["reliability_model"]["input_shape"] = 64
+    lin_w = dict(weights)                                   # (the head reads 64 values there: its weights from the concat model)
+    lin_w.update({k: v for k, v in ofwd.random_weights(lin, seed=5).items() if k.startswith("reliability")})
+    raw = ofwd.forward(lin, lin_w, ids)["nmd"].astype(np.float64)
+    pr = [np.maximum(raw[:, :32] @ weights["rep/nmd_merge/proj_0/kernel"].astype(np.float64), 0),
+          np.maximum(raw[:, 32:] @ weights["rep/nmd_merge/proj_1/kernel"].astype(np.float64), 0)]
+    if mode == "weighted":
+        lw = weights["rep/nmd_merge/layer_weights"].astype(np.float64)
+        sm = np.exp(lw - lw.max()) / np.exp(lw - lw.max()).sum()
+        want = sm[0] * pr[0] + sm[1] * pr[1]
+    else:
+        want = {"sum": pr[0] + pr[1], "mean": (pr[0] + pr[1]) / 2, "max": np.maximum(pr[0], pr[1])}[mode]
+    np.testing.assert_allclose(out["nmd"], want, atol=1e-4, rtol=1e-4)
+    # what stays rejected, loudly: a projection keyword the reference's Dense call would not survive / this engine does not build
+    rel["merge"] = {"mode": mode, "target_dim": 24, "projection_kwargs": {"use_bias": True}}
+    with pytest.raises(UnsupportedLayer):
+        build_plan(cfg)
+    rel["merge"] = {"mode": mode, "target_dim": 24, "projection_kwargs": {"activation": "swish"}}
     with pytest.raises(UnsupportedLayer):
         build_plan(cfg)
     rel["merge"] = {"mode": "bogus"}

@@ -75,6 +75,23 @@ def test_oracle_forward_shapes_and_merge_methods():
     cs = copy.deepcopy(cfg)
     cs["classifier"]["branch"]["hidden_layers"][-1]["config"]["method"] = "sum"
     np.testing.assert_allclose(ost.forward(cs, w, ids)["prediction"], 2 * out["prediction"], rtol=1e-6, atol=1e-6)
+    # "concat" (builder.py:1262-1265, round 6): the two strands' head outputs side by side - their mean is the "average" merge
+    cs["classifier"]["branch"]["hidden_layers"][-1]["config"]["method"] = "concat"
+    cat = ost.forward(cs, w, ids)["prediction"]
+    assert cat.shape == (6, 6)
+    np.testing.assert_allclose((cat[:, :3] + cat[:, 3:]) / 2, out["prediction"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ost.forward(cs, w, ids[:, ::-1])["prediction"], np.concatenate([cat[:, 3:], cat[:, :3]], axis=1), atol=1e-6)
+    from jaeger_amd import _lib as L
+    from jaeger_amd.plan import build_plan
+    from jaeger_amd.program import compile_plan
+    from jaeger_amd.weights import random_weights
+    plan = build_plan(cs)
+    assert plan.merge == "concat" and compile_plan(plan, random_weights(plan, 1)).ops[-1].arg == L.MERGE_CONCAT
+    cs["classifier"]["branch"]["hidden_layers"][-1]["config"]["method"] = "median"
+    with pytest.raises(ValueError, match="Unknown merge method"):
+        build_plan(cs)
+    with pytest.raises(ValueError, match="Unknown merge method"):
+        ost.forward(cs, w, ids)
 
 
 def test_branched_model_with_an_nmd_merge_is_refused():
