@@ -30,6 +30,19 @@ for name, fsize, stride in (("brain", 1500, 1500), ("brain", 2000, 1500), ("brai
     print("   placement:", eng.model.placement())
     run(name, eng, fsize, stride, lambda b, s, l, f: eng.predict_windows(b, s, l, f, want=("prediction", "reliability")))
     eng.close()
+# SURVEY 8(d) config 2's variant: 1 % of the bases in N runs of length 1 - 20 (masks at work in every layer)
+bases_n = bases.copy()
+rn = np.random.Generator(np.random.PCG64(2))
+pos = rn.integers(0, bases_n.size - 20, int(bases_n.size * 0.01 / 10.5))
+for p_, l_ in zip(pos.tolist(), rn.integers(1, 21, pos.size).tolist()):
+    bases_n[p_:p_ + l_] = ord("N")
+cfg = load_model_cfg("brain")
+eng = JaegerHipEngine(model_cfg=cfg, weights=random_weights(build_plan(cfg), 1))
+keep = bases
+bases = bases_n
+run("brain, 1 % N runs", eng, 1500, 1500, lambda b, s, l, f: eng.predict_windows(b, s, l, f, want=("prediction", "reliability")))
+bases = keep
+eng.close()
 w = legacy.load_legacy_h5('tests/golden/legacy_data/models/default/WRes_1024.h5')
 for prec in ("f32", "f16x3"):
     eng = legacy.LegacyHipEngine(w, precision=prec)
