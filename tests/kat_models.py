@@ -280,3 +280,30 @@ def strided_block_partial_mask_case(norm_type: str, seed: int = 3):
     ids = rng.integers(1, 65, (2, 6, length))
     ids[:, :, valid:] = 0
     return cfg, w, ids
+
+
+# ---- MaskedLayerNormalization: masked positions zero, unmasked ones normalised ---------------------------------------
+def layernorm_zeroes_masked_case(seed: int = 21):
+    """tests/unit/test_nnlib_v2_layers.py:94-107: MaskedLayerNormalization(epsilon 1e-3) over inputs of standard deviation 5
+    with two masked positions: |masked| < 1e-5, mean of the unmasked values within 0.05 of 0, their standard deviation within
+    0.05 of 1.  The model twin reads both through an unmasking identity conv and the plain mean pool (as the DyT case does):
+    the pooled vector is the sum of LN(x) over the VALID positions / all positions - a non-zeroed masked position would add
+    LN(E[0]) / L per channel -, and the per-position statistics are asserted on the numpy expectation the pooled vector must
+    equal."""
+    dim, length = 16, 8
+    rng = np.random.default_rng(seed)
+    cfg = _base(dim, [{"name": "masked_layernorm", "config": {"epsilon": 1e-3}},
+                      {"name": "masked_conv1d", "config": {"filters": dim, "kernel_size": 1, "padding": "valid",
+                                                           "use_bias": False, "use_masking": False}}], "average", dim)
+    table = (5.0 * rng.normal(size=(65, dim))).astype(np.float32)
+    w = {"embedding/embeddings": table, "rep/0/gamma": np.ones(dim, np.float32), "rep/0/beta": np.zeros(dim, np.float32),
+         "rep/1/kernel": np.eye(dim, dtype=np.float32)[None], "classifier/0/kernel": np.eye(dim, dtype=np.float32)}
+    ids = rng.integers(1, 65, (2, 6, length))
+    ids[0, :, 0] = 0                                        # the reference masks [0, 0, 0] and [1, 2, 3]: one position per window
+    ids[1, :, 3] = 0
+    x = table.astype(np.float64)[ids]                                       # (2, 6, L, C)
+    ln = (x - x.mean(-1, keepdims=True)) / np.sqrt(x.var(-1, keepdims=True) + 1e-3)
+    valid = (ids != 0)[..., None]
+    want = (ln * valid).sum(axis=(1, 2)) / (6 * length)
+    not_zeroed = ln.sum(axis=(1, 2)) / (6 * length)
+    return cfg, w, ids, want, not_zeroed, ln[np.broadcast_to(valid, ln.shape)]

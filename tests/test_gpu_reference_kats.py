@@ -144,3 +144,16 @@ def test_strided_block_on_a_half_padded_batch(norm_type, precision):
     inside = ids.copy()
     inside[:, :, 3] = (inside[:, :, 3] % 64) + 1
     assert np.abs(_run(cfg, w, inside, precision)["embedding"] - out["embedding"]).max() > 1e-4
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_masked_layernorm_zeroes_masked_and_normalises_unmasked(precision):
+    """tests/unit/test_nnlib_v2_layers.py:94-107: masked positions hold zeros behind MaskedLayerNormalization (|.| < 1e-5), the
+    unmasked values are normalised (mean within 0.05 of 0, std within 0.05 of 1) - the pooled vector equals the numpy
+    expectation that carries both."""
+    from kat_models import layernorm_zeroes_masked_case
+    cfg, w, ids, want, not_zeroed, unmasked = layernorm_zeroes_masked_case()
+    assert abs(unmasked.mean()) < 0.05 and abs(unmasked.std() - 1.0) < 0.05
+    got = _run(cfg, w, ids, precision)["embedding"]
+    np.testing.assert_allclose(got, want, atol=1e-5)
+    assert np.abs(got - not_zeroed).max() > 1e-2

@@ -214,3 +214,23 @@ def test_strided_block_on_a_half_padded_batch():
                                   True, True, torch.float32)
         assert y.shape[2] == 16 and om.shape[2] == 16 and np.isfinite(y.numpy()).all(), nt
         assert np.isfinite(F.forward(cfg, w, ids)["embedding"]).all()
+
+
+def test_masked_layernorm_zeroes_masked_and_normalises_unmasked():
+    """tests/unit/test_nnlib_v2_layers.py:94-107 on the layer and through the model of kat_models."""
+    from kat_models import layernorm_zeroes_masked_case
+    from oracle import forward as F
+    rng = np.random.default_rng(0)
+    x = torch.tensor((5.0 * rng.normal(size=(2, 4, 8, 16))).astype(np.float32))
+    m = torch.ones(2, 4, 8)
+    m[0, 0, 0] = 0
+    m[1, 2, 3] = 0
+    out = F.masked_layernorm(x, m, {"gamma": torch.ones(16), "beta": torch.zeros(16)}, eps=1e-3).numpy()
+    mb = m.numpy().astype(bool)
+    assert np.abs(out[~mb]).max() < 1e-5
+    assert abs(out[mb].mean()) < 0.05 and abs(out[mb].std() - 1.0) < 0.05
+    cfg, w, ids, want, not_zeroed, unmasked = layernorm_zeroes_masked_case()
+    assert abs(unmasked.mean()) < 0.05 and abs(unmasked.std() - 1.0) < 0.05          # the reference's two bounds
+    got = F.forward(cfg, w, ids)["embedding"]
+    np.testing.assert_allclose(got, want, atol=1e-5)
+    assert np.abs(not_zeroed - want).max() > 1e-2
