@@ -426,6 +426,13 @@ def main():
         print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world_env}", file=sys.stderr)
         sys.exit(2)
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio at communicator set-up, and
+    # with stdout redirected that buffer only empties at exit - behind the line (seen in round 6's first world-1 RCCL run).
+    # So this process's fd 1 goes to /dev/null for its whole life, and rank 0 writes the line to the real stdout itself.
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+
     import torch
     import torch.distributed as dist
     import yaml
@@ -463,7 +470,9 @@ def main():
                coll=coll)
     line = measure(args, args.config, args.steps, args.warmup, ctx, headline=True)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        data = (json.dumps(line) + "\n").encode()
+        while data:
+            data = data[os.write(real_stdout, data):]
     if coll:
         dist.barrier()
         dist.destroy_process_group()

@@ -299,7 +299,9 @@ def test_bench_one_rank_over_rccl(tmp_path):
     res = subprocess.run(base + ["--collective", "nccl", "--dump-gather", str(tmp_path / "rccl.npy")], capture_output=True,
                          text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-4000:]
-    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    # exactly ONE line on stdout - RCCL's version banner (C stdio, flushed at exit) must not follow the JSON line
+    assert len(res.stdout.strip().splitlines()) == 1, res.stdout[-600:]
+    line = json.loads(res.stdout.strip())
     assert line["n_gpus"] == 1 and line["config"]["collective_backend"] == "nccl"
     assert line["config"]["parallelism"].endswith("final RCCL gather (executed)")
     assert line["per_rank"]["gather_ms_per_step"]["max"] > 0 and line["per_rank"]["windows"] == [400]
