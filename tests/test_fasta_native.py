@@ -163,3 +163,33 @@ def test_names_container_stands_for_the_list_of_names(tmp_path):
     raw2 = bytearray(raw)
     raw2[8 * 777:8 * 778] = raw[8 * 299_000:8 * 299_001]
     assert not frag.Names(np.frombuffer(bytes(raw2), np.uint8), np.arange(n + 1, dtype=np.int64) * 8).is_unique()
+
+
+def test_names_container_property():
+    """Property test (hypothesis): ``fragment.Names`` built from arbitrary name lists compares, indexes and slices like the list,
+    finds duplicates exactly, and ``plain()`` is true exactly when io.py:109's normalisation is the identity on every name."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    alphabet = st.characters(blacklist_categories=("Cs",), blacklist_characters="\x00")
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(st.text(alphabet, max_size=10), max_size=30), st.booleans())
+    def check(names, duplicate):
+        if duplicate and names:
+            names = names + [names[len(names) // 2]]
+        raw = [n.encode() for n in names]
+        off = np.concatenate(([0], np.cumsum([len(r) for r in raw]))).astype(np.int64)
+        got = frag.Names(np.frombuffer(b"".join(raw) or b"\0", np.uint8)[:int(off[-1])] if raw else np.zeros(0, np.uint8), off)
+        assert got == names and list(got) == names and len(got) == len(names)
+        for i in range(len(names)):
+            assert got[i] == names[i] and got[i - len(names)] == names[i]
+        assert got[1:3] == names[1:3]
+        assert got.is_unique() == (len(set(names)) == len(names))
+        if got.plain():                         # (conservative the other way: a name it calls not plain may still be unchanged)
+            assert all(n.strip().replace(",", "___") == n for n in names)
+        assert frag.normalise_headers(got).tolist() == [n.strip().replace(",", "___") for n in names]
+        buf, b, e = got.spans()
+        assert [buf[x:y].tobytes().decode() for x, y in zip(b.tolist(), e.tolist())] == names
+
+    check()

@@ -411,3 +411,40 @@ def test_table_format_span_columns_and_the_file_writer(tmp_path):
     assert written.value == len(body) and (tmp_path / "t.tsv").read_bytes() == b"head\n" + body
     assert body.split(b"\n")[17] == b"\t%.3f" % vals[17] and body.count(b"\n") == n
     assert lib.jg_table_write(2, kinds.ctypes.data, col_ptrs, start_ptrs, None, n, 3, -1, C.byref(written)) != 0   # a bad descriptor
+
+
+def test_byte_columns_print_what_object_columns_print_property():
+    """Property test (hypothesis): for arbitrary lists of names - unicode, empty, spaces, commas, triple underscores - a
+    ``SpanColumn`` / ``EnumColumn`` table renders byte for byte what the same strings render as object arrays, for every
+    row selection; names the csv writer would quote make BOTH forms decline (None: the caller goes through pandas)."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from jaeger_amd import postprocess as P
+    alphabet = st.characters(blacklist_categories=("Cs",), blacklist_characters="\x00")
+    names_st = st.lists(st.text(alphabet, max_size=12), min_size=1, max_size=40)
+
+    @settings(max_examples=120, deadline=None)
+    @given(names_st, st.data())
+    def check(names, data):
+        n = len(names)
+        codes = np.array(data.draw(st.lists(st.integers(0, 3), min_size=n, max_size=n)))
+        vals = np.array(data.draw(st.lists(st.one_of(st.floats(-1e6, 1e6, allow_nan=False, width=32), st.just(float("nan"))),
+                                           min_size=n, max_size=n)), np.float64)
+        rows = sorted(set(data.draw(st.lists(st.integers(0, n - 1), max_size=n))))
+        labels = [None, "DTR", "ITR", "LTR_DTR"]
+        obj_names = np.array(names, dtype=object)
+        obj_kinds = np.array([np.nan if labels[c] is None else labels[c] for c in codes], dtype=object)
+        cols = ["contig_id", "score", "terminal_repeats"]
+        span = P.SpanColumn.from_strings(names)
+        assert span.tolist() == names and len(span) == n
+        for sel in (None, np.array(rows, np.int64) if rows else None):
+            ref = P._columns_text(cols, [obj_names, vals, obj_kinds], sel, header=True)
+            got = P._columns_text(cols, [span, vals, P.EnumColumn(codes, labels)], sel, header=True)
+            quoted = any(c in s for s in names for c in '\t"\n\r')
+            if quoted:
+                assert got is None and ref is None
+            else:
+                assert got == ref and got is not None
+
+    check()
