@@ -100,6 +100,14 @@ def random_model(rng):
         else:
             base.pop("reliability_model", None)
         base["representation_learner"]["hidden_layers"] = layers
+    # round 6: NMDMerge over several taps (nmd.py:93-155) - projecting modes, now and then with an activated projection
+    taps = sum(1 for l in base["representation_learner"]["hidden_layers"]
+               if l["name"] == "nmd" or (l.get("config") or {}).get("return_nmd"))
+    if "reliability_model" in base and taps >= 2 and rng.random() < 0.4:
+        merge = {"mode": str(rng.choice(["sum", "mean", "max", "weighted"])), "target_dim": int(rng.choice([8, 24, 40]))}
+        if rng.random() < 0.5:
+            merge["projection_kwargs"] = {"activation": str(rng.choice(["gelu", "relu", "tanh"]))}
+        base["reliability_model"]["merge"] = merge
     return base
 
 
