@@ -225,8 +225,15 @@ class _Aggregator:
     (commands/predict.py:846).  Per-contig statistics do not depend on which other contigs share a batch, so the merged
     result equals one ``pred_to_dict`` call over everything (tests/test_postprocess.py)."""
 
-    def __init__(self, table: "frag.WindowTable", names: list[str], out: dict, pred_kw: dict, min_batch: int):
+    def __init__(self, table: "frag.WindowTable", names: list[str], out: dict, pred_kw: dict, min_batch: int, workers: int = 1):
         self.table, self.out, self.kw = table, out, pred_kw
+        # workers > 1 (round 6): batches are aggregated on a small pool - ``parts`` then holds futures, in batch order - so
+        # that on files of very many short contigs the aggregation keeps pace with the forward (numpy and the native
+        # reductions run without the interpreter lock); consumers take the batches in order whatever finished first
+        self.pool = None
+        if workers > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(max_workers=int(workers), thread_name_prefix="jaeger-agg")
         # names straight from the native parser (fragment.Names) that io.py:109's normalisation leaves as they are stay BYTES
         # from the FASTA image to the table rows; anything else goes through the per-record strings as before
         self._names = names
@@ -256,13 +263,38 @@ class _Aggregator:
         w1 = int(self.ends[k - 1]) if k else 0
         if w1 <= self.w_done or (not final and w1 - self.w_done < self.min_batch):
             return
+        w0, self.w_done = self.w_done, w1
+        if self.pool is not None:
+            self.parts.append(self.pool.submit(self._batch, w0, w1))
+        else:
+            part = self._batch(w0, w1)
+            if part is not None:
+                self.parts.append(part)
+
+    def _batch(self, w0: int, w1: int):
+        """(data, data_full) of the contigs whose windows are [w0, w1), or None."""
         t0 = time.time()
-        rec = self.table.contig[self.w_done:w1]
+        rec = self.table.contig[w0:w1]
         first = np.ones(len(rec), dtype=bool)
         first[1:] = rec[1:] != rec[:-1]
-        self.add(self.slice(self.w_done, w1, with_names=self.names_bytes is None), records=np.asarray(rec[first], dtype=np.int64))
-        self.w_done = w1
+        part = self._aggregate(self.slice(w0, w1, with_names=self.names_bytes is None), np.asarray(rec[first], dtype=np.int64))
         self.busy_s += time.time() - t0
+        return part
+
+    def _part(self, i: int, wait: bool = True):
+        """Batch ``i`` as (data, data_full) (None: an empty one); with ``wait`` False, the string "pending" while a worker
+        still has it."""
+        item = self.parts[i]
+        if hasattr(item, "result"):
+            if not wait and not item.done():
+                return "pending"
+            item = self.parts[i] = item.result()          # (a worker's exception surfaces here, in the consumer)
+        return item
+
+    def close(self) -> None:
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+            self.pool = None
 
     def names_unique(self) -> bool:
         """No record name twice (then a join by record number IS the reference's merge on the name).  One hash pass over
@@ -285,6 +317,11 @@ class _Aggregator:
         return y
 
     def add(self, y_pred: dict, records: np.ndarray | None = None) -> None:
+        part = self._aggregate(y_pred, records)
+        if part is not None:
+            self.parts.append(part)
+
+    def _aggregate(self, y_pred: dict, records: np.ndarray | None = None):
         from .postprocess import SpanColumn, _Summaries, pred_to_dict, window_letters
         if y_pred and len(y_pred["meta_2"]):
             kw = self.kw
@@ -297,14 +334,21 @@ class _Aggregator:
             data["frag_pred"] = _Summaries(blob=blob, n=len(runs)) if blob is not None else _Summaries(runs.summaries(letters))
             if records is not None and len(records) == len(data["headers"]):
                 data["record_index"] = records        # FASTA record of every contig of the batch: the repeat table joins by it
-            self.parts.append((data, full))
+            return data, full
+        return None
 
-    def flush(self, writer, term_repeats) -> None:
-        """Hand the batches aggregated so far to the table writer (needs the repeat table: the left merge of
-        collect.py:527-532 is part of a row)."""
+    def flush(self, writer, term_repeats, wait: bool = True) -> None:
+        """Hand the batches aggregated so far to the table writer, in order (needs the repeat table: the left merge of
+        collect.py:527-532 is part of a row).  ``wait`` False: stop at the first batch a worker has not finished."""
         t0 = time.time()
         while self.flushed < len(self.parts):
-            data = self.parts[self.flushed][0]
+            part = self._part(self.flushed, wait)
+            if part == "pending":
+                break
+            if part is None:
+                self.flushed += 1
+                continue
+            data = part[0]
             data["repeats"] = term_repeats
             row_of = getattr(term_repeats, "row_of_record", None)
             if row_of is None and term_repeats is not None and hasattr(term_repeats, "attrs"):
@@ -318,7 +362,8 @@ class _Aggregator:
 
     def result_full(self):
         from .postprocess import merge_data
-        return merge_data([p[1] for p in self.parts])
+        parts = [self._part(i) for i in range(len(self.parts))]
+        return merge_data([p[1] for p in parts if p is not None])
 
 
 # ---- torchrun: contig-sharded prediction, one gather of f32 rows ---------------------------------------------
@@ -769,7 +814,7 @@ def run_core(**kwargs) -> int:
         writer = _LazyTableWriter(class_map, table_path, phage_path, kwargs.get("rc", 0.5), kwargs.get("pc", 1))
         agg = _Aggregator(table, fa.names, out, dict(class_map=class_map, fsize=fsize, term_repeats=None,
                                                      want_full=bool(kwargs.get("window_scores") or kwargs.get("prophage")),
-                                                     **crf_kw), min_batch=n_long // 16)
+                                                     **crf_kw), min_batch=n_long // 16, workers=2 if piped else 1)
 
         def classify():
             t0 = time.time()
@@ -795,8 +840,8 @@ def run_core(**kwargs) -> int:
                     try:
                         while True:
                             stopping = flush_stop.is_set()
-                            if "frame" in scan:
-                                agg.flush(writer, scan["frame"])
+                            if "frame" in scan:     # (the pass after the stop signal waits for the pool's last batches)
+                                agg.flush(writer, scan["frame"], wait=stopping)
                             if stopping:
                                 break
                             time.sleep(0.002)
@@ -839,6 +884,7 @@ def run_core(**kwargs) -> int:
             if flusher is not None:             # (an error path: the row thread must not outlive the writer it uses)
                 flush_stop.set()
                 flusher.join()
+            agg.close()                         # (every batch handed to the pool has been aggregated)
             if pool is not None:
                 pool.shutdown(wait=True)
         t_predict = time.time() - t_predict
